@@ -1,0 +1,186 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU checker (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+INTER_NN, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
+OK = 0
+INVALID_ARGS = 50
+NO_SUCH_FILTER = 52
+TOO_BIG_TARGET = 54
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    P = C.c_void_p
+    lib.orc_image_create.restype = P
+    lib.orc_image_create.argtypes = [C.c_int] * 3
+    lib.orc_image_from.restype = P
+    lib.orc_image_from.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.orc_image_free.argtypes = [P]
+    lib.orc_image_data.restype = C.c_void_p
+    lib.orc_image_data.argtypes = [P]
+    for f in ("width", "height", "channels", "step"):
+        fn = getattr(lib, "orc_image_" + f)
+        fn.restype = C.c_int
+        fn.argtypes = [P]
+    lib.orc_crop_geometry.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p] + [C.POINTER(C.c_int)] * 4
+    lib.orc_crop.argtypes = [C.POINTER(P), C.c_char_p, C.c_char_p]
+    lib.orc_resize_geometry.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint, C.c_uint, C.c_int] + [C.POINTER(C.c_int)] * 3
+    lib.orc_resize.argtypes = [C.POINTER(P), C.c_char_p, C.c_uint, C.c_uint, C.c_int]
+    lib.orc_cv_resize.argtypes = [P, P, C.c_int]
+    lib.orc_set_cv_simd.argtypes = [C.c_int]
+    lib.orc_cv_smooth_gaussian.argtypes = [P, C.c_double]
+    lib.orc_gaussian_ksize.argtypes = [C.c_double]
+    lib.orc_filter.argtypes = [C.POINTER(P), C.c_char_p, C.c_int]
+    lib.orc_rgb2hsv.argtypes = [P]
+    lib.orc_hsv2rgb.argtypes = [P]
+    lib.orc_watermark.argtypes = [P, P, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int]
+    lib.orc_blend_with_paper.argtypes = [P]
+    lib.orc_calc_perceived_brightness.restype = C.c_float
+    lib.orc_calc_perceived_brightness.argtypes = [P]
+    lib.orc_ascii.restype = C.c_long
+    lib.orc_ascii.argtypes = [P, C.c_char_p, C.c_void_p]
+    lib.orc_gray2bgr.argtypes = [C.POINTER(P)]
+    return lib
+
+
+lib = _load()
+
+
+def _b(s):
+    return None if s is None else (s if isinstance(s, bytes) else s.encode())
+
+
+class Img:
+    """Owning handle on an orc_image; numpy in, numpy out (H x W x C uint8, tightly packed)."""
+
+    def __init__(self, arr=None, handle=None):
+        if handle is not None:
+            self.h = C.c_void_p(handle)
+            return
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        if arr.ndim == 2:
+            arr = arr[:, :, None]
+        hh, ww, cc = arr.shape
+        self.h = C.c_void_p(lib.orc_image_from(arr.ctypes.data, ww, hh, cc, ww * cc))
+        if not self.h:
+            raise ValueError("bad image shape %r" % (arr.shape,))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_image_free(self.h)
+            self.h = None
+
+    @property
+    def shape(self):
+        return (lib.orc_image_height(self.h), lib.orc_image_width(self.h), lib.orc_image_channels(self.h))
+
+    def numpy(self):
+        hh, ww, cc = self.shape
+        step = lib.orc_image_step(self.h)
+        buf = (C.c_ubyte * (step * hh)).from_address(lib.orc_image_data(self.h))
+        a = np.frombuffer(buf, dtype=np.uint8).reshape(hh, step)[:, : ww * cc].reshape(hh, ww, cc)
+        return a.copy()
+
+
+def crop_geometry(col, row, args, gravity=None):
+    x, y, w, h = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib.orc_crop_geometry(col, row, _b(args), _b(gravity), x, y, w, h)
+    return rc, (x.value, y.value, w.value, h.value)
+
+
+def resize_geometry(col, row, args, max_w=2000, max_h=2000, simple=0):
+    w, h, i = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.orc_resize_geometry(col, row, _b(args), max_w, max_h, simple, w, h, i)
+    return rc, (w.value, h.value, i.value)
+
+
+def crop(arr, args, gravity=None):
+    im = Img(arr)
+    rc = lib.orc_crop(C.byref(im.h), _b(args), _b(gravity))
+    return rc, (im.numpy() if rc == 0 else None)
+
+
+def resize(arr, args, max_w=2000, max_h=2000, simple=0):
+    im = Img(arr)
+    rc = lib.orc_resize(C.byref(im.h), _b(args), max_w, max_h, simple)
+    return rc, (im.numpy() if rc == 0 else None)
+
+
+def cv_resize(arr, dw, dh, interp):
+    src = Img(arr)
+    dst = Img(handle=lib.orc_image_create(dw, dh, src.shape[2]))
+    rc = lib.orc_cv_resize(src.h, dst.h, interp)
+    if rc:
+        raise ValueError("orc_cv_resize rc=%d" % rc)
+    return dst.numpy()
+
+
+def filter(arr, request, allow_experiments=1):
+    im = Img(arr)
+    rc = lib.orc_filter(C.byref(im.h), _b(request), allow_experiments)
+    return rc, (im.numpy() if rc == 0 else None)
+
+
+def gaussian(arr, sigma):
+    im = Img(arr)
+    lib.orc_cv_smooth_gaussian(im.h, sigma)
+    return im.numpy()
+
+
+def watermark(arr, overlay, gx, gy, ox, oy, opacity):
+    im, ov = Img(arr), Img(overlay)
+    rc = lib.orc_watermark(im.h, ov.h, _b(gx), _b(gy), ox, oy, opacity)
+    return rc, (im.numpy() if rc == 0 else None)
+
+
+def blend_with_paper(arr):
+    im = Img(arr)
+    lib.orc_blend_with_paper(im.h)
+    return im.numpy()
+
+
+def brightness(arr):
+    return float(lib.orc_calc_perceived_brightness(Img(arr).h))
+
+
+def ascii_art(arr, args=""):
+    im = Img(arr)
+    hh, ww, _ = im.shape
+    out = (C.c_ubyte * ((ww + 1) * hh))()
+    n = lib.orc_ascii(im.h, _b(args), out)
+    return bytes(out[:n])
+
+
+def gray2bgr(arr):
+    im = Img(arr)
+    lib.orc_gray2bgr(C.byref(im.h))
+    return im.numpy()
+
+
+def rgb2hsv(arr):
+    im = Img(arr)
+    lib.orc_rgb2hsv(im.h)
+    return im.numpy()
+
+
+def hsv2rgb(arr):
+    im = Img(arr)
+    lib.orc_hsv2rgb(im.h)
+    return im.numpy()
