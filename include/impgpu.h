@@ -1,0 +1,180 @@
+/*
+ * impgpu.h -- C ABI of libimpgpu.so: the MI355X (gfx950) pixel-transform path that
+ * replaces the operator segment of IMP's RunJob (reference bridge.c:574-656) and the
+ * OpenCV/filters.c calls below it.  Plain C types only; no torch, no C++ in signatures.
+ *
+ * Each entry point cites the reference interface it stands in for.  Argument strings
+ * are the reference's GET-parameter values verbatim (docs/03 - Usage.md); return codes
+ * are the reference's IMP_* codes (required.h:28-41).  All pixel work runs in HIP
+ * kernels on the device selected by impgpu_env_start(); there is no CPU fallback --
+ * every device-touching call returns IMP_ERROR_DEVICE when HIP is unavailable.
+ *
+ * Images are 8-bit interleaved B,G,R[,A] (required.h:66-69), top-left origin, rows
+ * padded to 4 bytes exactly like cvCreateImage (widthStep = (w*channels + 3) & ~3).
+ */
+#ifndef IMPGPU_H
+#define IMPGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: required.h:28-41 ---- */
+#define IMP_OK                      0
+#define IMP_ERROR_UNSUPPORTED       1
+#define IMP_ERROR_MALLOC_FAILED     2
+#define IMP_ERROR_DECODE_FAILED     3
+#define IMP_ERROR_ENCODE_FAILED     4
+#define IMP_ERROR_INVALID_ARGS      50
+#define IMP_ERROR_UPSCALE           51
+#define IMP_ERROR_NO_SUCH_FILTER    52
+#define IMP_ERROR_NO_SUCH_WATERMARK 53
+#define IMP_ERROR_TOO_BIG_TARGET    54
+#define IMP_ERROR_TOO_MUCH_FILTERS  55
+#define IMP_ERROR_FEATURE_DISABLED  56
+/* not in the reference: a HIP runtime call failed or no device/env (maps to HTTP 500 like any other code) */
+#define IMP_ERROR_DEVICE            90
+
+/* ---- step codes: required.h:46-54 ---- */
+#define IMP_STEP_START     0
+#define IMP_STEP_VALIDATE  1
+#define IMP_STEP_DECODE    2
+#define IMP_STEP_CROP      3
+#define IMP_STEP_RESIZE    4
+#define IMP_STEP_FILTERING 5
+#define IMP_STEP_WATERMARK 6
+#define IMP_STEP_INFO      7
+#define IMP_STEP_ENCODE    8
+
+/* ---- interpolation ids: OpenCV 2.4 CV_INTER_* as passed to cvResize at bridge.c:190-191 ---- */
+#define IMP_INTER_NN       0
+#define IMP_INTER_LINEAR   1
+#define IMP_INTER_CUBIC    2
+#define IMP_INTER_AREA     3
+#define IMP_INTER_LANCZOS4 4
+
+/* Device-resident stand-in for the IplImage* the reference passes between operators
+ * (required.h:129-134 Frame.Image). Opaque; query with the accessors. */
+typedef struct impgpu_image impgpu_image;
+
+/* The fields of Config (required.h:108-118) that the operators read, plus Position
+ * (required.h:86-91).  watermark replaces RecoverInfo (required.h:99-106): the overlay's
+ * pixels live in HBM, uploaded once per worker by impgpu_prepare_watermark. */
+typedef struct {
+    unsigned int  max_target_w;         /* MaxTargetDimensions->W, 0 = unlimited (module.c:172-175 default 2000) */
+    unsigned int  max_target_h;         /* MaxTargetDimensions->H */
+    int           max_filters_count;    /* MaxFiltersCount (module.c:181 default 5) */
+    int           allow_experiments;    /* AllowExperiments */
+    int           watermark_opacity;    /* WatermarkOpacity 1..100 (module.c:144-148) */
+    char          watermark_gravity_x;  /* Position.GravityX: 'l' 'c' 'r' */
+    char          watermark_gravity_y;  /* Position.GravityY: 't' 'c' 'b' */
+    int           watermark_offset_x;   /* Position.OffsetX */
+    int           watermark_offset_y;   /* Position.OffsetY */
+    impgpu_image* watermark;            /* WatermarkInfo; NULL = no watermark configured */
+} impgpu_config;
+
+/* What RunJob has parsed out of the query string by bridge.c:372, i.e. the inputs of
+ * the operator segment bridge.c:574-656. */
+typedef struct {
+    const char*        crop;            /* value of crop=, NULL if absent */
+    const char*        gravity;         /* value of gravity=, NULL if absent */
+    const char*        resize;          /* value of resize=, NULL if absent */
+    int                simple;          /* bridge.c:594: GIF output forces nearest-neighbour */
+    const char* const* filters;         /* "name=args" strings in query order (bridge.c:365) */
+    int                filter_count;
+    int                need_flatten;    /* encoder lacks alpha (bridge.c:642-648) */
+} impgpu_job;
+
+/* ---- lifecycle: OnEnvStart / OnEnvDestroy (bridge.h:1-2, bridge.c:10-16; called from
+ *      module.c:100-107 once per worker process, after fork) ---- */
+/* device < 0: take $IMPGPU_DEVICE, else $LOCAL_RANK, else 0. */
+int         impgpu_env_start(int device);
+void        impgpu_env_destroy(void);
+int         impgpu_env_device(void);            /* -1 when no env */
+const char* impgpu_last_error(void);            /* text of the last HIP failure on this thread */
+int         impgpu_sync(void);                  /* wait for the env stream */
+void*       impgpu_env_stream(void);            /* the env's hipStream_t */
+
+/* ---- frames: the decode -> operators hand-over (bridge.c:547-552, advancedio.c:310-318)
+ *      and the operators -> encode hand-over (bridge.c:703-704, advancedio.c:65-101) ---- */
+int   impgpu_image_upload(const unsigned char* data, int width, int height, int channels,
+                          int step, impgpu_image** out);   /* pinned staging + hipMemcpyAsync */
+int   impgpu_image_create(int width, int height, int channels, impgpu_image** out);
+int   impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int step,
+                        impgpu_image** out);               /* borrow memory already in HBM */
+int   impgpu_image_clone(const impgpu_image* src, impgpu_image** out);
+int   impgpu_image_download(const impgpu_image* image, unsigned char* data, int step); /* syncs */
+int   impgpu_image_width(const impgpu_image* image);
+int   impgpu_image_height(const impgpu_image* image);
+int   impgpu_image_channels(const impgpu_image* image);
+int   impgpu_image_step(const impgpu_image* image);
+void* impgpu_image_device_ptr(const impgpu_image* image);
+void  impgpu_image_release(impgpu_image** image);          /* cvReleaseImage */
+
+/* ---- operators.  `pointer` operators may replace *pointer and release the old image,
+ *      exactly as the reference's IplImage** operators do. ---- */
+
+/* int Crop(IplImage** pointer, char* args, char* gravity)            bridge.h:4, bridge.c:18-141 */
+int impgpu_crop(impgpu_image** pointer, const char* args, const char* gravity);
+/* int Resize(IplImage** pointer, char* args, Config* config, int simple)  bridge.h:5, bridge.c:143-197 */
+int impgpu_resize(impgpu_image** pointer, const char* args, const impgpu_config* config, int simple);
+/* cvResize(image, resized, filter)                                    bridge.c:189-191.
+ * The reference only ever passes NN / CUBIC (enlarging) / AREA (shrinking); this entry
+ * point also takes LINEAR and LANCZOS4 and CUBIC-on-downscale with OpenCV 2.4.9 semantics. */
+int impgpu_cv_resize(impgpu_image** pointer, int width, int height, int interpolation);
+/* int Filter(IplImage** pointer, char* request, int allowExperiments) filters.h:1, filters.c:43-70 */
+int impgpu_filter(impgpu_image** pointer, const char* request, int allow_experiments);
+/* int PrepareWatermark(Config* cfg, ngx_pool_t* pool)                 bridge.h:6, bridge.c:199-237.
+ * File read + decode stay on the host (cvDecodeImage); this takes the decoded pixels
+ * (what bridge.c:221-234 parks in RecoverInfo) and uploads them to HBM. */
+int impgpu_prepare_watermark(impgpu_config* config, const unsigned char* pixels, int width,
+                             int height, int channels, int step);
+/* int Watermark(IplImage* image, Config* config)                      bridge.h:7, bridge.c:239-281 */
+int impgpu_watermark(impgpu_image* image, const impgpu_config* config);
+/* void BlendWithPaper(IplImage* source)                               filters.h:30, filters.c:666-687 */
+int impgpu_blend_with_paper(impgpu_image* image);
+/* float CalcPerceivedBrightness(IplImage* image)                      filters.h:34, filters.c:707-729 */
+int impgpu_calc_perceived_brightness(const impgpu_image* image, float* brightness);
+/* Memory ASCII(IplImage* input, char* args, ngx_pool_t* pool)         filters.h:18, filters.c:486-522.
+ * out must hold (width+1)*height-1 bytes; like the reference it leaves the image in HSV. */
+int impgpu_ascii(impgpu_image* image, const char* args, unsigned char* out, long capacity, long* length);
+/* cvCvtColor(image, colored, CV_GRAY2BGR)                             bridge.c:613-618 */
+int impgpu_gray2bgr(impgpu_image** pointer);
+/* void RGB2HSV(IplImage*) / void HSV2RGB(IplImage*)                   helpers.h:17-18, helpers.c:70-176 */
+int impgpu_rgb2hsv(impgpu_image* image);
+int impgpu_hsv2rgb(impgpu_image* image);
+
+/* The operator segment of RunJob, bridge.c:574-656: crop -> resize -> [gray->BGR] ->
+ * filters in order -> watermark -> flatten.  *step receives the IMP_STEP_* that was
+ * running when a non-zero code was returned (JobResult.Step, required.h:78-84).
+ * Crop is folded into the next operator's source view, consecutive pointwise filters
+ * run as one kernel. */
+int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_config* config, int* step);
+
+/* ---- argument grammar only (host, no device): what Crop / Resize decide before they
+ *      touch pixels.  Used by the module to answer 400/405/413 without a GPU round trip. ---- */
+int impgpu_crop_geometry(int width, int height, const char* args, const char* gravity,
+                         int* x, int* y, int* w, int* h);                      /* bridge.c:18-128 */
+int impgpu_resize_geometry(int width, int height, const char* args, const impgpu_config* config,
+                           int simple, int* w, int* h, int* interpolation);   /* bridge.c:143-190 */
+int impgpu_filter_check(const char* request, int allow_experiments);           /* filters.c:43-70 + per-filter arg checks */
+int impgpu_check_destructive(const char* request);                             /* filters.c:32-40 */
+
+/* ---- batch entry points (benchmark / multi-frame albums: bridge.c:578,591,608,632).
+ *      `count` frames of identical geometry, frame i at base + i*frame_stride bytes,
+ *      already resident in HBM.  stream = hipStream_t to launch on (NULL = env stream).
+ *      Asynchronous: returns after enqueue. ---- */
+int impgpu_batch_cv_resize(const void* src, long long src_frame_stride, int src_width, int src_height, int src_step,
+                           void* dst, long long dst_frame_stride, int dst_width, int dst_height, int dst_step,
+                           int channels, int count, int interpolation, void* stream);
+/* cfg3 chain on a batch: resize (AREA/CUBIC by the reference's rule) -> rotate -> watermark.
+ * rotate in {0, 90, 180, 270}; config->watermark may be NULL. dst geometry must match. */
+int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_stride, int src_width, int src_height, int src_step,
+                                         void* dst, long long dst_frame_stride, int dst_step,
+                                         int resize_width, int resize_height, int rotate,
+                                         const impgpu_config* config, int channels, int count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMPGPU_H */

@@ -1,0 +1,108 @@
+"""ctypes signatures of libimpgpu.so (include/impgpu.h). Import fails loudly if the library is absent."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libimpgpu.so")
+
+
+class ImpError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = "impgpu: %s failed with code %d" % (what, code)
+        try:
+            detail = lib.impgpu_last_error().decode()
+            if code == 90 and detail:
+                msg += " (%s)" % detail
+        except Exception:
+            pass
+        super().__init__(msg)
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "ngx_http_imgproc_amd: %s is missing. Build it with `python -m ngx_http_imgproc_amd.build` "
+        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+
+class CConfig(C.Structure):
+    _fields_ = [
+        ("max_target_w", C.c_uint),
+        ("max_target_h", C.c_uint),
+        ("max_filters_count", C.c_int),
+        ("allow_experiments", C.c_int),
+        ("watermark_opacity", C.c_int),
+        ("watermark_gravity_x", C.c_char),
+        ("watermark_gravity_y", C.c_char),
+        ("watermark_offset_x", C.c_int),
+        ("watermark_offset_y", C.c_int),
+        ("watermark", C.c_void_p),
+    ]
+
+
+class CJob(C.Structure):
+    _fields_ = [
+        ("crop", C.c_char_p),
+        ("gravity", C.c_char_p),
+        ("resize", C.c_char_p),
+        ("simple", C.c_int),
+        ("filters", C.POINTER(C.c_char_p)),
+        ("filter_count", C.c_int),
+        ("need_flatten", C.c_int),
+    ]
+
+
+P = C.c_void_p
+PP = C.POINTER(C.c_void_p)
+IP = C.POINTER(C.c_int)
+
+# every symbol include/impgpu.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "impgpu_env_start": (C.c_int, [C.c_int]),
+    "impgpu_env_destroy": (None, []),
+    "impgpu_env_device": (C.c_int, []),
+    "impgpu_last_error": (C.c_char_p, []),
+    "impgpu_sync": (C.c_int, []),
+    "impgpu_env_stream": (P, []),
+    "impgpu_image_upload": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),
+    "impgpu_image_create": (C.c_int, [C.c_int, C.c_int, C.c_int, PP]),
+    "impgpu_image_wrap": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),
+    "impgpu_image_clone": (C.c_int, [P, PP]),
+    "impgpu_image_download": (C.c_int, [P, P, C.c_int]),
+    "impgpu_image_width": (C.c_int, [P]),
+    "impgpu_image_height": (C.c_int, [P]),
+    "impgpu_image_channels": (C.c_int, [P]),
+    "impgpu_image_step": (C.c_int, [P]),
+    "impgpu_image_device_ptr": (P, [P]),
+    "impgpu_image_release": (None, [PP]),
+    "impgpu_crop": (C.c_int, [PP, C.c_char_p, C.c_char_p]),
+    "impgpu_resize": (C.c_int, [PP, C.c_char_p, C.POINTER(CConfig), C.c_int]),
+    "impgpu_cv_resize": (C.c_int, [PP, C.c_int, C.c_int, C.c_int]),
+    "impgpu_filter": (C.c_int, [PP, C.c_char_p, C.c_int]),
+    "impgpu_prepare_watermark": (C.c_int, [C.POINTER(CConfig), P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "impgpu_watermark": (C.c_int, [P, C.POINTER(CConfig)]),
+    "impgpu_blend_with_paper": (C.c_int, [P]),
+    "impgpu_calc_perceived_brightness": (C.c_int, [P, C.POINTER(C.c_float)]),
+    "impgpu_ascii": (C.c_int, [P, C.c_char_p, P, C.c_long, C.POINTER(C.c_long)]),
+    "impgpu_gray2bgr": (C.c_int, [PP]),
+    "impgpu_rgb2hsv": (C.c_int, [P]),
+    "impgpu_hsv2rgb": (C.c_int, [P]),
+    "impgpu_run_ops": (C.c_int, [PP, C.POINTER(CJob), C.POINTER(CConfig), IP]),
+    "impgpu_crop_geometry": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, IP, IP, IP, IP]),
+    "impgpu_resize_geometry": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(CConfig), C.c_int, IP, IP, IP]),
+    "impgpu_filter_check": (C.c_int, [C.c_char_p, C.c_int]),
+    "impgpu_check_destructive": (C.c_int, [C.c_char_p]),
+    "impgpu_batch_cv_resize": (C.c_int, [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, C.c_longlong, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, P]),
+    "impgpu_batch_resize_rotate_watermark": (C.c_int, [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, C.c_longlong,
+                                                       C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(CConfig),
+                                                       C.c_int, C.c_int, P]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args

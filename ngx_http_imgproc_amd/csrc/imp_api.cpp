@@ -1,0 +1,399 @@
+// imp_api.cpp -- the operator entry points of include/impgpu.h: each takes the reference's
+// argument string, decides everything the reference decides on the CPU before touching pixels
+// (imp_args.cpp), then enqueues kernels on the env stream.  impgpu_run_ops is the operator
+// segment of RunJob (bridge.c:574-656) with Crop folded into the next operator's source view
+// and runs of pointwise filters fused into one launch.
+#include <cstring>
+#include "imp_internal.h"
+
+using namespace imp;
+
+namespace {
+
+int need_env() {
+    if (!env_ready()) { set_error("impgpu_env_start has not been called", hipErrorNotInitialized); return IMP_ERROR_DEVICE; }
+    return IMP_OK;
+}
+
+Frames one_frame(const View& v, impgpu_image* dst) {
+    Frames f{};
+    f.src = v.d; f.src_stride = 0; f.v = v;
+    f.dst = dst->d; f.dst_stride = 0; f.dw = dst->w; f.dh = dst->h; f.dstep = dst->step;
+    f.count = 1;
+    return f;
+}
+
+// The image being worked on: `owner` holds the memory, `v` is the window of it that is the
+// current frame (smaller than owner after a folded Crop).
+struct Work {
+    impgpu_image* owner;
+    View v;
+    bool is_view() const { return v.d != owner->d || v.w != owner->w || v.h != owner->h; }
+    void adopt(impgpu_image* im) {
+        image_delete(owner);
+        owner = im;
+        v = view_of(im);
+    }
+};
+
+int materialize(Work& wk) {
+    if (!wk.is_view()) return IMP_OK;
+    impgpu_image* out = nullptr;
+    if (int rc = image_new(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
+    if (int rc = launch_copy(one_frame(wk.v, out), env_stream())) { image_delete(out); return rc; }
+    wk.adopt(out);
+    return IMP_OK;
+}
+
+int do_resize(Work& wk, int w, int h, int interp) {
+    impgpu_image* out = nullptr;
+    if (int rc = image_new(w, h, wk.v.c, &out)) return rc;
+    if (int rc = launch_cv_resize(one_frame(wk.v, out), interp, env_stream())) { image_delete(out); return rc; }
+    wk.adopt(out);
+    return IMP_OK;
+}
+
+int flush_program(Work& wk, PixelProgram& prog) {
+    if (prog.empty()) return IMP_OK;
+    int rc = launch_pixel_program(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.c, wk.v.step, 1, prog, env_stream());
+    prog.clear();
+    return rc;
+}
+
+int apply_plan(Work& wk, const FilterPlan& plan) {
+    switch (plan.cls) {
+        case FC_FLIP: {
+            impgpu_image* out = nullptr;
+            if (int rc = image_new(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
+            if (int rc = launch_flip(one_frame(wk.v, out), plan.flip_mode, env_stream())) { image_delete(out); return rc; }
+            wk.adopt(out);
+            return IMP_OK;
+        }
+        case FC_ROTATE: {
+            impgpu_image* out = nullptr;
+            const bool swap = plan.rotate != 180;
+            if (int rc = image_new(swap ? wk.v.h : wk.v.w, swap ? wk.v.w : wk.v.h, wk.v.c, &out)) return rc;
+            if (int rc = launch_rotate(one_frame(wk.v, out), plan.rotate, env_stream())) { image_delete(out); return rc; }
+            wk.adopt(out);
+            return IMP_OK;
+        }
+        case FC_BLUR:
+            return launch_gaussian(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.c, wk.v.step, 1, plan.sigma, env_stream());
+        default:
+            return IMP_OK;
+    }
+}
+
+int do_filter(Work& wk, const char* request, int allow, PixelProgram& prog) {
+    FilterPlan plan;
+    if (int rc = filter_plan(request, allow, wk.v.c, wk.v.w, wk.v.h, &plan, &prog)) return rc;
+    if (plan.cls == FC_POINTWISE || plan.cls == FC_NOOP) return IMP_OK;     // stays queued in prog
+    if (int rc = flush_program(wk, prog)) return rc;
+    return apply_plan(wk, plan);
+}
+
+int do_watermark(Work& wk, const impgpu_config* cfg) {
+    const impgpu_image* ov = cfg->watermark;
+    if (wk.v.c < 3 || ov->c < 3) return IMP_ERROR_INVALID_ARGS;   // reference indexes B,G,R unconditionally
+    int rx, ry, maxcol, maxrow;
+    if (int rc = watermark_rect(wk.v.w, wk.v.h, ov->w, ov->h, cfg, &rx, &ry, &maxcol, &maxrow)) return rc;
+    const float opacity = (float)(cfg->watermark_opacity / 100.0);   // bridge.c:275
+    const float alpha = 1 - opacity;                                  // filters.c:620
+    return launch_blend_over(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.c, wk.v.step, 1, ov,
+                             rx, ry, maxcol, maxrow, alpha, env_stream());
+}
+
+}  // namespace
+
+extern "C" {
+
+int impgpu_crop_geometry(int width, int height, const char* args, const char* gravity, int* x, int* y, int* w, int* h) {
+    if (!args || !x || !y || !w || !h) return IMP_ERROR_INVALID_ARGS;
+    return crop_geometry(width, height, args, gravity, x, y, w, h);
+}
+
+int impgpu_resize_geometry(int width, int height, const char* args, const impgpu_config* config, int simple,
+                           int* w, int* h, int* interpolation) {
+    if (!args || !w || !h || !interpolation) return IMP_ERROR_INVALID_ARGS;
+    return resize_geometry(width, height, args, config ? config->max_target_w : 0, config ? config->max_target_h : 0,
+                           simple, w, h, interpolation);
+}
+
+int impgpu_filter_check(const char* request, int allow_experiments) {
+    if (!request) return IMP_ERROR_INVALID_ARGS;
+    FilterPlan plan;
+    PixelProgram prog;
+    return filter_plan(request, allow_experiments, 4, 64, 64, &plan, &prog);
+}
+
+int impgpu_check_destructive(const char* request) { return check_destructive(request); }
+
+int impgpu_image_clone(const impgpu_image* src, impgpu_image** out) {
+    if (!src || !out) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    impgpu_image* im = nullptr;
+    if (int rc = image_new(src->w, src->h, src->c, &im)) return rc;
+    if (int rc = launch_copy(one_frame(view_of(src), im), env_stream())) { image_delete(im); return rc; }
+    *out = im;
+    return IMP_OK;
+}
+
+int impgpu_crop(impgpu_image** pointer, const char* args, const char* gravity) {
+    if (!pointer || !*pointer || !args) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    int x, y, w, h;
+    if (int rc = crop_geometry((*pointer)->w, (*pointer)->h, args, gravity, &x, &y, &w, &h)) return rc;
+    Work wk{*pointer, view_sub(view_of(*pointer), x, y, w, h)};
+    int rc = IMP_OK;
+    if (wk.is_view()) rc = materialize(wk);
+    else {   // full-frame crop still yields a fresh image in the reference; the pixels are identical
+    }
+    *pointer = wk.owner;
+    return rc;
+}
+
+int impgpu_resize(impgpu_image** pointer, const char* args, const impgpu_config* config, int simple) {
+    if (!pointer || !*pointer || !args) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    int w, h, interp;
+    if (int rc = resize_geometry((*pointer)->w, (*pointer)->h, args, config ? config->max_target_w : 0,
+                                 config ? config->max_target_h : 0, simple, &w, &h, &interp))
+        return rc;
+    Work wk{*pointer, view_of(*pointer)};
+    int rc = do_resize(wk, w, h, interp);
+    *pointer = wk.owner;
+    return rc;
+}
+
+int impgpu_cv_resize(impgpu_image** pointer, int width, int height, int interpolation) {
+    if (!pointer || !*pointer || width <= 0 || height <= 0) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    Work wk{*pointer, view_of(*pointer)};
+    int rc = do_resize(wk, width, height, interpolation);
+    *pointer = wk.owner;
+    return rc;
+}
+
+int impgpu_filter(impgpu_image** pointer, const char* request, int allow_experiments) {
+    if (!pointer || !*pointer || !request) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    Work wk{*pointer, view_of(*pointer)};
+    PixelProgram prog;
+    int rc = do_filter(wk, request, allow_experiments, prog);
+    if (!rc) rc = flush_program(wk, prog);
+    *pointer = wk.owner;
+    return rc;
+}
+
+int impgpu_prepare_watermark(impgpu_config* config, const unsigned char* pixels, int width, int height,
+                             int channels, int step) {
+    if (!config || !pixels) return IMP_ERROR_NO_SUCH_WATERMARK;
+    if (int rc = need_env()) return rc;
+    impgpu_image* im = nullptr;
+    if (int rc = impgpu_image_upload(pixels, width, height, channels, step, &im)) return rc == IMP_ERROR_INVALID_ARGS ? IMP_ERROR_NO_SUCH_WATERMARK : rc;
+    if (config->watermark) image_delete(config->watermark);
+    config->watermark = im;
+    return IMP_OK;
+}
+
+int impgpu_watermark(impgpu_image* image, const impgpu_config* config) {
+    if (!image || !config || !config->watermark) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    Work wk{image, view_of(image)};
+    return do_watermark(wk, config);
+}
+
+int impgpu_blend_with_paper(impgpu_image* image) {
+    if (!image) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    if (image->c != 4) return IMP_ERROR_INVALID_ARGS;   // reference reads channel 3 unconditionally; RunJob only calls it for 4 channels
+    return launch_blend_paper(image->d, 0, image->w, image->h, image->step, 1, env_stream());
+}
+
+int impgpu_calc_perceived_brightness(const impgpu_image* image, float* brightness) {
+    if (!image || !brightness) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    return launch_brightness(view_of(image), brightness, env_stream());
+}
+
+int impgpu_ascii(impgpu_image* image, const char* args, unsigned char* out, long capacity, long* length) {
+    static const unsigned char wide[] = "$@B%8&WM#*oahkbdpqwmZO0QLCJUYXzcvunxrjft/\\|()1{}[]?-_+~<>i!lI;:,\"^`'. ";
+    static const unsigned char narrow[] = "@%8#*+=-:. ";
+    if (!image || !out || !length) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    if (image->c < 3) return IMP_ERROR_INVALID_ARGS;
+    const unsigned char* table = (args && !std::strcmp(args, "wide")) ? wide : narrow;
+    const int tablelen = (int)std::strlen((const char*)table);
+    const float factor = (float)(256.0 / tablelen);
+    const long buflen = (long)(image->w + 1) * image->h - 1;
+    if (capacity < buflen) return IMP_ERROR_INVALID_ARGS;
+    void *dev_table = nullptr, *dev_out = nullptr;
+    if (int rc = upload_small(table, (size_t)tablelen + 1, &dev_table, env_stream())) return rc;
+    if (int rc = dev_alloc((size_t)buflen + 1, &dev_out)) { dev_free(dev_table); return rc; }
+    int rc = launch_ascii(image->d, image->w, image->h, image->c, image->step, (const uint8_t*)dev_table, tablelen, factor,
+                          (uint8_t*)dev_out, env_stream());
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, dev_out, (size_t)buflen, hipMemcpyDeviceToHost, env_stream());
+        if (e == hipSuccess) e = hipStreamSynchronize(env_stream());
+        if (e != hipSuccess) { set_error("ascii readback", e); rc = IMP_ERROR_DEVICE; }
+    }
+    dev_free(dev_table);
+    dev_free(dev_out);
+    if (!rc) *length = buflen;
+    return rc;
+}
+
+int impgpu_gray2bgr(impgpu_image** pointer) {
+    if (!pointer || !*pointer) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    if ((*pointer)->c != 1) return IMP_OK;
+    impgpu_image* out = nullptr;
+    if (int rc = image_new((*pointer)->w, (*pointer)->h, 3, &out)) return rc;
+    if (int rc = launch_gray2bgr(one_frame(view_of(*pointer), out), env_stream())) { image_delete(out); return rc; }
+    image_delete(*pointer);
+    *pointer = out;
+    return IMP_OK;
+}
+
+static int single_stage(impgpu_image* image, int kind) {
+    if (!image) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    if (image->c < 3) return IMP_ERROR_INVALID_ARGS;
+    PixelProgram prog;
+    Stage s{};
+    s.kind = kind;
+    prog.stages.push_back(s);
+    return launch_pixel_program(image->d, 0, image->w, image->h, image->c, image->step, 1, prog, env_stream());
+}
+int impgpu_rgb2hsv(impgpu_image* image) { return single_stage(image, ST_RGB2HSV); }
+int impgpu_hsv2rgb(impgpu_image* image) { return single_stage(image, ST_HSV2RGB); }
+
+int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_config* config, int* step) {
+    int dummy;
+    if (!step) step = &dummy;
+    *step = IMP_STEP_START;
+    if (!pointer || !*pointer || !job || !config) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    // bridge.c:361-363 rejects the request while parsing; same limit here
+    if (config->max_filters_count > 0 && job->filter_count > config->max_filters_count) return IMP_ERROR_TOO_MUCH_FILTERS;
+    Work wk{*pointer, view_of(*pointer)};
+    int rc = IMP_OK;
+    PixelProgram prog;
+
+    *step = IMP_STEP_CROP;                                             // bridge.c:575-586
+    if (job->crop) {
+        int x, y, w, h;
+        rc = crop_geometry(wk.v.w, wk.v.h, job->crop, job->gravity, &x, &y, &w, &h);
+        if (rc) goto done;
+        wk.v = view_sub(wk.v, x, y, w, h);                             // no copy: the next operator reads the window
+    }
+    *step = IMP_STEP_RESIZE;                                           // bridge.c:588-604
+    if (job->resize) {
+        int w, h, interp;
+        rc = resize_geometry(wk.v.w, wk.v.h, job->resize, config->max_target_w, config->max_target_h, job->simple, &w, &h, &interp);
+        if (rc) goto done;
+        rc = do_resize(wk, w, h, interp);
+        if (rc) goto done;
+    }
+    *step = IMP_STEP_FILTERING;                                        // bridge.c:606-627
+    if (wk.v.c == 1) {
+        impgpu_image* out = nullptr;
+        rc = image_new(wk.v.w, wk.v.h, 3, &out);
+        if (rc) goto done;
+        rc = launch_gray2bgr(one_frame(wk.v, out), env_stream());
+        if (rc) { image_delete(out); goto done; }
+        wk.adopt(out);
+    }
+    for (int i = 0; i < job->filter_count; i++) {
+        rc = do_filter(wk, job->filters[i], config->allow_experiments, prog);
+        if (rc) goto done;
+    }
+    rc = flush_program(wk, prog);
+    if (rc) goto done;
+    *step = IMP_STEP_WATERMARK;                                        // bridge.c:629-640
+    if (config->watermark) {
+        rc = do_watermark(wk, config);
+        if (rc) goto done;
+    }
+    if (job->need_flatten && wk.v.c == 4) {                            // bridge.c:642-656
+        rc = launch_blend_paper(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.step, 1, env_stream());
+        if (rc) goto done;
+    }
+    rc = materialize(wk);
+    if (!rc) *step = IMP_STEP_INFO;
+done:
+    *pointer = wk.owner;
+    return rc;
+}
+
+// ------------------------------------------------------------------ batch entry points
+int impgpu_batch_cv_resize(const void* src, long long src_frame_stride, int src_width, int src_height, int src_step,
+                           void* dst, long long dst_frame_stride, int dst_width, int dst_height, int dst_step,
+                           int channels, int count, int interpolation, void* stream) {
+    if (!src || !dst || (channels != 1 && channels != 3 && channels != 4)) return IMP_ERROR_INVALID_ARGS;
+    if (src_step < src_width * channels || dst_step < dst_width * channels) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    Frames f{};
+    f.src = (const uint8_t*)src; f.src_stride = src_frame_stride;
+    f.v = View{(const uint8_t*)src, src_width, src_height, channels, src_step};
+    f.dst = (uint8_t*)dst; f.dst_stride = dst_frame_stride; f.dw = dst_width; f.dh = dst_height; f.dstep = dst_step;
+    f.count = count;
+    return launch_cv_resize(f, interpolation, stream ? (hipStream_t)stream : env_stream());
+}
+
+int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_stride, int src_width, int src_height, int src_step,
+                                         void* dst, long long dst_frame_stride, int dst_step,
+                                         int resize_width, int resize_height, int rotate,
+                                         const impgpu_config* config, int channels, int count, void* stream) {
+    if (!src || !dst || !config || (channels != 3 && channels != 4)) return IMP_ERROR_INVALID_ARGS;
+    if (rotate != 0 && rotate != 90 && rotate != 180 && rotate != 270) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : env_stream();
+    const int interp = (resize_width > src_width || resize_height > src_height) ? IMP_INTER_CUBIC : IMP_INTER_AREA;  // bridge.c:190
+    const bool swap = rotate == 90 || rotate == 270;
+    const int fw = swap ? resize_height : resize_width, fh = swap ? resize_width : resize_height;
+    if (dst_step < fw * channels) return IMP_ERROR_INVALID_ARGS;
+
+    Frames rs{};
+    rs.src = (const uint8_t*)src; rs.src_stride = src_frame_stride;
+    rs.v = View{(const uint8_t*)src, src_width, src_height, channels, src_step};
+    rs.count = count;
+    rs.dw = resize_width; rs.dh = resize_height;
+    void* mid = nullptr;
+    int rc;
+    if (rotate == 0) {
+        rs.dst = (uint8_t*)dst; rs.dst_stride = dst_frame_stride; rs.dstep = dst_step;
+        rc = launch_cv_resize(rs, interp, s);
+    } else {
+        const int mstep = aligned_step(resize_width, channels);
+        const long long mstride = ((long long)mstep * resize_height + 15) & ~15LL;
+        rc = dev_alloc((size_t)mstride * count + 16, &mid);
+        if (rc) return rc;
+        rs.dst = (uint8_t*)mid; rs.dst_stride = mstride; rs.dstep = mstep;
+        rc = launch_cv_resize(rs, interp, s);
+        if (!rc) {
+            Frames rt{};
+            rt.src = (const uint8_t*)mid; rt.src_stride = mstride;
+            rt.v = View{(const uint8_t*)mid, resize_width, resize_height, channels, mstep};
+            rt.dst = (uint8_t*)dst; rt.dst_stride = dst_frame_stride; rt.dw = fw; rt.dh = fh; rt.dstep = dst_step;
+            rt.count = count;
+            rc = launch_rotate(rt, rotate, s);
+        }
+    }
+    if (!rc && config->watermark) {
+        int rx, ry, maxcol, maxrow;
+        rc = watermark_rect(fw, fh, config->watermark->w, config->watermark->h, config, &rx, &ry, &maxcol, &maxrow);
+        if (!rc) {
+            const float opacity = (float)(config->watermark_opacity / 100.0);
+            rc = launch_blend_over((uint8_t*)dst, dst_frame_stride, fw, fh, channels, dst_step, count, config->watermark,
+                                   rx, ry, maxcol, maxrow, 1 - opacity, s);
+        }
+    }
+    if (mid) {
+        if (s != env_stream()) (void)hipStreamSynchronize(s);
+        dev_free(mid);
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+// imp_geom.hip -- exact byte movers: the copy behind Crop (cvSetImageROI + cvCopy,
+// bridge.c:130-135), cvFlip (filters.c:93-99, :126), cvTranspose + cvFlip as one rotation
+// (filters.c:116-119) and cvCvtColor(GRAY2BGR) (bridge.c:613-618).  Bit-exact by nature.
+//
+// Rotation by 90 / 270 of BGRA goes through a 32x32-pixel LDS tile (33-dword row pitch, so
+// the transposed read is bank-conflict free): global reads run along source rows, global
+// writes along destination rows, both coalesced, in one pass instead of the reference's
+// transpose + flip pair.
+#include "imp_internal.h"
+
+namespace imp {
+
+struct GArgs {
+    const uint8_t* src; long long src_stride; int sstep, sw, sh;
+    uint8_t* dst; long long dst_stride; int dstep, dw, dh;
+};
+
+// ---- copy: `unit` bytes per thread (4 when everything is dword aligned, else 1) ----
+template <int UNIT>
+__global__ __launch_bounds__(256) void k_copy(GArgs a, int row_units) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)row_units * a.dh) return;
+    const int y = (int)(idx / row_units), u = (int)(idx - (long long)y * row_units);
+    const uint8_t* s = a.src + (long long)blockIdx.y * a.src_stride + (size_t)y * a.sstep + (size_t)u * UNIT;
+    uint8_t* d = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)y * a.dstep + (size_t)u * UNIT;
+    if (UNIT == 4) *(uint32_t*)d = *(const uint32_t*)s;
+    else *d = *s;
+}
+
+// ---- cvFlip: mode 0 = vertical (around x axis), > 0 = horizontal, < 0 = both ----
+template <int CN>
+__global__ __launch_bounds__(256) void k_flip(GArgs a, int mode) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.dw * a.dh) return;
+    const int y = (int)(idx / a.dw), x = (int)(idx - (long long)y * a.dw);
+    const int sy = mode <= 0 ? a.sh - 1 - y : y;
+    const int sx = mode != 0 ? a.sw - 1 - x : x;
+    const uint8_t* s = a.src + (long long)blockIdx.y * a.src_stride + (size_t)sy * a.sstep + (size_t)sx * CN;
+    uint8_t* d = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)y * a.dstep + (size_t)x * CN;
+    if (CN == 4) *(uint32_t*)d = *(const uint32_t*)s;
+    else {
+#pragma unroll
+        for (int c = 0; c < CN; c++) d[c] = s[c];
+    }
+}
+
+// ---- rotate 90 (clockwise): R[i][j] = S[H-1-j][i];  270: R[i][j] = S[j][W-1-i]  (filters.c:116-119) ----
+__global__ __launch_bounds__(256) void k_rotate_bgra(GArgs a, int amount) {
+    __shared__ uint32_t tile[32][33];
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;   // destination tile origin (x along dw = sh)
+    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
+    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride;
+    const int li = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int lj = threadIdx.y + 8 * r;
+        const int j = tx0 + lj, i = ty0 + li;                  // destination (x = j, y = i)
+        if (j < a.dw && i < a.dh) {
+            const int srow = amount == 90 ? a.sh - 1 - j : j;
+            const int scol = amount == 90 ? i : a.sw - 1 - i;
+            tile[lj][li] = *(const uint32_t*)(S + (size_t)srow * a.sstep + (size_t)scol * 4);
+        }
+    }
+    __syncthreads();
+    const int lj = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int l = threadIdx.y + 8 * r;
+        const int j = tx0 + lj, i = ty0 + l;
+        if (j < a.dw && i < a.dh) *(uint32_t*)(D + (size_t)i * a.dstep + (size_t)j * 4) = tile[lj][l];
+    }
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_rotate_any(GArgs a, int amount) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.dw * a.dh) return;
+    const int i = (int)(idx / a.dw), j = (int)(idx - (long long)i * a.dw);
+    const int srow = amount == 90 ? a.sh - 1 - j : j;
+    const int scol = amount == 90 ? i : a.sw - 1 - i;
+    const uint8_t* s = a.src + (long long)blockIdx.y * a.src_stride + (size_t)srow * a.sstep + (size_t)scol * CN;
+    uint8_t* d = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)i * a.dstep + (size_t)j * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) d[c] = s[c];
+}
+
+__global__ __launch_bounds__(256) void k_gray2bgr(GArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.dw * a.dh) return;
+    const int y = (int)(idx / a.dw), x = (int)(idx - (long long)y * a.dw);
+    const uint8_t v = a.src[(long long)blockIdx.y * a.src_stride + (size_t)y * a.sstep + x];
+    uint8_t* d = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)y * a.dstep + (size_t)x * 3;
+    d[0] = v; d[1] = v; d[2] = v;
+}
+
+static GArgs gargs(const Frames& f) {
+    return GArgs{f.src, f.src_stride, f.v.step, f.v.w, f.v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
+}
+static bool dword_ok(const Frames& f) {
+    return !(((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)f.v.step | (uintptr_t)f.dstep |
+              (uintptr_t)f.src_stride | (uintptr_t)f.dst_stride) & 3);
+}
+static unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+int launch_copy(const Frames& f, hipStream_t s) {
+    if (f.count <= 0) return IMP_OK;
+    if (f.dw != f.v.w || f.dh != f.v.h || f.count > 65535) return IMP_ERROR_INVALID_ARGS;
+    GArgs a = gargs(f);
+    const int rowbytes = f.dw * f.v.c;
+    if (dword_ok(f) && rowbytes % 4 == 0) {
+        const int units = rowbytes / 4;
+        hipLaunchKernelGGL((k_copy<4>), dim3(blocks_for((long long)units * f.dh), f.count), dim3(256), 0, s, a, units);
+    } else {
+        hipLaunchKernelGGL((k_copy<1>), dim3(blocks_for((long long)rowbytes * f.dh), f.count), dim3(256), 0, s, a, rowbytes);
+    }
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+int launch_flip(const Frames& f, int mode, hipStream_t s) {
+    if (f.count <= 0) return IMP_OK;
+    if (f.dw != f.v.w || f.dh != f.v.h || f.count > 65535) return IMP_ERROR_INVALID_ARGS;
+    GArgs a = gargs(f);
+    const dim3 grid(blocks_for((long long)f.dw * f.dh), f.count), block(256);
+    if (f.v.c == 4 && dword_ok(f)) hipLaunchKernelGGL((k_flip<4>), grid, block, 0, s, a, mode);
+    else if (f.v.c == 4) return IMP_ERROR_INVALID_ARGS;
+    else if (f.v.c == 3) hipLaunchKernelGGL((k_flip<3>), grid, block, 0, s, a, mode);
+    else hipLaunchKernelGGL((k_flip<1>), grid, block, 0, s, a, mode);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+int launch_rotate(const Frames& f, int amount, hipStream_t s) {
+    if (f.count <= 0) return IMP_OK;
+    if (amount == 180) return launch_flip(f, -1, s);
+    if ((amount != 90 && amount != 270) || f.dw != f.v.h || f.dh != f.v.w || f.count > 65535) return IMP_ERROR_INVALID_ARGS;
+    GArgs a = gargs(f);
+    if (f.v.c == 4) {
+        if (!dword_ok(f)) return IMP_ERROR_INVALID_ARGS;
+        const dim3 grid((f.dw + 31) / 32, (f.dh + 31) / 32, f.count), block(32, 8);
+        if (grid.y > 65535) return IMP_ERROR_INVALID_ARGS;
+        hipLaunchKernelGGL(k_rotate_bgra, grid, block, 0, s, a, amount);
+    } else {
+        const dim3 grid(blocks_for((long long)f.dw * f.dh), f.count), block(256);
+        if (f.v.c == 3) hipLaunchKernelGGL((k_rotate_any<3>), grid, block, 0, s, a, amount);
+        else hipLaunchKernelGGL((k_rotate_any<1>), grid, block, 0, s, a, amount);
+    }
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+int launch_gray2bgr(const Frames& f, hipStream_t s) {
+    if (f.count <= 0) return IMP_OK;
+    if (f.v.c != 1 || f.dw != f.v.w || f.dh != f.v.h || f.count > 65535) return IMP_ERROR_INVALID_ARGS;
+    GArgs a = gargs(f);
+    hipLaunchKernelGGL(k_gray2bgr, dim3(blocks_for((long long)f.dw * f.dh), f.count), dim3(256), 0, s, a);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+}  // namespace imp

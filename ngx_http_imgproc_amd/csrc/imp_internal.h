@@ -1,0 +1,144 @@
+// imp_internal.h -- shared declarations of libimpgpu.so (not installed; the public ABI is include/impgpu.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/impgpu.h"
+
+namespace imp {
+
+// ---------------------------------------------------------------- images
+}  // namespace imp
+
+struct impgpu_image {
+    uint8_t* d = nullptr;   // device pointer
+    int w = 0, h = 0, c = 0, step = 0;
+    size_t cap = 0;         // bytes owned (0 for borrowed views)
+    bool owned = false;
+};
+
+namespace imp {
+
+// A read-only window into device memory: how Crop is folded into the next operator.
+struct View {
+    const uint8_t* d;
+    int w, h, c, step;
+};
+inline View view_of(const impgpu_image* im) { return View{im->d, im->w, im->h, im->c, im->step}; }
+inline View view_sub(const View& v, int x, int y, int w, int h) {
+    return View{v.d + (size_t)y * v.step + (size_t)x * v.c, w, h, v.c, v.step};
+}
+inline int aligned_step(int w, int c) { return (w * c + 3) & ~3; }
+
+// ---------------------------------------------------------------- runtime (imp_runtime.hip)
+void set_error(const char* what, hipError_t e);
+bool env_ready();
+hipStream_t env_stream();
+int  dev_alloc(size_t bytes, void** out);          // stream-ordered pool; IMP_* code
+void dev_free(void* p);
+int  image_new(int w, int h, int c, impgpu_image** out);
+void image_delete(impgpu_image* im);
+// Copy a small host blob (tables, taps) into pool memory through the pinned ring, ordered on `s`.
+int  upload_small(const void* host, size_t bytes, void** dev, hipStream_t s);
+#define IMP_HIP(call)                                             \
+    do {                                                          \
+        hipError_t _e = (call);                                   \
+        if (_e != hipSuccess) { imp::set_error(#call, _e); return IMP_ERROR_DEVICE; } \
+    } while (0)
+
+// ---------------------------------------------------------------- host grammar (imp_args.cpp)
+int crop_geometry(int col, int row, const char* args, const char* gravity, int* x, int* y, int* w, int* h);
+int resize_geometry(int col, int row, const char* args, unsigned max_w, unsigned max_h, int simple,
+                    int* w, int* h, int* interp);
+
+// One stage of the fused pointwise program (imp_pixel.hip runs them per pixel, in order,
+// keeping the reference's per-stage 8-bit truncation).
+enum StageKind : int {
+    ST_LUT4 = 0,      // per-channel 256-entry tables, channels 0..3 (identity rows where unused)
+    ST_RGB2HSV,       // helpers.c:70-107
+    ST_HSV2RGB,       // helpers.c:109-176
+    ST_GRADMAP,       // filters.c:264-276: 768-byte RGB table indexed by ((R+G+B)/3)*3
+    ST_VIGNETTE,      // filters.c:312-317 on HSV value; params cx, cy, maxrad, power
+    ST_RAINBOW,       // filters.c:368-398; param sat
+    ST_SCANLINE,      // filters.c:434-451; params freq, width, s_byte, v_byte
+};
+struct Stage {
+    int kind;
+    int lut_off;      // byte offset into the program's table blob (LUT4: 1024 B, GRADMAP: 768 B)
+    int i0, i1, i2, i3;
+    float f0, f1;
+};
+struct PixelProgram {
+    std::vector<Stage> stages;
+    std::vector<uint8_t> tables;
+    void clear() { stages.clear(); tables.clear(); }
+    bool empty() const { return stages.empty(); }
+};
+
+// What one filter-* request turns into.
+enum FilterClass : int { FC_POINTWISE = 0, FC_FLIP, FC_ROTATE, FC_BLUR, FC_NOOP };
+struct FilterPlan {
+    int cls = FC_NOOP;
+    int flip_mode = 0;       // cvFlip mode: 0 vertical, 1 horizontal, -1 both
+    int rotate = 0;          // 90 / 180 / 270
+    float sigma = 0;         // blur
+    // pointwise stages are appended to the caller's PixelProgram
+};
+// Parses "name=args" (filters.c:43-70 + the callback's own checks). For pointwise filters
+// appends stages for an image of `channels` channels and w x h pixels to `prog`.
+int filter_plan(const char* request, int allow_experiments, int channels, int w, int h,
+                FilterPlan* plan, PixelProgram* prog);
+int check_destructive(const char* request);
+
+// ---------------------------------------------------------------- coefficient tables (imp_tables.cpp)
+struct TapAxis {            // LINEAR / CUBIC / LANCZOS4: one axis of cv::resize's generic branch
+    int ksize;
+    std::vector<int> ofs;       // dsize entries: source index of the tap-window centre
+    std::vector<short> coef;    // dsize * ksize fixed-point (11-bit) weights
+};
+void build_tap_axis(int ssize, int dsize, double scale, int interp, bool is_x, TapAxis* out);
+struct AreaAxis {           // general INTER_AREA: per destination index a run of source indices
+    std::vector<int> start;     // first source index of the run
+    std::vector<int> count;     // run length
+    std::vector<int> aoff;      // offset of the run's first weight in alpha
+    std::vector<float> alpha;
+    int max_count = 0;
+};
+void build_area_axis(int ssize, int dsize, double scale, AreaAxis* out);
+int  gaussian_ksize(double sigma);
+void gaussian_kernel_fixed(int n, double sigma, std::vector<int>* ik);
+
+// ---------------------------------------------------------------- launchers
+struct Frames {             // `count` frames of one geometry
+    const uint8_t* src; long long src_stride; View v;   // v.d == src (frame 0)
+    uint8_t* dst; long long dst_stride; int dw, dh, dstep;
+    int count;
+};
+// imp_resize.hip
+int launch_cv_resize(const Frames& f, int interp, hipStream_t s);
+// imp_geom.hip
+int launch_copy(const Frames& f, hipStream_t s);                       // crop copy / clone (dw,dh = v.w,v.h)
+int launch_flip(const Frames& f, int mode, hipStream_t s);             // cvFlip
+int launch_rotate(const Frames& f, int amount, hipStream_t s);         // 90 / 270 (dw,dh = v.h,v.w), 180
+int launch_gray2bgr(const Frames& f, hipStream_t s);
+// imp_pixel.hip
+int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int step, int count,
+                         const PixelProgram& prog, hipStream_t s);
+int launch_blend_over(uint8_t* d, long long stride, int w, int h, int c, int step, int count,
+                      const impgpu_image* overlay, int rx, int ry, int maxcol, int maxrow,
+                      float alpha, hipStream_t s);
+int launch_blend_paper(uint8_t* d, long long stride, int w, int h, int step, int count, hipStream_t s);
+int launch_brightness(const View& v, float* host_result, hipStream_t s);
+int launch_ascii(uint8_t* d, int w, int h, int c, int step, const uint8_t* table, int tablelen,
+                 float factor, uint8_t* dev_out, hipStream_t s);
+// imp_blur.hip
+int launch_gaussian(uint8_t* d, long long stride, int w, int h, int c, int step, int count,
+                    double sigma, hipStream_t s);
+
+// Watermark placement (bridge.c:254-274 + cvSetImageROI clipping). Returns IMP_* code.
+int watermark_rect(int basew, int baseh, int overw, int overh, const impgpu_config* cfg,
+                   int* rx, int* ry, int* maxcol, int* maxrow);
+
+}  // namespace imp

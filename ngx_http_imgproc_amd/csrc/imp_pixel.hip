@@ -1,0 +1,367 @@
+// imp_pixel.hip -- the per-pixel operators of filters.c / helpers.c as gfx950 kernels:
+//   * the fused pixel program: RGB2HSV / HSV2RGB (helpers.c:70-176), per-channel tables
+//     (ModulateHSV, AlphaBlendAddColor, ApplyGamma, BrightnessContrast, Lomo), Gradmap,
+//     Vignette, Rainbow, Scanline -- any run of pointwise filters is ONE read + ONE write of
+//     the frame, where the reference makes up to six read-modify-write sweeps (Gotham);
+//   * AlphaBlendOver (filters.c:619-662) for Watermark, BlendWithPaper (filters.c:666-687);
+//   * CalcPerceivedBrightness (filters.c:707-729), ASCII (filters.c:486-522).
+//
+// Arithmetic mirrors the reference's C exactly: integer HSV with C division (toward zero),
+// float sector maths with truncation, low-byte stores into `char`.  Built with
+// -ffp-contract=off and explicit __f*_rn so no multiply-add is fused; IEEE float and
+// double division / sqrt on gfx950 are correctly rounded, as on the CPU.
+// All kernels are HBM-bound streams: coalesced dword (BGRA) accesses, tables in LDS.
+#include <cmath>
+#include "imp_internal.h"
+
+namespace imp {
+
+#define IMP_MAX_STAGES 24
+#define IMP_MAX_TABLE_BYTES 12288
+
+struct ProgDev {
+    int n;
+    int table_bytes;
+    Stage st[IMP_MAX_STAGES];
+};
+
+// exact floor(n / d) for 0 <= n < 2^24, 1 <= d < 2^24 without the 32-bit divide expansion
+__device__ __forceinline__ int udiv_small(int n, int d) {
+    int q = (int)(__fmul_rn((float)n, __builtin_amdgcn_rcpf((float)d)));   // +-1 at most; fixed up below
+    int r = n - q * d;
+    q += (r >= d);
+    q -= (r < 0);
+    return q;
+}
+// C99 signed division (toward zero) for |n| < 2^24
+__device__ __forceinline__ int sdiv_small(int n, int d) {
+    int q = udiv_small(n < 0 ? -n : n, d);
+    return n < 0 ? -q : q;
+}
+
+// helpers.c:70-107 on one pixel; b,g,r in -> h,s,v out (same registers)
+__device__ __forceinline__ void px_rgb2hsv(int& c0, int& c1, int& c2) {
+    const int b = c0, g = c1, r = c2;
+    const int mn = min(b, min(g, r)), mx = max(b, max(g, r));
+    const int delta = mx - mn;
+    int h = 0, s = 0;
+    const int v = mx;
+    if (v != 0) s = udiv_small(255 * delta, v);
+    if (s != 0) {
+        if (mx == r) h = sdiv_small(30 * (g - b), delta);
+        else if (mx == g) h = 60 + sdiv_small(30 * (b - r), delta);
+        else h = 120 + sdiv_small(30 * (r - g), delta);
+    }
+    if (h < 0) h += 180;
+    c0 = h & 0xff; c1 = s & 0xff; c2 = v;
+}
+
+// helpers.c:109-176 on one pixel; h,s,v in -> b,g,r out
+__device__ __forceinline__ void px_hsv2rgb(int& c0, int& c1, int& c2) {
+    float h = (float)(c0 * 2), s = (float)c1;
+    const float v = (float)c2;
+    int r, g, b;
+    if (c1 == 0) {
+        r = g = b = c2;
+    } else {
+        s = __fdiv_rn(s, 255.f);
+        h = __fdiv_rn(h, 60.f);
+        const int i = (int)floorf(h);
+        const float f = __fsub_rn(h, (float)i);
+        const int p = (int)__fmul_rn(v, __fsub_rn(1.f, s));
+        const int q = (int)__fmul_rn(v, __fsub_rn(1.f, __fmul_rn(s, f)));
+        const int t = (int)__fmul_rn(v, __fsub_rn(1.f, __fmul_rn(s, __fsub_rn(1.f, f))));
+        const int vi = c2;
+        switch (i) {
+            case 0: r = vi; g = t; b = p; break;
+            case 1: r = q; g = vi; b = p; break;
+            case 2: r = p; g = vi; b = t; break;
+            case 3: r = p; g = q; b = vi; break;
+            case 4: r = t; g = p; b = vi; break;
+            default: r = vi; g = p; b = q; break;
+        }
+    }
+    c0 = b & 0xff; c1 = g & 0xff; c2 = r & 0xff;
+}
+
+// (char)float as x86-64 gcc does it: truncate, NaN / out of range -> INT_MIN, keep the low byte
+__device__ __forceinline__ int store_f(float v) {
+    int i = (v > -2147483904.f && v < 2147483648.f) ? (int)v : (int)0x80000000;
+    return i & 0xff;
+}
+
+#define PIX_PER_THREAD 8
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long stride, int w, int h, int step,
+                                                       ProgDev prog, const uint8_t* __restrict__ tables) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[IMP_MAX_TABLE_BYTES];
+    for (int i = threadIdx.x * 4; i < prog.table_bytes; i += 256 * 4)
+        *(uint32_t*)(lut + i) = *(const uint32_t*)(tables + i);
+    __syncthreads();
+    uint8_t* img = base + (long long)blockIdx.y * stride;
+    const long long npix = (long long)w * h;
+    const long long first = (long long)blockIdx.x * (256 * PIX_PER_THREAD) + threadIdx.x;
+#pragma unroll 1
+    for (int it = 0; it < PIX_PER_THREAD; it++) {
+        const long long idx = first + (long long)it * 256;
+        if (idx >= npix) break;
+        const int y = (int)(idx / w), x = (int)(idx - (long long)y * w);
+        uint8_t* p = img + (size_t)y * step + (size_t)x * CN;
+        int c0, c1, c2, c3 = 255;
+        if (CN == 4) {
+            const uint32_t u = *(const uint32_t*)p;
+            c0 = u & 0xff; c1 = (u >> 8) & 0xff; c2 = (u >> 16) & 0xff; c3 = u >> 24;
+        } else if (CN == 3) {
+            c0 = p[0]; c1 = p[1]; c2 = p[2];
+        } else {
+            c0 = p[0]; c1 = c2 = 0;
+        }
+        for (int si = 0; si < prog.n; si++) {
+            const Stage& st = prog.st[si];
+            switch (st.kind) {
+                case ST_LUT4: {
+                    const uint8_t* t = lut + st.lut_off;
+                    c0 = t[c0];
+                    if (CN >= 3) { c1 = t[256 + c1]; c2 = t[512 + c2]; }
+                    if (CN == 4) c3 = t[768 + c3];
+                } break;
+                case ST_RGB2HSV: px_rgb2hsv(c0, c1, c2); break;
+                case ST_HSV2RGB: px_hsv2rgb(c0, c1, c2); break;
+                case ST_GRADMAP: {                      // filters.c:264-276 (table is R,G,B order)
+                    const uint8_t* t = lut + st.lut_off;
+                    const int off = ((c2 + c1 + c0) / 3) * 3;
+                    c2 = t[off]; c1 = t[off + 1]; c0 = t[off + 2];
+                } break;
+                case ST_VIGNETTE: {                     // filters.c:312-317 with the mask of :693-703 inline
+                    const double ddx = (double)(st.i0 - x), ddy = (double)(st.i1 - y);
+                    const float dist = (float)sqrt(ddx * ddx + ddy * ddy);
+                    const float raw = __fmul_rn(__fdiv_rn(dist, st.f0), st.f1);
+                    const double cs = cos((double)raw);
+                    const double c2d = cs * cs;
+                    const float mask = (float)(c2d * c2d);
+                    c2 = store_f(__fmul_rn((float)c2, mask));
+                } break;
+                case ST_RAINBOW: {                      // filters.c:371-397
+                    int hue = c0 * 2, light = c2, sat = st.i0;
+                    if (light < 20) { light = 0; sat = 0; }
+                    else if (light > 254) sat = 0;
+                    else if (hue <= 10 || hue > 340) hue = 0;
+                    else if (hue < 35) hue = 30;
+                    else if (hue < 68) hue = 60;
+                    else if (hue < 150) hue = 120;
+                    else if (hue < 200) hue = 195;
+                    else if (hue < 250) hue = 225;
+                    else hue = 285;
+                    c0 = (hue >> 1) & 0xff;             // (char)(hue / 2.0): truncation
+                    c1 = sat; c2 = light;
+                } break;
+                case ST_SCANLINE: {                     // filters.c:434-451: period freq+width+1
+                    const int ph = y % (st.i0 + st.i1 + 1);
+                    if (ph >= st.i0 && ph < st.i0 + st.i1) { c1 = st.i2; c2 = st.i3; }
+                } break;
+            }
+        }
+        if (CN == 4) *(uint32_t*)p = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16) | ((uint32_t)c3 << 24);
+        else if (CN == 3) { p[0] = (uint8_t)c0; p[1] = (uint8_t)c1; p[2] = (uint8_t)c2; }
+        else p[0] = (uint8_t)c0;
+    }
+}
+
+int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int step, int count,
+                         const PixelProgram& prog, hipStream_t s) {
+    if (prog.empty() || count <= 0) return IMP_OK;
+    if (count > 65535) return IMP_ERROR_INVALID_ARGS;
+    if (prog.stages.size() > IMP_MAX_STAGES || prog.tables.size() > IMP_MAX_TABLE_BYTES) return IMP_ERROR_TOO_MUCH_FILTERS;
+    if (c == 4 && (((uintptr_t)d | (uintptr_t)step | (uintptr_t)stride) & 3)) return IMP_ERROR_INVALID_ARGS;
+    ProgDev pd{};
+    pd.n = (int)prog.stages.size();
+    for (int i = 0; i < pd.n; i++) pd.st[i] = prog.stages[i];
+    std::vector<uint8_t> tb = prog.tables;
+    while (tb.size() % 4) tb.push_back(0);
+    if (tb.empty()) tb.resize(4, 0);
+    pd.table_bytes = (int)prog.tables.size();
+    pd.table_bytes = (pd.table_bytes + 3) & ~3;
+    void* dev_tables = nullptr;
+    if (int rc = upload_small(tb.data(), tb.size(), &dev_tables, s)) return rc;
+    hipError_t e;
+    const long long npix = (long long)w * h;
+    const dim3 grid((unsigned)((npix + 256 * PIX_PER_THREAD - 1) / (256 * PIX_PER_THREAD)), (unsigned)count), block(256);
+    if (c == 4) hipLaunchKernelGGL((k_pixel_program<4>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    else if (c == 3) hipLaunchKernelGGL((k_pixel_program<3>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    else hipLaunchKernelGGL((k_pixel_program<1>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    e = hipGetLastError();
+    // the table buffer goes back to the pool; on a foreign stream wait first, since pool reuse
+    // is only ordered on the env stream
+    if (s != env_stream()) (void)hipStreamSynchronize(s);
+    dev_free(dev_tables);
+    if (e != hipSuccess) { set_error("k_pixel_program", e); return IMP_ERROR_DEVICE; }
+    return IMP_OK;
+}
+
+// ------------------------------------------------------------------ AlphaBlendOver, filters.c:619-662
+template <int DC, int SC>
+__global__ __launch_bounds__(256) void k_blend_over(uint8_t* base, long long stride, int step,
+                                                    const uint8_t* __restrict__ ov, int ostep,
+                                                    int rx, int ry, int maxcol, int maxrow, float alpha) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= maxcol * maxrow) return;
+    const int row = idx / maxcol, col = idx - row * maxcol;
+    uint8_t* d = base + (long long)blockIdx.y * stride + (size_t)(row + ry) * step + (size_t)(col + rx) * DC;
+    const uint8_t* sp = ov + (size_t)row * ostep + (size_t)col * SC;
+    const int dB = d[0], dG = d[1], dR = d[2];
+    const float dA = DC == 4 ? (float)((double)d[3] / 255.0) : 1.f;
+    const int sB = sp[0], sG = sp[1], sR = sp[2];
+    float sA = SC == 4 ? (float)((double)sp[3] / 255.0) : 1.f;
+    sA = (float)fmax((double)__fsub_rn(sA, alpha), 0.0);
+    const float inv = __fsub_rn(1.f, sA);
+    const float tA = __fadd_rn(sA, __fmul_rn(dA, inv));
+    int tB = 0, tG = 0, tR = 0;
+    if (tA != 0.f) {
+        tB = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sB, sA), __fmul_rn(__fmul_rn((float)dB, dA), inv)), tA);
+        tG = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sG, sA), __fmul_rn(__fmul_rn((float)dG, dA), inv)), tA);
+        tR = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sR, sA), __fmul_rn(__fmul_rn((float)dR, dA), inv)), tA);
+    }
+    d[0] = (uint8_t)tB; d[1] = (uint8_t)tG; d[2] = (uint8_t)tR;
+    if (DC == 4) d[3] = (uint8_t)store_f(__fmul_rn(tA, 255.f));
+}
+
+int launch_blend_over(uint8_t* d, long long stride, int w, int h, int c, int step, int count,
+                      const impgpu_image* ov, int rx, int ry, int maxcol, int maxrow, float alpha, hipStream_t s) {
+    if (count <= 0 || maxcol <= 0 || maxrow <= 0) return IMP_OK;
+    if (count > 65535 || c < 3 || ov->c < 3) return IMP_ERROR_INVALID_ARGS;
+    (void)w; (void)h;
+    const dim3 grid((unsigned)(((long long)maxcol * maxrow + 255) / 256), (unsigned)count), block(256);
+    if (c == 4 && ov->c == 4) hipLaunchKernelGGL((k_blend_over<4, 4>), grid, block, 0, s, d, stride, step, ov->d, ov->step, rx, ry, maxcol, maxrow, alpha);
+    else if (c == 4) hipLaunchKernelGGL((k_blend_over<4, 3>), grid, block, 0, s, d, stride, step, ov->d, ov->step, rx, ry, maxcol, maxrow, alpha);
+    else if (ov->c == 4) hipLaunchKernelGGL((k_blend_over<3, 4>), grid, block, 0, s, d, stride, step, ov->d, ov->step, rx, ry, maxcol, maxrow, alpha);
+    else hipLaunchKernelGGL((k_blend_over<3, 3>), grid, block, 0, s, d, stride, step, ov->d, ov->step, rx, ry, maxcol, maxrow, alpha);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+// ------------------------------------------------------------------ BlendWithPaper, filters.c:666-687
+__global__ __launch_bounds__(256) void k_blend_paper(uint8_t* base, long long stride, int w, int h, int step) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)w * h) return;
+    const int y = (int)(idx / w), x = (int)(idx - (long long)y * w);
+    uint32_t* p = (uint32_t*)(base + (long long)blockIdx.y * stride + (size_t)y * step + (size_t)x * 4);
+    const uint32_t u = *p;
+    const int a = u >> 24;
+    const int diff = 255 - a;
+    const float prod = (float)((double)a / 255.0);
+    const int tb = (int)__fadd_rn((float)diff, __fmul_rn((float)(u & 0xff), prod));
+    const int tg = (int)__fadd_rn((float)diff, __fmul_rn((float)((u >> 8) & 0xff), prod));
+    const int tr = (int)__fadd_rn((float)diff, __fmul_rn((float)((u >> 16) & 0xff), prod));
+    *p = (uint32_t)(tb & 0xff) | ((uint32_t)(tg & 0xff) << 8) | ((uint32_t)(tr & 0xff) << 16) | 0xff000000u;
+}
+
+int launch_blend_paper(uint8_t* d, long long stride, int w, int h, int step, int count, hipStream_t s) {
+    if (count <= 0) return IMP_OK;
+    if (count > 65535 || (((uintptr_t)d | (uintptr_t)step | (uintptr_t)stride) & 3)) return IMP_ERROR_INVALID_ARGS;
+    hipLaunchKernelGGL(k_blend_paper, dim3((unsigned)(((long long)w * h + 255) / 256), (unsigned)count), dim3(256), 0, s,
+                       d, stride, w, h, step);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+// ------------------------------------------------------------------ CalcPerceivedBrightness, filters.c:707-729
+// The reference adds one double term per pixel into a FLOAT accumulator, walking x-outer /
+// y-inner.  That running float sum rounds at every step (by up to 16 once it passes 2^28 on
+// a 1080p frame), so the result is not the true mean and depends on the order; a tree
+// reduction would differ from it.  Two kernels reproduce it exactly: a parallel one that
+// evaluates the per-pixel terms into HBM in the reference's visiting order, and a single
+// wave that replays the float accumulation serially (64 terms per coalesced load, every
+// lane running the same dependent chain on v_readlane'd values).
+template <int CN>
+__global__ __launch_bounds__(256) void k_brightness_terms(const uint8_t* __restrict__ src, int w, int h, int step,
+                                                          double* __restrict__ terms) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)w * h) return;
+    const int x = (int)(idx / h), y = (int)(idx - (long long)x * h);   // x outer, y inner
+    const uint8_t* p = src + (size_t)y * step + (size_t)x * CN;
+    double t;
+    if (CN == 1) t = (double)p[0];
+    else {
+        const int b = p[0], g = p[1], r = p[2];
+        t = sqrt((double)(r * r) * 0.241 + (double)(g * g) * 0.691 + (double)(b * b) * 0.068);
+    }
+    terms[idx] = t;
+}
+
+__global__ __launch_bounds__(64) void k_brightness_serial(const double* __restrict__ terms, long long n, float* out) {
+    const int lane = threadIdx.x;
+    float sum = 0.f;
+    for (long long base = 0; base < n; base += 64) {
+        const long long i = base + lane;
+        const double t = i < n ? terms[i] : 0.0;
+        const int lo = __double2loint(t), hi = __double2hiint(t);
+        const int m = (n - base) < 64 ? (int)(n - base) : 64;
+        if (m == 64) {
+#pragma unroll
+            for (int k = 0; k < 64; k++) {
+                const double tk = __hiloint2double(__builtin_amdgcn_readlane(hi, k), __builtin_amdgcn_readlane(lo, k));
+                sum = (float)__dadd_rn((double)sum, tk);
+            }
+        } else {
+            for (int k = 0; k < m; k++) {
+                const double tk = __hiloint2double(__shfl(hi, k), __shfl(lo, k));
+                sum = (float)__dadd_rn((double)sum, tk);
+            }
+        }
+    }
+    if (lane == 0) *out = sum;
+}
+
+int launch_brightness(const View& v, float* host_result, hipStream_t s) {
+    const long long n = (long long)v.w * v.h;
+    void* terms = nullptr;
+    void* out = nullptr;
+    if (int rc = dev_alloc((size_t)n * sizeof(double), &terms)) return rc;
+    if (int rc = dev_alloc(sizeof(float), &out)) { dev_free(terms); return rc; }
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (v.c == 1) hipLaunchKernelGGL((k_brightness_terms<1>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
+    else if (v.c == 3) hipLaunchKernelGGL((k_brightness_terms<3>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
+    else hipLaunchKernelGGL((k_brightness_terms<4>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
+    hipLaunchKernelGGL(k_brightness_serial, dim3(1), dim3(64), 0, s, (const double*)terms, n, (float*)out);
+    hipError_t e = hipGetLastError();
+    float sum = 0.f;
+    if (e == hipSuccess) e = hipMemcpyAsync(&sum, out, sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dev_free(terms);
+    dev_free(out);
+    if (e != hipSuccess) { set_error("brightness", e); return IMP_ERROR_DEVICE; }
+    // filters.c:728: float / int -> float, then / 255.0 in double, returned as float
+    const float mean = sum / (float)(v.w * v.h);
+    *host_result = (float)((double)mean / 255.0);
+    return IMP_OK;
+}
+
+// ------------------------------------------------------------------ ASCII, filters.c:486-522
+template <int CN>
+__global__ __launch_bounds__(256) void k_ascii(uint8_t* img, int w, int h, int step, const uint8_t* __restrict__ table,
+                                               float factor, uint8_t* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)w * h) return;
+    const int y = (int)(idx / w), x = (int)(idx - (long long)y * w);
+    uint8_t* p = img + (size_t)y * step + (size_t)x * CN;
+    int c0 = p[0], c1 = p[1], c2 = p[2];
+    px_rgb2hsv(c0, c1, c2);                     // the reference converts the frame in place and leaves it so
+    p[0] = (uint8_t)c0; p[1] = (uint8_t)c1; p[2] = (uint8_t)c2;
+    const long long ro = (long long)y * (w + 1);
+    out[ro + x] = table[(int)floorf(__fdiv_rn((float)c2, factor))];
+    if (x == 0 && ro > 0) out[ro - 1] = '\n';
+}
+
+int launch_ascii(uint8_t* d, int w, int h, int c, int step, const uint8_t* table, int tablelen, float factor,
+                 uint8_t* dev_out, hipStream_t s) {
+    (void)tablelen;
+    const dim3 grid((unsigned)(((long long)w * h + 255) / 256)), block(256);
+    if (c == 4) hipLaunchKernelGGL((k_ascii<4>), grid, block, 0, s, d, w, h, step, table, factor, dev_out);
+    else if (c == 3) hipLaunchKernelGGL((k_ascii<3>), grid, block, 0, s, d, w, h, step, table, factor, dev_out);
+    else return IMP_ERROR_INVALID_ARGS;
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+}  // namespace imp

@@ -1,0 +1,249 @@
+"""Python mirror of the reference's operator interface (bridge.h / filters.h) over libimpgpu.so.
+
+`Image` stands for the IplImage* the reference hands from operator to operator; its methods
+carry the reference's names and take the reference's argument strings.  Methods return the
+IMP_* code (0 = IMP_OK) exactly like the C functions, so tests read like calls into bridge.c.
+numpy arrays are H x W x C uint8 in B,G,R[,A] order.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, CConfig, CJob, ImpError
+
+IMP_OK = 0
+IMP_ERROR_INVALID_ARGS = 50
+IMP_ERROR_UPSCALE = 51
+IMP_ERROR_NO_SUCH_FILTER = 52
+IMP_ERROR_NO_SUCH_WATERMARK = 53
+IMP_ERROR_TOO_BIG_TARGET = 54
+IMP_ERROR_TOO_MUCH_FILTERS = 55
+IMP_ERROR_DEVICE = 90
+INTER_NN, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
+
+
+def _b(s):
+    return None if s is None else (s if isinstance(s, bytes) else str(s).encode())
+
+
+def env_start(device=-1):
+    """OnEnvStart (bridge.c:10). Raises when no GPU is usable."""
+    rc = lib.impgpu_env_start(device)
+    if rc:
+        raise ImpError(rc, "impgpu_env_start")
+    return lib.impgpu_env_device()
+
+
+def env_destroy():
+    lib.impgpu_env_destroy()
+
+
+def sync():
+    rc = lib.impgpu_sync()
+    if rc:
+        raise ImpError(rc, "impgpu_sync")
+
+
+class Config:
+    """The Config fields the operators read (required.h:108-118); defaults of module.c:168-187."""
+
+    def __init__(self, max_w=2000, max_h=2000, max_filters=5, allow_experiments=False):
+        self.c = CConfig()
+        self.c.max_target_w = max_w
+        self.c.max_target_h = max_h
+        self.c.max_filters_count = max_filters
+        self.c.allow_experiments = int(bool(allow_experiments))
+        self.c.watermark_opacity = 100
+        self.c.watermark_gravity_x = b"l"
+        self.c.watermark_gravity_y = b"t"
+        self.c.watermark_offset_x = 0
+        self.c.watermark_offset_y = 0
+        self.c.watermark = None
+
+    def prepare_watermark(self, overlay, gravity_x="r", gravity_y="b", offset_x=0, offset_y=0, opacity=100):
+        """PrepareWatermark (bridge.c:199-237) minus file read / decode: upload the decoded overlay once."""
+        ov = np.ascontiguousarray(overlay, dtype=np.uint8)
+        if ov.ndim == 2:
+            ov = ov[:, :, None]
+        h, w, c = ov.shape
+        rc = lib.impgpu_prepare_watermark(C.byref(self.c), ov.ctypes.data, w, h, c, w * c)
+        if rc:
+            return rc
+        self.c.watermark_gravity_x = _b(gravity_x)
+        self.c.watermark_gravity_y = _b(gravity_y)
+        self.c.watermark_offset_x = offset_x
+        self.c.watermark_offset_y = offset_y
+        self.c.watermark_opacity = opacity
+        return IMP_OK
+
+    def release(self):
+        if self.c.watermark:
+            h = C.c_void_p(self.c.watermark)
+            lib.impgpu_image_release(C.byref(h))
+            self.c.watermark = None
+
+
+class Image:
+    """Device-resident frame (impgpu_image*)."""
+
+    def __init__(self, arr=None, handle=None):
+        self.h = C.c_void_p()
+        if handle is not None:
+            self.h = C.c_void_p(handle)
+            return
+        a = np.ascontiguousarray(arr, dtype=np.uint8)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        hh, ww, cc = a.shape
+        rc = lib.impgpu_image_upload(a.ctypes.data, ww, hh, cc, ww * cc, C.byref(self.h))
+        if rc:
+            raise ImpError(rc, "impgpu_image_upload")
+
+    @classmethod
+    def wrap(cls, device_ptr, width, height, channels, step):
+        h = C.c_void_p()
+        rc = lib.impgpu_image_wrap(C.c_void_p(device_ptr), width, height, channels, step, C.byref(h))
+        if rc:
+            raise ImpError(rc, "impgpu_image_wrap")
+        return cls(handle=h.value)
+
+    def release(self):
+        if self.h:
+            lib.impgpu_image_release(C.byref(self.h))
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @property
+    def shape(self):
+        return (lib.impgpu_image_height(self.h), lib.impgpu_image_width(self.h), lib.impgpu_image_channels(self.h))
+
+    @property
+    def device_ptr(self):
+        return lib.impgpu_image_device_ptr(self.h)
+
+    def numpy(self):
+        hh, ww, cc = self.shape
+        out = np.empty((hh, ww, cc), dtype=np.uint8)
+        rc = lib.impgpu_image_download(self.h, out.ctypes.data, ww * cc)
+        if rc:
+            raise ImpError(rc, "impgpu_image_download")
+        return out
+
+    def clone(self):
+        h = C.c_void_p()
+        rc = lib.impgpu_image_clone(self.h, C.byref(h))
+        if rc:
+            raise ImpError(rc, "impgpu_image_clone")
+        return Image(handle=h.value)
+
+    # ---- the reference's operators ----
+    def crop(self, args, gravity=None):
+        """Crop(IplImage**, args, gravity), bridge.c:18."""
+        return lib.impgpu_crop(C.byref(self.h), _b(args), _b(gravity))
+
+    def resize(self, args, config=None, simple=0):
+        """Resize(IplImage**, args, config, simple), bridge.c:143."""
+        cfg = config or Config()
+        return lib.impgpu_resize(C.byref(self.h), _b(args), C.byref(cfg.c), simple)
+
+    def cv_resize(self, width, height, interpolation):
+        """cvResize(image, resized, filter), bridge.c:191."""
+        return lib.impgpu_cv_resize(C.byref(self.h), width, height, interpolation)
+
+    def filter(self, request, allow_experiments=1):
+        """Filter(IplImage**, "name=args", allowExperiments), filters.c:43."""
+        return lib.impgpu_filter(C.byref(self.h), _b(request), int(allow_experiments))
+
+    def watermark(self, config):
+        """Watermark(IplImage*, Config*), bridge.c:239."""
+        return lib.impgpu_watermark(self.h, C.byref(config.c))
+
+    def blend_with_paper(self):
+        """BlendWithPaper(IplImage*), filters.c:666."""
+        return lib.impgpu_blend_with_paper(self.h)
+
+    def calc_perceived_brightness(self):
+        """CalcPerceivedBrightness(IplImage*), filters.c:707."""
+        out = C.c_float()
+        rc = lib.impgpu_calc_perceived_brightness(self.h, C.byref(out))
+        if rc:
+            raise ImpError(rc, "impgpu_calc_perceived_brightness")
+        return out.value
+
+    def ascii(self, args=""):
+        """ASCII(IplImage*, args, pool), filters.c:488."""
+        hh, ww, _ = self.shape
+        cap = (ww + 1) * hh
+        buf = (C.c_ubyte * cap)()
+        n = C.c_long()
+        rc = lib.impgpu_ascii(self.h, _b(args), buf, cap, C.byref(n))
+        if rc:
+            raise ImpError(rc, "impgpu_ascii")
+        return bytes(buf[: n.value])
+
+    def gray2bgr(self):
+        return lib.impgpu_gray2bgr(C.byref(self.h))
+
+    def rgb2hsv(self):
+        return lib.impgpu_rgb2hsv(self.h)
+
+    def hsv2rgb(self):
+        return lib.impgpu_hsv2rgb(self.h)
+
+
+def run_ops(image, config, crop=None, gravity=None, resize=None, simple=0, filters=(), need_flatten=0):
+    """RunJob's operator segment, bridge.c:574-656. Returns (code, step)."""
+    job = CJob()
+    job.crop = _b(crop)
+    job.gravity = _b(gravity)
+    job.resize = _b(resize)
+    job.simple = simple
+    arr = (C.c_char_p * max(1, len(filters)))(*[_b(f) for f in filters])
+    job.filters = arr
+    job.filter_count = len(filters)
+    job.need_flatten = need_flatten
+    step = C.c_int()
+    rc = lib.impgpu_run_ops(C.byref(image.h), C.byref(job), C.byref(config.c), C.byref(step))
+    return rc, step.value
+
+
+def crop_geometry(width, height, args, gravity=None):
+    x, y, w, h = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib.impgpu_crop_geometry(width, height, _b(args), _b(gravity), x, y, w, h)
+    return rc, (x.value, y.value, w.value, h.value)
+
+
+def resize_geometry(width, height, args, config=None, simple=0):
+    cfg = config or Config()
+    w, h, i = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.impgpu_resize_geometry(width, height, _b(args), C.byref(cfg.c), simple, w, h, i)
+    return rc, (w.value, h.value, i.value)
+
+
+def filter_check(request, allow_experiments=1):
+    return lib.impgpu_filter_check(_b(request), int(allow_experiments))
+
+
+def check_destructive(request):
+    return lib.impgpu_check_destructive(_b(request))
+
+
+def batch_cv_resize(src_ptr, src_stride, sw, sh, sstep, dst_ptr, dst_stride, dw, dh, dstep, channels, count,
+                    interpolation, stream=None):
+    rc = lib.impgpu_batch_cv_resize(C.c_void_p(src_ptr), src_stride, sw, sh, sstep, C.c_void_p(dst_ptr), dst_stride,
+                                    dw, dh, dstep, channels, count, interpolation, C.c_void_p(stream or 0))
+    if rc:
+        raise ImpError(rc, "impgpu_batch_cv_resize")
+
+
+def batch_resize_rotate_watermark(src_ptr, src_stride, sw, sh, sstep, dst_ptr, dst_stride, dstep, rw, rh, rotate,
+                                  config, channels, count, stream=None):
+    rc = lib.impgpu_batch_resize_rotate_watermark(C.c_void_p(src_ptr), src_stride, sw, sh, sstep, C.c_void_p(dst_ptr),
+                                                  dst_stride, dstep, rw, rh, rotate, C.byref(config.c), channels,
+                                                  count, C.c_void_p(stream or 0))
+    if rc:
+        raise ImpError(rc, "impgpu_batch_resize_rotate_watermark")

@@ -1,0 +1,94 @@
+"""GPU parity: cvResize (bridge.c:191) kernels vs the CPU oracle, through the C ABI. Bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import noise_image, smooth_image
+
+pytestmark = pytest.mark.gpu
+
+MODES = [orc.INTER_NN, orc.INTER_LINEAR, orc.INTER_CUBIC, orc.INTER_AREA, orc.INTER_LANCZOS4]
+NAMES = {0: "nn", 1: "linear", 2: "cubic", 3: "area", 4: "lanczos4"}
+
+
+def gpu_resize(imp, arr, dw, dh, interp):
+    im = imp.Image(arr)
+    rc = im.cv_resize(dw, dh, interp)
+    assert rc == 0, rc
+    out = im.numpy()
+    im.release()
+    return out
+
+
+@pytest.mark.parametrize("interp", MODES, ids=lambda m: NAMES[m])
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("shape", [((48, 64), (17, 23)), ((29, 37), (13, 11)), ((100, 100), (50, 50)),
+                                   ((90, 120), (30, 40)), ((61, 53), (61, 53)), ((8, 8), (1, 1)), ((5, 300), (3, 7))])
+def test_downscale_bit_exact(gpu, interp, c, shape):
+    (sh, sw), (dh, dw) = shape
+    for arr in (noise_image(sh, sw, c, 1), smooth_image(sh, sw, c)):
+        want = orc.cv_resize(arr, dw, dh, interp)
+        got = gpu_resize(gpu, arr, dw, dh, interp)
+        assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
+
+
+@pytest.mark.parametrize("interp", [orc.INTER_NN, orc.INTER_LINEAR, orc.INTER_CUBIC, orc.INTER_LANCZOS4], ids=lambda m: NAMES[m])
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("shape", [((17, 23), (48, 64)), ((13, 11), (29, 37)), ((1, 1), (9, 5)), ((2, 3), (40, 41)),
+                                   ((30, 40), (20, 80))])
+def test_upscale_and_mixed_bit_exact(gpu, interp, c, shape):
+    (sh, sw), (dh, dw) = shape
+    arr = noise_image(sh, sw, c, 2)
+    want = orc.cv_resize(arr, dw, dh, interp)
+    got = gpu_resize(gpu, arr, dw, dh, interp)
+    assert np.array_equal(got, want)
+
+
+def test_area_upscale_rejected(gpu):
+    im = gpu.Image(noise_image(10, 10, 4, 3))
+    assert im.cv_resize(20, 20, orc.INTER_AREA) == gpu.IMP_ERROR_INVALID_ARGS
+    im.release()
+
+
+@pytest.mark.parametrize("interp", [orc.INTER_CUBIC, orc.INTER_AREA], ids=lambda m: NAMES[m])
+def test_headline_geometry_1080p_to_224(gpu, interp):
+    """BASELINE cfg2 geometry on a few frames: 1920x1080 BGRA -> 224x224."""
+    for seed in range(2):
+        arr = noise_image(1080, 1920, 4, 10 + seed) if seed == 0 else smooth_image(1080, 1920, 4)
+        want = orc.cv_resize(arr, 224, 224, interp)
+        got = gpu_resize(gpu, arr, 224, 224, interp)
+        assert np.array_equal(got, want)
+
+
+def test_cfg4_geometry_4k_to_1080p_lanczos(gpu):
+    arr = noise_image(2160, 3840, 4, 20)
+    want = orc.cv_resize(arr, 1920, 1080, orc.INTER_LANCZOS4)
+    got = gpu_resize(gpu, arr, 1920, 1080, orc.INTER_LANCZOS4)
+    assert np.array_equal(got, want)
+
+
+def test_resize_args_reference_rule(gpu):
+    """Resize() picks AREA when shrinking, CUBIC when any axis grows, NN when simple (bridge.c:190)."""
+    arr = noise_image(60, 80, 3, 5)
+    for args, simple in [("40,30", 0), ("40", 0), ("0,30", 0), ("160,120,up", 0), ("160,20,up", 0), ("40,30", 1), ("500,500", 0)]:
+        rc_o, want = orc.resize(arr, args, 2000, 2000, simple)
+        im = gpu.Image(arr)
+        rc = im.resize(args, gpu.Config(), simple)
+        assert rc == rc_o == 0
+        assert np.array_equal(im.numpy(), want), args
+        im.release()
+
+
+def test_batch_matches_single(gpu):
+    import ctypes as C
+    n, sh, sw, dh, dw = 5, 120, 160, 33, 47
+    frames = [noise_image(sh, sw, 4, 30 + i) for i in range(n)]
+    src = gpu.Image(np.concatenate(frames, axis=0))            # n frames stacked: stride = sh*sw*4
+    dst = gpu.Image(np.zeros((n * dh, dw, 4), np.uint8))
+    for interp in MODES:
+        gpu.batch_cv_resize(src.device_ptr, sh * sw * 4, sw, sh, sw * 4, dst.device_ptr, dh * dw * 4, dw, dh, dw * 4,
+                            4, n, interp)
+        out = dst.numpy().reshape(n, dh, dw, 4)
+        for i in range(n):
+            assert np.array_equal(out[i], orc.cv_resize(frames[i], dw, dh, interp)), (interp, i)
+    src.release(); dst.release()
