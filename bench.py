@@ -106,7 +106,9 @@ def main():
     g.manual_seed(0x1A4D0001 + rank)
     src = torch.randint(0, 256, (batch, sh, sw, 4), dtype=torch.uint8, device="cuda", generator=g)
     dst = torch.zeros((batch, dh, dw, 4), dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream()
+    # a real (non-null) stream: the library launches on exactly this one, so the events below see the kernels
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
 
     def step():
         imp.batch_cv_resize(src.data_ptr(), sh * sw * 4, sw, sh, sw * 4, dst.data_ptr(), dh * dw * 4, dw, dh, dw * 4,

@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void k_blur_col_any(const int* __restrict__ tm
         int s = kyi[0] * t[idx];
         for (int k = 1; k <= ry; k++)
             s += kyi[k] * (t[(long long)clampb(y + k, h - 1) * roww + e] + t[(long long)clampb(y - k, h - 1) * roww + e]);
-        out = sat8((s + (1 << 15)) >> 16);
+        int t = (s + (1 << 15)) >> 16;
+        asm volatile("" : "+v"(t));     // keep shift and clamp apart (v_ashr_pk_u8_i32 hazard, see imp_resize.hip)
+        out = sat8(t);
     }
     dst[(long long)blockIdx.y * stride + (size_t)y * step + e] = (uint8_t)out;
 }

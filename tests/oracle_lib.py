@@ -157,7 +157,8 @@ def blend_with_paper(arr):
 
 
 def brightness(arr):
-    return float(lib.orc_calc_perceived_brightness(Img(arr).h))
+    im = Img(arr)
+    return float(lib.orc_calc_perceived_brightness(im.h))
 
 
 def ascii_art(arr, args=""):

@@ -1,0 +1,150 @@
+"""GPU parity for Crop and RunJob's operator segment (bridge.c:574-656) vs the oracle chain."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import noise_image, smooth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_chain(arr, crop=None, gravity=None, resize=None, simple=0, filters=(), overlay=None, wm=None, flatten=0,
+                 allow=1, max_w=2000, max_h=2000):
+    cur = arr
+    if crop is not None:
+        rc, cur = orc.crop(cur, crop, gravity)
+        if rc:
+            return rc, 3, None
+    if resize is not None:
+        rc, cur = orc.resize(cur, resize, max_w, max_h, simple)
+        if rc:
+            return rc, 4, None
+    if cur.shape[2] == 1:
+        cur = orc.gray2bgr(cur)
+    for f in filters:
+        rc, cur = orc.filter(cur, f, allow)
+        if rc:
+            return rc, 5, None
+    if overlay is not None:
+        rc, cur = orc.watermark(cur, overlay, *wm)
+        if rc:
+            return rc, 6, None
+    if flatten and cur.shape[2] == 4:
+        cur = orc.blend_with_paper(cur)
+    return 0, 7, cur
+
+
+CROPS = ["320px,240px,0px,0px", "320px,240px", "1,1", "16,9,l,t", "4,3,r,b", "400px,200px,46px,0px", "1,2,c,c",
+         "100px,100px,c,c", "640px,480px", "3,1,0px,20px"]
+
+
+@pytest.mark.parametrize("args", CROPS)
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_crop_bit_exact(gpu, args, c):
+    arr = noise_image(480, 640, c, 40)
+    rc_o, want = orc.crop(arr, args)
+    im = gpu.Image(arr)
+    rc = im.crop(args)
+    assert rc == rc_o == 0
+    assert np.array_equal(im.numpy(), want)
+    im.release()
+
+
+def test_crop_with_gravity_and_errors(gpu):
+    arr = noise_image(120, 160, 3, 41)
+    for args, grav in [("1,1,c,c", "r,b"), ("1,1", "l,t"), ("100px,50px", "10px,20px"), ("1,1", "r"), ("1,1", "xx"),
+                       ("0,0,320,240", None), ("500px,10px", None), ("10px,10", None), ("", None), ("1,1,q,t", None),
+                       ("50px,50px,150px,0px", None), ("50px,50px,-5px,0px", None)]:
+        rc_o, want = orc.crop(arr, args, grav)
+        im = gpu.Image(arr)
+        rc = im.crop(args, grav)
+        assert rc == rc_o, (args, grav, rc, rc_o)
+        if rc == 0:
+            assert np.array_equal(im.numpy(), want)
+        im.release()
+
+
+CHAINS = [
+    dict(crop="16,9", resize="160,90", filters=["rotate=90", "gamma=1.8"]),
+    dict(resize="100,0", filters=["modulate=20,130,90", "colorize=203040,0.3", "contrast=1.2"]),
+    dict(crop="1,1,c,c", gravity="r,b", resize="64,64", filters=["gotham=1", "flip=10", "kelvin=1"]),
+    dict(filters=["blur=1.5", "lomo=1", "rotate=270", "vignette=0.5"]),
+    dict(crop="200px,100px,7px,9px", filters=["rainbow=mid", "scanline=0.4,0.2,2,2"]),
+    dict(crop="150px,111px,3px,5px"),
+    dict(resize="300,300,up", filters=["gradmap=001122,ffeedd"]),
+    dict(resize="120,90", simple=1),
+    dict(crop="2,1", resize="0,40", filters=["rotate=180", "blur=0.8", "gamma=0.7"], flatten=1),
+]
+
+
+@pytest.mark.parametrize("chain", CHAINS, ids=lambda d: "-".join(k for k in d))
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_run_ops_matches_oracle_chain(gpu, chain, c):
+    arr = smooth_image(240, 320, c) if c > 1 else noise_image(240, 320, 1, 42)
+    ov = noise_image(20, 48, 4, 43)
+    wm = ("r", "b", 4, 4, 60)
+    has_vig = any(f.startswith("vignette") for f in chain.get("filters", ()))
+    rc_o, step_o, want = oracle_chain(arr, overlay=ov, wm=wm, **chain)
+    cfg = gpu.Config(allow_experiments=True, max_filters=5)
+    assert cfg.prepare_watermark(ov, *wm) == 0
+    im = gpu.Image(arr)
+    kw = dict(chain)
+    kw["need_flatten"] = kw.pop("flatten", 0)
+    rc, step = gpu.run_ops(im, cfg, **kw)
+    assert rc == rc_o == 0, (rc, step)
+    got = im.numpy()
+    if has_vig:
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    else:
+        assert np.array_equal(got, want)
+    im.release(); cfg.release()
+
+
+def test_run_ops_error_steps(gpu):
+    arr = noise_image(60, 80, 3, 44)
+    cfg = gpu.Config(max_w=100, max_h=100, max_filters=2)
+    cases = [
+        (dict(crop="0,0,320,240"), 50, 3),
+        (dict(resize="0,0"), 50, 4),
+        (dict(resize="500,500,up"), 54, 4),
+        (dict(filters=["nosuch=1"]), 52, 5),
+        (dict(filters=["gotham=1"]), 52, 5),            # experiments off
+        (dict(filters=["gamma=1", "gamma=1", "gamma=1"]), 55, 0),
+    ]
+    for kw, code, step in cases:
+        im = gpu.Image(arr)
+        rc, st = gpu.run_ops(im, cfg, **kw)
+        assert (rc, st) == (code, step), (kw, rc, st)
+        im.release()
+
+
+def test_cfg1_crop_plumbing(gpu):
+    """BASELINE configs[0] in IMP grammar: 640x480 3-channel frame, crop=320px,240px,0px,0px."""
+    arr = smooth_image(480, 640, 3)
+    im = gpu.Image(arr)
+    assert im.crop("0,0,320,240") == 50              # the literal BASELINE spelling is invalid IMP grammar
+    assert im.crop("320px,240px,0px,0px") == 0
+    got = im.numpy()
+    assert got.shape == (240, 320, 3) and np.array_equal(got, arr[:240, :320])
+    im.release()
+
+
+def test_cfg3_chain_batch(gpu):
+    """BASELINE configs[2]: resize(960x540, AREA 2x2) -> rotate 90 -> watermark, on a small batch at full size."""
+    n = 3
+    frames = [noise_image(1080, 1920, 4, 50 + i) for i in range(n)]
+    ov = noise_image(64, 256, 4, 0xFF)
+    ov[:, :, 3] = np.linspace(0, 255, 256).astype(np.uint8)[None, :]
+    cfg = gpu.Config()
+    assert cfg.prepare_watermark(ov, "r", "b", 16, 16, 60) == 0
+    src = gpu.Image(np.concatenate(frames, axis=0))
+    dst = gpu.Image(np.zeros((n * 960, 540, 4), np.uint8))
+    gpu.batch_resize_rotate_watermark(src.device_ptr, 1080 * 1920 * 4, 1920, 1080, 1920 * 4, dst.device_ptr,
+                                      960 * 540 * 4, 540 * 4, 960, 540, 90, cfg, 4, n)
+    out = dst.numpy().reshape(n, 960, 540, 4)
+    for i in range(n):
+        rc, step, want = oracle_chain(frames[i], resize="960,540", filters=["rotate=90"], overlay=ov, wm=("r", "b", 16, 16, 60))
+        assert rc == 0 and np.array_equal(out[i], want), i
+    src.release(); dst.release(); cfg.release()

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 passes: a known-size device copy (calibration) followed by the bench kernels.
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 tools/pmc_probe.py
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d OUT -- python3 tools/pmc_probe.py
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d OUT -- python3 tools/pmc_probe.py
+
+The copy moves exactly `batch * 1080 * 1920 * 4` bytes each way with 16-byte lanes, which pins the
+FETCH_SIZE / WRITE_SIZE scale on this device (MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 on gfx950 for
+wide coalesced loads) before the resize kernels' counters are read.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import ngx_http_imgproc_amd as imp  # noqa: E402
+
+batch = int(os.environ.get("PROBE_BATCH", "1024"))
+reps = int(os.environ.get("PROBE_REPS", "3"))
+torch.cuda.set_device(0)
+imp.env_start(0)
+g = torch.Generator(device="cuda")
+g.manual_seed(0x1A4D0001)
+src = torch.randint(0, 256, (batch, 1080, 1920, 4), dtype=torch.uint8, device="cuda", generator=g)
+cpy = torch.empty_like(src)
+dst = torch.zeros((batch, 224, 224, 4), dtype=torch.uint8, device="cuda")
+stream = torch.cuda.Stream()
+stream.wait_stream(torch.cuda.current_stream())
+torch.cuda.synchronize()
+with torch.cuda.stream(stream):
+    for _ in range(reps):
+        cpy.view(torch.int32).copy_(src.view(torch.int32))          # calibration: known bytes
+    for interp in (imp.INTER_CUBIC, imp.INTER_AREA, imp.INTER_NN, imp.INTER_LINEAR):
+        for _ in range(reps):
+            imp.batch_cv_resize(src.data_ptr(), 1080 * 1920 * 4, 1920, 1080, 1920 * 4, dst.data_ptr(), 224 * 224 * 4,
+                                224, 224, 224 * 4, 4, batch, interp, stream=stream.cuda_stream)
+torch.cuda.synchronize()
+print("probe done: batch", batch, "reps", reps)
+imp.env_destroy()
