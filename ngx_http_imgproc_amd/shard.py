@@ -1,0 +1,21 @@
+"""Request sharding across the GPUs of one node: frames are independent, so frame i goes to
+rank i mod world and there is no data-path collective.  torch.distributed is only used by bench.py for the
+barrier and the max-over-ranks of the elapsed time (`elapsed_max`)."""
+
+
+def round_robin(n_items, rank, world):
+    """Indices of the items rank `rank` of `world` processes owns: i with i % world == rank."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank/world %r/%r" % (rank, world))
+    return list(range(rank, n_items, world))
+
+
+def elapsed_max(seconds, dist=None, device=None):
+    """Max over ranks of a local elapsed time (identity when not distributed)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    import torch
+
+    t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])

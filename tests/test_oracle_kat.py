@@ -1,0 +1,144 @@
+"""Pins on the CPU oracle that need no GPU.
+
+The reference ships no tests or golden vectors, so the only reference-derived known answers are the
+seven Crop results SURVEY.md 8(c) recorded from the reference's own Crop(); everything else here is a closed-form
+property of the restated algorithm (identity, exact 2x2 box, constant images, NN index rule) or an independent
+cross-check (torch CPU bicubic, same a = -0.75 kernel and sample centres, float arithmetic, +-1 LSB).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import noise_image, smooth_image
+
+# (args, gravity) -> rc or (x, y, w, h) on a 640x480 frame: SURVEY.md 8(c)
+SURVEY_CROP_KAT = [
+    ("0,0,320,240", None, 50),
+    ("320px,240px,0px,0px", None, (0, 0, 320, 240)),
+    ("320px,240px", None, (160, 0, 320, 240)),
+    ("1,1", None, (80, 0, 480, 480)),
+    ("16,9,l,t", None, (0, 0, 640, 360)),
+    ("1,1,c,c", "r,b", (160, 0, 480, 480)),
+    ("400px,200px,46px,0px", None, (46, 0, 400, 200)),
+]
+
+
+@pytest.mark.parametrize("args,gravity,want", SURVEY_CROP_KAT)
+def test_crop_known_answers_from_survey(args, gravity, want):
+    rc, geom = orc.crop_geometry(640, 480, args, gravity)
+    if isinstance(want, int):
+        assert rc == want
+    else:
+        assert rc == 0 and geom == want
+
+
+def test_resize_mode_rule_and_dims():
+    # bridge.c:190: NN when simple, CUBIC when any axis grows, AREA otherwise; :167-173 aspect fill; :178-181 clamp
+    assert orc.resize_geometry(1920, 1080, "224,224") == (0, (224, 224, orc.INTER_AREA))
+    assert orc.resize_geometry(1920, 1080, "224") == (0, (224, 126, orc.INTER_AREA))
+    assert orc.resize_geometry(1920, 1080, "0,224") == (0, (398, 224, orc.INTER_AREA))
+    assert orc.resize_geometry(100, 100, "300,300") == (0, (100, 100, orc.INTER_AREA))
+    assert orc.resize_geometry(100, 100, "300,300,up") == (0, (300, 300, orc.INTER_CUBIC))
+    assert orc.resize_geometry(100, 100, "300,50,up") == (0, (300, 50, orc.INTER_CUBIC))
+    assert orc.resize_geometry(100, 100, "50,50", simple=1) == (0, (50, 50, orc.INTER_NN))
+    assert orc.resize_geometry(100, 100, "0,0")[0] == 50
+    assert orc.resize_geometry(3000, 3000, "2500,100")[0] == 54
+    # the reference compares width against H (bridge.c:184): a tall target passes, a wide one does not
+    assert orc.resize_geometry(3000, 3000, "100,2500")[0] == 0
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_resize_closed_forms(c):
+    a = noise_image(60, 80, c, 1)
+    assert np.array_equal(orc.cv_resize(a, 80, 60, orc.INTER_AREA), a)                 # scale 1
+    assert np.array_equal(orc.cv_resize(a, 80, 60, orc.INTER_NN), a)
+    for interp in (orc.INTER_LINEAR, orc.INTER_CUBIC, orc.INTER_LANCZOS4):
+        assert np.array_equal(orc.cv_resize(a, 80, 60, interp), a), interp             # taps collapse to the centre
+    box = (a[0::2, 0::2].astype(int) + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(orc.cv_resize(a, 40, 30, orc.INTER_AREA), box.astype(np.uint8))
+    k = np.full((33, 47, c), 173, np.uint8)
+    for interp in (orc.INTER_NN, orc.INTER_LINEAR, orc.INTER_AREA):
+        assert (orc.cv_resize(k, 20, 11, interp) == 173).all()
+    sy = np.minimum(np.floor(np.arange(11) * (1.0 / (11 / 33))).astype(int), 32)
+    sx = np.minimum(np.floor(np.arange(20) * (1.0 / (20 / 47))).astype(int), 46)
+    b = noise_image(33, 47, c, 2)
+    assert np.array_equal(orc.cv_resize(b, 20, 11, orc.INTER_NN), b[sy][:, sx])
+
+
+def test_cubic_matches_float_bicubic_within_one():
+    import torch
+    import torch.nn.functional as F
+
+    for arr, size in ((smooth_image(270, 480, 4), (56, 56)), (noise_image(100, 140, 3, 3), (37, 51)),
+                      (noise_image(40, 50, 3, 4), (90, 120))):
+        got = orc.cv_resize(arr, size[1], size[0], orc.INTER_CUBIC).astype(np.float64)
+        t = torch.from_numpy(arr).permute(2, 0, 1)[None].double()
+        ref = F.interpolate(t, size=size, mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+        d = np.abs(got - np.clip(np.rint(ref), 0, 255))
+        assert d.max() <= 1        # 11-bit fixed-point weights vs float: never more than one LSB
+        assert (d > 0).mean() < 0.08
+
+
+def test_cubic_simd_and_scalar_vertical_paths_differ_by_at_most_one():
+    arr = noise_image(200, 300, 4, 5)
+    orc.lib.orc_set_cv_simd(1)
+    a = orc.cv_resize(arr, 57, 41, orc.INTER_CUBIC)
+    orc.lib.orc_set_cv_simd(0)
+    b = orc.cv_resize(arr, 57, 41, orc.INTER_CUBIC)
+    orc.lib.orc_set_cv_simd(1)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+
+
+def test_gaussian_properties():
+    assert orc.lib.orc_gaussian_ksize(2.0) == 13 and orc.lib.orc_gaussian_ksize(25.0) == 151
+    assert orc.lib.orc_gaussian_ksize(0.1) == 3 and orc.lib.orc_gaussian_ksize(0.01) == 1
+    a = noise_image(40, 50, 3, 6)
+    assert np.array_equal(orc.gaussian(a, 0.01), a)       # ksize 1 -> copy
+    assert np.array_equal(orc.gaussian(a, 0.0), a)        # defined no-op (reference would assert)
+    s = orc.gaussian(a, 3.0)
+    assert s.std() < a.std() / 3 and abs(s.mean() - a.mean()) < 2
+
+
+def test_hsv_known_values_and_ranges():
+    px = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0], [0, 0, 0], [255, 255, 255], [10, 200, 100]]], np.uint8)  # B,G,R
+    hsv = orc.rgb2hsv(px)[0]
+    assert hsv[0].tolist() == [0, 255, 255]          # red
+    assert hsv[1].tolist() == [60, 255, 255]         # green
+    assert hsv[2].tolist() == [120, 255, 255]        # blue
+    assert hsv[3].tolist() == [0, 0, 0] and hsv[4].tolist() == [0, 0, 255]
+    allpx = noise_image(64, 64, 3, 7)
+    h = orc.rgb2hsv(allpx)
+    assert h[:, :, 0].max() <= 179
+    back = orc.hsv2rgb(h)
+    assert np.abs(back.astype(int) - allpx.astype(int)).max() <= 12    # lossy by construction (integer hue), but close
+
+
+def test_filter_codes_and_geometry_ops():
+    a = noise_image(20, 30, 3, 8)
+    assert orc.filter(a, "rotate=90")[1].shape == (30, 20, 3)
+    r90 = orc.filter(a, "rotate=90")[1]
+    assert np.array_equal(r90, np.rot90(a, k=-1))                       # clockwise
+    assert np.array_equal(orc.filter(a, "rotate=270")[1], np.rot90(a, k=1))
+    assert np.array_equal(orc.filter(a, "rotate=180")[1], a[::-1, ::-1])
+    assert np.array_equal(orc.filter(a, "flip=10")[1], a[:, ::-1])      # first digit = horizontal
+    assert np.array_equal(orc.filter(a, "flip=01")[1], a[::-1])
+    assert orc.filter(a, "gotham=1", 0)[0] == 52 and orc.filter(a, "gotham=1", 1)[0] == 0
+    assert orc.filter(a, "flip")[0] == 50 and orc.filter(a, "bogus=1")[0] == 52
+
+
+def test_scanline_row_rule_closed_form():
+    """rows freq <= (y mod (freq+width+1)) < freq+width are drawn."""
+    a = np.full((40, 8, 3), 200, np.uint8)
+    for freq, width in ((1, 1), (2, 3), (5, 2)):
+        rc, out = orc.filter(a, "scanline=0,0,%d,%d" % (freq, width))     # drawn rows become V=0 -> black
+        drawn = [y for y in range(40) if freq <= y % (freq + width + 1) < freq + width]
+        assert rc == 0 and [y for y in range(40) if out[y, 0, 0] == 0] == drawn
+
+
+def test_brightness_float_accumulator_is_not_the_true_mean():
+    """Why the GPU replays the accumulation serially: on a large flat frame the float running sum stalls."""
+    a = np.full((1080, 1920, 3), 100, np.uint8)
+    b = orc.brightness(a)
+    # past 2^27 the float sum can only move in steps of 16, so each +100.0 lands as +96: -2.7 % on this frame
+    assert abs(b / (100 / 255) - 1) > 0.02
+    assert int(round(b * 100)) == 38 and int(round(100 / 255 * 100)) == 39    # the JSON integer percent differs too
