@@ -17,6 +17,7 @@
 // row are one (4-byte aligned) 8/16/32-byte vector load per lane.  The per-geometry weight
 // tables (a few KB, built on the host in imp_tables.cpp) stay L1/L2 resident.
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -39,6 +40,13 @@ __device__ __forceinline__ int shr_sat_u8(int v, int sh) {
     int t = v >> sh;
     asm volatile("" : "+v"(t));
     return sat_u8(t);
+}
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ short2_t as_short2(uint32_t v) {
+    short2_t r;
+    __builtin_memcpy(&r, &v, 4);
+    return r;
 }
 
 // ------------------------------------------------------------------ LINEAR / CUBIC / LANCZOS4
@@ -101,9 +109,9 @@ __global__ __launch_bounds__(256) void k_resize_taps(RArgs a, const int* __restr
     int out[CN];
 #pragma unroll
     for (int c = 0; c < CN; c++) {
-        if (MODE == M_LINEAR) {
+        if constexpr (MODE == M_LINEAR) {
             out[c] = (uint8_t)((((by[0] * (hs[0][c] >> 4)) >> 16) + ((by[1] * (hs[1][c] >> 4)) >> 16) + 2) >> 2);
-        } else if (MODE == M_CUBIC) {
+        } else if constexpr (MODE == M_CUBIC) {
             if (dx * CN + c < vec_end) {
                 const float sc = 1.f / (2048.f * 2048.f);
                 float s = __fmul_rn(__int2float_rn(hs[0][c]), __fmul_rn((float)by[0], sc));
@@ -132,80 +140,92 @@ __global__ __launch_bounds__(256) void k_resize_taps(RArgs a, const int* __restr
 
 // ------------------------------------------------------------------ LDS-tiled separable variant
 // For scale factors <= 2 per axis (4K -> 1080p Lanczos, every enlargement) neighbouring
-// destination pixels share most of their taps: the gather kernel above would pull each source
-// pixel through L1 up to KS*KS/scale^2 times.  Here a 256-thread block owns a 64 x 16 destination
-// tile: (0) its source footprint (<= 136 x 40 BGRA pixels, edge-replicated) is staged in LDS with
-// coalesced dword loads, (1) the horizontal pass runs once per (source row, destination column)
-// out of LDS into an int32x4 LDS plane, (2) the vertical pass reads that plane 16 bytes per lane,
-// conflict-free, and writes coalesced dwords.  Every source byte leaves HBM once.
+// destination pixels share most of their taps: the gather kernel above would redo the horizontal
+// pass of each source row KS/scale times.  Here a 256-thread block owns a 64 x TH destination tile:
+// (1) the horizontal pass runs once per (source row of the footprint, destination column): each
+// lane pulls its KS-pixel window straight from global memory (neighbouring lanes' windows overlap,
+// so a wave's request is a few contiguous lines served by L1) and leaves int32x4 in an LDS plane;
+// (2) the vertical pass reads that plane 16 bytes per lane, bank-conflict free, and writes
+// coalesced dwords.  LDS holds only the plane (TH=16: 40 KB -> 4 tiles per CU).
 #define TL_TW 64
-#define TL_TH 16
-#define TL_SXW 136
-#define TL_SYH 40
 
-template <int KS, int MODE>
+// Tiles are numbered so that the 8 XCDs (blocks are dealt to them round-robin, so linear block id
+// mod 8 labels the XCD group) each own a contiguous band of tile rows: vertically adjacent tiles,
+// which share KS-1 halo rows, then meet in the same XCD's L2 instead of each pulling the halo
+// from HBM.  Speed only; any placement gives the same bytes.
+__device__ __forceinline__ void tile_of_block(int lin, int ntx, int nty, int* bx, int* by) {
+    const int n = ntx * nty;
+    const int per = (n + 7) >> 3;
+    int t = (lin & 7) * per + (lin >> 3);
+    if (t >= n) { *bx = -1; *by = -1; return; }      // padding blocks of the last band
+    *by = t / ntx;
+    *bx = t - *by * ntx;
+}
+
+template <int KS, int MODE, int TL_TH>
 __global__ __launch_bounds__(256) void k_resize_tiled(RArgs a, const int* __restrict__ xofs,
                                                       const short* __restrict__ xco,
                                                       const int* __restrict__ yofs,
-                                                      const short* __restrict__ yco, int vec_end) {
-    __shared__ uint32_t s_src[TL_SYH * TL_SXW];
+                                                      const short* __restrict__ yco, int vec_end, int ntx, int nty) {
+    constexpr int TL_SYH = (TL_TH - 1) * 2 + 10;
     __shared__ __attribute__((aligned(16))) int4 s_hs[TL_SYH * TL_TW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tx0 = blockIdx.x * TL_TW, ty0 = blockIdx.y * TL_TH;
+    int bx, by;
+    tile_of_block(blockIdx.x, ntx, nty, &bx, &by);
+    if (bx < 0) return;
+    const int tx0 = bx * TL_TW, ty0 = by * TL_TH;
     const int txn = min(TL_TW, a.dw - tx0), tyn = min(TL_TH, a.dh - ty0);
     const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
-    const int xlo = xofs[tx0] - (KS / 2 - 1), ylo = yofs[ty0] - (KS / 2 - 1);
-    const int sxw = xofs[tx0 + txn - 1] + KS / 2 - xlo + 1;
+    const int ylo = yofs[ty0] - (KS / 2 - 1);
     const int syh = yofs[ty0 + tyn - 1] + KS / 2 - ylo + 1;
-    if (sxw > TL_SXW || syh > TL_SYH) return;   // cannot happen for scales <= 2 (launcher's condition); keeps LDS indexing safe
+    if (syh > TL_SYH) return;   // cannot happen for scales <= 2 (launcher's condition); keeps LDS indexing safe
 
-    // (0) source footprint -> LDS, replicate borders by clamping the coordinates
-    // wave wv takes rows wv, wv+4, ...; a lane takes columns lane, lane+64, lane+128.  Four rows
-    // (12 dword loads per lane) are issued before the first LDS store so their latencies overlap.
-    {
-        int sxc[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) sxc[q] = clampi(xlo + lane + 64 * q, 0, a.sw - 1) * 4;
-        for (int r0 = wv; r0 < syh; r0 += 16) {
-            uint32_t v[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int r = r0 + 4 * u;
-                const uint8_t* row = S + (size_t)clampi(ylo + r, 0, a.sh - 1) * a.sstep;
-#pragma unroll
-                for (int q = 0; q < 3; q++)
-                    v[u][q] = (r < syh && lane + 64 * q < sxw) ? *(const uint32_t*)(row + sxc[q]) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int r = r0 + 4 * u;
-#pragma unroll
-                for (int q = 0; q < 3; q++)
-                    if (r < syh && lane + 64 * q < sxw) s_src[r * TL_SXW + lane + 64 * q] = v[u][q];
-            }
-        }
-    }
-    __syncthreads();
-
-    // (1) horizontal pass: lane = destination column of the tile, waves stride over source rows
+    // (1) horizontal pass: lane = destination column of the tile, waves stride over source rows.
+    // Two taps per instruction: v_perm_b32 gathers channel c of pixels 2j and 2j+1 into the two
+    // 16-bit halves of a dword, v_dot2_i32_i16 multiplies them with the packed weight pair and
+    // accumulates in int32 -- exact, and half the VALU work of byte-extract + mad.
     if (lane < txn) {
-        int ax[KS];
+        short2_t axp[KS / 2];
 #pragma unroll
-        for (int k = 0; k < KS; k++) ax[k] = xco[(tx0 + lane) * KS + k];
-        const int sxl = xofs[tx0 + lane] - (KS / 2 - 1) - xlo;
+        for (int j = 0; j < KS / 2; j++) {
+            axp[j].x = xco[(tx0 + lane) * KS + 2 * j];
+            axp[j].y = xco[(tx0 + lane) * KS + 2 * j + 1];
+        }
+        const int sx0 = xofs[tx0 + lane] - (KS / 2 - 1);
+        const bool interior = sx0 >= 0 && sx0 + KS <= a.sw;
+        const int sxv = clampi(sx0, 0, a.sw - KS) * 4;      // launcher guarantees sw >= KS
+        int sxk[KS];
+#pragma unroll
+        for (int k = 0; k < KS; k++) sxk[k] = clampi(sx0 + k, 0, a.sw - 1) * 4;
         for (int r = wv; r < syh; r += 4) {
-            const uint32_t* row = s_src + r * TL_SXW + sxl;
-            int h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+            const uint8_t* row = S + (size_t)clampi(ylo + r, 0, a.sh - 1) * a.sstep;
+            uint32_t p[KS];
+            // every lane issues the vector load (window start clamped into the row); only lanes whose
+            // taps are replicated at the image border re-read tap by tap.  Keeping the vector load
+            // unconditional stops the compiler from folding both forms into 8 dword loads.
+            __builtin_memcpy(p, __builtin_assume_aligned(row + sxv, 4), KS * 4);
 #pragma unroll
-            for (int k = 0; k < KS; k++) {
-                const uint32_t p = row[k];
-                h0 += (int)(p & 0xff) * ax[k]; h1 += (int)((p >> 8) & 0xff) * ax[k];
-                h2 += (int)((p >> 16) & 0xff) * ax[k]; h3 += (int)(p >> 24) * ax[k];
+            for (int k = 0; k < KS; k++) asm volatile("" : "+v"(p[k]));   // opaque: or the compiler proves tap k == window[k] and drops the wide load
+            if (!interior) {
+#pragma unroll
+                for (int k = 0; k < KS; k++) p[k] = *(const uint32_t*)(row + sxk[k]);
             }
-            s_hs[r * TL_TW + lane] = make_int4(h0, h1, h2, h3);
+            int h[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                int acc = 0;
+#pragma unroll
+                for (int j = 0; j < KS / 2; j++) {
+                    const uint32_t pr = __builtin_amdgcn_perm(p[2 * j + 1], p[2 * j], 0x0c040c00u + (c << 16) + c);
+                    acc = __builtin_amdgcn_sdot2(as_short2(pr), axp[j], acc, false);
+                }
+                h[c] = acc;
+            }
+            s_hs[r * TL_TW + lane] = make_int4(h[0], h[1], h[2], h[3]);
         }
     }
     __syncthreads();
+
 
     // (2) vertical pass
     if (lane < txn) {
@@ -225,9 +245,9 @@ __global__ __launch_bounds__(256) void k_resize_tiled(RArgs a, const int* __rest
                 int hc[KS];
 #pragma unroll
                 for (int k = 0; k < KS; k++) hc[k] = c == 0 ? h[k].x : (c == 1 ? h[k].y : (c == 2 ? h[k].z : h[k].w));
-                if (MODE == M_LINEAR) {
+                if constexpr (MODE == M_LINEAR) {
                     out[c] = (uint8_t)((((by[0] * (hc[0] >> 4)) >> 16) + ((by[1] * (hc[1] >> 4)) >> 16) + 2) >> 2);
-                } else if (MODE == M_CUBIC) {
+                } else if constexpr (MODE == M_CUBIC) {
                     if (dx * 4 + c < vec_end) {
                         const float sc = 1.f / (2048.f * 2048.f);
                         float s = __fmul_rn(__int2float_rn(hc[0]), __fmul_rn((float)by[0], sc));
@@ -240,10 +260,10 @@ __global__ __launch_bounds__(256) void k_resize_tiled(RArgs a, const int* __rest
                         out[c] = shr_sat_u8(v + (1 << 21), 22);
                     }
                 } else {
-                    uint32_t v = 0;
+                    int v = 1 << 21;      // |hs| < 2^23: v_mad_i32_i24 is exact mod 2^32 (int32 wrap like the CPU build)
 #pragma unroll
-                    for (int k = 0; k < KS; k++) v += (uint32_t)__mul24(hc[k], by[k]);   // |hs| < 2^23: 24-bit multiply is exact mod 2^32
-                    out[c] = shr_sat_u8((int)(v + (1u << 21)), 22);
+                    for (int k = 0; k < KS; k++) v = __mul24(hc[k], by[k]) + v;
+                    out[c] = shr_sat_u8(v, 22);
                 }
             }
             *(uint32_t*)(a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dy * a.dstep + (size_t)dx * 4) =
@@ -313,8 +333,11 @@ __global__ __launch_bounds__(256) void k_resize_area_int(RArgs a, int isx, int i
 struct AreaDev {
     const int *xstart, *xcount, *xaoff; const float* xalpha;
     const int *ystart, *ycount, *yaoff; const float* yalpha;
-    const float* xalpha_pad;    // [dw][4*nv] weights of each run, zero-padded (nv = 0: not built)
-    int nv;
+    // k_resize_area_v4 only (nv = 0: not built)
+    const int* xstart_pad;      // [dw] run start clamped to sw - 4*nv
+    const float* xalpha_pad;    // [dw][4*nv] weights of each run, shifted to xstart_pad and zero-padded
+    const float* ybeta_pad;     // [dh][nyp] row weights, zero-padded
+    int nv, nyp;
 };
 
 template <int CN>
@@ -365,49 +388,65 @@ __global__ __launch_bounds__(256) void k_resize_area(RArgs a, AreaDev t) {
 }
 
 // BGRA with source runs of at most 4*NV pixels (scale_x < 4*NV - 1): every lane pulls its whole
-// run of a source row with NV 16-byte loads instead of one dword per tap.  Weights come from the
-// zero-padded table; adding pixel * 0.f leaves the (non-negative) partial sum unchanged, so the
-// float sequence is still exactly resizeArea_'s.
+// run of a source row with NV 16-byte loads instead of one dword per tap.  The host tables give a
+// window start clamped so the vector loads never leave the row, the run's weights shifted to that
+// start and zero-padded to 4*NV, and the row weights zero-padded to a launch-uniform count, so the
+// kernel has no edge path and a uniform trip count.  Zero weights are exact no-ops on the
+// non-negative partial sums (x + p*0.f == x), so the float sequence is still exactly resizeArea_'s.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// Frame-per-XCD block order for kernels whose neighbouring blocks re-read the same source rows
+// (AREA: consecutive destination rows share their boundary source row).  Blocks are dealt to the
+// 8 XCDs round-robin, so linear id mod 8 labels an XCD group; here a group works through whole
+// frames, so the shared rows are found in that XCD's L2 instead of being pulled from HBM twice.
+// Speed only.  Returns false for the padding blocks of an incomplete last group of 8 frames.
+__device__ __forceinline__ bool frame_block(int bpf, int count, int* frame, int* blk) {
+    const long long lin = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const int g = (int)(lin & 7);
+    const long long q = lin >> 3;
+    const int f = (int)(q / bpf) * 8 + g;
+    *frame = f;
+    *blk = (int)(q % bpf);
+    return f < count;
+}
+
 template <int NV>
-__global__ __launch_bounds__(256) void k_resize_area_v4(RArgs a, AreaDev t) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_resize_area_v4(RArgs a, AreaDev t, int bpf, int count) {
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int idx = blk * 256 + threadIdx.x;
     if (idx >= a.dw * a.dh) return;
     const int dy = idx / a.dw, dx = idx - dy * a.dw;
-    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride;
-    const int xs = t.xstart[dx];
+    const uint8_t* S = a.src + (long long)frame * a.src_stride;
+    const int xs = t.xstart_pad[dx];
     float al[NV * 4];
     __builtin_memcpy(al, __builtin_assume_aligned(t.xalpha_pad + (size_t)dx * (NV * 4), 16), NV * 16);
-    const int ys = t.ystart[dy], ny = t.ycount[dy];
-    const float* ya = t.yalpha + t.yaoff[dy];
-    const bool whole = xs + NV * 4 <= a.sw;     // the padded run stays inside the row
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int j = 0; j < ny; j++) {
-        const uint8_t* row = S + (size_t)(ys + j) * a.sstep + (size_t)xs * 4;
+    const int ys = t.ystart[dy];
+    const float* yb = t.ybeta_pad + (size_t)dy * t.nyp;
+    // channels (0,1) and (2,3) ride in the two halves of packed-FP32 registers: v_pk_mul_f32 and
+    // v_pk_add_f32 round each half exactly like the scalar ops (contraction is off)
+    float2_t s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+    for (int j = 0; j < t.nyp; j++) {
+        const int sy = min(ys + j, a.sh - 1);
+        const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 4;
         uint32_t px[NV * 4];
-        if (whole) {
-            __builtin_memcpy(px, __builtin_assume_aligned(row, 4), NV * 16);
-        } else {
-#pragma unroll
-            for (int k = 0; k < NV * 4; k++) px[k] = (xs + k < a.sw) ? *(const uint32_t*)(row + k * 4) : 0u;
-        }
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        __builtin_memcpy(px, __builtin_assume_aligned(row, 4), NV * 16);
+        float2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < NV * 4; k++) {
-            b0 = __fadd_rn(b0, __fmul_rn((float)(px[k] & 0xff), al[k]));
-            b1 = __fadd_rn(b1, __fmul_rn((float)((px[k] >> 8) & 0xff), al[k]));
-            b2 = __fadd_rn(b2, __fmul_rn((float)((px[k] >> 16) & 0xff), al[k]));
-            b3 = __fadd_rn(b3, __fmul_rn((float)(px[k] >> 24), al[k]));
+            const float2_t w = {al[k], al[k]};
+            const float2_t p01 = {(float)(px[k] & 0xff), (float)((px[k] >> 8) & 0xff)};
+            const float2_t p23 = {(float)((px[k] >> 16) & 0xff), (float)(px[k] >> 24)};
+            b01 = b01 + p01 * w;
+            b23 = b23 + p23 * w;
         }
-        const float be = ya[j];
-        if (j == 0) { s0 = __fmul_rn(be, b0); s1 = __fmul_rn(be, b1); s2 = __fmul_rn(be, b2); s3 = __fmul_rn(be, b3); }
-        else {
-            s0 = __fadd_rn(s0, __fmul_rn(be, b0)); s1 = __fadd_rn(s1, __fmul_rn(be, b1));
-            s2 = __fadd_rn(s2, __fmul_rn(be, b2)); s3 = __fadd_rn(s3, __fmul_rn(be, b3));
-        }
+        const float2_t be = {yb[j], yb[j]};
+        if (j == 0) { s01 = be * b01; s23 = be * b23; }
+        else { s01 = s01 + be * b01; s23 = s23 + be * b23; }
     }
-    uint8_t* d = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep + (size_t)dx * 4;
-    *(uint32_t*)d = (uint32_t)sat_u8(__float2int_rn(s0)) | ((uint32_t)sat_u8(__float2int_rn(s1)) << 8) |
-                    ((uint32_t)sat_u8(__float2int_rn(s2)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s3)) << 24);
+    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)dy * a.dstep + (size_t)dx * 4;
+    *(uint32_t*)d = (uint32_t)sat_u8(__float2int_rn(s01.x)) | ((uint32_t)sat_u8(__float2int_rn(s01.y)) << 8) |
+                    ((uint32_t)sat_u8(__float2int_rn(s23.x)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s23.y)) << 24);
 }
 
 // ------------------------------------------------------------------ per-geometry table cache
@@ -442,20 +481,27 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
     }
     std::vector<uint8_t> blob;
     TableSet ts;
-    size_t o[9] = {0};
-    int nv = 0;
+    size_t o[11] = {0};
+    int nv = 0, nyp = 0;
     if (interp == IMP_INTER_AREA) {
         AreaAxis ax, ay;
         build_area_axis(sw, dw, scale_x, &ax);
         build_area_axis(sh, dh, scale_y, &ay);
         o[0] = put(blob, ax.start); o[1] = put(blob, ax.count); o[2] = put(blob, ax.aoff); o[3] = put(blob, ax.alpha);
         o[4] = put(blob, ay.start); o[5] = put(blob, ay.count); o[6] = put(blob, ay.aoff); o[7] = put(blob, ay.alpha);
-        if (ax.max_count <= 16) {        // zero-padded per-destination weight rows for k_resize_area_v4
+        if (ax.max_count <= 16 && ay.max_count <= 32 && sw >= 4 * ((ax.max_count + 3) / 4)) {   // k_resize_area_v4 tables
             nv = (ax.max_count + 3) / 4;
-            std::vector<float> pad((size_t)dw * nv * 4, 0.f);
-            for (int d = 0; d < dw; d++)
-                for (int k = 0; k < ax.count[d]; k++) pad[(size_t)d * nv * 4 + k] = ax.alpha[ax.aoff[d] + k];
-            o[8] = put(blob, pad);
+            nyp = ay.max_count;
+            std::vector<int> xsp(dw);
+            std::vector<float> pad((size_t)dw * nv * 4, 0.f), ypad((size_t)dh * nyp, 0.f);
+            for (int d = 0; d < dw; d++) {
+                xsp[d] = ax.start[d] < sw - nv * 4 ? ax.start[d] : sw - nv * 4;
+                const int shift = ax.start[d] - xsp[d];      // shift + count <= 4*nv because start + count <= sw
+                for (int k = 0; k < ax.count[d]; k++) pad[(size_t)d * nv * 4 + shift + k] = ax.alpha[ax.aoff[d] + k];
+            }
+            for (int d = 0; d < dh; d++)
+                for (int k = 0; k < ay.count[d]; k++) ypad[(size_t)d * nyp + k] = ay.alpha[ay.aoff[d] + k];
+            o[8] = put(blob, pad); o[9] = put(blob, xsp); o[10] = put(blob, ypad);
         }
     } else {
         TapAxis tx, ty;
@@ -474,7 +520,10 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         ts.area.ystart = (const int*)(dev + o[4]); ts.area.ycount = (const int*)(dev + o[5]);
         ts.area.yaoff = (const int*)(dev + o[6]);  ts.area.yalpha = (const float*)(dev + o[7]);
         ts.area.xalpha_pad = nv ? (const float*)(dev + o[8]) : nullptr;
+        ts.area.xstart_pad = nv ? (const int*)(dev + o[9]) : nullptr;
+        ts.area.ybeta_pad = nv ? (const float*)(dev + o[10]) : nullptr;
         ts.area.nv = nv;
+        ts.area.nyp = nyp;
     } else {
         ts.xofs = (const int*)(dev + o[0]); ts.xco = (const short*)(dev + o[1]);
         ts.yofs = (const int*)(dev + o[2]); ts.yco = (const short*)(dev + o[3]);
@@ -497,25 +546,33 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
         } else {
             TableSet ts;
             if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, &ts)) return rc;
-            if (CN == 4 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4<1>), grid, block, 0, s, a, ts.area);
-            else if (CN == 4 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4<2>), grid, block, 0, s, a, ts.area);
-            else if (CN == 4 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4<3>), grid, block, 0, s, a, ts.area);
-            else if (CN == 4 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v4<4>), grid, block, 0, s, a, ts.area);
+            const int bpf = (int)grid.x;                       // blocks per frame
+            const dim3 fgrid(grid.x, (unsigned)((count + 7) / 8 * 8));   // whole groups of 8 frames (frame-per-XCD order)
+            if (CN == 4 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4<1>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            else if (CN == 4 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4<2>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            else if (CN == 4 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4<3>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            else if (CN == 4 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v4<4>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else hipLaunchKernelGGL((k_resize_area<CN>), grid, block, 0, s, a, ts.area);
         }
     } else {
         TableSet ts;
         if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, &ts)) return rc;
         // both scales <= 2: neighbouring outputs share taps -> LDS-tiled separable kernel (BGRA)
-        if (CN == 4 && scale_x <= 2.0 && scale_y <= 2.0) {
-            const dim3 tgrid((a.dw + TL_TW - 1) / TL_TW, (a.dh + TL_TH - 1) / TL_TH, (unsigned)count);
-            if (tgrid.y > 65535) return IMP_ERROR_INVALID_ARGS;
-            if (interp == IMP_INTER_LINEAR)
-                hipLaunchKernelGGL((k_resize_tiled<2, M_LINEAR>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
-            else if (interp == IMP_INTER_CUBIC)
-                hipLaunchKernelGGL((k_resize_tiled<4, M_CUBIC>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, (a.dw * 4) & ~7);
-            else
-                hipLaunchKernelGGL((k_resize_tiled<8, M_LANCZOS>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
+        if (CN == 4 && scale_x <= 2.0 && scale_y <= 2.0 && a.sw >= 8) {
+            static const int th = std::getenv("IMPGPU_TILE_TH") ? std::atoi(std::getenv("IMPGPU_TILE_TH")) : 8;
+            const int ntx = (a.dw + TL_TW - 1) / TL_TW, nty = (a.dh + th - 1) / th;
+            const int per = (ntx * nty + 7) / 8;
+            const dim3 tgrid((unsigned)(per * 8), 1, (unsigned)count);
+#define IMP_TILED(KS_, MODE_, VEC_)                                                                                      \
+    do {                                                                                                                 \
+        if (th == 16) hipLaunchKernelGGL((k_resize_tiled<KS_, MODE_, 16>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, ntx, nty); \
+        else if (th == 4) hipLaunchKernelGGL((k_resize_tiled<KS_, MODE_, 4>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, ntx, nty); \
+        else hipLaunchKernelGGL((k_resize_tiled<KS_, MODE_, 8>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, ntx, nty); \
+    } while (0)
+            if (interp == IMP_INTER_LINEAR) IMP_TILED(2, M_LINEAR, 0);
+            else if (interp == IMP_INTER_CUBIC) IMP_TILED(4, M_CUBIC, (a.dw * 4) & ~7);
+            else IMP_TILED(8, M_LANCZOS, 0);
+#undef IMP_TILED
         } else if (interp == IMP_INTER_LINEAR)
             hipLaunchKernelGGL((k_resize_taps<2, CN, M_LINEAR>), grid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
         else if (interp == IMP_INTER_CUBIC)
