@@ -160,6 +160,24 @@ int impgpu_resize_geometry(int width, int height, const char* args, const impgpu
 int impgpu_filter_check(const char* request, int allow_experiments);           /* filters.c:43-70 + per-filter arg checks */
 int impgpu_check_destructive(const char* request);                             /* filters.c:32-40 */
 
+/* ---- request front end (host, no device): the part of RunJob above the operators.
+ *      URI unescape + GET grammar of bridge.c:304-372 ('?' split, '&' tokens, prefix-matched keys,
+ *      last crop/gravity/resize/quality/format/page wins, filters appended up to
+ *      config->max_filters_count) and the encoder choice of bridge.c:413-466 that decides
+ *      job.simple (GIF, bridge.c:594) and job.need_flatten (bridge.c:642-648).
+ *      `extension` is req->exten, used when format= is absent (bridge.c:413-416).
+ *      On error *out is still a valid object to free. The job's strings live inside it. ---- */
+typedef struct impgpu_request impgpu_request;
+int               impgpu_parse_request(const char* uri, const char* extension, const impgpu_config* config,
+                                       impgpu_request** out);
+const impgpu_job* impgpu_request_job(const impgpu_request* request);
+const char*       impgpu_request_quality(const impgpu_request* request);    /* value of quality= or NULL */
+const char*       impgpu_request_format(const impgpu_request* request);     /* value of format= or NULL */
+int               impgpu_request_page(const impgpu_request* request);       /* -1 when absent (bridge.c:324) */
+int               impgpu_request_mime(const impgpu_request* request);       /* IMP_MIME_* of required.h:57-62 */
+int               impgpu_request_destructive(const impgpu_request* request); /* CheckDestructive over the filters */
+void              impgpu_request_free(impgpu_request** request);
+
 /* ---- batch entry points (benchmark / multi-frame albums: bridge.c:578,591,608,632).
  *      `count` frames of identical geometry, frame i at base + i*frame_stride bytes,
  *      already resident in HBM.  stream = hipStream_t to launch on (NULL = env stream).

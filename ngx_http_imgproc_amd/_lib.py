@@ -95,6 +95,14 @@ SIGNATURES = {
     "impgpu_resize_geometry": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(CConfig), C.c_int, IP, IP, IP]),
     "impgpu_filter_check": (C.c_int, [C.c_char_p, C.c_int]),
     "impgpu_check_destructive": (C.c_int, [C.c_char_p]),
+    "impgpu_parse_request": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(CConfig), PP]),
+    "impgpu_request_job": (C.POINTER(CJob), [P]),
+    "impgpu_request_quality": (C.c_char_p, [P]),
+    "impgpu_request_format": (C.c_char_p, [P]),
+    "impgpu_request_page": (C.c_int, [P]),
+    "impgpu_request_mime": (C.c_int, [P]),
+    "impgpu_request_destructive": (C.c_int, [P]),
+    "impgpu_request_free": (None, [PP]),
     "impgpu_batch_cv_resize": (C.c_int, [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, C.c_longlong, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, P]),
     "impgpu_batch_resize_rotate_watermark": (C.c_int, [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, C.c_longlong,

@@ -1,7 +1,8 @@
 """Build recipe for libimpgpu.so (hipcc, gfx950 only) -- used by __graft_entry__.build().
 
-    python -m ngx_http_imgproc_amd.build          # rebuild if any source is newer
-    python -m ngx_http_imgproc_amd.build --force
+    python ngx_http_imgproc_amd/build.py          # rebuild if any source is newer
+    python ngx_http_imgproc_amd/build.py --force
+(run it as a script: `python -m ngx_http_imgproc_amd.build` would import the package, which loads the library)
 
 Flags that matter for parity: -ffp-contract=off (no fused multiply-add on host or device:
 the reference's float expressions round after every operation) and no fast-math.
@@ -21,6 +22,7 @@ SOURCES = [
     "imp_blur.hip",
     "imp_api.cpp",
     "imp_args.cpp",
+    "imp_request.cpp",
     "imp_tables.cpp",
 ]
 HEADERS = ["imp_internal.h", os.path.join("..", "..", "include", "impgpu.h")]

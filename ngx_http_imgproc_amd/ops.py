@@ -247,3 +247,35 @@ def batch_resize_rotate_watermark(src_ptr, src_stride, sw, sh, sstep, dst_ptr, d
                                                   count, C.c_void_p(stream or 0))
     if rc:
         raise ImpError(rc, "impgpu_batch_resize_rotate_watermark")
+
+
+class Request:
+    """RunJob's parsed request (bridge.c:304-372 + encoder choice :413-466)."""
+
+    def __init__(self, uri, extension="", config=None):
+        self.h = C.c_void_p()
+        cfg = config or Config()
+        self.code = lib.impgpu_parse_request(_b(uri), _b(extension), C.byref(cfg.c), C.byref(self.h))
+        j = lib.impgpu_request_job(self.h).contents
+        d = lambda v: None if v is None else v.decode()
+        self.crop, self.gravity, self.resize = d(j.crop), d(j.gravity), d(j.resize)
+        self.simple, self.need_flatten = j.simple, j.need_flatten
+        self.filters = [j.filters[i].decode() for i in range(j.filter_count)]
+        self.quality = d(lib.impgpu_request_quality(self.h))
+        self.format = d(lib.impgpu_request_format(self.h))
+        self.page = lib.impgpu_request_page(self.h)
+        self.mime = lib.impgpu_request_mime(self.h)
+        self.destructive = lib.impgpu_request_destructive(self.h)
+
+    def run(self, image, config):
+        """impgpu_run_ops with the parsed job. Returns (code, step)."""
+        step = C.c_int()
+        rc = lib.impgpu_run_ops(C.byref(image.h), lib.impgpu_request_job(self.h), C.byref(config.c), C.byref(step))
+        return rc, step.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib.impgpu_request_free(C.byref(self.h))
+        except Exception:
+            pass

@@ -123,6 +123,21 @@ typedef struct {
 } orc_chain;
 int orc_run_chain(orc_image** pointer, const orc_chain* chain, int* step);
 
+/* bridge.c:304-372 request parsing + bridge.c:413-466 encoder choice. Strings point into `buffer`. */
+#define ORC_MAX_FILTERS 64
+typedef struct {
+    char* buffer;
+    char *crop, *gravity, *resize, *quality, *format;
+    int page;
+    char* filters[ORC_MAX_FILTERS];
+    int filter_count;
+    int mime;            /* required.h:57-62: -1 jpg, -2 png, -3 json, -4 FreeImage, -5 text */
+    int simple;          /* encoder is GIF */
+    int need_flatten;    /* encoder cannot store alpha */
+} orc_request;
+int  orc_parse_request(const char* uri, const char* exten, int max_filters, orc_request** out);
+void orc_request_free(orc_request* r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,12 @@ NO_SUCH_FILTER = 52
 TOO_BIG_TARGET = 54
 
 
+class OrcRequest(C.Structure):
+    _fields_ = [("buffer", C.c_void_p), ("crop", C.c_char_p), ("gravity", C.c_char_p), ("resize", C.c_char_p),
+                ("quality", C.c_char_p), ("format", C.c_char_p), ("page", C.c_int), ("filters", C.c_char_p * 64),
+                ("filter_count", C.c_int), ("mime", C.c_int), ("simple", C.c_int), ("need_flatten", C.c_int)]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
 
@@ -57,6 +63,8 @@ def _load():
     lib.orc_ascii.restype = C.c_long
     lib.orc_ascii.argtypes = [P, C.c_char_p, C.c_void_p]
     lib.orc_gray2bgr.argtypes = [C.POINTER(P)]
+    lib.orc_parse_request.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.POINTER(OrcRequest))]
+    lib.orc_request_free.argtypes = [C.POINTER(OrcRequest)]
     return lib
 
 
@@ -185,3 +193,16 @@ def hsv2rgb(arr):
     im = Img(arr)
     lib.orc_hsv2rgb(im.h)
     return im.numpy()
+
+
+def parse_request(uri, exten="", max_filters=5):
+    """-> (code, dict) per bridge.c:304-372 + :413-466."""
+    r = C.POINTER(OrcRequest)()
+    rc = lib.orc_parse_request(_b(uri), _b(exten), max_filters, C.byref(r))
+    q = r.contents
+    d = lambda v: None if v is None else v.decode()
+    out = dict(crop=d(q.crop), gravity=d(q.gravity), resize=d(q.resize), quality=d(q.quality), format=d(q.format),
+               page=q.page, filters=[q.filters[i].decode() for i in range(q.filter_count)], mime=q.mime,
+               simple=q.simple, need_flatten=q.need_flatten)
+    lib.orc_request_free(r)
+    return rc, out
