@@ -36,7 +36,52 @@ WORKLOADS = {
              "batch 1024 of 1920x1080 BGRA resize->224x224 INTER_AREA (what the reference's Resize() dispatches)"),
     "lanczos": (3840, 2160, 1920, 1080, 64, 4, 3840 * 2160 * 4 + 1920 * 1080 * 4,
                 "batch 64 of 3840x2160 BGRA resize->1920x1080 INTER_LANCZOS4"),
+    # BASELINE configs[2]: resize=960,540 (AREA, exact 2x2) -> filter-rotate=90 -> configured watermark 256x64 r,b,16,16 @60
+    "chain": (1920, 1080, 540, 960, 1024, -1, 1920 * 1080 * 4 + 540 * 960 * 4,
+              "batch 1024 of 1920x1080 BGRA resize(960x540)+rotate(90)+watermark alpha-blend chain"),
 }
+
+
+def e2e(imp, n_requests, pinned):
+    """PCIe-inclusive request loop on one stream: upload 1080p frame -> cubic resize -> download 224x224.
+    Never the headline `value`; reported in DESIGN.md next to the device-resident number."""
+    import ctypes as C
+    import numpy as np
+
+    rng = np.random.Generator(np.random.PCG64(0x1A4D0001))
+    frame = rng.integers(0, 256, size=(1080, 1920, 4), dtype=np.uint8)
+    out = np.empty((224, 224, 4), np.uint8)
+    lib = imp.lib
+    if pinned:
+        hsrc = lib.impgpu_host_alloc(frame.nbytes)
+        hdst = lib.impgpu_host_alloc(out.nbytes)
+        C.memmove(hsrc, frame.ctypes.data, frame.nbytes)
+
+    def one():
+        h = C.c_void_p()
+        if pinned:
+            rc = lib.impgpu_image_upload_pinned(hsrc, 1920, 1080, 4, 1920 * 4, C.byref(h))
+        else:
+            rc = lib.impgpu_image_upload(frame.ctypes.data, 1920, 1080, 4, 1920 * 4, C.byref(h))
+        assert rc == 0
+        assert lib.impgpu_cv_resize(C.byref(h), 224, 224, imp.INTER_CUBIC) == 0
+        if pinned:
+            assert lib.impgpu_image_download_pinned(h, hdst, 224 * 4) == 0
+            assert lib.impgpu_sync() == 0
+        else:
+            assert lib.impgpu_image_download(h, out.ctypes.data, 224 * 4) == 0
+        lib.impgpu_image_release(C.byref(h))
+
+    for _ in range(8):
+        one()
+    t0 = time.perf_counter()
+    for _ in range(n_requests):
+        one()
+    dt = time.perf_counter() - t0
+    if pinned:
+        lib.impgpu_host_free(hsrc)
+        lib.impgpu_host_free(hdst)
+    return n_requests / dt
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -67,6 +112,72 @@ def cpu_baseline(seconds_budget=12.0):
     }
 
 
+def request_stream(imp, n_requests, n_threads):
+    """BASELINE configs[4] on one GPU: mixed-size request stream (long side log-uniform in [256, 3840], aspect in
+    {1:1, 4:3, 3:2, 16:9}, orientation coin flip, seed 0x1A4D0005), each request = upload (pinned) -> resize=224,0
+    (keep aspect; AREA, what the reference runs) -> download, n_threads host threads each on its own HIP stream."""
+    import ctypes as C
+    import threading
+    import numpy as np
+
+    rng = np.random.Generator(np.random.PCG64(0x1A4D0005))
+    aspects = [(1, 1), (4, 3), (3, 2), (16, 9)]
+    sizes = []
+    for _ in range(n_requests):
+        long_side = int(round(np.exp(rng.uniform(np.log(256), np.log(3840)))))
+        a, b = aspects[rng.integers(0, 4)]
+        short = max(1, int(round(long_side * b / a)))
+        sizes.append((long_side, short) if rng.integers(0, 2) else (short, long_side))
+    lib = imp.lib
+    # one pinned source buffer (largest frame) filled with noise: every request reads its w*h*4 prefix
+    maxpx = max(w * h for w, h in sizes)
+    hsrc = lib.impgpu_host_alloc(maxpx * 4)
+    noise = rng.integers(0, 256, size=maxpx * 4, dtype=np.uint8)
+    C.memmove(hsrc, noise.ctypes.data, noise.nbytes)
+    cfg = imp.Config()
+    counter = {"i": 0}
+    lock = threading.Lock()
+    errors = []
+
+    def worker():
+        hdst = lib.impgpu_host_alloc(224 * 224 * 4 * 4)
+        while True:
+            with lock:
+                i = counter["i"]
+                counter["i"] += 1
+            if i >= n_requests:
+                break
+            w, h = sizes[i]
+            img = C.c_void_p()
+            rc = lib.impgpu_image_upload_pinned(hsrc, w, h, 4, w * 4, C.byref(img))
+            if rc == 0:
+                rc = lib.impgpu_resize(C.byref(img), b"224,0", C.byref(cfg.c), 0)
+            if rc == 0:
+                ow = lib.impgpu_image_width(img)
+                rc = lib.impgpu_image_download_pinned(img, hdst, ow * 4) or lib.impgpu_sync()
+            lib.impgpu_image_release(C.byref(img))
+            if rc:
+                errors.append((i, rc))
+                break
+        lib.impgpu_sync()
+        lib.impgpu_host_free(hdst)
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=worker) for _ in range(n_threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    lib.impgpu_host_free(hsrc)
+    if errors:
+        raise SystemExit("request_stream failed: %r" % errors[:3])
+    src_bytes = sum(w * h * 4 for w, h in sizes)
+    return {"metric": "mixed-size request stream (256px-4K), resize=224,0, per-thread HIP stream, PCIe-inclusive",
+            "requests": n_requests, "threads": n_threads, "images_per_sec": round(n_requests / dt, 1),
+            "source_MB_per_sec": round(src_bytes / dt / 1e6, 1), "seconds": round(dt, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +186,11 @@ def main():
     ap.add_argument("--mode", default="cubic", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override frames per step (default: workload's)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--stream", type=int, default=0, metavar="N",
+                    help="instead of the headline, run N mixed-size PCIe-inclusive requests (cfg5) over --threads host threads")
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--e2e", type=int, default=0, metavar="N",
+                    help="instead of the headline, time N PCIe-inclusive requests (upload + resize + download) and exit")
     args = ap.parse_args()
 
     import torch
@@ -97,6 +213,17 @@ def main():
     import ngx_http_imgproc_amd as imp
 
     imp.env_start(local_rank)
+    if args.stream:
+        print(json.dumps(request_stream(imp, args.stream, args.threads)), flush=True)
+        imp.env_destroy()
+        return
+    if args.e2e:
+        res = {"metric": "PCIe-inclusive requests/sec: upload 1920x1080 BGRA + INTER_CUBIC ->224x224 + download, one stream",
+               "pageable_frame_via_staging": round(e2e(imp, args.e2e, False), 1),
+               "pinned_frame_direct": round(e2e(imp, args.e2e, True), 1), "requests": args.e2e, "unit": "images/sec"}
+        print(json.dumps(res), flush=True)
+        imp.env_destroy()
+        return
     sw, sh, dw, dh, batch, interp, alg_bytes, label = WORKLOADS[args.mode]
     if args.batch:
         batch = args.batch
@@ -110,7 +237,18 @@ def main():
     stream = torch.cuda.Stream()
     stream.wait_stream(torch.cuda.current_stream())
 
+    cfg = None
+    if args.mode == "chain":
+        ov = torch.randint(0, 256, (64, 256, 4), dtype=torch.uint8, generator=torch.Generator().manual_seed(0x1A4D00FF))
+        ov[:, :, 3] = torch.linspace(0, 255, 256).to(torch.uint8)[None, :]
+        cfg = imp.Config()
+        assert cfg.prepare_watermark(ov.numpy(), "r", "b", 16, 16, 60) == 0
+
     def step():
+        if cfg is not None:
+            imp.batch_resize_rotate_watermark(src.data_ptr(), sh * sw * 4, sw, sh, sw * 4, dst.data_ptr(), dh * dw * 4, dw * 4,
+                                              960, 540, 90, cfg, 4, batch, stream=stream.cuda_stream)
+            return
         imp.batch_cv_resize(src.data_ptr(), sh * sw * 4, sw, sh, sw * 4, dst.data_ptr(), dh * dw * 4, dw, dh, dw * 4,
                             4, batch, interp, stream=stream.cuda_stream)
 
@@ -139,7 +277,7 @@ def main():
         elapsed, dev_ms = float(t[0]), float(t[1])
 
     if rank == 0:
-        launch_ms = dev_ms / args.steps                  # one kernel launch per step
+        launch_ms = dev_ms / args.steps                  # one kernel launch per step (chain: its launches together)
         achieved = alg_bytes * batch / (launch_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.mode)

@@ -15,6 +15,8 @@
 #ifndef IMPGPU_H
 #define IMPGPU_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -100,6 +102,14 @@ void*       impgpu_env_stream(void);            /* the env's hipStream_t */
 int   impgpu_image_upload(const unsigned char* data, int width, int height, int channels,
                           int step, impgpu_image** out);   /* pinned staging + hipMemcpyAsync */
 int   impgpu_image_create(int width, int height, int channels, impgpu_image** out);
+/* Pinned-host variants for callers that decode into / encode from page-locked memory
+ * (impgpu_host_alloc): no staging pass, fully asynchronous on the env stream.  The host
+ * buffer must stay untouched until impgpu_sync() (upload) / is valid after impgpu_sync() (download). */
+void* impgpu_host_alloc(size_t bytes);
+void  impgpu_host_free(void* ptr);
+int   impgpu_image_upload_pinned(const unsigned char* data, int width, int height, int channels,
+                                 int step, impgpu_image** out);
+int   impgpu_image_download_pinned(const impgpu_image* image, unsigned char* data, int step);
 int   impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int step,
                         impgpu_image** out);               /* borrow memory already in HBM */
 int   impgpu_image_clone(const impgpu_image* src, impgpu_image** out);

@@ -70,6 +70,10 @@ SIGNATURES = {
     "impgpu_image_upload": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_create": (C.c_int, [C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_wrap": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),
+    "impgpu_host_alloc": (P, [C.c_size_t]),
+    "impgpu_host_free": (None, [P]),
+    "impgpu_image_upload_pinned": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),
+    "impgpu_image_download_pinned": (C.c_int, [P, P, C.c_int]),
     "impgpu_image_clone": (C.c_int, [P, PP]),
     "impgpu_image_download": (C.c_int, [P, P, C.c_int]),
     "impgpu_image_width": (C.c_int, [P]),

@@ -193,7 +193,7 @@ int impgpu_prepare_watermark(impgpu_config* config, const unsigned char* pixels,
     if (int rc = impgpu_image_upload(pixels, width, height, channels, step, &im)) return rc == IMP_ERROR_INVALID_ARGS ? IMP_ERROR_NO_SUCH_WATERMARK : rc;
     if (config->watermark) image_delete(config->watermark);
     config->watermark = im;
-    return IMP_OK;
+    return impgpu_sync();   // the overlay is read by every lane's stream afterwards: make the upload complete now
 }
 
 int impgpu_watermark(impgpu_image* image, const impgpu_config* config) {
@@ -361,7 +361,16 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
     rs.dw = resize_width; rs.dh = resize_height;
     void* mid = nullptr;
     int rc;
-    if (rotate == 0) {
+    rc = IMP_ERROR_UNSUPPORTED;
+    if (interp == IMP_INTER_AREA && swap && resize_width * 2 == src_width && resize_height * 2 == src_height) {
+        // exact 2x2 box + quarter turn: one pass, the half-size intermediate never reaches HBM
+        Frames fz = rs;
+        fz.dst = (uint8_t*)dst; fz.dst_stride = dst_frame_stride; fz.dstep = dst_step; fz.dw = fw; fz.dh = fh;
+        rc = launch_area2x2_rotate(fz, rotate, s);
+    }
+    if (rc != IMP_ERROR_UNSUPPORTED) {
+        // fused path taken (or failed with a device error)
+    } else if (rotate == 0) {
         rs.dst = (uint8_t*)dst; rs.dst_stride = dst_frame_stride; rs.dstep = dst_step;
         rc = launch_cv_resize(rs, interp, s);
     } else {

@@ -118,6 +118,8 @@ struct Frames {             // `count` frames of one geometry
 };
 // imp_resize.hip
 int launch_cv_resize(const Frames& f, int interp, hipStream_t s);
+// exact-2x AREA + rotate 90/270 of BGRA in one pass; IMP_ERROR_UNSUPPORTED when the geometry does not qualify
+int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s);
 // imp_geom.hip
 int launch_copy(const Frames& f, hipStream_t s);                       // crop copy / clone (dw,dh = v.w,v.h)
 int launch_flip(const Frames& f, int mode, hipStream_t s);             // cvFlip

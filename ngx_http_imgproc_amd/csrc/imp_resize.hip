@@ -585,6 +585,82 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
     return IMP_OK;
 }
 
+// ------------------------------------------------------------------ fused AREA 2x2 + rotate 90/270 (BGRA)
+// cfg3's resize=960,540 followed by filter-rotate=90: cvResize(AREA) with both scales exactly 2 is
+// (a+b+c+d+2)>>2 per channel, and the rotation (cvTranspose + cvFlip, filters.c:116-119) is a pure
+// permutation, so the two are one pass: a block averages a 32x32 tile of the halved image out of two
+// 8-byte loads per pixel (256 contiguous bytes per half-wave), parks it in a 33-dword-pitch LDS tile
+// and writes it transposed along destination rows.  The half-size intermediate never exists in HBM.
+__device__ __forceinline__ uint32_t box2x2(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++) {
+        const uint32_t sum = ((a >> (8 * ch)) & 0xff) + ((b >> (8 * ch)) & 0xff) + ((c >> (8 * ch)) & 0xff) + ((d >> (8 * ch)) & 0xff) + 2;
+        o |= (sum >> 2) << (8 * ch);
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount, int rw, int rh) {
+    // 64 x 64 tile of the halved image; 65-dword pitch makes the transposed read bank-conflict free
+    __shared__ uint32_t tile[64][65];
+    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
+    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride;
+    const int rx0 = blockIdx.x * 64, ry0 = blockIdx.y * 64;      // tile origin in the halved (pre-rotation) image
+    const int tid = threadIdx.x;
+    {   // (1) each thread averages two neighbouring outputs per row from two 16-byte loads (512 B per half-wave)
+        const int lx = (tid & 31) * 2, ty = tid >> 5;
+        const int rx = rx0 + lx;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int ly = ty + 8 * r, ry = ry0 + ly;
+            if (ry < rh && rx + 1 < rw) {
+                const uint4 t0 = *(const uint4*)(S + (size_t)(2 * ry) * a.sstep + (size_t)rx * 8);
+                const uint4 t1 = *(const uint4*)(S + (size_t)(2 * ry + 1) * a.sstep + (size_t)rx * 8);
+                tile[ly][lx] = box2x2(t0.x, t0.y, t1.x, t1.y);
+                tile[ly][lx + 1] = box2x2(t0.z, t0.w, t1.z, t1.w);
+            } else if (ry < rh && rx < rw) {
+                const uint2 t0 = *(const uint2*)(S + (size_t)(2 * ry) * a.sstep + (size_t)rx * 8);
+                const uint2 t1 = *(const uint2*)(S + (size_t)(2 * ry + 1) * a.sstep + (size_t)rx * 8);
+                tile[ly][lx] = box2x2(t0.x, t0.y, t1.x, t1.y);
+            }
+        }
+    }
+    __syncthreads();
+    // (2) destination: 90 -> R[i][j] = H[rh-1-j][i], 270 -> R[i][j] = H[j][rw-1-i]  (H = halved image; R is rh wide, rw tall).
+    // Lanes run along H's y, which is the destination's x: 256 contiguous bytes per wave store.
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        const int ry = ry0 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int l = wv + 4 * r;
+            const int rx = rx0 + l;
+            if (rx < rw && ry < rh) {
+                const int dx = amount == 90 ? rh - 1 - ry : ry;
+                const int dy = amount == 90 ? rx : rw - 1 - rx;
+                *(uint32_t*)(D + (size_t)dy * a.dstep + (size_t)dx * 4) = tile[lane][l];
+            }
+        }
+    }
+}
+
+// src: sw x sh BGRA with sw = 2*rw, sh = 2*rh; dst: rh x rw (rotated).  Returns IMP_ERROR_UNSUPPORTED when the
+// geometry is not the exact-2x BGRA case so the caller can fall back to resize + rotate.
+int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s) {
+    const View& v = f.v;
+    if (v.c != 4 || (amount != 90 && amount != 270) || (v.w & 1) || (v.h & 1)) return IMP_ERROR_UNSUPPORTED;
+    const int rw = v.w / 2, rh = v.h / 2;
+    if (f.dw != rh || f.dh != rw || f.count <= 0 || f.count > 65535) return IMP_ERROR_UNSUPPORTED;
+    if (((uintptr_t)f.src | (uintptr_t)v.step | (uintptr_t)f.src_stride) & 15) return IMP_ERROR_UNSUPPORTED;   // 16-byte loads
+    if (((uintptr_t)f.dst | (uintptr_t)f.dstep | (uintptr_t)f.dst_stride) & 3) return IMP_ERROR_UNSUPPORTED;
+    RArgs a{f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
+    const dim3 grid((rw + 63) / 64, (rh + 63) / 64, f.count), block(256);
+    hipLaunchKernelGGL(k_area2x2_rotate_bgra, grid, block, 0, s, a, amount, rw, rh);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
 int launch_cv_resize(const Frames& f, int interp, hipStream_t s) {
     if (f.count <= 0) return IMP_OK;
     if (f.count > 65535) return IMP_ERROR_INVALID_ARGS;

@@ -1,45 +1,84 @@
-// imp_runtime.hip -- per-worker environment: device, stream, HBM buffer pool, pinned staging,
+// imp_runtime.hip -- per-worker environment: device, streams, HBM buffer pools, pinned staging,
 // frame upload / download.  Stands where the reference's empty OnEnvStart / OnEnvDestroy
 // (bridge.c:10-16) and its cvCreateImage / cvReleaseImage calls are.
 //
-// One env per process (one nginx worker = one process = one stream, module.c:100-107).
-// Device buffers come from a size-bucketed free list; because every operator of a request
-// is enqueued on the same stream, a buffer released by one operator can be handed to the
-// next without a device sync (stream order is the only ordering needed).
+// One env per process (one nginx worker = one process, module.c:100-107).  Inside it every
+// calling thread gets its own LANE: a HIP stream, a size-bucketed pool of device buffers, a
+// pinned staging buffer for frame upload / download and a pinned ring for small tables.  All
+// operators of a request are enqueued on the lane's stream, so a buffer released by one operator
+// can be handed to the next without a device sync (stream order is the only ordering needed), and
+// requests driven from different threads overlap their H2D copies, kernels and D2H copies with no
+// shared lock on the hot path.  A frame belongs to the lane (thread) that created it.
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 #include "imp_internal.h"
 
 namespace imp {
 
-struct Env {
-    int device = -1;
+struct Lane {
     hipStream_t stream = nullptr;
-    std::mutex mu;
+    std::mutex mu;                              // guards the pool: frees may come from other threads
     std::multimap<size_t, void*> free_list;     // bucket size -> buffer
     std::map<void*, size_t> live;               // buffer -> bucket size
-    size_t pooled_bytes = 0;
-    // pinned staging for upload / download
-    uint8_t* stage = nullptr;
+    uint8_t* stage = nullptr;                   // pinned staging for pageable upload / download
     size_t stage_cap = 0;
     hipEvent_t stage_done = nullptr;
     bool stage_busy = false;
-    // pinned ring for the small per-launch tables (LUTs, Gaussian taps): async H2D copies need a
-    // source that outlives the call
-    uint8_t* ring = nullptr;
+    uint8_t* ring = nullptr;                    // pinned ring for per-launch tables (LUTs, Gaussian taps)
     size_t ring_cap = 0, ring_pos = 0;
 };
 
+struct Env {
+    int device = -1;
+    unsigned long long generation = 0;
+    std::mutex mu;
+    std::vector<Lane*> lanes;
+};
+
 static Env* g_env = nullptr;
+static unsigned long long g_generation = 0;
+static thread_local Lane* t_lane = nullptr;
+static thread_local unsigned long long t_lane_gen = 0;
 static thread_local std::string t_error;
 
 void set_error(const char* what, hipError_t e) {
     t_error = std::string(what) + ": " + hipGetErrorString(e);
 }
 bool env_ready() { return g_env != nullptr; }
-hipStream_t env_stream() { return g_env ? g_env->stream : nullptr; }
+
+static int no_env() {
+    t_error = "impgpu_env_start has not been called";
+    return IMP_ERROR_DEVICE;
+}
+
+// The calling thread's lane, created on first use (HIP's current device is per thread too).
+static Lane* lane() {
+    Env* E = g_env;
+    if (!E) return nullptr;
+    if (t_lane && t_lane_gen == E->generation) return t_lane;
+    if (hipSetDevice(E->device) != hipSuccess) return nullptr;
+    Lane* L = new Lane();
+    if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&L->stage_done, hipEventDisableTiming) != hipSuccess) {
+        delete L;
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lk(E->mu);
+        E->lanes.push_back(L);
+    }
+    t_lane = L;
+    t_lane_gen = E->generation;
+    return L;
+}
+
+hipStream_t env_stream() {
+    Lane* L = lane();
+    return L ? L->stream : nullptr;
+}
 
 static size_t bucket_of(size_t bytes) {
     size_t b = 4096;
@@ -53,45 +92,60 @@ static size_t bucket_of(size_t bytes) {
 }
 
 int dev_alloc(size_t bytes, void** out) {
-    if (!g_env) { t_error = "impgpu_env_start has not been called"; return IMP_ERROR_DEVICE; }
-    size_t b = bucket_of(bytes ? bytes : 1);
+    Lane* L = lane();
+    if (!L) return no_env();
+    const size_t b = bucket_of(bytes ? bytes : 1);
     {
-        std::lock_guard<std::mutex> lk(g_env->mu);
-        auto it = g_env->free_list.find(b);
-        if (it != g_env->free_list.end()) {
+        std::lock_guard<std::mutex> lk(L->mu);
+        auto it = L->free_list.find(b);
+        if (it != L->free_list.end()) {
             *out = it->second;
-            g_env->free_list.erase(it);
-            g_env->live[*out] = b;
+            L->free_list.erase(it);
+            L->live[*out] = b;
             return IMP_OK;
         }
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
-        // drop the cache and retry once
+        // drop this lane's cache and retry once
         {
-            std::lock_guard<std::mutex> lk(g_env->mu);
-            (void)hipStreamSynchronize(g_env->stream);
-            for (auto& kv : g_env->free_list) (void)hipFree(kv.second);
-            g_env->free_list.clear();
+            std::lock_guard<std::mutex> lk(L->mu);
+            (void)hipStreamSynchronize(L->stream);
+            for (auto& kv : L->free_list) (void)hipFree(kv.second);
+            L->free_list.clear();
         }
         e = hipMalloc(&p, b);
         if (e != hipSuccess) { set_error("hipMalloc", e); return IMP_ERROR_MALLOC_FAILED; }
     }
-    std::lock_guard<std::mutex> lk(g_env->mu);
-    g_env->live[p] = b;
-    g_env->pooled_bytes += b;
+    std::lock_guard<std::mutex> lk(L->mu);
+    L->live[p] = b;
     *out = p;
     return IMP_OK;
 }
 
+static bool lane_take_back(Lane* L, void* p) {
+    std::lock_guard<std::mutex> lk(L->mu);
+    auto it = L->live.find(p);
+    if (it == L->live.end()) return false;
+    L->free_list.emplace(it->second, p);
+    L->live.erase(it);
+    return true;
+}
+
 void dev_free(void* p) {
-    if (!p || !g_env) return;
-    std::lock_guard<std::mutex> lk(g_env->mu);
-    auto it = g_env->live.find(p);
-    if (it == g_env->live.end()) return;
-    g_env->free_list.emplace(it->second, p);
-    g_env->live.erase(it);
+    Env* E = g_env;
+    if (!p || !E) return;
+    Lane* mine = (t_lane && t_lane_gen == E->generation) ? t_lane : nullptr;
+    if (mine && lane_take_back(mine, p)) return;
+    // released from another thread (e.g. a garbage collector): hand it back to the lane that owns it
+    std::vector<Lane*> lanes;
+    {
+        std::lock_guard<std::mutex> lk(E->mu);
+        lanes = E->lanes;
+    }
+    for (Lane* L : lanes)
+        if (L != mine && lane_take_back(L, p)) return;
 }
 
 int image_new(int w, int h, int c, impgpu_image** out) {
@@ -101,7 +155,7 @@ int image_new(int w, int h, int c, impgpu_image** out) {
     im->step = aligned_step(w, c);
     im->cap = (size_t)im->step * h;
     void* p = nullptr;
-    int rc = dev_alloc(im->cap + 16, &p);   // +16: kernels may read one 16-byte vector that ends past the last pixel
+    int rc = dev_alloc(im->cap + 16, &p);
     if (rc) { delete im; return rc; }
     im->d = (uint8_t*)p;
     im->owned = true;
@@ -116,33 +170,29 @@ void image_delete(impgpu_image* im) {
 }
 
 int upload_small(const void* host, size_t bytes, void** dev, hipStream_t s) {
-    if (!g_env) { t_error = "impgpu_env_start has not been called"; return IMP_ERROR_DEVICE; }
+    Lane* L = lane();
+    if (!L) return no_env();
     void* p = nullptr;
     int rc = dev_alloc(bytes, &p);
     if (rc) return rc;
-    uint8_t* slot;
-    {
-        std::lock_guard<std::mutex> lk(g_env->mu);
-        Env* E = g_env;
-        const size_t need = (bytes + 63) & ~size_t(63);
-        if (need > E->ring_cap) {       // first use, or a blob larger than the ring
-            (void)hipDeviceSynchronize();
-            if (E->ring) (void)hipHostFree(E->ring);
-            E->ring = nullptr;
-            E->ring_cap = 0;
-            size_t cap = need * 2 > (size_t(4) << 20) ? need * 2 : (size_t(4) << 20);
-            hipError_t e = hipHostMalloc((void**)&E->ring, cap, hipHostMallocDefault);
-            if (e != hipSuccess) { set_error("hipHostMalloc(ring)", e); dev_free(p); return IMP_ERROR_DEVICE; }
-            E->ring_cap = cap;
-            E->ring_pos = 0;
-        }
-        if (E->ring_pos + need > E->ring_cap) {   // wrap: everything that read the ring must be done
-            (void)hipDeviceSynchronize();
-            E->ring_pos = 0;
-        }
-        slot = E->ring + E->ring_pos;
-        E->ring_pos += need;
+    const size_t need = (bytes + 63) & ~size_t(63);
+    if (need > L->ring_cap) {       // first use, or a blob larger than the ring
+        (void)hipDeviceSynchronize();
+        if (L->ring) (void)hipHostFree(L->ring);
+        L->ring = nullptr;
+        L->ring_cap = 0;
+        const size_t cap = need * 2 > (size_t(1) << 20) ? need * 2 : (size_t(1) << 20);
+        hipError_t e = hipHostMalloc((void**)&L->ring, cap, hipHostMallocDefault);
+        if (e != hipSuccess) { set_error("hipHostMalloc(ring)", e); dev_free(p); return IMP_ERROR_DEVICE; }
+        L->ring_cap = cap;
+        L->ring_pos = 0;
     }
+    if (L->ring_pos + need > L->ring_cap) {   // wrap: everything that read the ring must be done
+        (void)hipDeviceSynchronize();         // (device-wide: a batch call may have used a foreign stream)
+        L->ring_pos = 0;
+    }
+    uint8_t* slot = L->ring + L->ring_pos;
+    L->ring_pos += need;
     std::memcpy(slot, host, bytes);
     hipError_t e = hipMemcpyAsync(p, slot, bytes, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) { set_error("hipMemcpyAsync(small)", e); dev_free(p); return IMP_ERROR_DEVICE; }
@@ -150,20 +200,30 @@ int upload_small(const void* host, size_t bytes, void** dev, hipStream_t s) {
     return IMP_OK;
 }
 
-static int stage_reserve(size_t bytes) {
-    Env* E = g_env;
-    if (E->stage_busy) {
-        IMP_HIP(hipEventSynchronize(E->stage_done));
-        E->stage_busy = false;
+static int stage_reserve(Lane* L, size_t bytes) {
+    if (L->stage_busy) {
+        IMP_HIP(hipEventSynchronize(L->stage_done));
+        L->stage_busy = false;
     }
-    if (E->stage_cap >= bytes) return IMP_OK;
-    if (E->stage) IMP_HIP(hipHostFree(E->stage));
-    E->stage = nullptr;
-    E->stage_cap = 0;
-    size_t cap = bucket_of(bytes);
-    IMP_HIP(hipHostMalloc((void**)&E->stage, cap, hipHostMallocDefault));
-    E->stage_cap = cap;
+    if (L->stage_cap >= bytes) return IMP_OK;
+    if (L->stage) IMP_HIP(hipHostFree(L->stage));
+    L->stage = nullptr;
+    L->stage_cap = 0;
+    const size_t cap = bucket_of(bytes);
+    IMP_HIP(hipHostMalloc((void**)&L->stage, cap, hipHostMallocDefault));
+    L->stage_cap = cap;
     return IMP_OK;
+}
+
+static void lane_destroy(Lane* L) {
+    (void)hipStreamSynchronize(L->stream);
+    for (auto& kv : L->free_list) (void)hipFree(kv.second);
+    for (auto& kv : L->live) (void)hipFree(kv.first);
+    if (L->stage) (void)hipHostFree(L->stage);
+    if (L->ring) (void)hipHostFree(L->ring);
+    (void)hipEventDestroy(L->stage_done);
+    (void)hipStreamDestroy(L->stream);
+    delete L;
 }
 
 }  // namespace imp
@@ -190,35 +250,35 @@ int impgpu_env_start(int device) {
     IMP_HIP(hipSetDevice(device));
     Env* E = new Env();
     E->device = device;
-    e = hipStreamCreateWithFlags(&E->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { set_error("hipStreamCreate", e); delete E; return IMP_ERROR_DEVICE; }
-    e = hipEventCreateWithFlags(&E->stage_done, hipEventDisableTiming);
-    if (e != hipSuccess) { set_error("hipEventCreate", e); (void)hipStreamDestroy(E->stream); delete E; return IMP_ERROR_DEVICE; }
+    E->generation = ++g_generation;
     g_env = E;
+    if (!lane()) {  // the calling thread's lane: fails loudly here rather than at the first operator
+        g_env = nullptr;
+        delete E;
+        t_error = "could not create a HIP stream";
+        return IMP_ERROR_DEVICE;
+    }
     return IMP_OK;
 }
 
 void impgpu_env_destroy(void) {
     Env* E = g_env;
     if (!E) return;
-    (void)hipStreamSynchronize(E->stream);
-    for (auto& kv : E->free_list) (void)hipFree(kv.second);
-    for (auto& kv : E->live) (void)hipFree(kv.first);
-    if (E->stage) (void)hipHostFree(E->stage);
-    if (E->ring) (void)hipHostFree(E->ring);
-    (void)hipEventDestroy(E->stage_done);
-    (void)hipStreamDestroy(E->stream);
-    g_env = nullptr;
+    (void)hipDeviceSynchronize();
+    for (Lane* L : E->lanes) lane_destroy(L);
+    g_env = nullptr;        // other threads' t_lane pointers are invalidated by the generation counter
+    t_lane = nullptr;
     delete E;
 }
 
 int impgpu_env_device(void) { return g_env ? g_env->device : -1; }
 const char* impgpu_last_error(void) { return t_error.c_str(); }
-void* impgpu_env_stream(void) { return g_env ? (void*)g_env->stream : nullptr; }
+void* impgpu_env_stream(void) { return (void*)env_stream(); }
 
 int impgpu_sync(void) {
-    if (!g_env) { t_error = "impgpu_env_start has not been called"; return IMP_ERROR_DEVICE; }
-    IMP_HIP(hipStreamSynchronize(g_env->stream));
+    Lane* L = lane();
+    if (!L) return no_env();
+    IMP_HIP(hipStreamSynchronize(L->stream));
     return IMP_OK;
 }
 
@@ -230,27 +290,64 @@ int impgpu_image_create(int width, int height, int channels, impgpu_image** out)
 int impgpu_image_upload(const unsigned char* data, int width, int height, int channels, int step,
                         impgpu_image** out) {
     if (!data || !out || step < width * channels) return IMP_ERROR_INVALID_ARGS;
-    if (!g_env) { t_error = "impgpu_env_start has not been called"; return IMP_ERROR_DEVICE; }
+    Lane* L = lane();
+    if (!L) return no_env();
     impgpu_image* im = nullptr;
     int rc = image_new(width, height, channels, &im);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_env->mu);   // staging buffer is shared
-    size_t bytes = (size_t)im->step * height;
-    rc = stage_reserve(bytes);
+    const size_t bytes = (size_t)im->step * height;
+    rc = stage_reserve(L, bytes);
     if (rc) { image_delete(im); return rc; }
     // repack into the device row pitch (cvCreateImage alignment) inside pinned memory
-    size_t rowbytes = (size_t)width * channels;
+    const size_t rowbytes = (size_t)width * channels;
     if ((size_t)step == (size_t)im->step) {
-        std::memcpy(g_env->stage, data, bytes - (im->step - rowbytes));
+        std::memcpy(L->stage, data, bytes - (im->step - rowbytes));
     } else {
         for (int y = 0; y < height; y++)
-            std::memcpy(g_env->stage + (size_t)y * im->step, data + (size_t)y * step, rowbytes);
+            std::memcpy(L->stage + (size_t)y * im->step, data + (size_t)y * step, rowbytes);
     }
-    hipError_t e = hipMemcpyAsync(im->d, g_env->stage, bytes, hipMemcpyHostToDevice, g_env->stream);
-    if (e == hipSuccess) e = hipEventRecord(g_env->stage_done, g_env->stream);
+    hipError_t e = hipMemcpyAsync(im->d, L->stage, bytes, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess) e = hipEventRecord(L->stage_done, L->stream);
     if (e != hipSuccess) { set_error("hipMemcpyAsync(upload)", e); image_delete(im); return IMP_ERROR_DEVICE; }
-    g_env->stage_busy = true;
+    L->stage_busy = true;
     *out = im;
+    return IMP_OK;
+}
+
+void* impgpu_host_alloc(size_t bytes) {
+    if (!lane()) { no_env(); return nullptr; }
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { set_error("hipHostMalloc", e); return nullptr; }
+    return p;
+}
+
+void impgpu_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int impgpu_image_upload_pinned(const unsigned char* data, int width, int height, int channels, int step,
+                               impgpu_image** out) {
+    if (!data || !out || step < width * channels) return IMP_ERROR_INVALID_ARGS;
+    Lane* L = lane();
+    if (!L) return no_env();
+    impgpu_image* im = nullptr;
+    int rc = image_new(width, height, channels, &im);
+    if (rc) return rc;
+    // straight from the caller's pinned frame: no staging pass.  hipMemcpy2DAsync repacks the row pitch.
+    hipError_t e = hipMemcpy2DAsync(im->d, (size_t)im->step, data, (size_t)step, (size_t)width * channels, (size_t)height,
+                                    hipMemcpyHostToDevice, L->stream);
+    if (e != hipSuccess) { set_error("hipMemcpy2DAsync(upload_pinned)", e); image_delete(im); return IMP_ERROR_DEVICE; }
+    *out = im;
+    return IMP_OK;
+}
+
+int impgpu_image_download_pinned(const impgpu_image* im, unsigned char* data, int step) {
+    if (!im || !data || step < im->w * im->c) return IMP_ERROR_INVALID_ARGS;
+    Lane* L = lane();
+    if (!L) return no_env();
+    IMP_HIP(hipMemcpy2DAsync(data, (size_t)step, im->d, (size_t)im->step, (size_t)im->w * im->c, (size_t)im->h,
+                             hipMemcpyDeviceToHost, L->stream));
     return IMP_OK;
 }
 
@@ -269,16 +366,16 @@ int impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int
 
 int impgpu_image_download(const impgpu_image* im, unsigned char* data, int step) {
     if (!im || !data || step < im->w * im->c) return IMP_ERROR_INVALID_ARGS;
-    if (!g_env) { t_error = "impgpu_env_start has not been called"; return IMP_ERROR_DEVICE; }
-    std::lock_guard<std::mutex> lk(g_env->mu);
-    size_t bytes = (size_t)im->step * im->h;
-    int rc = stage_reserve(bytes);
+    Lane* L = lane();
+    if (!L) return no_env();
+    const size_t bytes = (size_t)im->step * im->h;
+    int rc = stage_reserve(L, bytes);
     if (rc) return rc;
-    IMP_HIP(hipMemcpyAsync(g_env->stage, im->d, bytes, hipMemcpyDeviceToHost, g_env->stream));
-    IMP_HIP(hipStreamSynchronize(g_env->stream));
-    size_t rowbytes = (size_t)im->w * im->c;
+    IMP_HIP(hipMemcpyAsync(L->stage, im->d, bytes, hipMemcpyDeviceToHost, L->stream));
+    IMP_HIP(hipStreamSynchronize(L->stream));
+    const size_t rowbytes = (size_t)im->w * im->c;
     for (int y = 0; y < im->h; y++)
-        std::memcpy(data + (size_t)y * step, g_env->stage + (size_t)y * im->step, rowbytes);
+        std::memcpy(data + (size_t)y * step, L->stage + (size_t)y * im->step, rowbytes);
     return IMP_OK;
 }
 

@@ -148,3 +148,70 @@ def test_cfg3_chain_batch(gpu):
         rc, step, want = oracle_chain(frames[i], resize="960,540", filters=["rotate=90"], overlay=ov, wm=("r", "b", 16, 16, 60))
         assert rc == 0 and np.array_equal(out[i], want), i
     src.release(); dst.release(); cfg.release()
+
+
+@pytest.mark.parametrize("rotate", [0, 90, 180, 270])
+@pytest.mark.parametrize("geom", [((96, 128), (64, 48)), ((96, 130), (64, 48)), ((70, 90), (45, 35)), ((66, 70), (35, 33))])
+def test_batch_resize_rotate_watermark_all_turns(gpu, rotate, geom):
+    """Batch chain API: the fused 2x2-box + quarter-turn kernel (exact halves) and the unfused fallback agree with the oracle."""
+    (sh, sw), (rw, rh) = geom
+    n = 3
+    frames = [noise_image(sh, sw, 4, 60 + i) for i in range(n)]
+    ov = noise_image(10, 14, 4, 61)
+    cfg = gpu.Config()
+    assert cfg.prepare_watermark(ov, "c", "b", 1, 2, 70) == 0
+    fw, fh = (rh, rw) if rotate in (90, 270) else (rw, rh)
+    src = gpu.Image(np.concatenate(frames, axis=0))
+    dst = gpu.Image(np.zeros((n * fh, fw, 4), np.uint8))
+    gpu.batch_resize_rotate_watermark(src.device_ptr, sh * sw * 4, sw, sh, sw * 4, dst.device_ptr, fh * fw * 4, fw * 4,
+                                      rw, rh, rotate, cfg, 4, n)
+    out = dst.numpy().reshape(n, fh, fw, 4)
+    filters = ["rotate=%d" % rotate] if rotate else []
+    for i in range(n):
+        rc, step, want = oracle_chain(frames[i], resize="%d,%d" % (rw, rh), filters=filters, overlay=ov, wm=("c", "b", 1, 2, 70))
+        assert rc == 0 and np.array_equal(out[i], want), (rotate, geom, i)
+    src.release(); dst.release(); cfg.release()
+
+
+def test_threads_have_independent_streams_and_pools(gpu):
+    """Requests driven from several host threads (one HIP stream + buffer pool per thread) give the same bytes as serial ones."""
+    import threading
+
+    cfg = gpu.Config(allow_experiments=True)
+    jobs = [(noise_image(120 + 7 * i, 160 + 5 * i, 4, 80 + i), dict(crop="4,3", resize="%d,0" % (40 + i), filters=["gotham=1", "rotate=90"]))
+            for i in range(12)]
+    want = []
+    for arr, kw in jobs:
+        rc, step, w = oracle_chain(arr, **kw)
+        assert rc == 0
+        want.append(w)
+    got = [None] * len(jobs)
+    errs = []
+
+    def worker(tid):
+        try:
+            for rep in range(3):
+                for i in range(tid, len(jobs), 4):
+                    im = gpu.Image(jobs[i][0])
+                    rc, step = gpu.run_ops(im, cfg, **jobs[i][1])
+                    assert rc == 0
+                    got[i] = im.numpy()
+                    im.release()
+        except Exception as e:      # surfaced below; a thread must not die silently
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(len(jobs)):
+        assert np.array_equal(got[i], want[i]), i
+    # distinct threads really got distinct streams
+    streams = []
+    ts = [threading.Thread(target=lambda: streams.append(gpu.lib.impgpu_env_stream())) for _ in range(3)]
+    for t in ts:
+        t.start()
+        t.join()
+    assert len(set(streams + [gpu.lib.impgpu_env_stream()])) == 4
