@@ -267,12 +267,21 @@ int launch_blend_paper(uint8_t* d, long long stride, int w, int h, int step, int
 
 // ------------------------------------------------------------------ CalcPerceivedBrightness, filters.c:707-729
 // The reference adds one double term per pixel into a FLOAT accumulator, walking x-outer /
-// y-inner.  That running float sum rounds at every step (by up to 16 once it passes 2^28 on
-// a 1080p frame), so the result is not the true mean and depends on the order; a tree
-// reduction would differ from it.  Two kernels reproduce it exactly: a parallel one that
-// evaluates the per-pixel terms into HBM in the reference's visiting order, and a single
-// wave that replays the float accumulation serially (64 terms per coalesced load, every
-// lane running the same dependent chain on v_readlane'd values).
+// y-inner: sum = (float)((double)sum + term).  The running float sum rounds at every step (by up
+// to 16 once it passes 2^28 on a 1080p frame), so the result is not the true mean -- a flat
+// 1080p frame of value 100 yields 0.3815, not 0.3922 -- and a tree reduction would differ from it.
+// It is reproduced bit for bit without a serial walk:
+//   * k_brightness_terms evaluates the per-pixel terms into HBM in the reference's visiting order;
+//   * k_brightness_replay replays the accumulation regime by regime.  While the sum stays inside
+//     one binade [2^e, 2^(e+1)) it is a multiple of u = 2^(e-23), and adding t = k*u + r moves it
+//     by k*u, plus u when r is above u/2, plus "round to even" when the double sum lands exactly on
+//     the midpoint -- which, because (double)sum + t is itself rounded to 53 bits first, happens
+//     precisely when |r - u/2| <= 2^(e-53) (the midpoint is a double; rounding is monotone).  So
+//     inside a regime each term is a function of ONE bit of state, the parity of the sum's mantissa:
+//     parity -> (steps, parity').  Such functions compose associatively, so 4096 terms are folded
+//     by a block-wide scan; the scan also tells where the sum leaves the binade, and only that one
+//     term is added with the literal float/double sequence before the next regime starts.
+//   A 1080p frame needs ~530 block iterations instead of 2 million dependent add chains.
 template <int CN>
 __global__ __launch_bounds__(256) void k_brightness_terms(const uint8_t* __restrict__ src, int w, int h, int step,
                                                           double* __restrict__ terms) {
@@ -289,28 +298,113 @@ __global__ __launch_bounds__(256) void k_brightness_terms(const uint8_t* __restr
     terms[idx] = t;
 }
 
-__global__ __launch_bounds__(64) void k_brightness_serial(const double* __restrict__ terms, long long n, float* out) {
-    const int lane = threadIdx.x;
-    float sum = 0.f;
-    for (long long base = 0; base < n; base += 64) {
-        const long long i = base + lane;
-        const double t = i < n ? terms[i] : 0.0;
-        const int lo = __double2loint(t), hi = __double2hiint(t);
-        const int m = (n - base) < 64 ? (int)(n - base) : 64;
-        if (m == 64) {
+struct ParityFn {            // mantissa parity in -> (steps of u added, parity out)
+    double inc0, inc1;
+    int b0, b1;
+};
+__device__ __forceinline__ ParityFn pf_identity() { return ParityFn{0.0, 0.0, 0, 1}; }
+// `first` applied before `second`
+__device__ __forceinline__ ParityFn pf_compose(const ParityFn& first, const ParityFn& second) {
+    ParityFn r;
+    r.inc0 = first.inc0 + (first.b0 ? second.inc1 : second.inc0);
+    r.b0 = first.b0 ? second.b1 : second.b0;
+    r.inc1 = first.inc1 + (first.b1 ? second.inc1 : second.inc0);
+    r.b1 = first.b1 ? second.b1 : second.b0;
+    return r;
+}
+__device__ __forceinline__ ParityFn pf_shfl_up(const ParityFn& f, int d) {
+    ParityFn r;
+    r.inc0 = __shfl_up(f.inc0, d);
+    r.inc1 = __shfl_up(f.inc1, d);
+    const int bits = __shfl_up(f.b0 | (f.b1 << 1), d);
+    r.b0 = bits & 1;
+    r.b1 = (bits >> 1) & 1;
+    return r;
+}
+
+#define BR_EPT 16
+__global__ __launch_bounds__(1024) void k_brightness_replay(const double* __restrict__ terms, long long n, float* out) {
+    __shared__ ParityFn s_wave[16];
+    __shared__ int s_stop[16];
+    __shared__ double s_excl[1024 / 64 * 64];     // inclusive totals (steps) per thread for the chosen start parity
+    __shared__ float s_sum;
+    __shared__ long long s_pos;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { s_sum = 0.f; s_pos = 0; }
+    __syncthreads();
+    for (;;) {
+        const float sum = s_sum;
+        const long long pos = s_pos;
+        if (pos >= n) break;
+        const unsigned sbits = __float_as_uint(sum);
+        const bool zero = sum == 0.f;
+        const int e = (int)((sbits >> 23) & 0xff) - 127;
+        const int binit = (int)(sbits & 1u);
+        const double u = ldexp(1.0, e - 23), invu = ldexp(1.0, 23 - e), eps = ldexp(1.0, e - 53), mid = 0.5 * u;
+        const double limit = (double)(0x800000u - (sbits & 0x7fffffu));     // steps until the binade ends
+
+        ParityFn f = pf_identity();
+        bool nonzero = false;
 #pragma unroll
-            for (int k = 0; k < 64; k++) {
-                const double tk = __hiloint2double(__builtin_amdgcn_readlane(hi, k), __builtin_amdgcn_readlane(lo, k));
-                sum = (float)__dadd_rn((double)sum, tk);
-            }
-        } else {
-            for (int k = 0; k < m; k++) {
-                const double tk = __hiloint2double(__shfl(hi, k), __shfl(lo, k));
-                sum = (float)__dadd_rn((double)sum, tk);
+        for (int j = 0; j < BR_EPT; j++) {
+            const long long i = pos + (long long)tid * BR_EPT + j;
+            if (i < n) {
+                const double t = terms[i];
+                if (zero) { nonzero |= (t != 0.0); continue; }
+                const double k = floor(t * invu);
+                const double diff = (t - k * u) - mid;            // exact: both products are exact, the differences are small
+                ParityFn g;
+                if (fabs(diff) <= eps) {                          // the double sum lands on the midpoint: ties-to-even
+                    const int kp = (int)((long long)k & 1);
+                    g.inc0 = k + (kp ? 1.0 : 0.0);
+                    g.inc1 = k + (kp ? 0.0 : 1.0);
+                    g.b0 = 0; g.b1 = 0;
+                } else {
+                    const double r = k + (diff > 0.0 ? 1.0 : 0.0);
+                    const int rp = (int)((long long)r & 1);
+                    g.inc0 = r; g.inc1 = r;
+                    g.b0 = rp; g.b1 = rp ^ 1;
+                }
+                f = pf_compose(f, g);
             }
         }
+        // inclusive scan of the per-thread functions: within the wave, then across the 16 waves
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const ParityFn prev = pf_shfl_up(f, d);
+            if (lane >= d) f = pf_compose(prev, f);
+        }
+        if (lane == 63) s_wave[wv] = f;
+        __syncthreads();
+        ParityFn pre = pf_identity();
+        for (int w2 = 0; w2 < wv; w2++) pre = pf_compose(pre, s_wave[w2]);
+        f = pf_compose(pre, f);
+        const double tot = binit ? f.inc1 : f.inc0;              // steps added by everything up to and including this thread
+        const bool stop = zero ? nonzero : (tot >= limit);
+        const unsigned long long bal = __ballot(stop);
+        if (lane == 0) s_stop[wv] = bal ? (wv * 64 + (int)__builtin_ctzll(bal)) : 1 << 30;
+        s_excl[tid] = tot;
+        __syncthreads();
+        if (tid == 0) {
+            int first = 1 << 30;
+            for (int w2 = 0; w2 < 16; w2++) first = min(first, s_stop[w2]);
+            float ns = sum;
+            long long np;
+            if (first >= 1024) {                                  // the whole chunk stays inside the binade
+                if (!zero) ns = __uint_as_float(sbits + (unsigned)(long long)s_excl[1023]);
+                np = pos + 1024LL * BR_EPT;
+            } else {
+                if (!zero && first > 0) ns = __uint_as_float(sbits + (unsigned)(long long)s_excl[first - 1]);
+                np = pos + (long long)first * BR_EPT;
+                // the thread's own terms hold the one that leaves the binade (or the first non-zero term): literal sequence
+                for (int j = 0; j < BR_EPT && np < n; j++, np++) ns = (float)__dadd_rn((double)ns, terms[np]);
+            }
+            s_sum = ns;
+            s_pos = np < n ? np : n;
+        }
+        __syncthreads();
     }
-    if (lane == 0) *out = sum;
+    if (tid == 0) *out = s_sum;
 }
 
 int launch_brightness(const View& v, float* host_result, hipStream_t s) {
@@ -323,7 +417,7 @@ int launch_brightness(const View& v, float* host_result, hipStream_t s) {
     if (v.c == 1) hipLaunchKernelGGL((k_brightness_terms<1>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
     else if (v.c == 3) hipLaunchKernelGGL((k_brightness_terms<3>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
     else hipLaunchKernelGGL((k_brightness_terms<4>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
-    hipLaunchKernelGGL(k_brightness_serial, dim3(1), dim3(64), 0, s, (const double*)terms, n, (float*)out);
+    hipLaunchKernelGGL(k_brightness_replay, dim3(1), dim3(1024), 0, s, (const double*)terms, n, (float*)out);
     hipError_t e = hipGetLastError();
     float sum = 0.f;
     if (e == hipSuccess) e = hipMemcpyAsync(&sum, out, sizeof(float), hipMemcpyDeviceToHost, s);

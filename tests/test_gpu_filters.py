@@ -187,3 +187,21 @@ def test_gray2bgr(gpu):
     assert im.gray2bgr() == 0
     assert np.array_equal(im.numpy(), orc.gray2bgr(arr))
     im.release()
+
+
+def test_brightness_adversarial_exact(gpu):
+    """Inputs that stress the regime replay: exact ties (gray pixels: sqrt term is integral), a long zero prefix,
+    all black, saturated white, 1-pixel frames, and a 4K frame whose sum passes 2^30."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    gray = rng.integers(0, 256, size=(1080, 1920, 1), dtype=np.uint8).repeat(3, axis=2)
+    zero_prefix = np.zeros((700, 900, 3), np.uint8); zero_prefix[:, 600:] = rng.integers(0, 256, size=(700, 300, 3), dtype=np.uint8)
+    cases = [gray, gray[:, :, :1], zero_prefix, np.zeros((300, 300, 4), np.uint8), np.full((1080, 1920, 3), 255, np.uint8),
+             np.full((1, 1, 3), 7, np.uint8), np.full((1, 5000, 1), 255, np.uint8), np.full((3000, 1, 1), 3, np.uint8),
+             rng.integers(0, 256, size=(2160, 3840, 4), dtype=np.uint8),
+             np.full((2160, 3840, 1), 254, np.uint8), (np.arange(1500 * 1500) % 2 * 255).astype(np.uint8).reshape(1500, 1500, 1)]
+    for arr in cases:
+        im = gpu.Image(arr)
+        got = im.calc_perceived_brightness()
+        im.release()
+        want = orc.brightness(arr)
+        assert np.float32(got) == np.float32(want), (arr.shape, got, want)

@@ -1,0 +1,151 @@
+"""Size-independent properties at BASELINE's full frame sizes (and a larger batch than the oracle could check frame by
+frame in seconds): round trips, idempotence, composition, and batch == single-call consistency via a checksum of
+checksums.  Everything goes through the C ABI."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import noise_image, smooth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def apply(imp, arr, *filters):
+    im = imp.Image(arr)
+    for f in filters:
+        assert im.filter(f, 1) == 0, f
+    out = im.numpy()
+    im.release()
+    return out
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_geometry_round_trips_1080p(gpu, c):
+    a = noise_image(1080, 1920, c, 300 + c)
+    assert np.array_equal(apply(gpu, a, "rotate=90", "rotate=270"), a)
+    assert np.array_equal(apply(gpu, a, "rotate=270", "rotate=90"), a)
+    assert np.array_equal(apply(gpu, a, "rotate=180", "rotate=180"), a)
+    assert np.array_equal(apply(gpu, a, "rotate=90", "rotate=90"), apply(gpu, a, "rotate=180"))
+    assert np.array_equal(apply(gpu, a, "rotate=90", "rotate=90", "rotate=90", "rotate=90"), a)
+    assert np.array_equal(apply(gpu, a, "flip=10", "flip=10"), a)
+    assert np.array_equal(apply(gpu, a, "flip=01", "flip=01"), a)
+    assert np.array_equal(apply(gpu, a, "flip=10", "flip=01"), apply(gpu, a, "flip=11"))
+    assert np.array_equal(apply(gpu, a, "flip=11"), apply(gpu, a, "rotate=180"))
+
+
+@pytest.mark.parametrize("shape", [(1080, 1920), (2160, 3840)])
+def test_identity_resizes_full_size(gpu, shape):
+    h, w = shape
+    a = noise_image(h, w, 4, 310)
+    for interp in range(5):
+        im = gpu.Image(a)
+        assert im.cv_resize(w, h, interp) == 0
+        assert np.array_equal(im.numpy(), a), interp       # scale 1: every mode collapses to a copy
+        im.release()
+
+
+def test_crop_composition_and_fold(gpu):
+    a = noise_image(1080, 1920, 4, 311)
+    im = gpu.Image(a)
+    assert im.crop("1000px,800px,100px,50px") == 0 and im.crop("300px,200px,10px,20px") == 0
+    one = gpu.Image(a)
+    assert one.crop("300px,200px,110px,70px") == 0
+    assert np.array_equal(im.numpy(), one.numpy())
+    im.release(); one.release()
+    # crop folded into the resize's source window (run_ops) == crop copy followed by resize
+    cfg = gpu.Config()
+    x = gpu.Image(a)
+    assert gpu.run_ops(x, cfg, crop="16,10", resize="224,0")[0] == 0
+    y = gpu.Image(a)
+    assert y.crop("16,10") == 0 and y.resize("224,0", cfg) == 0
+    assert np.array_equal(x.numpy(), y.numpy())
+    x.release(); y.release()
+
+
+def test_watermark_noop_and_opaque_cases(gpu):
+    a = noise_image(540, 960, 4, 312)
+    ov = noise_image(64, 256, 4, 313)
+    ov0 = ov.copy(); ov0[:, :, 3] = 0                      # fully transparent overlay: colours unchanged where dst alpha > 0
+    cfg = gpu.Config(); cfg.prepare_watermark(ov0, "r", "b", 16, 16, 100)
+    im = gpu.Image(a); assert im.watermark(cfg) == 0
+    rc, want = orc.watermark(a, ov0, "r", "b", 16, 16, 100)
+    assert np.array_equal(im.numpy(), want)
+    im.release(); cfg.release()
+    ov1 = ov.copy(); ov1[:, :, 3] = 255                    # opaque overlay at opacity 100 replaces the rectangle
+    a1 = a.copy(); a1[:, :, 3] = 255
+    cfg = gpu.Config(); cfg.prepare_watermark(ov1, "l", "t", 0, 0, 100)
+    im = gpu.Image(a1); assert im.watermark(cfg) == 0
+    out = im.numpy()
+    assert np.array_equal(out[:64, :256], ov1) and np.array_equal(out[64:], a1[64:]) and np.array_equal(out[:, 256:], a1[:, 256:])
+    im.release(); cfg.release()
+
+
+def test_pointwise_fusion_equals_sequential(gpu):
+    """run_ops fuses runs of pointwise filters into one launch; results must equal one launch per filter."""
+    a = smooth_image(1080, 1920, 4)
+    filters = ["modulate=20,130,90", "colorize=203040,0.3", "gamma=1.4", "contrast=1.2", "rainbow=mid"]
+    cfg = gpu.Config(allow_experiments=True)
+    fused = gpu.Image(a)
+    assert gpu.run_ops(fused, cfg, filters=filters)[0] == 0
+    seq = apply(gpu, a, *filters)
+    assert np.array_equal(fused.numpy(), seq)
+    fused.release()
+
+
+def test_flatten_idempotent_and_opaque(gpu):
+    a = noise_image(1080, 1920, 4, 314)
+    im = gpu.Image(a)
+    assert im.blend_with_paper() == 0
+    once = im.numpy()
+    assert (once[:, :, 3] == 255).all()
+    assert im.blend_with_paper() == 0
+    assert np.array_equal(im.numpy(), once)                # alpha 255: prod = 1.0f, diff = 0 -> unchanged
+    im.release()
+
+
+@pytest.mark.parametrize("interp,name", [(2, "cubic"), (3, "area")])
+def test_batch_of_1080p_frames_matches_single_calls(gpu, interp, name):
+    """BASELINE cfg2 shape: a batch launch must produce, frame for frame, the bytes of the single-frame operator
+    (which the parity tests pin against the oracle).  Checked through a checksum of per-frame checksums."""
+    n = 96
+    frames = np.stack([noise_image(1080, 1920, 4, 400 + (i % 6)) for i in range(6)])
+    src = gpu.Image(np.concatenate([frames[i % 6] for i in range(n)], axis=0))
+    dst = gpu.Image(np.zeros((n * 224, 224, 4), np.uint8))
+    gpu.batch_cv_resize(src.device_ptr, 1080 * 1920 * 4, 1920, 1080, 1920 * 4, dst.device_ptr, 224 * 224 * 4, 224, 224,
+                        224 * 4, 4, n, interp)
+    out = dst.numpy().reshape(n, 224, 224, 4)
+    singles = []
+    for i in range(6):
+        im = gpu.Image(frames[i])
+        assert im.cv_resize(224, 224, interp) == 0
+        singles.append(im.numpy())
+        im.release()
+        assert np.array_equal(singles[i], orc.cv_resize(frames[i], 224, 224, interp))     # and the oracle, on the 6 distinct frames
+    h_batch = hashlib.sha256(b"".join(hashlib.sha256(out[i].tobytes()).digest() for i in range(n))).hexdigest()
+    h_single = hashlib.sha256(b"".join(hashlib.sha256(singles[i % 6].tobytes()).digest() for i in range(n))).hexdigest()
+    assert h_batch == h_single
+    src.release(); dst.release()
+
+
+def test_tiny_and_degenerate_frames(gpu):
+    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (3, 5)]:
+        for c in (1, 3, 4):
+            a = noise_image(shape[0], shape[1], c, 320)
+            for interp in range(5):
+                for (dw, dh) in [(1, 1), (shape[1], shape[0]), (5, 4)]:
+                    if interp == 3 and (dw > shape[1] or dh > shape[0]):
+                        continue
+                    im = gpu.Image(a)
+                    assert im.cv_resize(dw, dh, interp) == 0
+                    assert np.array_equal(im.numpy(), orc.cv_resize(a, dw, dh, interp)), (shape, c, interp, dw, dh)
+                    im.release()
+            if c >= 3:
+                for f in ("rotate=90", "flip=11", "gamma=2", "modulate=10,110,90", "blur=1.5"):
+                    rc, want = orc.filter(a, f)
+                    im = gpu.Image(a)
+                    assert im.filter(f, 1) == rc == 0
+                    assert np.array_equal(im.numpy(), want), (shape, c, f)
+                    im.release()
