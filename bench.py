@@ -210,6 +210,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    lib_path = os.path.join(ROOT, "ngx_http_imgproc_amd", "libimpgpu.so")
+    if not os.path.exists(lib_path) and local_rank == 0:     # normally built by __graft_entry__.build(); hipcc is on the box
+        import subprocess
+
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "ngx_http_imgproc_amd", "build.py")])
+        subprocess.call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    if world > 1:
+        dist.barrier()
     import ngx_http_imgproc_amd as imp
 
     imp.env_start(local_rank)

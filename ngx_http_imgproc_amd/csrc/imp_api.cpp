@@ -77,8 +77,17 @@ int apply_plan(Work& wk, const FilterPlan& plan) {
             wk.adopt(out);
             return IMP_OK;
         }
-        case FC_BLUR:
+        case FC_BLUR: {
+            if (wk.v.c == 4) {      // one-pass fused kernel into a fresh frame; falls through when it does not apply
+                impgpu_image* out = nullptr;
+                if (int rc = image_new(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
+                int rc = launch_gaussian_fused(one_frame(wk.v, out), plan.sigma, env_stream());
+                if (rc == IMP_OK) { wk.adopt(out); return IMP_OK; }
+                image_delete(out);
+                if (rc != IMP_ERROR_UNSUPPORTED) return rc;
+            }
             return launch_gaussian(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.c, wk.v.step, 1, plan.sigma, env_stream());
+        }
         default:
             return IMP_OK;
     }

@@ -102,6 +102,155 @@ __global__ __launch_bounds__(256) void k_blur_col_any(const int* __restrict__ tm
     dst[(long long)blockIdx.y * stride + (size_t)y * step + e] = (uint8_t)out;
 }
 
+// ------------------------------------------------------------------ fused BGRA Gaussian (radius <= 16)
+// One kernel, one read and one write of the frame: a 256-thread block owns a 64 x TH tile of the
+// output.  (0) its (64+2r) x (TH+2r) source footprint goes to LDS (edge-replicated, coalesced dword
+// loads, 12 in flight per lane); (1) the row pass runs once per (footprint row, column) out of
+// LDS -- lane i reads dwords i..i+2r of its row, conflict free -- two taps per v_dot2_i32_i16 after a
+// v_perm_b32 pairs the channel bytes, and parks the four sums as u16 in an LDS plane (they fit: the
+// host checks 255 * sum(kx) <= 65535); (2) the column pass is SymmColumnVec_32s8u's float sequence
+// on (row[+k] + row[-k]) read 8 bytes per lane from the plane, then a coalesced dword store.  Runs
+// out of place (a tile's halo belongs to its neighbours), which also materialises a cropped view.
+typedef short bl_short2 __attribute__((ext_vector_type(2)));
+
+template <int TH>
+__global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
+                                                     uint8_t* __restrict__ dst, long long dstride, int dstep,
+                                                     const int* __restrict__ kxp, const float* __restrict__ kyf, int rx, int ry) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int SW = 64 + 2 * rx + 2, SH = TH + 2 * ry;         // +2: the padded last tap pair reads one dword further
+    const int npair = rx + 1;                                 // 2*rx+1 taps -> rx+1 pairs, last one (tap, 0)
+    uint32_t* s_kx = (uint32_t*)smem;                         // packed (k[2j], k[2j+1]) as 2 x i16
+    float* s_ky = (float*)(s_kx + ((npair + 3) & ~3));
+    uint32_t* s_src = (uint32_t*)(s_ky + ((ry + 1 + 3) & ~3));
+    uint2* s_pl = (uint2*)(s_src + ((SW * SH + 3) & ~3));     // [SH][64] x 4 x u16
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * TH;
+    const uint8_t* S = src + (long long)blockIdx.z * sstride;
+    for (int i = tid; i < npair; i += 256) s_kx[i] = (uint32_t)kxp[i];
+    for (int i = tid; i <= ry; i += 256) s_ky[i] = kyf[i];
+
+    // (0) footprint -> LDS
+    {
+        int sxc[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int sx = tx0 - rx + lane + 64 * q;
+            sxc[q] = (sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx)) * 4;
+        }
+        for (int r0 = wv; r0 < SH; r0 += 16) {
+            uint32_t v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + 4 * u;
+                const int sy = ty0 - ry + r;
+                const uint8_t* row = S + (size_t)(sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy)) * sstep;
+#pragma unroll
+                for (int q = 0; q < 3; q++) v[u][q] = (r < SH && lane + 64 * q < SW) ? *(const uint32_t*)(row + sxc[q]) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + 4 * u;
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    if (r < SH && lane + 64 * q < SW) s_src[r * SW + lane + 64 * q] = v[u][q];
+            }
+        }
+    }
+    __syncthreads();
+
+    // (1) row pass -> u16 plane
+    for (int r = wv; r < SH; r += 4) {
+        const uint32_t* row = s_src + r * SW + lane;
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int j = 0; j < npair; j++) {
+            const uint32_t p0 = row[2 * j], p1 = row[2 * j + 1];
+            bl_short2 kk;
+            const uint32_t kw = s_kx[j];
+            __builtin_memcpy(&kk, &kw, 4);
+            bl_short2 c;
+            uint32_t pr;
+            pr = __builtin_amdgcn_perm(p1, p0, 0x0c040c00u); __builtin_memcpy(&c, &pr, 4); a0 = __builtin_amdgcn_sdot2(c, kk, a0, false);
+            pr = __builtin_amdgcn_perm(p1, p0, 0x0c050c01u); __builtin_memcpy(&c, &pr, 4); a1 = __builtin_amdgcn_sdot2(c, kk, a1, false);
+            pr = __builtin_amdgcn_perm(p1, p0, 0x0c060c02u); __builtin_memcpy(&c, &pr, 4); a2 = __builtin_amdgcn_sdot2(c, kk, a2, false);
+            pr = __builtin_amdgcn_perm(p1, p0, 0x0c070c03u); __builtin_memcpy(&c, &pr, 4); a3 = __builtin_amdgcn_sdot2(c, kk, a3, false);
+        }
+        s_pl[r * 64 + lane] = make_uint2((uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16));
+    }
+    __syncthreads();
+
+    // (2) column pass
+    const int x = tx0 + lane;
+    if (x < w) {
+        for (int yl = wv; yl < TH; yl += 4) {
+            const int y = ty0 + yl;
+            if (y >= h) break;
+            const uint2* col = s_pl + (yl + ry) * 64 + lane;
+            const uint2 c = col[0];
+            const float f0 = s_ky[0];
+            float s0 = __fadd_rn(__fmul_rn((float)(c.x & 0xffff), f0), 0.f), s1 = __fadd_rn(__fmul_rn((float)(c.x >> 16), f0), 0.f);
+            float s2 = __fadd_rn(__fmul_rn((float)(c.y & 0xffff), f0), 0.f), s3 = __fadd_rn(__fmul_rn((float)(c.y >> 16), f0), 0.f);
+            for (int k = 1; k <= ry; k++) {
+                const uint2 a = col[k * 64], b = col[-k * 64];
+                const float f = s_ky[k];
+                s0 = __fadd_rn(s0, __fmul_rn((float)((a.x & 0xffff) + (b.x & 0xffff)), f));
+                s1 = __fadd_rn(s1, __fmul_rn((float)((a.x >> 16) + (b.x >> 16)), f));
+                s2 = __fadd_rn(s2, __fmul_rn((float)((a.y & 0xffff) + (b.y & 0xffff)), f));
+                s3 = __fadd_rn(s3, __fmul_rn((float)((a.y >> 16) + (b.y >> 16)), f));
+            }
+            const uint32_t o = (uint32_t)sat8(__float2int_rn(s0)) | ((uint32_t)sat8(__float2int_rn(s1)) << 8) |
+                               ((uint32_t)sat8(__float2int_rn(s2)) << 16) | ((uint32_t)sat8(__float2int_rn(s3)) << 24);
+            *(uint32_t*)(dst + (long long)blockIdx.z * dstride + (size_t)y * dstep + (size_t)x * 4) = o;
+        }
+    }
+}
+
+// src view -> dst (same size, BGRA, separate buffers).  IMP_ERROR_UNSUPPORTED when the fused form does not apply
+// (other channel counts, radius > 16, fixed-point taps summing above 257, 1-pixel axes): callers fall back to
+// launch_gaussian.  sigma must give ksize > 1.
+int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
+    const View& v = f.v;
+    if (v.c != 4 || f.count <= 0 || f.count > 65535 || f.dw != v.w || f.dh != v.h || v.w < 2 || v.h < 2) return IMP_ERROR_UNSUPPORTED;
+    if (f.src == f.dst) return IMP_ERROR_UNSUPPORTED;
+    if (((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)v.step | (uintptr_t)f.dstep | (uintptr_t)f.src_stride | (uintptr_t)f.dst_stride) & 3)
+        return IMP_ERROR_UNSUPPORTED;
+    const int ks = gaussian_ksize(sigma);
+    const int r = ks / 2;
+    if (ks <= 1 || r > 16) return IMP_ERROR_UNSUPPORTED;
+    std::vector<int> ik;
+    gaussian_kernel_fixed(ks, sigma, &ik);
+    long long sum = 0;
+    for (int k : ik) sum += k;
+    if (sum > 257) return IMP_ERROR_UNSUPPORTED;              // row sums must fit 16 bits
+    std::vector<int> blob;
+    for (int j = 0; j <= r; j++) {                           // pairs (k[2j], k[2j+1]); the pair past the end is (k[2r], 0)
+        const int lo = ik[2 * j], hi = (2 * j + 1 < ks) ? ik[2 * j + 1] : 0;
+        blob.push_back((lo & 0xffff) | (hi << 16));
+    }
+    while (blob.size() % 4) blob.push_back(0);
+    const size_t off_f = blob.size();
+    for (int k = 0; k <= r; k++) {
+        float fk = (float)(ik[r + k] * (1. / 65536));
+        int bits;
+        std::memcpy(&bits, &fk, 4);
+        blob.push_back(bits);
+    }
+    void* dev_k = nullptr;
+    if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
+    const int TH = 32;
+    const int SW = 64 + 2 * r + 2, SH = TH + 2 * r;
+    const size_t lds = (size_t)(((r + 1 + 3) & ~3) + ((r + 1 + 3) & ~3) + ((SW * SH + 3) & ~3)) * 4 + (size_t)SH * 64 * 8;
+    const dim3 grid((v.w + 63) / 64, (v.h + TH - 1) / TH, f.count), block(256);
+    if (grid.y > 65535) { dev_free(dev_k); return IMP_ERROR_UNSUPPORTED; }
+    hipLaunchKernelGGL((k_blur_fused4<32>), grid, block, lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
+                       (const int*)dev_k, (const float*)((const int*)dev_k + off_f), r, r);
+    hipError_t e = hipGetLastError();
+    if (s != env_stream()) (void)hipStreamSynchronize(s);
+    dev_free(dev_k);
+    if (e != hipSuccess) { set_error("k_blur_fused4", e); return IMP_ERROR_DEVICE; }
+    return IMP_OK;
+}
+
 int launch_gaussian(uint8_t* d, long long stride, int w, int h, int c, int step, int count, double sigma, hipStream_t s) {
     if (count <= 0 || !(sigma > 0)) return IMP_OK;
     int kxs = gaussian_ksize(sigma), kys = kxs;

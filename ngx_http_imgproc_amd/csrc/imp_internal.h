@@ -139,6 +139,9 @@ int launch_ascii(uint8_t* d, int w, int h, int c, int step, const uint8_t* table
 int launch_gaussian(uint8_t* d, long long stride, int w, int h, int c, int step, int count,
                     double sigma, hipStream_t s);
 
+// fused single-pass BGRA Gaussian, out of place; IMP_ERROR_UNSUPPORTED when it does not apply
+int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s);
+
 // Watermark placement (bridge.c:254-274 + cvSetImageROI clipping). Returns IMP_* code.
 int watermark_rect(int basew, int baseh, int overw, int overh, const impgpu_config* cfg,
                    int* rx, int* ry, int* maxcol, int* maxrow);

@@ -49,6 +49,25 @@ __device__ __forceinline__ short2_t as_short2(uint32_t v) {
     return r;
 }
 
+// Source frames are read once per launch and are far larger than L2 / Infinity Cache: load them
+// with the non-temporal hint so they do not displace the tables and the neighbours' lines
+// (measured +5.7 % on the cubic headline).  The hardware takes any 4-byte aligned address.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2), aligned(4)));
+template <int N>
+__device__ __forceinline__ void load_stream(uint32_t* dst, const uint8_t* p) {
+    static_assert(N % 2 == 0, "even dword counts only");
+#pragma unroll
+    for (int i = 0; i + 4 <= N; i += 4) {
+        const u32x4_t q = __builtin_nontemporal_load((const u32x4_t*)(p + i * 4));
+        dst[i] = q.x; dst[i + 1] = q.y; dst[i + 2] = q.z; dst[i + 3] = q.w;
+    }
+    if (N % 4) {
+        const u32x2_t q = __builtin_nontemporal_load((const u32x2_t*)(p + (N - 2) * 4));
+        dst[N - 2] = q.x; dst[N - 1] = q.y;
+    }
+}
+
 // ------------------------------------------------------------------ LINEAR / CUBIC / LANCZOS4
 enum { M_LINEAR = 0, M_CUBIC = 1, M_LANCZOS = 2 };
 
@@ -77,7 +96,7 @@ __global__ __launch_bounds__(256) void k_resize_taps(RArgs a, const int* __restr
         for (int r = 0; r < KS; r++) {
             const int sy = clampi(sy0 + r, 0, a.sh - 1);
             const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)sx0 * 4;
-            __builtin_memcpy(px[r], __builtin_assume_aligned(row, 4), KS * 4);
+            load_stream<KS>(px[r], row);
         }
 #pragma unroll
         for (int r = 0; r < KS; r++)
@@ -430,6 +449,8 @@ __global__ __launch_bounds__(256) void k_resize_area_v4(RArgs a, AreaDev t, int 
         const int sy = min(ys + j, a.sh - 1);
         const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 4;
         uint32_t px[NV * 4];
+        // plain (temporal) loads: neighbouring lanes' runs and the next destination row's first source
+        // row overlap this one's, and those re-reads must hit in cache (non-temporal cost -37 % here)
         __builtin_memcpy(px, __builtin_assume_aligned(row, 4), NV * 16);
         float2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
 #pragma unroll
@@ -615,10 +636,11 @@ __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount
         for (int r = 0; r < 8; r++) {
             const int ly = ty + 8 * r, ry = ry0 + ly;
             if (ry < rh && rx + 1 < rw) {
-                const uint4 t0 = *(const uint4*)(S + (size_t)(2 * ry) * a.sstep + (size_t)rx * 8);
-                const uint4 t1 = *(const uint4*)(S + (size_t)(2 * ry + 1) * a.sstep + (size_t)rx * 8);
-                tile[ly][lx] = box2x2(t0.x, t0.y, t1.x, t1.y);
-                tile[ly][lx + 1] = box2x2(t0.z, t0.w, t1.z, t1.w);
+                uint32_t t0[4], t1[4];
+                load_stream<4>(t0, S + (size_t)(2 * ry) * a.sstep + (size_t)rx * 8);
+                load_stream<4>(t1, S + (size_t)(2 * ry + 1) * a.sstep + (size_t)rx * 8);
+                tile[ly][lx] = box2x2(t0[0], t0[1], t1[0], t1[1]);
+                tile[ly][lx + 1] = box2x2(t0[2], t0[3], t1[2], t1[3]);
             } else if (ry < rh && rx < rw) {
                 const uint2 t0 = *(const uint2*)(S + (size_t)(2 * ry) * a.sstep + (size_t)rx * 8);
                 const uint2 t1 = *(const uint2*)(S + (size_t)(2 * ry + 1) * a.sstep + (size_t)rx * 8);

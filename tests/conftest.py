@@ -12,6 +12,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the library and the oracle are normally built by __graft_entry__.build(); build them here if the .so files
+    # did not travel (hipcc cross-compiles without a GPU, gcc builds the oracle)
+    import subprocess
+
+    if not os.path.exists(os.path.join(ROOT, "ngx_http_imgproc_amd", "libimpgpu.so")):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "ngx_http_imgproc_amd", "build.py")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
 
 
 @pytest.fixture(scope="session")
