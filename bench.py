@@ -264,7 +264,7 @@ def main():
         step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -275,7 +275,7 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream, whole timed region
     elapsed = max(wall, dev_ms / 1e3)

@@ -37,6 +37,20 @@ with torch.cuda.stream(stream):
         for _ in range(reps):
             imp.batch_cv_resize(src.data_ptr(), 1080 * 1920 * 4, 1920, 1080, 1920 * 4, dst.data_ptr(), 224 * 224 * 4,
                                 224, 224, 224 * 4, 4, batch, interp, stream=stream.cuda_stream)
+    # cfg3 chain (fused 2x2 box + rotate, then watermark) and cfg4 Lanczos on smaller batches
+    ov = torch.randint(0, 256, (64, 256, 4), dtype=torch.uint8).numpy()
+    cfg = imp.Config()
+    cfg.prepare_watermark(ov, "r", "b", 16, 16, 60)
+    dst3 = torch.zeros((batch, 960, 540, 4), dtype=torch.uint8, device="cuda")
+    for _ in range(reps):
+        imp.batch_resize_rotate_watermark(src.data_ptr(), 1080 * 1920 * 4, 1920, 1080, 1920 * 4, dst3.data_ptr(), 960 * 540 * 4,
+                                          540 * 4, 960, 540, 90, cfg, 4, batch, stream=stream.cuda_stream)
+    n4 = max(1, batch // 16)
+    src4 = src.view(-1)[: n4 * 2160 * 3840 * 4]
+    dst4 = torch.zeros((n4, 1080, 1920, 4), dtype=torch.uint8, device="cuda")
+    for _ in range(reps):
+        imp.batch_cv_resize(src4.data_ptr(), 2160 * 3840 * 4, 3840, 2160, 3840 * 4, dst4.data_ptr(), 1080 * 1920 * 4,
+                            1920, 1080, 1920 * 4, 4, n4, imp.INTER_LANCZOS4, stream=stream.cuda_stream)
 torch.cuda.synchronize()
 print("probe done: batch", batch, "reps", reps)
 imp.env_destroy()
