@@ -609,9 +609,11 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
 // ------------------------------------------------------------------ fused AREA 2x2 + rotate 90/270 (BGRA)
 // cfg3's resize=960,540 followed by filter-rotate=90: cvResize(AREA) with both scales exactly 2 is
 // (a+b+c+d+2)>>2 per channel, and the rotation (cvTranspose + cvFlip, filters.c:116-119) is a pure
-// permutation, so the two are one pass: a block averages a 32x32 tile of the halved image out of two
-// 8-byte loads per pixel (256 contiguous bytes per half-wave), parks it in a 33-dword-pitch LDS tile
-// and writes it transposed along destination rows.  The half-size intermediate never exists in HBM.
+// permutation, so the two are one pass: a block averages a TX x TY tile of the halved image (two 16-byte
+// non-temporal loads per two outputs, all issued before the first use), parks it in an odd-pitch LDS
+// tile and writes it transposed, 16 bytes per lane along destination rows.  The half-size intermediate
+// never exists in HBM.  Measured on cfg3: reads alone run at 6.8 TB/s; the 2.1 GB of scattered stores
+// add ~1.1 ms whatever their width, cache policy or run length (128x32 tiles are the best of four shapes).
 __device__ __forceinline__ uint32_t box2x2(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     uint32_t o = 0;
 #pragma unroll
@@ -622,46 +624,75 @@ __device__ __forceinline__ uint32_t box2x2(uint32_t a, uint32_t b, uint32_t c, u
     return o;
 }
 
+template <int TX, int TY>      // tile of the halved image: TX columns x TY rows, TX * TY == 4096
 __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount, int rw, int rh) {
-    // 64 x 64 tile of the halved image; 65-dword pitch makes the transposed read bank-conflict free
-    __shared__ uint32_t tile[64][65];
+    __shared__ uint32_t tile[TY][TX + 1];                     // odd pitch: the transposed read is bank-conflict free
     const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
     uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride;
-    const int rx0 = blockIdx.x * 64, ry0 = blockIdx.y * 64;      // tile origin in the halved (pre-rotation) image
+    const int rx0 = blockIdx.x * TX, ry0 = blockIdx.y * TY;   // tile origin in the halved (pre-rotation) image
     const int tid = threadIdx.x;
-    {   // (1) each thread averages two neighbouring outputs per row from two 16-byte loads (512 B per half-wave)
-        const int lx = (tid & 31) * 2, ty = tid >> 5;
+    {   // (1) each thread averages two neighbouring outputs per row from two 16-byte loads.  Addresses are clamped into
+        // the frame so all loads issue back to back with no branch between them; only the LDS stores are predicated.
+        constexpr int LPR = TX / 2;                           // lanes per tile row
+        constexpr int RPP = 256 / LPR;                        // rows per pass
+        constexpr int NP = TY / RPP;                          // passes (8 for every shape)
+        const int lx = (tid % LPR) * 2, ty = tid / LPR;
         const int rx = rx0 + lx;
+        const int rxc = min(rx, rw - 2);                      // launcher guarantees rw >= 2
+        uint32_t t0[NP][4], t1[NP][4];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int ly = ty + 8 * r, ry = ry0 + ly;
-            if (ry < rh && rx + 1 < rw) {
-                uint32_t t0[4], t1[4];
-                load_stream<4>(t0, S + (size_t)(2 * ry) * a.sstep + (size_t)rx * 8);
-                load_stream<4>(t1, S + (size_t)(2 * ry + 1) * a.sstep + (size_t)rx * 8);
-                tile[ly][lx] = box2x2(t0[0], t0[1], t1[0], t1[1]);
-                tile[ly][lx + 1] = box2x2(t0[2], t0[3], t1[2], t1[3]);
-            } else if (ry < rh && rx < rw) {
-                const uint2 t0 = *(const uint2*)(S + (size_t)(2 * ry) * a.sstep + (size_t)rx * 8);
-                const uint2 t1 = *(const uint2*)(S + (size_t)(2 * ry + 1) * a.sstep + (size_t)rx * 8);
-                tile[ly][lx] = box2x2(t0.x, t0.y, t1.x, t1.y);
+        for (int r = 0; r < NP; r++) {
+            const int ryc = min(ry0 + ty + RPP * r, rh - 1);
+            const uint8_t* p = S + (size_t)(2 * ryc) * a.sstep + (size_t)rxc * 8;
+            load_stream<4>(t0[r], p);
+            load_stream<4>(t1[r], p + a.sstep);
+        }
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+            const int ly = ty + RPP * r;
+            if (ry0 + ly < rh) {
+                if (rx + 1 < rw) {
+                    tile[ly][lx] = box2x2(t0[r][0], t0[r][1], t1[r][0], t1[r][1]);
+                    tile[ly][lx + 1] = box2x2(t0[r][2], t0[r][3], t1[r][2], t1[r][3]);
+                } else if (rx < rw) {                          // odd rw: the clamped window ends on this pixel
+                    tile[ly][lx] = box2x2(t0[r][2], t0[r][3], t1[r][2], t1[r][3]);
+                }
             }
         }
     }
     __syncthreads();
     // (2) destination: 90 -> R[i][j] = H[rh-1-j][i], 270 -> R[i][j] = H[j][rw-1-i]  (H = halved image; R is rh wide, rw tall).
-    // Lanes run along H's y, which is the destination's x: 256 contiguous bytes per wave store.
+    // A lane gathers FOUR consecutive destination pixels (four H rows of one H column) from the tile and stores them as
+    // one 16-byte vector: TY/4 lanes cover a TY*4-byte run of a destination row.
     {
-        const int lane = tid & 63, wv = tid >> 6;
-        const int ry = ry0 + lane;
+        constexpr int LPC = TY / 4;                           // lanes per H column
+        constexpr int CPP = 256 / LPC;                        // H columns per pass
+        constexpr int NP2 = TX / CPP;
+        const int q = tid % LPC, col = tid / LPC;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int l = wv + 4 * r;
+        for (int r = 0; r < NP2; r++) {
+            const int l = col + CPP * r;                       // H column inside the tile
             const int rx = rx0 + l;
-            if (rx < rw && ry < rh) {
-                const int dx = amount == 90 ? rh - 1 - ry : ry;
-                const int dy = amount == 90 ? rx : rw - 1 - rx;
-                *(uint32_t*)(D + (size_t)dy * a.dstep + (size_t)dx * 4) = tile[lane][l];
+            const int ryb = ry0 + 4 * q;                       // first of the four H rows
+            if (rx >= rw || ryb >= rh) continue;
+            uint32_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = tile[4 * q + j][l];
+            const int dy = amount == 90 ? rx : rw - 1 - rx;
+            uint8_t* drow = D + (size_t)dy * a.dstep;
+            if (ryb + 3 < rh) {
+                if (amount == 90) {     // dx = rh-1-ry descends: reverse the four
+                    const u32x4_t o = {v[3], v[2], v[1], v[0]};
+                    *(u32x4_t*)(drow + (size_t)(rh - 1 - (ryb + 3)) * 4) = o;
+                } else {
+                    const u32x4_t o = {v[0], v[1], v[2], v[3]};
+                    *(u32x4_t*)(drow + (size_t)ryb * 4) = o;
+                }
+            } else {
+                for (int j = 0; j < 4 && ryb + j < rh; j++) {
+                    const int dx = amount == 90 ? rh - 1 - (ryb + j) : ryb + j;
+                    *(uint32_t*)(drow + (size_t)dx * 4) = v[j];
+                }
             }
         }
     }
@@ -671,14 +702,21 @@ __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount
 // geometry is not the exact-2x BGRA case so the caller can fall back to resize + rotate.
 int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s) {
     const View& v = f.v;
+    static const int shape = std::getenv("IMPGPU_CHAIN_TILE") ? std::atoi(std::getenv("IMPGPU_CHAIN_TILE")) : 128;   // measured: 128x32 fastest (1 KB read runs)
     if (v.c != 4 || (amount != 90 && amount != 270) || (v.w & 1) || (v.h & 1)) return IMP_ERROR_UNSUPPORTED;
     const int rw = v.w / 2, rh = v.h / 2;
+    if (rw < 2 || rh < 1) return IMP_ERROR_UNSUPPORTED;
     if (f.dw != rh || f.dh != rw || f.count <= 0 || f.count > 65535) return IMP_ERROR_UNSUPPORTED;
     if (((uintptr_t)f.src | (uintptr_t)v.step | (uintptr_t)f.src_stride) & 15) return IMP_ERROR_UNSUPPORTED;   // 16-byte loads
     if (((uintptr_t)f.dst | (uintptr_t)f.dstep | (uintptr_t)f.dst_stride) & 3) return IMP_ERROR_UNSUPPORTED;
     RArgs a{f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
-    const dim3 grid((rw + 63) / 64, (rh + 63) / 64, f.count), block(256);
-    hipLaunchKernelGGL(k_area2x2_rotate_bgra, grid, block, 0, s, a, amount, rw, rh);
+    const dim3 block(256);
+    const int tx = shape, ty = 4096 / shape;
+    const dim3 grid((rw + tx - 1) / tx, (rh + ty - 1) / ty, f.count);
+    if (tx == 16) hipLaunchKernelGGL((k_area2x2_rotate_bgra<16, 256>), grid, block, 0, s, a, amount, rw, rh);
+    else if (tx == 32) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 128>), grid, block, 0, s, a, amount, rw, rh);
+    else if (tx == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 32>), grid, block, 0, s, a, amount, rw, rh);
+    else hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 64>), grid, block, 0, s, a, amount, rw, rh);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }
