@@ -291,6 +291,129 @@ __global__ __launch_bounds__(256) void k_resize_tiled(RArgs a, const int* __rest
     }
 }
 
+// ------------------------------------------------------------------ exact 2x decimation, register-rolling
+// When both scale factors are exactly 2 (4K -> 1080p, cfg4) the tap window of consecutive destination
+// rows advances by exactly two source rows.  A lane then owns one destination column and walks down a
+// strip of rows keeping the horizontal-pass results of its last KS source rows in a register ring: each
+// new destination row costs two horizontal passes (two wide non-temporal loads each) and one vertical
+// pass -- no LDS, no barriers, no halo recomputation except KS-2 rows at the top of a strip.  The ring
+// advances by two slots per row, so unrolling KS/2 rows makes every ring index a compile-time constant.
+// Weights still come from the per-geometry tables (nothing about their values is assumed); the host
+// only checks that the tap offsets are the arithmetic progressions 2*d + const.
+#define ROLL_STRIP 60      // destination rows per wave strip (a multiple of the ring period KS/2 = 1, 2, 4)
+
+// Measured alternatives that did NOT beat this form on cfg4 (0.96 ms / 64 frames): double-buffered and 4-deep
+// register prefetch of the windows (same time, fewer waves), and fetching each row segment once per wave into a
+// wave-private LDS row with ds_read_b64 windows (1.04-1.07 ms).  tools/valu_rate.hip explains the floor:
+// v_perm_b32 and v_dot2c_i32_i16 issue at half rate on gfx950 (3.8 cycles per wave-instruction against 2.3 for
+// v_mul_f32), so the 64 of them per destination pixel cost about as much as the HBM traffic of that pixel.
+template <int KS>
+__device__ __forceinline__ void hpass_row(const uint8_t* row, int sxv, const int* sxk, bool interior,
+                                          const short2_t* axp, int* h) {
+    uint32_t p[KS];
+    // temporal loads: the two 16-byte halves of a window, the neighbouring lanes' windows and the next wave's
+    // share these lines, so they must stay cached (with the non-temporal hint PMC showed every line fetched 1.5x)
+    __builtin_memcpy(p, __builtin_assume_aligned(row + sxv, 4), KS * 4);
+#pragma unroll
+    for (int k = 0; k < KS; k++) asm volatile("" : "+v"(p[k]));     // opaque: keeps the wide load (see k_resize_tiled)
+    if (!interior) {
+#pragma unroll
+        for (int k = 0; k < KS; k++) p[k] = *(const uint32_t*)(row + sxk[k]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < KS / 2; j++) {
+            const uint32_t pr = __builtin_amdgcn_perm(p[2 * j + 1], p[2 * j], 0x0c040c00u + (c << 16) + c);
+            acc = __builtin_amdgcn_sdot2(as_short2(pr), axp[j], acc, false);
+        }
+        h[c] = acc;
+    }
+}
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(256) void k_resize_2x_roll(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                        const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the four waves of a block take four neighbouring 64-column strips of the SAME rows: together they read
+    // 2 KB contiguous runs of each source row (DRAM page locality) and share the overlapping window columns in L1
+    const int dx = (blockIdx.x * 4 + wv) * 64 + lane;
+    const int dy0 = blockIdx.y * ROLL_STRIP;
+    if ((blockIdx.x * 4 + wv) * 64 >= a.dw) return;
+    const int dyn = min(ROLL_STRIP, a.dh - dy0);
+    const bool live = dx < a.dw;
+    const int dxc = live ? dx : a.dw - 1;                       // idle lanes shadow the last column (no stores)
+    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
+    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride;
+
+    short2_t axp[KS / 2];
+#pragma unroll
+    for (int j = 0; j < KS / 2; j++) { axp[j].x = xco[dxc * KS + 2 * j]; axp[j].y = xco[dxc * KS + 2 * j + 1]; }
+    const int sx0 = xofs[dxc] - (KS / 2 - 1);
+    const bool interior = sx0 >= 0 && sx0 + KS <= a.sw;
+    const int sxv = clampi(sx0, 0, a.sw - KS) * 4;
+    int sxk[KS];
+#pragma unroll
+    for (int k = 0; k < KS; k++) sxk[k] = clampi(sx0 + k, 0, a.sw - 1) * 4;
+    int by[KS];                                                 // identical for every destination row (host-checked)
+#pragma unroll
+    for (int k = 0; k < KS; k++) by[k] = yco[dy0 * KS + k];
+
+    // ring[(k + 2*i) % KS] holds the horizontal pass of source row (first tap row of destination row dy0+i) + k
+    int ring[KS][4];
+    const int sy_first = yofs[dy0] - (KS / 2 - 1);              // yofs[dy] = yofs[dy0] + 2*(dy - dy0), checked on the host
+#pragma unroll
+    for (int k = 0; k < KS - 2; k++)
+        hpass_row<KS>(S + (size_t)clampi(sy_first + k, 0, a.sh - 1) * a.sstep, sxv, sxk, interior, axp, ring[k]);
+
+    constexpr int UN = KS / 2;                                  // ring period: every ring index below is a constant
+    for (int i0 = 0; i0 < dyn; i0 += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int i = i0 + u;
+            if (i < dyn) {
+                const int dy = dy0 + i;
+                const int sy = sy_first + 2 * i;
+                hpass_row<KS>(S + (size_t)clampi(sy + KS - 2, 0, a.sh - 1) * a.sstep, sxv, sxk, interior, axp, ring[(KS - 2 + 2 * u) % KS]);
+                hpass_row<KS>(S + (size_t)clampi(sy + KS - 1, 0, a.sh - 1) * a.sstep, sxv, sxk, interior, axp, ring[(KS - 1 + 2 * u) % KS]);
+                int out[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    int hc[KS];
+#pragma unroll
+                    for (int k = 0; k < KS; k++) hc[k] = ring[(k + 2 * u) % KS][c];
+                    const int* b = by;
+                    if constexpr (MODE == M_LINEAR) {
+                        out[c] = (uint8_t)((((b[0] * (hc[0] >> 4)) >> 16) + ((b[1] * (hc[1] >> 4)) >> 16) + 2) >> 2);
+                    } else if constexpr (MODE == M_CUBIC) {
+                        if (dx * 4 + c < vec_end) {
+                            const float sc = 1.f / (2048.f * 2048.f);
+                            float s = __fmul_rn(__int2float_rn(hc[0]), __fmul_rn((float)b[0], sc));
+                            s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[1]), __fmul_rn((float)b[1], sc)));
+                            s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[2]), __fmul_rn((float)b[2], sc)));
+                            s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[3]), __fmul_rn((float)b[3], sc)));
+                            out[c] = sat_u8(__float2int_rn(s));
+                        } else {
+                            int v = __mul24(hc[0], b[0]) + __mul24(hc[1], b[1]) + __mul24(hc[2], b[2]) + __mul24(hc[3], b[3]);
+                            out[c] = shr_sat_u8(v + (1 << 21), 22);
+                        }
+                    } else {
+                        int v = 1 << 21;
+#pragma unroll
+                        for (int k = 0; k < KS; k++) v = __mul24(hc[k], b[k]) + v;
+                        out[c] = shr_sat_u8(v, 22);
+                    }
+                }
+                if (live)
+                    *(uint32_t*)(D + (size_t)dy * a.dstep + (size_t)dx * 4) =
+                        (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ NN
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_nn(RArgs a, double scale_x, double scale_y) {
@@ -475,6 +598,7 @@ struct TableSet {
     void* blob = nullptr;     // one device allocation
     const int *xofs = nullptr, *yofs = nullptr;
     const short *xco = nullptr, *yco = nullptr;
+    bool step2 = false;       // xofs[d] = xofs[0] + 2d and yofs[d] = yofs[0] + 2d: k_resize_2x_roll applies
     AreaDev area{};
 };
 using Key = std::tuple<int, int, int, int, int>;
@@ -529,6 +653,11 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         build_tap_axis(sw, dw, scale_x, interp, true, &tx);
         build_tap_axis(sh, dh, scale_y, interp, false, &ty);
         o[0] = put(blob, tx.ofs); o[1] = put(blob, tx.coef); o[2] = put(blob, ty.ofs); o[3] = put(blob, ty.coef);
+        ts.step2 = true;
+        for (int d = 1; d < dw && ts.step2; d++) ts.step2 = tx.ofs[d] == tx.ofs[0] + 2 * d;
+        for (int d = 1; d < dh && ts.step2; d++) ts.step2 = ty.ofs[d] == ty.ofs[0] + 2 * d;
+        for (int d = 1; d < dh && ts.step2; d++)          // and one set of row weights (true when the scale is exactly 2)
+            for (int k = 0; k < ty.ksize; k++) ts.step2 = ts.step2 && ty.coef[(size_t)d * ty.ksize + k] == ty.coef[k];
     }
     uint8_t* dev = nullptr;
     IMP_HIP(hipMalloc((void**)&dev, blob.size()));
@@ -579,7 +708,18 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
         TableSet ts;
         if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, &ts)) return rc;
         // both scales <= 2: neighbouring outputs share taps -> LDS-tiled separable kernel (BGRA)
-        if (CN == 4 && scale_x <= 2.0 && scale_y <= 2.0 && a.sw >= 8) {
+        static const bool no_roll = std::getenv("IMPGPU_NO_ROLL") != nullptr;
+        if (CN == 4 && ts.step2 && a.sw >= 8 && !no_roll) {
+            // exact 2x decimation: register-rolling kernel, one wave per 64-column x ROLL_STRIP-row strip
+            const int nstrips = (a.dh + ROLL_STRIP - 1) / ROLL_STRIP;
+            const dim3 rgrid((a.dw + 255) / 256, nstrips, (unsigned)count);
+            if (interp == IMP_INTER_LINEAR)
+                hipLaunchKernelGGL((k_resize_2x_roll<2, M_LINEAR>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
+            else if (interp == IMP_INTER_CUBIC)
+                hipLaunchKernelGGL((k_resize_2x_roll<4, M_CUBIC>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, (a.dw * 4) & ~7);
+            else
+                hipLaunchKernelGGL((k_resize_2x_roll<8, M_LANCZOS>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
+        } else if (CN == 4 && scale_x <= 2.0 && scale_y <= 2.0 && a.sw >= 8) {
             static const int th = std::getenv("IMPGPU_TILE_TH") ? std::atoi(std::getenv("IMPGPU_TILE_TH")) : 8;
             const int ntx = (a.dw + TL_TW - 1) / TL_TW, nty = (a.dh + th - 1) / th;
             const int per = (ntx * nty + 7) / 8;
