@@ -593,6 +593,49 @@ __global__ __launch_bounds__(256) void k_resize_area_v4(RArgs a, AreaDev t, int 
                     ((uint32_t)sat_u8(__float2int_rn(s23.x)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s23.y)) << 24);
 }
 
+// The same for 3-channel BGR frames -- what cvDecodeImage hands the reference for every JPEG, and the mode its
+// Resize() picks for every shrink.  A run of 4*NV pixels is 12*NV bytes at an arbitrary byte address; gfx950
+// takes unaligned vector loads, and every (pixel, channel) sits at a compile-time byte of the loaded dwords,
+// so each tap is v_cvt_f32_ubyteN + mul + add with no shuffling.
+template <int NV>
+__global__ __launch_bounds__(256) void k_resize_area_v3(RArgs a, AreaDev t, int bpf, int count) {
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int idx = blk * 256 + threadIdx.x;
+    if (idx >= a.dw * a.dh) return;
+    const int dy = idx / a.dw, dx = idx - dy * a.dw;
+    const uint8_t* S = a.src + (long long)frame * a.src_stride;
+    const int xs = t.xstart_pad[dx];
+    float al[NV * 4];
+    __builtin_memcpy(al, __builtin_assume_aligned(t.xalpha_pad + (size_t)dx * (NV * 4), 16), NV * 16);
+    const int ys = t.ystart[dy];
+    const float* yb = t.ybeta_pad + (size_t)dy * t.nyp;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < t.nyp; j++) {
+        const int sy = min(ys + j, a.sh - 1);
+        const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 3;
+        uint32_t w[NV * 3];
+        __builtin_memcpy(w, row, NV * 12);                    // byte-aligned vector loads
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV * 4; k++) {
+            const int o0 = 3 * k, o1 = 3 * k + 1, o2 = 3 * k + 2;
+            b0 = __fadd_rn(b0, __fmul_rn((float)((w[o0 >> 2] >> (8 * (o0 & 3))) & 0xff), al[k]));
+            b1 = __fadd_rn(b1, __fmul_rn((float)((w[o1 >> 2] >> (8 * (o1 & 3))) & 0xff), al[k]));
+            b2 = __fadd_rn(b2, __fmul_rn((float)((w[o2 >> 2] >> (8 * (o2 & 3))) & 0xff), al[k]));
+        }
+        const float be = yb[j];
+        if (j == 0) { s0 = __fmul_rn(be, b0); s1 = __fmul_rn(be, b1); s2 = __fmul_rn(be, b2); }
+        else {
+            s0 = __fadd_rn(s0, __fmul_rn(be, b0)); s1 = __fadd_rn(s1, __fmul_rn(be, b1)); s2 = __fadd_rn(s2, __fmul_rn(be, b2));
+        }
+    }
+    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)dy * a.dstep + (size_t)dx * 3;
+    d[0] = (uint8_t)sat_u8(__float2int_rn(s0));
+    d[1] = (uint8_t)sat_u8(__float2int_rn(s1));
+    d[2] = (uint8_t)sat_u8(__float2int_rn(s2));
+}
+
 // ------------------------------------------------------------------ per-geometry table cache
 struct TableSet {
     void* blob = nullptr;     // one device allocation
@@ -702,6 +745,10 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             else if (CN == 4 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4<2>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else if (CN == 4 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4<3>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else if (CN == 4 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v4<4>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            else if (CN == 3 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v3<1>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            else if (CN == 3 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v3<2>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            else if (CN == 3 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v3<3>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            else if (CN == 3 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v3<4>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else hipLaunchKernelGGL((k_resize_area<CN>), grid, block, 0, s, a, ts.area);
         }
     } else {

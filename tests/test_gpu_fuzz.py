@@ -1,0 +1,103 @@
+"""Randomised parity (hypothesis, derandomised): arbitrary geometries, channel counts and modes through every resize
+kernel variant (gather, LDS-tiled, rolling 2x, vector AREA for BGR / BGRA, integer AREA, generic), random filter
+chains through run_ops, random watermark placements.  Bit-exact against the oracle."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+import oracle_lib as orc
+from conftest import noise_image
+
+pytestmark = pytest.mark.gpu
+COMMON = dict(deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@settings(max_examples=250, **COMMON)
+@given(sw=st.integers(1, 300), sh=st.integers(1, 200), dw=st.integers(1, 300), dh=st.integers(1, 200),
+       c=st.sampled_from([1, 3, 4]), interp=st.integers(0, 4), seed=st.integers(0, 1000))
+def test_resize_any_geometry(gpu, sw, sh, dw, dh, c, interp, seed):
+    if interp == orc.INTER_AREA and (dw > sw or dh > sh):
+        dw, dh = min(dw, sw), min(dh, sh)
+    arr = noise_image(sh, sw, c, seed)
+    want = orc.cv_resize(arr, dw, dh, interp)
+    im = gpu.Image(arr)
+    assert im.cv_resize(dw, dh, interp) == 0
+    got = im.numpy()
+    im.release()
+    assert np.array_equal(got, want), (sw, sh, dw, dh, c, interp)
+
+
+@settings(max_examples=60, **COMMON)
+@given(half_w=st.integers(1, 200), half_h=st.integers(1, 150), interp=st.sampled_from([1, 2, 4]), seed=st.integers(0, 100))
+def test_resize_exact_halves(gpu, half_w, half_h, interp, seed):
+    arr = noise_image(2 * half_h, 2 * half_w, 4, seed)
+    want = orc.cv_resize(arr, half_w, half_h, interp)
+    im = gpu.Image(arr)
+    assert im.cv_resize(half_w, half_h, interp) == 0
+    assert np.array_equal(im.numpy(), want), (half_w, half_h, interp)
+    im.release()
+
+
+POINTWISE = ["modulate=%d,%d,%d", "colorize=%02x%02x%02x,0.%d", "gamma=%d.%d", "contrast=%d.%d", "gotham=1", "lomo=1", "kelvin=1",
+             "rainbow=full", "rainbow=mid", "scanline=0.%d,0.%d,%d,%d", "flip=10", "flip=01", "rotate=90", "rotate=180",
+             "rotate=270", "blur=%d.%d", "gradmap=%02x%02x%02x,%02x%02x%02x"]
+
+
+@st.composite
+def filter_chain(draw):
+    n = draw(st.integers(1, 5))
+    out = []
+    for _ in range(n):
+        t = draw(st.sampled_from(POINTWISE))
+        k = t.count("%")
+        if t.startswith("modulate"):
+            vals = (draw(st.integers(0, 180)), draw(st.integers(-50, 300)), draw(st.integers(1, 300)))
+        elif t.startswith("colorize"):
+            vals = (draw(st.integers(0, 255)), draw(st.integers(0, 255)), draw(st.integers(0, 255)), draw(st.integers(0, 9)))
+        elif t.startswith("gradmap"):
+            vals = tuple(draw(st.integers(0, 255)) for _ in range(6))
+        elif t.startswith("scanline"):
+            vals = (draw(st.integers(0, 9)), draw(st.integers(0, 9)), draw(st.integers(1, 5)), draw(st.integers(1, 5)))
+        elif t.startswith("blur"):
+            vals = (draw(st.integers(0, 6)), draw(st.integers(1, 9)))
+        elif k:
+            vals = (draw(st.integers(0, 3)), draw(st.integers(1, 9)))
+        else:
+            vals = ()
+        out.append(t % vals)
+    return out
+
+
+@settings(max_examples=80, **COMMON)
+@given(w=st.integers(2, 120), h=st.integers(2, 90), c=st.sampled_from([3, 4]), filters=filter_chain(), seed=st.integers(0, 100),
+       crop=st.sampled_from([None, "1,1", "4,3,r,b", "2,1,l,t"]), resize=st.sampled_from([None, "40", "0,33", "50,20", "200,200,up"]))
+def test_run_ops_random_chain(gpu, w, h, c, filters, seed, crop, resize):
+    from test_gpu_chain import oracle_chain
+
+    arr = noise_image(h, w, c, seed)
+    rc_o, step_o, want = oracle_chain(arr, crop=crop, resize=resize, filters=filters)
+    cfg = gpu.Config(allow_experiments=True, max_filters=8)
+    im = gpu.Image(arr)
+    rc, step = gpu.run_ops(im, cfg, crop=crop, resize=resize, filters=filters)
+    assert rc == rc_o, (rc, rc_o, step, filters)
+    if rc == 0:
+        assert np.array_equal(im.numpy(), want), (w, h, c, crop, resize, filters)
+    im.release()
+
+
+@settings(max_examples=80, **COMMON)
+@given(bw=st.integers(1, 90), bh=st.integers(1, 70), ow=st.integers(1, 60), oh=st.integers(1, 50), dc=st.sampled_from([3, 4]),
+       sc=st.sampled_from([3, 4]), gx=st.sampled_from("lcr"), gy=st.sampled_from("tcb"), ox=st.integers(-40, 40),
+       oy=st.integers(-40, 40), op=st.integers(1, 100), seed=st.integers(0, 50))
+def test_watermark_random_placement(gpu, bw, bh, ow, oh, dc, sc, gx, gy, ox, oy, op, seed):
+    base = noise_image(bh, bw, dc, seed)
+    ov = noise_image(oh, ow, sc, seed + 1)
+    rc_o, want = orc.watermark(base, ov, gx, gy, ox, oy, op)
+    cfg = gpu.Config()
+    assert cfg.prepare_watermark(ov, gx, gy, ox, oy, op) == 0
+    im = gpu.Image(base)
+    rc = im.watermark(cfg)
+    assert rc == rc_o
+    if rc == 0:
+        assert np.array_equal(im.numpy(), want)
+    im.release(); cfg.release()
