@@ -37,6 +37,11 @@ WORKLOADS = {
     "lanczos": (3840, 2160, 1920, 1080, 64, 4, 3840 * 2160 * 4 + 1920 * 1080 * 4,
                 "batch 64 of 3840x2160 BGRA resize->1920x1080 INTER_LANCZOS4"),
     # BASELINE configs[2]: resize=960,540 (AREA, exact 2x2) -> filter-rotate=90 -> configured watermark 256x64 r,b,16,16 @60
+    # a GIF-album style batch: filter-gotham (HSV modulate + colorize + gamma + contrast, 6 CPU sweeps) fused, in place
+    "gotham": (1920, 1080, 1920, 1080, 256, -2, 2 * 1920 * 1080 * 4,
+               "batch 256 of 1920x1080 BGRA filter-gotham in place (one fused pointwise launch)"),
+    "gamma": (1920, 1080, 1920, 1080, 256, -3, 2 * 1920 * 1080 * 4,
+              "batch 256 of 1920x1080 BGRA filter-gamma=2.2 in place (LUT)"),
     "chain": (1920, 1080, 540, 960, 1024, -1, 1920 * 1080 * 4 + 540 * 960 * 4,
               "batch 1024 of 1920x1080 BGRA resize(960x540)+rotate(90)+watermark alpha-blend chain"),
 }
@@ -253,6 +258,11 @@ def main():
         assert cfg.prepare_watermark(ov.numpy(), "r", "b", 16, 16, 60) == 0
 
     def step():
+        if interp in (-2, -3):
+            rc = imp.batch_filters(src.data_ptr(), sh * sw * 4, sw, sh, 4, sw * 4, batch,
+                                   ["gotham=1"] if interp == -2 else ["gamma=2.2"], 1, stream=stream.cuda_stream)
+            assert rc == 0, rc
+            return
         if cfg is not None:
             imp.batch_resize_rotate_watermark(src.data_ptr(), sh * sw * 4, sw, sh, sw * 4, dst.data_ptr(), dh * dw * 4, dw * 4,
                                               960, 540, 90, cfg, 4, batch, stream=stream.cuda_stream)

@@ -202,6 +202,13 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
                                          int resize_width, int resize_height, int rotate,
                                          const impgpu_config* config, int channels, int count, void* stream);
 
+/* A run of pointwise filter-* requests (everything but flip / rotate / blur) applied in place to every frame of a
+ * batch with ONE fused launch: the per-frame filter loop of bridge.c:606-627 for albums (animated GIFs).  Returns
+ * IMP_ERROR_UNSUPPORTED if a request is not pointwise (the caller then goes frame by frame), otherwise the code the
+ * first failing Filter() would return. */
+int impgpu_batch_filters(void* frames, long long frame_stride, int width, int height, int channels, int step, int count,
+                         const char* const* filters, int filter_count, int allow_experiments, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

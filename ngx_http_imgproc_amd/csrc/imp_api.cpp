@@ -414,4 +414,18 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
     return rc;
 }
 
+int impgpu_batch_filters(void* frames, long long frame_stride, int width, int height, int channels, int step, int count,
+                         const char* const* filters, int filter_count, int allow_experiments, void* stream) {
+    if (!frames || !filters || filter_count < 0 || (channels != 3 && channels != 4) || step < width * channels) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    PixelProgram prog;
+    for (int i = 0; i < filter_count; i++) {
+        FilterPlan plan;
+        if (int rc = filter_plan(filters[i], allow_experiments, channels, width, height, &plan, &prog)) return rc;
+        if (plan.cls != FC_POINTWISE && plan.cls != FC_NOOP) return IMP_ERROR_UNSUPPORTED;
+    }
+    return launch_pixel_program((uint8_t*)frames, frame_stride, width, height, channels, step, count, prog,
+                                stream ? (hipStream_t)stream : env_stream());
+}
+
 }  // extern "C"

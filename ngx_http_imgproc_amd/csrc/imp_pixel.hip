@@ -92,6 +92,56 @@ __device__ __forceinline__ int store_f(float v) {
 
 #define PIX_PER_THREAD 8
 
+// all stages of the program on one pixel held in registers (c3 = alpha, untouched unless a table covers it)
+template <int CN>
+__device__ __forceinline__ void run_stages(int& c0, int& c1, int& c2, int& c3, int x, int y, const ProgDev& prog, const uint8_t* lut) {
+    for (int si = 0; si < prog.n; si++) {
+        const Stage& st = prog.st[si];
+        switch (st.kind) {
+            case ST_LUT4: {
+                const uint8_t* t = lut + st.lut_off;
+                c0 = t[c0];
+                if (CN >= 3) { c1 = t[256 + c1]; c2 = t[512 + c2]; }
+                if (CN == 4) c3 = t[768 + c3];
+            } break;
+            case ST_RGB2HSV: px_rgb2hsv(c0, c1, c2); break;
+            case ST_HSV2RGB: px_hsv2rgb(c0, c1, c2); break;
+            case ST_GRADMAP: {                      // filters.c:264-276 (table is R,G,B order)
+                const uint8_t* t = lut + st.lut_off;
+                const int off = ((c2 + c1 + c0) / 3) * 3;
+                c2 = t[off]; c1 = t[off + 1]; c0 = t[off + 2];
+            } break;
+            case ST_VIGNETTE: {                     // filters.c:312-317 with the mask of :693-703 inline
+                const double ddx = (double)(st.i0 - x), ddy = (double)(st.i1 - y);
+                const float dist = (float)sqrt(ddx * ddx + ddy * ddy);
+                const float raw = __fmul_rn(__fdiv_rn(dist, st.f0), st.f1);
+                const double cs = cos((double)raw);
+                const double c2d = cs * cs;
+                const float mask = (float)(c2d * c2d);
+                c2 = store_f(__fmul_rn((float)c2, mask));
+            } break;
+            case ST_RAINBOW: {                      // filters.c:371-397
+                int hue = c0 * 2, light = c2, sat = st.i0;
+                if (light < 20) { light = 0; sat = 0; }
+                else if (light > 254) sat = 0;
+                else if (hue <= 10 || hue > 340) hue = 0;
+                else if (hue < 35) hue = 30;
+                else if (hue < 68) hue = 60;
+                else if (hue < 150) hue = 120;
+                else if (hue < 200) hue = 195;
+                else if (hue < 250) hue = 225;
+                else hue = 285;
+                c0 = (hue >> 1) & 0xff;             // (char)(hue / 2.0): truncation
+                c1 = sat; c2 = light;
+            } break;
+            case ST_SCANLINE: {                     // filters.c:434-451: period freq+width+1
+                const int ph = y % (st.i0 + st.i1 + 1);
+                if (ph >= st.i0 && ph < st.i0 + st.i1) { c1 = st.i2; c2 = st.i3; }
+            } break;
+        }
+    }
+}
+
 template <int CN>
 __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long stride, int w, int h, int step,
                                                        ProgDev prog, const uint8_t* __restrict__ tables) {
@@ -117,54 +167,47 @@ __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long 
         } else {
             c0 = p[0]; c1 = c2 = 0;
         }
-        for (int si = 0; si < prog.n; si++) {
-            const Stage& st = prog.st[si];
-            switch (st.kind) {
-                case ST_LUT4: {
-                    const uint8_t* t = lut + st.lut_off;
-                    c0 = t[c0];
-                    if (CN >= 3) { c1 = t[256 + c1]; c2 = t[512 + c2]; }
-                    if (CN == 4) c3 = t[768 + c3];
-                } break;
-                case ST_RGB2HSV: px_rgb2hsv(c0, c1, c2); break;
-                case ST_HSV2RGB: px_hsv2rgb(c0, c1, c2); break;
-                case ST_GRADMAP: {                      // filters.c:264-276 (table is R,G,B order)
-                    const uint8_t* t = lut + st.lut_off;
-                    const int off = ((c2 + c1 + c0) / 3) * 3;
-                    c2 = t[off]; c1 = t[off + 1]; c0 = t[off + 2];
-                } break;
-                case ST_VIGNETTE: {                     // filters.c:312-317 with the mask of :693-703 inline
-                    const double ddx = (double)(st.i0 - x), ddy = (double)(st.i1 - y);
-                    const float dist = (float)sqrt(ddx * ddx + ddy * ddy);
-                    const float raw = __fmul_rn(__fdiv_rn(dist, st.f0), st.f1);
-                    const double cs = cos((double)raw);
-                    const double c2d = cs * cs;
-                    const float mask = (float)(c2d * c2d);
-                    c2 = store_f(__fmul_rn((float)c2, mask));
-                } break;
-                case ST_RAINBOW: {                      // filters.c:371-397
-                    int hue = c0 * 2, light = c2, sat = st.i0;
-                    if (light < 20) { light = 0; sat = 0; }
-                    else if (light > 254) sat = 0;
-                    else if (hue <= 10 || hue > 340) hue = 0;
-                    else if (hue < 35) hue = 30;
-                    else if (hue < 68) hue = 60;
-                    else if (hue < 150) hue = 120;
-                    else if (hue < 200) hue = 195;
-                    else if (hue < 250) hue = 225;
-                    else hue = 285;
-                    c0 = (hue >> 1) & 0xff;             // (char)(hue / 2.0): truncation
-                    c1 = sat; c2 = light;
-                } break;
-                case ST_SCANLINE: {                     // filters.c:434-451: period freq+width+1
-                    const int ph = y % (st.i0 + st.i1 + 1);
-                    if (ph >= st.i0 && ph < st.i0 + st.i1) { c1 = st.i2; c2 = st.i3; }
-                } break;
-            }
-        }
+        run_stages<CN>(c0, c1, c2, c3, x, y, prog, lut);
         if (CN == 4) *(uint32_t*)p = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16) | ((uint32_t)c3 << 24);
         else if (CN == 3) { p[0] = (uint8_t)c0; p[1] = (uint8_t)c1; p[2] = (uint8_t)c2; }
         else p[0] = (uint8_t)c0;
+    }
+}
+
+// BGRA frames whose rows are contiguous (step == 4*w) and 16-byte aligned: the frame is one linear run of pixels,
+// a lane moves four of them per 16-byte load / store (the coalescing sweet spot) and only derives (x, y) when a
+// stage of the program needs coordinates.
+#define PV4_GROUPS 4      // 16-byte groups per thread
+__global__ __launch_bounds__(256) void k_pixel_program_v4(uint8_t* base, long long stride, int w, long long npix,
+                                                          ProgDev prog, const uint8_t* __restrict__ tables, int need_xy) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[IMP_MAX_TABLE_BYTES];
+    for (int i = threadIdx.x * 4; i < prog.table_bytes; i += 256 * 4)
+        *(uint32_t*)(lut + i) = *(const uint32_t*)(tables + i);
+    __syncthreads();
+    uint4* img = (uint4*)(base + (long long)blockIdx.y * stride);
+    const long long ngroups = npix >> 2;                        // npix % 4 == 0 (launcher)
+    const long long first = (long long)blockIdx.x * (256 * PV4_GROUPS) + threadIdx.x;
+    uint4 v[PV4_GROUPS];
+#pragma unroll
+    for (int it = 0; it < PV4_GROUPS; it++) {
+        const long long gi = first + (long long)it * 256;
+        if (gi < ngroups) v[it] = img[gi];
+    }
+#pragma unroll
+    for (int it = 0; it < PV4_GROUPS; it++) {
+        const long long gi = first + (long long)it * 256;
+        if (gi >= ngroups) break;
+        int x = 0, y = 0;
+        if (need_xy) { const long long pix = gi * 4; y = (int)(pix / w); x = (int)(pix - (long long)y * w); }
+        uint32_t u[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int c0 = u[k] & 0xff, c1 = (u[k] >> 8) & 0xff, c2 = (u[k] >> 16) & 0xff, c3 = u[k] >> 24;
+            run_stages<4>(c0, c1, c2, c3, x, y, prog, lut);
+            u[k] = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16) | ((uint32_t)c3 << 24);
+            if (need_xy && ++x == w) { x = 0; y++; }
+        }
+        img[gi] = make_uint4(u[0], u[1], u[2], u[3]);
     }
 }
 
@@ -187,7 +230,12 @@ int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int 
     hipError_t e;
     const long long npix = (long long)w * h;
     const dim3 grid((unsigned)((npix + 256 * PIX_PER_THREAD - 1) / (256 * PIX_PER_THREAD)), (unsigned)count), block(256);
-    if (c == 4) hipLaunchKernelGGL((k_pixel_program<4>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    bool need_xy = false;
+    for (const Stage& st : prog.stages) need_xy = need_xy || st.kind == ST_VIGNETTE || st.kind == ST_SCANLINE;
+    if (c == 4 && step == 4 * w && (npix & 3) == 0 && !(((uintptr_t)d | (uintptr_t)stride) & 15)) {
+        const dim3 vgrid((unsigned)(((npix >> 2) + 256 * PV4_GROUPS - 1) / (256 * PV4_GROUPS)), (unsigned)count);
+        hipLaunchKernelGGL(k_pixel_program_v4, vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+    } else if (c == 4) hipLaunchKernelGGL((k_pixel_program<4>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else if (c == 3) hipLaunchKernelGGL((k_pixel_program<3>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else hipLaunchKernelGGL((k_pixel_program<1>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     e = hipGetLastError();

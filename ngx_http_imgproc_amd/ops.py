@@ -249,6 +249,13 @@ def batch_resize_rotate_watermark(src_ptr, src_stride, sw, sh, sstep, dst_ptr, d
         raise ImpError(rc, "impgpu_batch_resize_rotate_watermark")
 
 
+def batch_filters(ptr, stride, w, h, c, step, count, filters, allow_experiments=1, stream=None):
+    """Pointwise filter-* requests on every frame of a resident batch, one fused launch. Returns the IMP_* code."""
+    arr = (C.c_char_p * max(1, len(filters)))(*[_b(f) for f in filters])
+    return lib.impgpu_batch_filters(C.c_void_p(ptr), stride, w, h, c, step, count, arr, len(filters), int(allow_experiments),
+                                    C.c_void_p(stream or 0))
+
+
 class Request:
     """RunJob's parsed request (bridge.c:304-372 + encoder choice :413-466)."""
 

@@ -205,3 +205,21 @@ def test_brightness_adversarial_exact(gpu):
         im.release()
         want = orc.brightness(arr)
         assert np.float32(got) == np.float32(want), (arr.shape, got, want)
+
+
+def test_batch_filters_matches_per_frame(gpu):
+    n, h, w = 5, 60, 80
+    frames = [noise_image(h, w, 4, 500 + i) for i in range(n)]
+    filters = ["modulate=20,130,90", "colorize=203040,0.3", "gamma=1.4", "rainbow=mid", "gradmap=001122,ffeedd"]
+    batch = gpu.Image(np.concatenate(frames, axis=0))
+    assert gpu.batch_filters(batch.device_ptr, h * w * 4, w, h, 4, w * 4, n, filters) == 0
+    out = batch.numpy().reshape(n, h, w, 4)
+    for i in range(n):
+        cur = frames[i]
+        for f in filters:
+            rc, cur = orc.filter(cur, f)
+            assert rc == 0
+        assert np.array_equal(out[i], cur), i
+    assert gpu.batch_filters(batch.device_ptr, h * w * 4, w, h, 4, w * 4, n, ["rotate=90"]) == 1       # not pointwise
+    assert gpu.batch_filters(batch.device_ptr, h * w * 4, w, h, 4, w * 4, n, ["nosuch=1"]) == 52
+    batch.release()
