@@ -110,6 +110,12 @@ void  impgpu_host_free(void* ptr);
 int   impgpu_image_upload_pinned(const unsigned char* data, int width, int height, int channels,
                                  int step, impgpu_image** out);
 int   impgpu_image_download_pinned(const impgpu_image* image, unsigned char* data, int step);
+/* The FreeImage side of the hand-overs (advancedio.c): bitmaps there are bottom-up with 4-byte aligned rows.
+ * upload_fi32 = LoadSingle's copy loop (advancedio.c:310-318): 32-bit bits -> 4-channel top-down frame.
+ * download_fi = IplToFI32 / IplToFI24 (advancedio.c:65-101): flip, and B,G,R,A with A = 255 for 3-channel frames
+ * (bpp 32) or B,G,R with alpha dropped (bpp 24), written into the encoder's bitmap; the repack runs on the device. */
+int   impgpu_image_upload_fi32(const unsigned char* bits, int width, int height, int pitch, impgpu_image** out);
+int   impgpu_image_download_fi(const impgpu_image* image, int bpp, unsigned char* bits, int pitch);   /* syncs */
 int   impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int step,
                         impgpu_image** out);               /* borrow memory already in HBM */
 int   impgpu_image_clone(const impgpu_image* src, impgpu_image** out);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "impgpu_host_free": (None, [P]),
     "impgpu_image_upload_pinned": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_download_pinned": (C.c_int, [P, P, C.c_int]),
+    "impgpu_image_upload_fi32": (C.c_int, [P, C.c_int, C.c_int, C.c_int, PP]),
+    "impgpu_image_download_fi": (C.c_int, [P, C.c_int, P, C.c_int]),
     "impgpu_image_clone": (C.c_int, [P, PP]),
     "impgpu_image_download": (C.c_int, [P, P, C.c_int]),
     "impgpu_image_width": (C.c_int, [P]),

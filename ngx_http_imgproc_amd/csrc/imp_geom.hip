@@ -93,6 +93,32 @@ __global__ __launch_bounds__(256) void k_gray2bgr(GArgs a) {
     d[0] = v; d[1] = v; d[2] = v;
 }
 
+// IplToFI32 / IplToFI24 (advancedio.c:65-101): vertical flip + channel repack into FreeImage's row pitch
+template <int SC, int DC>
+__global__ __launch_bounds__(256) void k_pack_fi(const uint8_t* __restrict__ src, int sstep, int w, int h, uint8_t* __restrict__ dst, int dpitch) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)w * h) return;
+    const int y = (int)(idx / w), x = (int)(idx - (long long)y * w);
+    const uint8_t* s = src + (size_t)(h - 1 - y) * sstep + (size_t)x * SC;
+    uint8_t* d = dst + (size_t)y * dpitch + (size_t)x * DC;
+    if (SC == 4 && DC == 4) { *(uint32_t*)d = *(const uint32_t*)s; return; }
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    if (DC == 4) d[3] = SC == 4 ? s[3] : 255;
+}
+
+int launch_pack_fi(const View& v, int bpp, uint8_t* dst, int dpitch, hipStream_t s) {
+    if (v.c < 3 || (bpp != 24 && bpp != 32)) return IMP_ERROR_INVALID_ARGS;
+    const dim3 grid((unsigned)(((long long)v.w * v.h + 255) / 256)), block(256);
+    if (v.c == 4 && bpp == 32) {
+        if (((uintptr_t)v.d | (uintptr_t)v.step | (uintptr_t)dst | (uintptr_t)dpitch) & 3) return IMP_ERROR_INVALID_ARGS;
+        hipLaunchKernelGGL((k_pack_fi<4, 4>), grid, block, 0, s, v.d, v.step, v.w, v.h, dst, dpitch);
+    } else if (v.c == 4) hipLaunchKernelGGL((k_pack_fi<4, 3>), grid, block, 0, s, v.d, v.step, v.w, v.h, dst, dpitch);
+    else if (bpp == 32) hipLaunchKernelGGL((k_pack_fi<3, 4>), grid, block, 0, s, v.d, v.step, v.w, v.h, dst, dpitch);
+    else hipLaunchKernelGGL((k_pack_fi<3, 3>), grid, block, 0, s, v.d, v.step, v.w, v.h, dst, dpitch);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
 static GArgs gargs(const Frames& f) {
     return GArgs{f.src, f.src_stride, f.v.step, f.v.w, f.v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
 }

@@ -125,6 +125,7 @@ int launch_copy(const Frames& f, hipStream_t s);                       // crop c
 int launch_flip(const Frames& f, int mode, hipStream_t s);             // cvFlip
 int launch_rotate(const Frames& f, int amount, hipStream_t s);         // 90 / 270 (dw,dh = v.h,v.w), 180
 int launch_gray2bgr(const Frames& f, hipStream_t s);
+int launch_pack_fi(const View& v, int bpp, uint8_t* dst, int dpitch, hipStream_t s);   // IplToFI32/24: flip + repack
 // imp_pixel.hip
 int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int step, int count,
                          const PixelProgram& prog, hipStream_t s);

@@ -351,6 +351,50 @@ int impgpu_image_download_pinned(const impgpu_image* im, unsigned char* data, in
     return IMP_OK;
 }
 
+int impgpu_image_upload_fi32(const unsigned char* bits, int width, int height, int pitch, impgpu_image** out) {
+    if (!bits || !out || pitch < width * 4) return IMP_ERROR_INVALID_ARGS;
+    Lane* L = lane();
+    if (!L) return no_env();
+    impgpu_image* im = nullptr;
+    int rc = image_new(width, height, 4, &im);
+    if (rc) return rc;
+    const size_t bytes = (size_t)im->step * height;
+    rc = stage_reserve(L, bytes);
+    if (rc) { image_delete(im); return rc; }
+    // LoadSingle (advancedio.c:310-318): FreeImage rows are bottom-up; the flip rides on the staging copy
+    for (int y = 0; y < height; y++)
+        std::memcpy(L->stage + (size_t)(height - 1 - y) * im->step, bits + (size_t)y * pitch, (size_t)width * 4);
+    hipError_t e = hipMemcpyAsync(im->d, L->stage, bytes, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess) e = hipEventRecord(L->stage_done, L->stream);
+    if (e != hipSuccess) { set_error("hipMemcpyAsync(upload_fi32)", e); image_delete(im); return IMP_ERROR_DEVICE; }
+    L->stage_busy = true;
+    *out = im;
+    return IMP_OK;
+}
+
+int impgpu_image_download_fi(const impgpu_image* im, int bpp, unsigned char* bits, int pitch) {
+    if (!im || !bits || (bpp != 24 && bpp != 32) || im->c < 3 || pitch < im->w * (bpp / 8)) return IMP_ERROR_INVALID_ARGS;
+    Lane* L = lane();
+    if (!L) return no_env();
+    const int dpitch = (im->w * (bpp / 8) + 3) & ~3;            // FreeImage's own pitch rule
+    const size_t bytes = (size_t)dpitch * im->h;
+    void* tmp = nullptr;
+    int rc = dev_alloc(bytes, &tmp);
+    if (rc) return rc;
+    rc = launch_pack_fi(view_of(im), bpp, (uint8_t*)tmp, dpitch, L->stream);
+    if (!rc) rc = stage_reserve(L, bytes);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(L->stage, tmp, bytes, hipMemcpyDeviceToHost, L->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
+        if (e != hipSuccess) { set_error("download_fi", e); rc = IMP_ERROR_DEVICE; }
+    }
+    dev_free(tmp);
+    if (rc) return rc;
+    const size_t rowbytes = (size_t)im->w * (bpp / 8);
+    for (int y = 0; y < im->h; y++) std::memcpy(bits + (size_t)y * pitch, L->stage + (size_t)y * dpitch, rowbytes);
+    return IMP_OK;
+}
+
 int impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int step, impgpu_image** out) {
     if (!device_ptr || !out || width <= 0 || height <= 0 || (channels != 1 && channels != 3 && channels != 4) ||
         step < width * channels)

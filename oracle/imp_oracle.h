@@ -123,6 +123,10 @@ typedef struct {
 } orc_chain;
 int orc_run_chain(orc_image** pointer, const orc_chain* chain, int* step);
 
+/* advancedio.c:65-101 IplToFI32/24 and advancedio.c:310-318 LoadSingle's copy */
+int orc_ipl_to_fi(const orc_image* img, int bpp, unsigned char* out, int pitch);
+orc_image* orc_fi32_to_ipl(const unsigned char* bits, int width, int height, int pitch);
+
 /* bridge.c:304-372 request parsing + bridge.c:413-466 encoder choice. Strings point into `buffer`. */
 #define ORC_MAX_FILTERS 64
 typedef struct {

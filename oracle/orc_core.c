@@ -246,3 +246,31 @@ int orc_run_chain(orc_image** pointer, const orc_chain* ch, int* step) {
     *step = ORC_STEP_INFO;
     return ORC_OK;
 }
+
+/* ---- codec-adjacent repacks: advancedio.c:65-101 (IplToFI32 / IplToFI24) and :310-318 (LoadSingle) ---- */
+
+/* FreeImage bitmaps are bottom-up with 4-byte aligned rows. bpp = 32: B,G,R,A (A = 255 for 3-channel sources);
+ * bpp = 24: B,G,R (alpha dropped). out must hold pitch * height bytes. */
+int orc_ipl_to_fi(const orc_image* img, int bpp, unsigned char* out, int pitch) {
+    if ((bpp != 24 && bpp != 32) || img->channels < 3) return ORC_ERROR_INVALID_ARGS;
+    const int bc = bpp / 8;
+    for (int y = 0; y < img->height; y++) {
+        const int row = img->height - 1 - y;
+        for (int x = 0; x < img->width; x++) {
+            const unsigned char* s = img->data + (size_t)row * img->step + (size_t)x * img->channels;
+            unsigned char* d = out + (size_t)y * pitch + (size_t)x * bc;
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+            if (bc == 4) d[3] = img->channels == 4 ? s[3] : 255;
+        }
+    }
+    return ORC_OK;
+}
+
+/* LoadSingle: 32-bit bottom-up FreeImage bits (pitch = 4 * w there) -> 4-channel top-down image */
+orc_image* orc_fi32_to_ipl(const unsigned char* bits, int width, int height, int pitch) {
+    orc_image* img = orc_image_create(width, height, 4);
+    if (!img) return NULL;
+    for (int y = 0; y < height; y++)
+        memcpy(img->data + (size_t)(height - 1 - y) * img->step, bits + (size_t)y * pitch, (size_t)width * 4);
+    return img;
+}

@@ -63,6 +63,9 @@ def _load():
     lib.orc_ascii.restype = C.c_long
     lib.orc_ascii.argtypes = [P, C.c_char_p, C.c_void_p]
     lib.orc_gray2bgr.argtypes = [C.POINTER(P)]
+    lib.orc_ipl_to_fi.argtypes = [P, C.c_int, C.c_void_p, C.c_int]
+    lib.orc_fi32_to_ipl.restype = P
+    lib.orc_fi32_to_ipl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.orc_parse_request.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.POINTER(OrcRequest))]
     lib.orc_request_free.argtypes = [C.POINTER(OrcRequest)]
     return lib
@@ -206,3 +209,18 @@ def parse_request(uri, exten="", max_filters=5):
                simple=q.simple, need_flatten=q.need_flatten)
     lib.orc_request_free(r)
     return rc, out
+
+
+def ipl_to_fi(arr, bpp):
+    """IplToFI32 / IplToFI24 -> (h, pitch) uint8 array in FreeImage layout."""
+    im = Img(arr)
+    hh, ww, _ = im.shape
+    pitch = (ww * (bpp // 8) + 3) & ~3
+    out = np.zeros((hh, pitch), np.uint8)
+    assert lib.orc_ipl_to_fi(im.h, bpp, out.ctypes.data, pitch) == 0
+    return out
+
+
+def fi32_to_ipl(bits, w, h):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    return Img(handle=lib.orc_fi32_to_ipl(bits.ctypes.data, w, h, w * 4)).numpy()

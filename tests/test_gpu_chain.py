@@ -215,3 +215,27 @@ def test_threads_have_independent_streams_and_pools(gpu):
         t.start()
         t.join()
     assert len(set(streams + [gpu.lib.impgpu_env_stream()])) == 4
+
+
+@pytest.mark.parametrize("c", [3, 4])
+@pytest.mark.parametrize("bpp", [24, 32])
+def test_freeimage_side_repacks(gpu, c, bpp):
+    """advancedio.c:65-101 (IplToFI32/24) on the device and advancedio.c:310-318 (LoadSingle's flip) on upload."""
+    import ctypes as C
+
+    arr = noise_image(37, 53, c, 90)
+    im = gpu.Image(arr)
+    pitch = (53 * (bpp // 8) + 3) & ~3
+    out = np.zeros((37, pitch), np.uint8)
+    assert gpu.lib.impgpu_image_download_fi(im.h, bpp, out.ctypes.data, pitch) == 0
+    want = orc.ipl_to_fi(arr, bpp)
+    assert np.array_equal(out[:, : 53 * (bpp // 8)], want[:, : 53 * (bpp // 8)])
+    im.release()
+    if c == 4 and bpp == 32:
+        bits = np.ascontiguousarray(noise_image(37, 53, 4, 91))
+        h = C.c_void_p()
+        assert gpu.lib.impgpu_image_upload_fi32(bits.ctypes.data, 53, 37, 53 * 4, C.byref(h)) == 0
+        up = gpu.Image(handle=h.value)
+        assert np.array_equal(up.numpy(), orc.fi32_to_ipl(bits, 53, 37))
+        assert np.array_equal(up.numpy(), bits[::-1])
+        up.release()
