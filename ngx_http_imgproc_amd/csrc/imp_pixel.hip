@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long 
 // BGRA frames whose rows are contiguous (step == 4*w) and 16-byte aligned: the frame is one linear run of pixels,
 // a lane moves four of them per 16-byte load / store (the coalescing sweet spot) and only derives (x, y) when a
 // stage of the program needs coordinates.
-#define PV4_GROUPS 4      // 16-byte groups per thread
+template <int PV4_GROUPS>      // 16-byte groups per thread: 4 for big batches (bytes in flight), 1 for a single frame (enough blocks)
 __global__ __launch_bounds__(256) void k_pixel_program_v4(uint8_t* base, long long stride, int w, long long npix,
                                                           ProgDev prog, const uint8_t* __restrict__ tables, int need_xy) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[IMP_MAX_TABLE_BYTES];
@@ -233,8 +233,13 @@ int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int 
     bool need_xy = false;
     for (const Stage& st : prog.stages) need_xy = need_xy || st.kind == ST_VIGNETTE || st.kind == ST_SCANLINE;
     if (c == 4 && step == 4 * w && (npix & 3) == 0 && !(((uintptr_t)d | (uintptr_t)stride) & 15)) {
-        const dim3 vgrid((unsigned)(((npix >> 2) + 256 * PV4_GROUPS - 1) / (256 * PV4_GROUPS)), (unsigned)count);
-        hipLaunchKernelGGL(k_pixel_program_v4, vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+        if (npix * count >= (16LL << 20)) {
+            const dim3 vgrid((unsigned)(((npix >> 2) + 256 * 4 - 1) / (256 * 4)), (unsigned)count);
+            hipLaunchKernelGGL((k_pixel_program_v4<4>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+        } else {        // a single frame or a small album: one group per thread keeps every CU busy
+            const dim3 vgrid((unsigned)(((npix >> 2) + 255) / 256), (unsigned)count);
+            hipLaunchKernelGGL((k_pixel_program_v4<1>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+        }
     } else if (c == 4) hipLaunchKernelGGL((k_pixel_program<4>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else if (c == 3) hipLaunchKernelGGL((k_pixel_program<3>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else hipLaunchKernelGGL((k_pixel_program<1>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
