@@ -812,11 +812,22 @@ __device__ __forceinline__ uint32_t box2x2(uint32_t a, uint32_t b, uint32_t c, u
 }
 
 template <int TX, int TY>      // tile of the halved image: TX columns x TY rows, TX * TY == 4096
-__global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount, int rw, int rh) {
+__global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount, int rw, int rh, int ntx, int nty, int count, int order) {
     __shared__ uint32_t tile[TY][TX + 1];                     // odd pitch: the transposed read is bank-conflict free
-    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
-    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride;
-    const int rx0 = blockIdx.x * TX, ry0 = blockIdx.y * TY;   // tile origin in the halved (pre-rotation) image
+    // Block order: a group of 8 frames is dealt one frame per XCD (linear id mod 8), and inside a frame the tiles of
+    // one tile column are walked top to bottom back to back.  Vertically adjacent tiles store neighbouring column
+    // segments of the SAME destination rows, so those partial rows meet in one L2 before they are written back.
+    const long long lin = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const int tpf = ntx * nty;
+    const long long q = lin >> 3;
+    const int frame = (int)(q / tpf) * 8 + (int)(lin & 7);
+    if (frame >= count) return;
+    const int t = (int)(q % tpf);
+    int bx, by;
+    if (order) { by = t / ntx; bx = t - by * ntx; } else { bx = t / nty; by = t - bx * nty; }
+    const uint8_t* S = a.src + (long long)frame * a.src_stride;
+    uint8_t* D = a.dst + (long long)frame * a.dst_stride;
+    const int rx0 = bx * TX, ry0 = by * TY;                   // tile origin in the halved (pre-rotation) image
     const int tid = threadIdx.x;
     {   // (1) each thread averages two neighbouring outputs per row from two 16-byte loads.  Addresses are clamped into
         // the frame so all loads issue back to back with no branch between them; only the LDS stores are predicated.
@@ -889,7 +900,7 @@ __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount
 // geometry is not the exact-2x BGRA case so the caller can fall back to resize + rotate.
 int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s) {
     const View& v = f.v;
-    static const int shape = std::getenv("IMPGPU_CHAIN_TILE") ? std::atoi(std::getenv("IMPGPU_CHAIN_TILE")) : 128;   // measured: 128x32 fastest (1 KB read runs)
+    static const int shape = std::getenv("IMPGPU_CHAIN_TILE") ? std::atoi(std::getenv("IMPGPU_CHAIN_TILE")) : 64;   // measured (profiles/r01_chain_tiles.txt): 64x64 with the column walk
     if (v.c != 4 || (amount != 90 && amount != 270) || (v.w & 1) || (v.h & 1)) return IMP_ERROR_UNSUPPORTED;
     const int rw = v.w / 2, rh = v.h / 2;
     if (rw < 2 || rh < 1) return IMP_ERROR_UNSUPPORTED;
@@ -899,11 +910,14 @@ int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s) {
     RArgs a{f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
     const dim3 block(256);
     const int tx = shape, ty = 4096 / shape;
-    const dim3 grid((rw + tx - 1) / tx, (rh + ty - 1) / ty, f.count);
-    if (tx == 16) hipLaunchKernelGGL((k_area2x2_rotate_bgra<16, 256>), grid, block, 0, s, a, amount, rw, rh);
-    else if (tx == 32) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 128>), grid, block, 0, s, a, amount, rw, rh);
-    else if (tx == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 32>), grid, block, 0, s, a, amount, rw, rh);
-    else hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 64>), grid, block, 0, s, a, amount, rw, rh);
+    const int ntx = (rw + tx - 1) / tx, nty = (rh + ty - 1) / ty;
+    static const int order = std::getenv("IMPGPU_CHAIN_ORDER") ? std::atoi(std::getenv("IMPGPU_CHAIN_ORDER")) : 0;
+    const dim3 grid((unsigned)(ntx * nty), (unsigned)((f.count + 7) / 8 * 8));
+    if (tx == 16) hipLaunchKernelGGL((k_area2x2_rotate_bgra<16, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else if (tx == 32) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else if (tx == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 32>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else if (tx == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<256, 16>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }
