@@ -30,6 +30,14 @@ struct RArgs {
     uint8_t* dst; long long dst_stride; int dstep, dw, dh;
 };
 
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {           // f(integral_constant<int, I>) for I = 0..N-1
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int sat_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 // clamp(v >> sh) for the fixed-point casts.  The empty asm keeps the shift and the clamp apart:
@@ -332,16 +340,76 @@ __device__ __forceinline__ void hpass_row(const uint8_t* row, int sxv, const int
     }
 }
 
+// horizontal pass of one window held in registers: v_perm_b32 gathers channel c of two taps, v_dot2c multiplies
+template <int KS>
+__device__ __forceinline__ void hpass_px(const uint32_t* p, const short2_t* axp, int* h) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < KS / 2; j++) {
+            const uint32_t pr = __builtin_amdgcn_perm(p[2 * j + 1], p[2 * j], 0x0c040c00u + (c << 16) + c);
+            acc = __builtin_amdgcn_sdot2(as_short2(pr), axp[j], acc, false);
+        }
+        h[c] = acc;
+    }
+}
+
+// vertical pass over the register ring at phase U of its period; returns the packed BGRA destination pixel
+// a * b + c on the 24-bit multiplier as ONE instruction (hipcc otherwise splits it into v_mul_i32_i24 + v_add3_u32,
+// and every integer multiply form issues at half rate on gfx950: profiles/r01_valu_rates.txt)
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// VSYM: the KS row weights are mirror-symmetric (host-checked; true at the half-pixel phase of an exact 2x scale),
+// so mirrored ring rows are added first (full-rate v_add_u32, exact) and the multiplies halve.
+template <int KS, int MODE, int U, bool VSYM = false>
+__device__ __forceinline__ uint32_t vpass_px(const int (*ring)[4], const int* b, int dx, int vec_end) {
+    int out[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int hc[KS];
+#pragma unroll
+        for (int k = 0; k < KS; k++) hc[k] = ring[(k + 2 * U) % KS][c];
+        if constexpr (MODE == M_LINEAR) {
+            out[c] = (uint8_t)((((b[0] * (hc[0] >> 4)) >> 16) + ((b[1] * (hc[1] >> 4)) >> 16) + 2) >> 2);
+        } else if constexpr (MODE == M_CUBIC) {
+            if (dx * 4 + c < vec_end) {
+                const float sc = 1.f / (2048.f * 2048.f);
+                float s = __fmul_rn(__int2float_rn(hc[0]), __fmul_rn((float)b[0], sc));
+                s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[1]), __fmul_rn((float)b[1], sc)));
+                s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[2]), __fmul_rn((float)b[2], sc)));
+                s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[3]), __fmul_rn((float)b[3], sc)));
+                out[c] = sat_u8(__float2int_rn(s));
+            } else {
+                int v = __mul24(hc[0], b[0]) + __mul24(hc[1], b[1]) + __mul24(hc[2], b[2]) + __mul24(hc[3], b[3]);
+                out[c] = shr_sat_u8(v + (1 << 21), 22);
+            }
+        } else {
+            int v = 1 << 21;                                   // |hc| < 2^23: the 24-bit multiplier is exact
+            if constexpr (VSYM) {
+#pragma unroll
+                for (int k = 0; k < KS / 2; k++) v = mad24(hc[k] + hc[KS - 1 - k], b[k], v);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KS; k++) v = mad24(hc[k], b[k], v);
+            }
+            out[c] = shr_sat_u8(v, 22);
+        }
+    }
+    return (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
+}
+
+// one wave's strip with the windows loaded straight into registers (any column range, clamped taps at the borders)
 template <int KS, int MODE>
-__global__ __launch_bounds__(256) void k_resize_2x_roll(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
-                                                        const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end) {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the four waves of a block take four neighbouring 64-column strips of the SAME rows: together they read
-    // 2 KB contiguous runs of each source row (DRAM page locality) and share the overlapping window columns in L1
-    const int dx = (blockIdx.x * 4 + wv) * 64 + lane;
+__device__ __forceinline__ void roll_strip(const RArgs& a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                           const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end,
+                                           int strip, int lane) {
+    const int dx = strip * 64 + lane;
     const int dy0 = blockIdx.y * ROLL_STRIP;
-    if ((blockIdx.x * 4 + wv) * 64 >= a.dw) return;
     const int dyn = min(ROLL_STRIP, a.dh - dy0);
     const bool live = dx < a.dw;
     const int dxc = live ? dx : a.dw - 1;                       // idle lanes shadow the last column (no stores)
@@ -370,48 +438,145 @@ __global__ __launch_bounds__(256) void k_resize_2x_roll(RArgs a, const int* __re
 
     constexpr int UN = KS / 2;                                  // ring period: every ring index below is a constant
     for (int i0 = 0; i0 < dyn; i0 += UN) {
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
+        static_for<UN>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
             const int i = i0 + u;
             if (i < dyn) {
                 const int dy = dy0 + i;
                 const int sy = sy_first + 2 * i;
                 hpass_row<KS>(S + (size_t)clampi(sy + KS - 2, 0, a.sh - 1) * a.sstep, sxv, sxk, interior, axp, ring[(KS - 2 + 2 * u) % KS]);
                 hpass_row<KS>(S + (size_t)clampi(sy + KS - 1, 0, a.sh - 1) * a.sstep, sxv, sxk, interior, axp, ring[(KS - 1 + 2 * u) % KS]);
-                int out[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    int hc[KS];
-#pragma unroll
-                    for (int k = 0; k < KS; k++) hc[k] = ring[(k + 2 * u) % KS][c];
-                    const int* b = by;
-                    if constexpr (MODE == M_LINEAR) {
-                        out[c] = (uint8_t)((((b[0] * (hc[0] >> 4)) >> 16) + ((b[1] * (hc[1] >> 4)) >> 16) + 2) >> 2);
-                    } else if constexpr (MODE == M_CUBIC) {
-                        if (dx * 4 + c < vec_end) {
-                            const float sc = 1.f / (2048.f * 2048.f);
-                            float s = __fmul_rn(__int2float_rn(hc[0]), __fmul_rn((float)b[0], sc));
-                            s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[1]), __fmul_rn((float)b[1], sc)));
-                            s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[2]), __fmul_rn((float)b[2], sc)));
-                            s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[3]), __fmul_rn((float)b[3], sc)));
-                            out[c] = sat_u8(__float2int_rn(s));
-                        } else {
-                            int v = __mul24(hc[0], b[0]) + __mul24(hc[1], b[1]) + __mul24(hc[2], b[2]) + __mul24(hc[3], b[3]);
-                            out[c] = shr_sat_u8(v + (1 << 21), 22);
-                        }
-                    } else {
-                        int v = 1 << 21;
-#pragma unroll
-                        for (int k = 0; k < KS; k++) v = __mul24(hc[k], b[k]) + v;
-                        out[c] = shr_sat_u8(v, 22);
-                    }
-                }
-                if (live)
-                    *(uint32_t*)(D + (size_t)dy * a.dstep + (size_t)dx * 4) =
-                        (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
+                const uint32_t px = vpass_px<KS, MODE, u>(ring, by, dx, vec_end);
+                if (live) *(uint32_t*)(D + (size_t)dy * a.dstep + (size_t)dx * 4) = px;
             }
-        }
+        });
     }
+}
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(256) void k_resize_2x_roll(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                        const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the four waves of a block take four neighbouring 64-column strips of the SAME rows: together they read
+    // 2 KB contiguous runs of each source row (DRAM page locality) and share the overlapping window columns in L1
+    const int strip = blockIdx.x * 4 + wv;
+    if (strip * 64 >= a.dw) return;
+    roll_strip<KS, MODE>(a, xofs, xco, yofs, yco, vec_end, strip, lane);
+}
+
+// ------------------------------------------------------------------ exact 2x decimation, LDS-DMA row ring
+// The register-rolling strip above keeps only ~1 KB of unique source bytes in flight per wave (two 536-byte row
+// segments), ~20 KB per CU -- under half of what Little's law asks for at HBM speed, and prefetching further ahead
+// into registers costs the occupancy it buys.  Here each wave streams its row segments D iterations ahead with
+// global_load_lds_dwordx4 (global -> LDS DMA: no VGPRs, no ds_write) into a private ring of 2D+2 LDS row slots and
+// takes its tap windows from there.  Nothing is shared between waves, so there are no barriers: a wave orders its
+// own DMA against its own reads with s_waitcnt vmcnt(2D) (VMEM retires in order; the destination stores in the
+// queue only make the wait conservative).  In strips that touch the image border the granules outside the row are
+// masked off and the taps are read from LDS at clamped indices (a wave-uniform branch).
+#define DMA_SLOT 576       // bytes per LDS row slot: (2 * 64 + KS + 3 rounded to 4) pixels = 34 lanes x 16 B, padded
+
+#ifndef DMA_WAVES
+#define DMA_WAVES 7
+#endif
+template <int KS, int MODE, int DEPTH, bool VSYM>
+__global__ __launch_bounds__(256, DMA_WAVES) void k_resize_2x_dma(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                       const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end) {
+    constexpr int R = 2 * DEPTH + 2;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][R][DMA_SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dx0 = (blockIdx.x * 4 + wv) * 64;
+    if (dx0 >= a.dw) return;
+    const int sx00 = __builtin_amdgcn_readfirstlane(xofs[dx0]) - (KS / 2 - 1);   // first tap of the strip's first column
+    const int wstart = sx00 & ~3;                                                // window start, 16-byte aligned (may be < 0)
+    const int nl = (sx00 - wstart + 126 + KS + 3) >> 2;                          // lanes (x 16 B) that cover the window
+    // border strips: granules outside the row are not fetched and every tap index is clamped like the CPU's
+    const bool edge = wstart < 0 || wstart + nl * 4 > a.sw || dx0 + 64 > a.dw;   // wave-uniform
+    const int dx = dx0 + lane;
+    const bool live = dx < a.dw;
+    const int dxc = live ? dx : a.dw - 1;                                        // idle lanes shadow the last column
+    const int gpx = wstart + 4 * lane;                                           // first pixel of this lane's DMA granule
+    const bool fetch = lane < nl && gpx >= 0 && gpx + 4 <= a.sw;                 // sw % 4 == 0 (host-checked): never partial
+    const int sx0e = xofs[dxc] - (KS / 2 - 1);
+    const int dy0 = blockIdx.y * ROLL_STRIP;
+    const int dyn = min(ROLL_STRIP, a.dh - dy0);
+    // wave-uniform bases (scalar registers) + 32-bit lane offsets: the saddr + voffset form of global_load_lds / store
+    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride + (size_t)wstart * 4;
+    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dx0 * 4;
+    const unsigned lane16 = lane * 16u, lane4 = lane * 4u;
+
+    short2_t axp[KS / 2];
+#pragma unroll
+    for (int j = 0; j < KS / 2; j++) { axp[j].x = xco[dxc * KS + 2 * j]; axp[j].y = xco[dxc * KS + 2 * j + 1]; }
+    int by[KS];                                                 // wave-uniform: scalar registers
+#pragma unroll
+    for (int k = 0; k < KS; k++) by[k] = __builtin_amdgcn_readfirstlane((int)yco[dy0 * KS + k]);
+    const int lane_dw = 2 * lane + (sx00 - wstart);             // this lane's first tap, in dwords from the slot start
+    const int sy_first = yofs[dy0] - (KS / 2 - 1);
+
+    // source row sy_first + r (clamped) -> slot r % R
+    auto issue = [&](int r) {
+        const uint8_t* g = S + (size_t)clampi(sy_first + r, 0, a.sh - 1) * a.sstep + lane16;
+        if (fetch)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)&lds[wv][r % R][0], 16, 0, 0);
+    };
+    // the whole strip twice, under one wave-uniform branch: written as a single loop with the branch inside the
+    // window read, hipcc if-converts it and every wave pays the border's per-tap clamped addressing
+    auto strip = [&](auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        auto window = [&](int r, uint32_t* p) {
+            const uint32_t* w = (const uint32_t*)&lds[wv][r % R][0];
+#pragma unroll
+            for (int k = 0; k < KS; k++) p[k] = EDGE ? w[clampi(sx0e + k, 0, a.sw - 1) - wstart] : w[lane_dw + k];
+        };
+
+        // prologue: fill the ring, take the KS-2 rows above the first destination row, then top the queue up to
+        // DEPTH iterations ahead (those rows reuse the slots just consumed)
+        static_assert(R >= KS - 2 && R <= KS - 2 + 2 * DEPTH, "ring too small for the prologue");
+        int ring[KS][4];
+#pragma unroll
+        for (int r = 0; r < R; r++) issue(r);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - (KS - 2)) : "memory");
+#pragma unroll
+        for (int k = 0; k < KS - 2; k++) {
+            uint32_t p[KS];
+            window(k, p);
+            hpass_px<KS>(p, axp, ring[k]);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = R; r < KS - 2 + 2 * DEPTH; r++) issue(r);
+
+        constexpr int UN = KS / 2;
+        for (int i0 = 0; i0 < dyn; i0 += UN) {
+            static_for<UN>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int i = i0 + u;
+                if (i < dyn) {
+                    const int r0 = KS - 2 + 2 * i;
+                    if (i + DEPTH < dyn) {
+                        issue(r0 + 2 * DEPTH);
+                        issue(r0 + 2 * DEPTH + 1);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DEPTH) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    uint32_t p[KS], q[KS];
+                    window(r0, p);
+                    window(r0 + 1, q);
+                    hpass_px<KS>(p, axp, ring[(KS - 2 + 2 * u) % KS]);
+                    hpass_px<KS>(q, axp, ring[(KS - 1 + 2 * u) % KS]);
+                    asm volatile("" ::: "memory");             // the slots just read may be refilled from here on
+                    const uint32_t px = vpass_px<KS, MODE, u, VSYM>(ring, by, dx, vec_end);
+                    if (!EDGE || live) *(uint32_t*)(D + (size_t)(dy0 + i) * a.dstep + lane4) = px;
+                }
+            });
+        }
+    };
+    if (edge) strip(std::true_type{});
+    else strip(std::false_type{});
 }
 
 // ------------------------------------------------------------------ NN
@@ -641,6 +806,7 @@ struct TableSet {
     void* blob = nullptr;     // one device allocation
     const int *xofs = nullptr, *yofs = nullptr;
     const short *xco = nullptr, *yco = nullptr;
+    bool ysym = false;        // step2 and the one set of row weights is mirror-symmetric (vpass_px's VSYM form)
     bool step2 = false;       // xofs[d] = xofs[0] + 2d and yofs[d] = yofs[0] + 2d: k_resize_2x_roll applies
     AreaDev area{};
 };
@@ -701,6 +867,8 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         for (int d = 1; d < dh && ts.step2; d++) ts.step2 = ty.ofs[d] == ty.ofs[0] + 2 * d;
         for (int d = 1; d < dh && ts.step2; d++)          // and one set of row weights (true when the scale is exactly 2)
             for (int k = 0; k < ty.ksize; k++) ts.step2 = ts.step2 && ty.coef[(size_t)d * ty.ksize + k] == ty.coef[k];
+        ts.ysym = ts.step2;
+        for (int k = 0; k < ty.ksize && ts.ysym; k++) ts.ysym = ty.coef[k] == ty.coef[ty.ksize - 1 - k];
     }
     uint8_t* dev = nullptr;
     IMP_HIP(hipMalloc((void**)&dev, blob.size()));
@@ -759,8 +927,23 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
         if (CN == 4 && ts.step2 && a.sw >= 8 && !no_roll) {
             // exact 2x decimation: register-rolling kernel, one wave per 64-column x ROLL_STRIP-row strip
             const int nstrips = (a.dh + ROLL_STRIP - 1) / ROLL_STRIP;
+            // LDS-DMA row ring when the 16-byte DMA granules line up with the rows; IMPGPU_DMA_DEPTH = iterations
+            // prefetched (0 = off: the register-rolling kernel, which has no alignment demands)
+            static const int dma_depth = std::getenv("IMPGPU_DMA_DEPTH") ? std::atoi(std::getenv("IMPGPU_DMA_DEPTH")) : 3;
+            const bool dma_ok = dma_depth > 0 && interp != IMP_INTER_LINEAR && (a.sw & 3) == 0 &&
+                                !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 15);
             const dim3 rgrid((a.dw + 255) / 256, nstrips, (unsigned)count);
-            if (interp == IMP_INTER_LINEAR)
+#define IMP_DMA(KS_, MODE_, VEC_, VS_)                                                                                   \
+    do {                                                                                                                 \
+        if (dma_depth == 2) hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, 2, VS_>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_); \
+        else if (dma_depth == 4) hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, 4, VS_>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_); \
+        else hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, 3, VS_>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_); \
+    } while (0)
+            if (dma_ok && interp == IMP_INTER_CUBIC) IMP_DMA(4, M_CUBIC, (a.dw * 4) & ~7, false);
+            else if (dma_ok && ts.ysym) IMP_DMA(8, M_LANCZOS, 0, true);
+            else if (dma_ok) IMP_DMA(8, M_LANCZOS, 0, false);
+#undef IMP_DMA
+            else if (interp == IMP_INTER_LINEAR)
                 hipLaunchKernelGGL((k_resize_2x_roll<2, M_LINEAR>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
             else if (interp == IMP_INTER_CUBIC)
                 hipLaunchKernelGGL((k_resize_2x_roll<4, M_CUBIC>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, (a.dw * 4) & ~7);
