@@ -299,6 +299,21 @@ __global__ __launch_bounds__(256) void k_resize_tiled(RArgs a, const int* __rest
     }
 }
 
+// Frame-per-XCD block order for kernels whose neighbouring blocks re-read the same source rows
+// (AREA: consecutive destination rows share their boundary source row).  Blocks are dealt to the
+// 8 XCDs round-robin, so linear id mod 8 labels an XCD group; here a group works through whole
+// frames, so the shared rows are found in that XCD's L2 instead of being pulled from HBM twice.
+// Speed only.  Returns false for the padding blocks of an incomplete last group of 8 frames.
+__device__ __forceinline__ bool frame_block(int bpf, int count, int* frame, int* blk) {
+    const long long lin = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const int g = (int)(lin & 7);
+    const long long q = lin >> 3;
+    const int f = (int)(q / bpf) * 8 + g;
+    *frame = f;
+    *blk = (int)(q % bpf);
+    return f < count;
+}
+
 // ------------------------------------------------------------------ exact 2x decimation, register-rolling
 // When both scale factors are exactly 2 (4K -> 1080p, cfg4) the tap window of consecutive destination
 // rows advances by exactly two source rows.  A lane then owns one destination column and walks down a
@@ -479,14 +494,20 @@ __global__ __launch_bounds__(256) void k_resize_2x_roll(RArgs a, const int* __re
 #ifndef DMA_WAVES
 #define DMA_WAVES 7
 #endif
-template <int KS, int MODE, int DEPTH, bool VSYM>
-__global__ __launch_bounds__(256, DMA_WAVES) void k_resize_2x_dma(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
-                                                       const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end) {
+template <int KS, int MODE, int DEPTH, bool VSYM, int WPB>
+__global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                       const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end,
+                                                       int nbx, int bpf, int count) {
     constexpr int R = 2 * DEPTH + 2;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4][R][DMA_SLOT];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WPB][R][DMA_SLOT];
+    // one frame per XCD at a time, its blocks in row-major order: an XCD then streams whole source rows (DRAM page
+    // runs of 15 KB instead of one 2 KB column band of every frame) and the strips' shared halo rows meet in its L2
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int bx = blk % nbx, byy = blk / nbx;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dx0 = (blockIdx.x * 4 + wv) * 64;
+    const int dx0 = (bx * WPB + wv) * 64;
     if (dx0 >= a.dw) return;
     const int sx00 = __builtin_amdgcn_readfirstlane(xofs[dx0]) - (KS / 2 - 1);   // first tap of the strip's first column
     const int wstart = sx00 & ~3;                                                // window start, 16-byte aligned (may be < 0)
@@ -499,11 +520,11 @@ __global__ __launch_bounds__(256, DMA_WAVES) void k_resize_2x_dma(RArgs a, const
     const int gpx = wstart + 4 * lane;                                           // first pixel of this lane's DMA granule
     const bool fetch = lane < nl && gpx >= 0 && gpx + 4 <= a.sw;                 // sw % 4 == 0 (host-checked): never partial
     const int sx0e = xofs[dxc] - (KS / 2 - 1);
-    const int dy0 = blockIdx.y * ROLL_STRIP;
+    const int dy0 = byy * ROLL_STRIP;
     const int dyn = min(ROLL_STRIP, a.dh - dy0);
     // wave-uniform bases (scalar registers) + 32-bit lane offsets: the saddr + voffset form of global_load_lds / store
-    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride + (size_t)wstart * 4;
-    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dx0 * 4;
+    const uint8_t* S = a.src + (long long)frame * a.src_stride + (size_t)wstart * 4;
+    uint8_t* D = a.dst + (long long)frame * a.dst_stride + (size_t)dx0 * 4;
     const unsigned lane16 = lane * 16u, lane4 = lane * 4u;
 
     short2_t axp[KS / 2];
@@ -701,21 +722,6 @@ __global__ __launch_bounds__(256) void k_resize_area(RArgs a, AreaDev t) {
 // kernel has no edge path and a uniform trip count.  Zero weights are exact no-ops on the
 // non-negative partial sums (x + p*0.f == x), so the float sequence is still exactly resizeArea_'s.
 typedef float float2_t __attribute__((ext_vector_type(2)));
-
-// Frame-per-XCD block order for kernels whose neighbouring blocks re-read the same source rows
-// (AREA: consecutive destination rows share their boundary source row).  Blocks are dealt to the
-// 8 XCDs round-robin, so linear id mod 8 labels an XCD group; here a group works through whole
-// frames, so the shared rows are found in that XCD's L2 instead of being pulled from HBM twice.
-// Speed only.  Returns false for the padding blocks of an incomplete last group of 8 frames.
-__device__ __forceinline__ bool frame_block(int bpf, int count, int* frame, int* blk) {
-    const long long lin = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-    const int g = (int)(lin & 7);
-    const long long q = lin >> 3;
-    const int f = (int)(q / bpf) * 8 + g;
-    *frame = f;
-    *blk = (int)(q % bpf);
-    return f < count;
-}
 
 template <int NV>
 __global__ __launch_bounds__(256) void k_resize_area_v4(RArgs a, AreaDev t, int bpf, int count) {
@@ -933,15 +939,26 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             const bool dma_ok = dma_depth > 0 && interp != IMP_INTER_LINEAR && (a.sw & 3) == 0 &&
                                 !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 15);
             const dim3 rgrid((a.dw + 255) / 256, nstrips, (unsigned)count);
+            // waves of a block are independent (no barriers, private LDS rings): small blocks only shorten the tail
+            static const int wpb = std::getenv("IMPGPU_DMA_WPB") ? std::atoi(std::getenv("IMPGPU_DMA_WPB")) : 4;
+            const int nbx = (a.dw + 64 * wpb - 1) / (64 * wpb), bpf = nbx * nstrips;
+            const dim3 dgrid((unsigned)(bpf * 8), (unsigned)((count + 7) / 8));
+#define IMP_DMA_W(KS_, MODE_, VEC_, VS_, D_)                                                                             \
+    do {                                                                                                                 \
+        if (wpb == 1) hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, D_, VS_, 1>), dgrid, dim3(64), 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, nbx, bpf, count); \
+        else if (wpb == 2) hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, D_, VS_, 2>), dgrid, dim3(128), 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, nbx, bpf, count); \
+        else hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, D_, VS_, 4>), dgrid, dim3(256), 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, nbx, bpf, count); \
+    } while (0)
 #define IMP_DMA(KS_, MODE_, VEC_, VS_)                                                                                   \
     do {                                                                                                                 \
-        if (dma_depth == 2) hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, 2, VS_>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_); \
-        else if (dma_depth == 4) hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, 4, VS_>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_); \
-        else hipLaunchKernelGGL((k_resize_2x_dma<KS_, MODE_, 3, VS_>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_); \
+        if (dma_depth == 2) IMP_DMA_W(KS_, MODE_, VEC_, VS_, 2);                                                         \
+        else if (dma_depth == 4) IMP_DMA_W(KS_, MODE_, VEC_, VS_, 4);                                                    \
+        else IMP_DMA_W(KS_, MODE_, VEC_, VS_, 3);                                                                        \
     } while (0)
             if (dma_ok && interp == IMP_INTER_CUBIC) IMP_DMA(4, M_CUBIC, (a.dw * 4) & ~7, false);
             else if (dma_ok && ts.ysym) IMP_DMA(8, M_LANCZOS, 0, true);
             else if (dma_ok) IMP_DMA(8, M_LANCZOS, 0, false);
+#undef IMP_DMA_W
 #undef IMP_DMA
             else if (interp == IMP_INTER_LINEAR)
                 hipLaunchKernelGGL((k_resize_2x_roll<2, M_LINEAR>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
