@@ -92,11 +92,10 @@ __device__ __forceinline__ int store_f(float v) {
 
 #define PIX_PER_THREAD 8
 
-// all stages of the program on one pixel held in registers (c3 = alpha, untouched unless a table covers it)
+// one stage on one pixel held in registers (c3 = alpha, untouched unless a table covers it)
 template <int CN>
-__device__ __forceinline__ void run_stages(int& c0, int& c1, int& c2, int& c3, int x, int y, const ProgDev& prog, const uint8_t* lut) {
-    for (int si = 0; si < prog.n; si++) {
-        const Stage& st = prog.st[si];
+__device__ __forceinline__ void apply_stage(const Stage& st, int& c0, int& c1, int& c2, int& c3, int x, int y, const uint8_t* lut) {
+    {
         switch (st.kind) {
             case ST_LUT4: {
                 const uint8_t* t = lut + st.lut_off;
@@ -142,6 +141,12 @@ __device__ __forceinline__ void run_stages(int& c0, int& c1, int& c2, int& c3, i
     }
 }
 
+// all stages of the program on one pixel
+template <int CN>
+__device__ __forceinline__ void run_stages(int& c0, int& c1, int& c2, int& c3, int x, int y, const ProgDev& prog, const uint8_t* lut) {
+    for (int si = 0; si < prog.n; si++) apply_stage<CN>(prog.st[si], c0, c1, c2, c3, x, y, lut);
+}
+
 template <int CN>
 __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long stride, int w, int h, int step,
                                                        ProgDev prog, const uint8_t* __restrict__ tables) {
@@ -177,7 +182,51 @@ __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long 
 // BGRA frames whose rows are contiguous (step == 4*w) and 16-byte aligned: the frame is one linear run of pixels,
 // a lane moves four of them per 16-byte load / store (the coalescing sweet spot) and only derives (x, y) when a
 // stage of the program needs coordinates.
-template <int PV4_GROUPS>      // 16-byte groups per thread: 4 for big batches (bytes in flight), 1 for a single frame (enough blocks)
+// the same program on the four pixels of one 16-byte group, stage by stage: the stage dispatch (wave-uniform
+// branches) is paid once per group and the 16 table reads of a LUT stage are in flight together instead of four
+// at a time behind each pixel's own wait.  Pixel k sits at (x0 + k, y0) carried into the next row at x == w.
+__device__ __forceinline__ void run_stages_x4(int (&c)[4][4], int x0, int y0, int w, const ProgDev& prog, const uint8_t* lut) {
+    for (int si = 0; si < prog.n; si++) {
+        const Stage& st = prog.st[si];
+        switch (st.kind) {
+            case ST_LUT4: {
+                const uint8_t* t = lut + st.lut_off;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    c[k][0] = t[c[k][0]]; c[k][1] = t[256 + c[k][1]]; c[k][2] = t[512 + c[k][2]]; c[k][3] = t[768 + c[k][3]];
+                }
+            } break;
+            case ST_GRADMAP: {
+                const uint8_t* t = lut + st.lut_off;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int off = ((c[k][2] + c[k][1] + c[k][0]) / 3) * 3;
+                    c[k][2] = t[off]; c[k][1] = t[off + 1]; c[k][0] = t[off + 2];
+                }
+            } break;
+            case ST_RGB2HSV:
+#pragma unroll
+                for (int k = 0; k < 4; k++) px_rgb2hsv(c[k][0], c[k][1], c[k][2]);
+                break;
+            case ST_HSV2RGB:
+#pragma unroll
+                for (int k = 0; k < 4; k++) px_hsv2rgb(c[k][0], c[k][1], c[k][2]);
+                break;
+            default: {                               // coordinate-dependent stages
+                int x = x0, y = y0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    apply_stage<4>(st, c[k][0], c[k][1], c[k][2], c[k][3], x, y, lut);
+                    if (++x == w) { x = 0; y++; }
+                }
+            } break;
+        }
+    }
+}
+
+// LUT_ONLY: the program is a single four-channel table (gamma, contrast, colorize and whatever the host composed
+// into one table): no stage loop at all, every lookup of the thread's groups is independent.
+template <int PV4_GROUPS, bool LUT_ONLY>      // 16-byte groups per thread: 4 for big batches (bytes in flight), 1 for a single frame (enough blocks)
 __global__ __launch_bounds__(256) void k_pixel_program_v4(uint8_t* base, long long stride, int w, long long npix,
                                                           ProgDev prog, const uint8_t* __restrict__ tables, int need_xy) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[IMP_MAX_TABLE_BYTES];
@@ -199,15 +248,23 @@ __global__ __launch_bounds__(256) void k_pixel_program_v4(uint8_t* base, long lo
         if (gi >= ngroups) break;
         int x = 0, y = 0;
         if (need_xy) { const long long pix = gi * 4; y = (int)(pix / w); x = (int)(pix - (long long)y * w); }
-        uint32_t u[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        const uint32_t u[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        int c[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int c0 = u[k] & 0xff, c1 = (u[k] >> 8) & 0xff, c2 = (u[k] >> 16) & 0xff, c3 = u[k] >> 24;
-            run_stages<4>(c0, c1, c2, c3, x, y, prog, lut);
-            u[k] = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16) | ((uint32_t)c3 << 24);
-            if (need_xy && ++x == w) { x = 0; y++; }
+        for (int k = 0; k < 4; k++) { c[k][0] = u[k] & 0xff; c[k][1] = (u[k] >> 8) & 0xff; c[k][2] = (u[k] >> 16) & 0xff; c[k][3] = u[k] >> 24; }
+        if constexpr (LUT_ONLY) {
+            const uint8_t* t = lut + prog.st[0].lut_off;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c[k][0] = t[c[k][0]]; c[k][1] = t[256 + c[k][1]]; c[k][2] = t[512 + c[k][2]]; c[k][3] = t[768 + c[k][3]];
+            }
+        } else {
+            run_stages_x4(c, x, y, w, prog, lut);
         }
-        img[gi] = make_uint4(u[0], u[1], u[2], u[3]);
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = (uint32_t)c[k][0] | ((uint32_t)c[k][1] << 8) | ((uint32_t)c[k][2] << 16) | ((uint32_t)c[k][3] << 24);
+        img[gi] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -232,13 +289,16 @@ int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int 
     const dim3 grid((unsigned)((npix + 256 * PIX_PER_THREAD - 1) / (256 * PIX_PER_THREAD)), (unsigned)count), block(256);
     bool need_xy = false;
     for (const Stage& st : prog.stages) need_xy = need_xy || st.kind == ST_VIGNETTE || st.kind == ST_SCANLINE;
+    const bool lut_only = prog.stages.size() == 1 && prog.stages[0].kind == ST_LUT4;
     if (c == 4 && step == 4 * w && (npix & 3) == 0 && !(((uintptr_t)d | (uintptr_t)stride) & 15)) {
         if (npix * count >= (16LL << 20)) {
             const dim3 vgrid((unsigned)(((npix >> 2) + 256 * 4 - 1) / (256 * 4)), (unsigned)count);
-            hipLaunchKernelGGL((k_pixel_program_v4<4>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+            if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<4, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, 0);
+            else hipLaunchKernelGGL((k_pixel_program_v4<4, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
         } else {        // a single frame or a small album: one group per thread keeps every CU busy
             const dim3 vgrid((unsigned)(((npix >> 2) + 255) / 256), (unsigned)count);
-            hipLaunchKernelGGL((k_pixel_program_v4<1>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+            if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<1, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, 0);
+            else hipLaunchKernelGGL((k_pixel_program_v4<1, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
         }
     } else if (c == 4) hipLaunchKernelGGL((k_pixel_program<4>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else if (c == 3) hipLaunchKernelGGL((k_pixel_program<3>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
