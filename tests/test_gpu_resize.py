@@ -104,3 +104,38 @@ def test_exact_2x_decimation_rolling_kernel(gpu, interp, shape):
         want = orc.cv_resize(arr, sw // 2, sh // 2, interp)
         got = gpu_resize(gpu, arr, sw // 2, sh // 2, interp)
         assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
+
+
+@pytest.mark.parametrize("interp", [orc.INTER_CUBIC, orc.INTER_LANCZOS4], ids=lambda m: NAMES[m])
+@pytest.mark.parametrize("count", [1, 5, 8, 11])
+@pytest.mark.parametrize("pad", [0, 32, 4], ids=["tight", "pitch+32", "pitch+4"])
+def test_exact_2x_batch_dma_ring(gpu, interp, count, pad):
+    """Exact halves of a resident batch: the LDS-DMA row-ring kernel (16-byte aligned pitches: pad 0 / 32) with its
+    frame-per-XCD block order (batch sizes around the group of 8), a partial last column strip (260 = 4 * 64 + 4),
+    a 5-row last row strip, and the register-rolling fallback when the pitch is only 4-byte aligned (pad 4)."""
+    sh, sw = 250, 520
+    dh, dw = sh // 2, sw // 2
+    sstep = sw * 4 + pad
+    frames = [noise_image(sh, sw, 4, 90 + i) for i in range(count)]
+    packed = np.zeros((count, sh, sstep), np.uint8)
+    for i, f in enumerate(frames):
+        packed[i, :, :sw * 4] = f.reshape(sh, sw * 4)
+    src = gpu.Image(packed.reshape(count * sh, sstep // 4, 4))
+    dst = gpu.Image(np.zeros((count * dh, dw, 4), np.uint8))
+    gpu.batch_cv_resize(src.device_ptr, sh * sstep, sw, sh, sstep, dst.device_ptr, dh * dw * 4, dw, dh, dw * 4, 4, count, interp)
+    out = dst.numpy().reshape(count, dh, dw, 4)
+    for i in range(count):
+        assert np.array_equal(out[i], orc.cv_resize(frames[i], dw, dh, interp)), i
+    src.release(); dst.release()
+
+
+@pytest.mark.parametrize("interp", [orc.INTER_CUBIC, orc.INTER_LANCZOS4], ids=lambda m: NAMES[m])
+@pytest.mark.parametrize("shape", [(4, 4), (2, 8), (12, 4), (14, 136), (126, 128), (130, 132), (480, 640), (64, 1028)])
+def test_exact_2x_dma_ring_shapes(gpu, interp, shape):
+    """Widths that are multiples of 4 take the DMA ring: windows narrower than the tap count, one-strip images, a
+    strip boundary exactly at the image edge, and rows fewer than the ring depth."""
+    sh, sw = shape
+    for arr in (noise_image(sh, sw, 4, 75), smooth_image(sh, sw, 4)):
+        want = orc.cv_resize(arr, sw // 2, sh // 2, interp)
+        got = gpu_resize(gpu, arr, sw // 2, sh // 2, interp)
+        assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
