@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libimpgpu.so")
+LIB_PATH = os.environ.get("IMPGPU_LIB") or os.path.join(HERE, "libimpgpu.so")   # IMPGPU_LIB: A/B a differently built library
 
 
 class ImpError(RuntimeError):

@@ -666,7 +666,11 @@ struct AreaDev {
     const float* xalpha_pad;    // [dw][4*nv] weights of each run, shifted to xstart_pad and zero-padded
     const float* ybeta_pad;     // [dh][nyp] row weights, zero-padded
     int nv, nyp;
+    // k_resize_area_v4r: destination rows in groups of AREA_ROWS that share one walk over their source rows
+    const float* ybeta_grp;     // [ceil(dh / AREA_ROWS)][nypg][AREA_ROWS]: weight of source row (ystart[g*R] + j) in row g*R + k, else 0
+    int nypg;                   // source rows a group walks (max over groups)
 };
+#define AREA_ROWS 4
 
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_area(RArgs a, AreaDev t) {
@@ -764,6 +768,62 @@ __global__ __launch_bounds__(256) void k_resize_area_v4(RArgs a, AreaDev t, int 
                     ((uint32_t)sat_u8(__float2int_rn(s23.x)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s23.y)) << 24);
 }
 
+// AREA_ROWS vertically adjacent destination pixels per lane.  Consecutive destination rows share their boundary
+// source row (1080 -> 224: 5.82 rows fetched per output row for 4.82 new ones), and with a lane per output that row
+// is fetched -- and its horizontal sum computed -- twice, the second time often from HBM again (PMC: +16 %).  Here a
+// lane walks the source rows of its group once; each row's horizontal sum (the same float sequence as before, so
+// the same bits) is added to every row of the group with that row's weight, which is 0 where the source row does
+// not belong to it: s + 0 * b == s exactly, so the sums see the reference's additions in the reference's order.
+template <int NV>
+__global__ __launch_bounds__(256) void k_resize_area_v4r(RArgs a, AreaDev t, int bpf, int count) {
+    constexpr int R = AREA_ROWS;
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int ng = (a.dh + R - 1) / R;
+    const int idx = blk * 256 + threadIdx.x;
+    if (idx >= a.dw * ng) return;
+    const int g = idx / a.dw, dx = idx - g * a.dw;
+    const uint8_t* S = a.src + (long long)frame * a.src_stride;
+    const int xs = t.xstart_pad[dx];
+    float al[NV * 4];
+    __builtin_memcpy(al, __builtin_assume_aligned(t.xalpha_pad + (size_t)dx * (NV * 4), 16), NV * 16);
+    const int ys = t.ystart[g * R];
+    const float* yb = t.ybeta_grp + (size_t)g * t.nypg * R;
+    float2_t s01[R], s23[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) { s01[k] = float2_t{0.f, 0.f}; s23[k] = float2_t{0.f, 0.f}; }
+    for (int j = 0; j < t.nypg; j++) {
+        const int sy = min(ys + j, a.sh - 1);
+        const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 4;
+        uint32_t px[NV * 4];
+        __builtin_memcpy(px, __builtin_assume_aligned(row, 4), NV * 16);
+        float2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NV * 4; k++) {
+            const float2_t w = {al[k], al[k]};
+            const float2_t p01 = {(float)(px[k] & 0xff), (float)((px[k] >> 8) & 0xff)};
+            const float2_t p23 = {(float)((px[k] >> 16) & 0xff), (float)(px[k] >> 24)};
+            b01 = b01 + p01 * w;
+            b23 = b23 + p23 * w;
+        }
+        float be4[R];
+        __builtin_memcpy(be4, __builtin_assume_aligned(yb + (size_t)j * R, 16), R * 4);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const float2_t be = {be4[k], be4[k]};
+            s01[k] = s01[k] + be * b01;
+            s23[k] = s23[k] + be * b23;
+        }
+    }
+    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)(g * R) * a.dstep + (size_t)dx * 4;
+#pragma unroll
+    for (int k = 0; k < R; k++)
+        if (g * R + k < a.dh)
+            *(uint32_t*)(d + (size_t)k * a.dstep) =
+                (uint32_t)sat_u8(__float2int_rn(s01[k].x)) | ((uint32_t)sat_u8(__float2int_rn(s01[k].y)) << 8) |
+                ((uint32_t)sat_u8(__float2int_rn(s23[k].x)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s23[k].y)) << 24);
+}
+
 // The same for 3-channel BGR frames -- what cvDecodeImage hands the reference for every JPEG, and the mode its
 // Resize() picks for every shrink.  A run of 4*NV pixels is 12*NV bytes at an arbitrary byte address; gfx950
 // takes unaligned vector loads, and every (pixel, channel) sits at a compile-time byte of the loaded dwords,
@@ -841,8 +901,8 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
     }
     std::vector<uint8_t> blob;
     TableSet ts;
-    size_t o[11] = {0};
-    int nv = 0, nyp = 0;
+    size_t o[12] = {0};
+    int nv = 0, nyp = 0, nypg = 0;
     if (interp == IMP_INTER_AREA) {
         AreaAxis ax, ay;
         build_area_axis(sw, dw, scale_x, &ax);
@@ -862,6 +922,19 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
             for (int d = 0; d < dh; d++)
                 for (int k = 0; k < ay.count[d]; k++) ypad[(size_t)d * nyp + k] = ay.alpha[ay.aoff[d] + k];
             o[8] = put(blob, pad); o[9] = put(blob, xsp); o[10] = put(blob, ypad);
+            // row groups of k_resize_area_v4r
+            const int ng = (dh + AREA_ROWS - 1) / AREA_ROWS;
+            for (int g = 0; g < ng; g++) {
+                const int last = std::min(dh, (g + 1) * AREA_ROWS) - 1;
+                nypg = std::max(nypg, ay.start[last] + ay.count[last] - ay.start[g * AREA_ROWS]);
+            }
+            std::vector<float> ygrp((size_t)ng * nypg * AREA_ROWS, 0.f);
+            for (int d = 0; d < dh; d++) {
+                const int g = d / AREA_ROWS, k = d % AREA_ROWS, j0 = ay.start[d] - ay.start[g * AREA_ROWS];
+                for (int jj = 0; jj < ay.count[d]; jj++)
+                    ygrp[((size_t)g * nypg + j0 + jj) * AREA_ROWS + k] = ay.alpha[ay.aoff[d] + jj];
+            }
+            o[11] = put(blob, ygrp);
         }
     } else {
         TapAxis tx, ty;
@@ -891,6 +964,8 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         ts.area.ybeta_pad = nv ? (const float*)(dev + o[10]) : nullptr;
         ts.area.nv = nv;
         ts.area.nyp = nyp;
+        ts.area.ybeta_grp = nv ? (const float*)(dev + o[11]) : nullptr;
+        ts.area.nypg = nypg;
     } else {
         ts.xofs = (const int*)(dev + o[0]); ts.xco = (const short*)(dev + o[1]);
         ts.yofs = (const int*)(dev + o[2]); ts.yco = (const short*)(dev + o[3]);
@@ -915,7 +990,17 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, &ts)) return rc;
             const int bpf = (int)grid.x;                       // blocks per frame
             const dim3 fgrid(grid.x, (unsigned)((count + 7) / 8 * 8));   // whole groups of 8 frames (frame-per-XCD order)
-            if (CN == 4 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4<1>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            // BGRA: row groups share their source-row walk unless a group would walk a very long run (tiny outputs)
+            static const bool no_grp = std::getenv("IMPGPU_AREA_NO_GROUPS") != nullptr;
+            const int ng = (a.dh + AREA_ROWS - 1) / AREA_ROWS;
+            const int gbpf = (int)(((long long)a.dw * ng + 255) / 256);
+            const dim3 ggrid((unsigned)gbpf, (unsigned)((count + 7) / 8 * 8));
+            const bool grp = CN == 4 && !no_grp && ts.area.nv >= 1 && ts.area.nv <= 4 && ts.area.nypg <= 96;
+            if (grp && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4r<1>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4r<2>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4r<3>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v4r<4>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (CN == 4 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4<1>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else if (CN == 4 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4<2>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else if (CN == 4 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4<3>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else if (CN == 4 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v4<4>), fgrid, block, 0, s, a, ts.area, bpf, count);
