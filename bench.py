@@ -112,6 +112,7 @@ def cpu_baseline(seconds_budget=12.0):
     import threading
 
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = min(cores, int(os.environ.get("IMPGPU_BENCH_CPU_THREADS", "16")))   # a one-GPU box's CPU share is 16 cores
     counts = [0] * cores
     stop_at = time.perf_counter() + 6.0
 

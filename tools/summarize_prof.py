@@ -22,8 +22,8 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
-MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_v4<3>": "area", "k_resize_nn<4>": "nn",
-         "k_resize_taps<2, 4, 0>": "linear", "k_resize_tiled<8, 2": "lanczos", "k_area2x2_rotate_bgra": "chain"}
+MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_v4r<3>": "area", "k_resize_nn<4>": "nn",
+         "k_resize_taps<2, 4, 0>": "linear", "k_resize_2x_dma<8, 2": "lanczos", "k_area2x2_rotate_bgra": "chain"}
 
 
 def counter_means(kind):
