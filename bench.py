@@ -356,6 +356,15 @@ def main():
                 "kernel_ms_per_launch": round(launch_ms, 4),
             },
         }
+        if traffic and batch == json.load(open(tpath)).get("batch"):
+            # what rocprofv3's FETCH_SIZE + WRITE_SIZE saw per launch, at this run's launch time
+            out["roofline"]["traffic_rate_GBps"] = round(traffic / (launch_ms * 1e-3) / 1e9, 1)
+        if args.mode == "cubic":
+            # at a 34-byte tap pitch every 128-byte line of the 896 needed rows is touched, so the
+            # least HBM can move for this access pattern is 896 rows x 7680 B + the destination
+            lg = (896 * 7680 + dw * dh * 4) * batch
+            out["roofline"]["line_granular"] = {"bytes_per_launch": lg, "achieved": round(lg / (launch_ms * 1e-3) / 1e9, 1),
+                                                "frac": round(lg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
