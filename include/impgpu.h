@@ -194,6 +194,28 @@ int               impgpu_request_mime(const impgpu_request* request);       /* I
 int               impgpu_request_destructive(const impgpu_request* request); /* CheckDestructive over the filters */
 void              impgpu_request_free(impgpu_request** request);
 
+/* ---- GIF album hand-over: LoadGIF (advancedio.c:103-262).  FreeImage keeps decoding the pages on the host; the
+ *      per-pixel compositing loop of advancedio.c:204-247 -- the frame placed at FrameLeft/FrameTop on the first
+ *      page's canvas, the transparent index, the `master` index canvas carried from page to page when the request
+ *      is destructive (advancedio.c:195-240), the RGBQUAD palette lookup into a 4-channel frame (:242-246) -- runs
+ *      on the device.  A page is what FreeImage hands that loop: 8-bit indices in scanline order (bottom-up,
+ *      `pitch` bytes per row; FreeImage_ConvertTo8Bits first when the page is not 8-bit, :181-185).
+ *      frames[i] = page i (all `count` of them) when page < 0; with page >= 0 the walk stops there and frames[0]
+ *      is that page alone (advancedio.c:249-262).  Returns IMP_ERROR_INVALID_ARGS for page >= count. ---- */
+#define IMP_GIF_DISPOSAL_UNSPECIFIED 0
+#define IMP_GIF_DISPOSAL_LEAVE       1
+#define IMP_GIF_DISPOSAL_BACKGROUND  2
+#define IMP_GIF_DISPOSAL_PREVIOUS    3
+typedef struct impgpu_gif_page {
+    const unsigned char* indices;   /* FreeImage_GetBits of the 8-bit page (host memory) */
+    int width, height, pitch;       /* FreeImage_GetWidth / GetHeight / GetPitch */
+    int left, top;                  /* FIMD_ANIMATION FrameLeft / FrameTop (advancedio.c:159-174) */
+    int dispose;                    /* FIMD_ANIMATION DisposalMethod (advancedio.c:146-157) -> Frame.Dispose */
+    int transparency_key;           /* FreeImage_GetTransparentIndex, -1 = none (advancedio.c:176) */
+    const unsigned char* palette;   /* FreeImage_GetPalette: 256 RGBQUAD = B,G,R,reserved bytes (advancedio.c:178) */
+} impgpu_gif_page;
+int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** frames);
+
 /* ---- batch entry points (benchmark / multi-frame albums: bridge.c:578,591,608,632).
  *      `count` frames of identical geometry, frame i at base + i*frame_stride bytes,
  *      already resident in HBM.  stream = hipStream_t to launch on (NULL = env stream).

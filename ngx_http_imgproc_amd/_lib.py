@@ -55,6 +55,17 @@ class CJob(C.Structure):
     ]
 
 
+class CGifPage(C.Structure):
+    _fields_ = [
+        ("indices", C.c_void_p),
+        ("width", C.c_int), ("height", C.c_int), ("pitch", C.c_int),
+        ("left", C.c_int), ("top", C.c_int),
+        ("dispose", C.c_int),
+        ("transparency_key", C.c_int),
+        ("palette", C.c_void_p),
+    ]
+
+
 P = C.c_void_p
 PP = C.POINTER(C.c_void_p)
 IP = C.POINTER(C.c_int)
@@ -76,6 +87,7 @@ SIGNATURES = {
     "impgpu_image_download_pinned": (C.c_int, [P, P, C.c_int]),
     "impgpu_image_upload_fi32": (C.c_int, [P, C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_download_fi": (C.c_int, [P, C.c_int, P, C.c_int]),
+    "impgpu_gif_compose": (C.c_int, [C.POINTER(CGifPage), C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_clone": (C.c_int, [P, PP]),
     "impgpu_image_download": (C.c_int, [P, P, C.c_int]),
     "impgpu_image_width": (C.c_int, [P]),

@@ -219,6 +219,49 @@ int impgpu_blend_with_paper(impgpu_image* image) {
     return launch_blend_paper(image->d, 0, image->w, image->h, image->step, 1, env_stream());
 }
 
+int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** frames) {
+    if (!pages || !frames || count <= 0 || page >= count) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    const int cw = pages[0].width, ch = pages[0].height;           // advancedio.c:133-136: canvas = first page
+    if (cw <= 0 || ch <= 0) return IMP_ERROR_INVALID_ARGS;
+    const int npages = page >= 0 ? page + 1 : count;               // the walk stops at the requested page (:249-251)
+    const int nout = page >= 0 ? 1 : count;
+    // one blob: page table | output pointers | palettes | index planes
+    std::vector<GifPageDev> meta((size_t)npages);
+    size_t off = (size_t)npages * sizeof(GifPageDev) + (size_t)nout * sizeof(uint8_t*);
+    off = (off + 15) & ~size_t(15);
+    for (int f = 0; f < npages; f++) {
+        const impgpu_gif_page& p = pages[f];
+        if (!p.indices || !p.palette || p.width <= 0 || p.height <= 0 || p.pitch < p.width) return IMP_ERROR_INVALID_ARGS;
+        meta[f].pal_off = (long long)off; off += 1024;
+        meta[f].idx_off = (long long)off; off += ((size_t)p.pitch * p.height + 15) & ~size_t(15);
+        meta[f].w = p.width; meta[f].h = p.height; meta[f].pitch = p.pitch; meta[f].left = p.left; meta[f].top = p.top;
+        meta[f].dispose = p.dispose; meta[f].key = p.transparency_key; meta[f].pad = 0;
+    }
+    std::vector<impgpu_image*> imgs((size_t)nout, nullptr);
+    auto drop = [&]() { for (impgpu_image* im : imgs) if (im) image_delete(im); };
+    for (int i = 0; i < nout; i++)
+        if (int rc = image_new(cw, ch, 4, &imgs[i])) { drop(); return rc; }
+    std::vector<uint8_t> blob(off, 0);
+    std::memcpy(blob.data(), meta.data(), (size_t)npages * sizeof(GifPageDev));
+    uint8_t** optr = (uint8_t**)(blob.data() + (size_t)npages * sizeof(GifPageDev));
+    for (int i = 0; i < nout; i++) optr[i] = imgs[i]->d;
+    for (int f = 0; f < npages; f++) {
+        std::memcpy(blob.data() + meta[f].pal_off, pages[f].palette, 1024);
+        std::memcpy(blob.data() + meta[f].idx_off, pages[f].indices, (size_t)pages[f].pitch * pages[f].height);
+    }
+    void* dev = nullptr;
+    hipStream_t s = env_stream();
+    if (int rc = upload_small(blob.data(), blob.size(), &dev, s)) { drop(); return rc; }
+    const uint8_t* d = (const uint8_t*)dev;
+    int rc = launch_gif_compose(d, (const GifPageDev*)d, (uint8_t* const*)(d + (size_t)npages * sizeof(GifPageDev)), npages,
+                                cw, ch, imgs[0]->step, destructive ? 1 : 0, page, s);
+    dev_free(dev);                                                 // stream-ordered: after the kernel
+    if (rc) { drop(); return rc; }
+    for (int i = 0; i < nout; i++) frames[i] = imgs[i];
+    return IMP_OK;
+}
+
 int impgpu_calc_perceived_brightness(const impgpu_image* image, float* brightness) {
     if (!image || !brightness) return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;

@@ -119,6 +119,54 @@ int launch_pack_fi(const View& v, int bpp, uint8_t* dst, int dpitch, hipStream_t
     return IMP_OK;
 }
 
+// LoadGIF's compositing loop (advancedio.c:204-247), one lane per canvas pixel walking the pages in order: the
+// `master` index canvas of the destructive mode is that pixel's register.  Same definitions as the oracle where the
+// reference is undefined (read one byte past the frame row at x == left + w; index < 0 -> colour 0).
+__global__ __launch_bounds__(256) void k_gif_compose(const uint8_t* __restrict__ blob, const GifPageDev* __restrict__ pg,
+                                                     uint8_t* const* __restrict__ outs, int npages, int cw, int ch,
+                                                     int ostep, int destructive, int only) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)cw * ch) return;
+    const int y = (int)(idx / cw), x = (int)(idx - (long long)y * cw);
+    int master = 0;
+    for (int f = 0; f < npages; f++) {
+        const GifPageDev p = pg[f];
+        const int rowidx = p.h + p.top - y - 1;
+        int coloridx;
+        if (rowidx < 0 || x < p.left || y < p.top || x > p.left + p.w || y > p.top + p.h) {
+            coloridx = p.key;
+        } else {
+            const long long o = (long long)rowidx * p.pitch + (x - p.left);
+            coloridx = o < (long long)p.pitch * p.h ? (int)blob[p.idx_off + o] : p.key;
+        }
+        if (destructive) {
+            if (p.dispose == 2) {
+                if (coloridx == p.key) coloridx = 0;
+                else master = coloridx;
+            } else {
+                if (coloridx == p.key && f > 0) coloridx = master;
+                else master = coloridx;
+            }
+        }
+        if (only >= 0 && f != only) continue;
+        uint32_t px = 0;
+        if (coloridx >= 0 && coloridx < 256) {
+            const uint8_t* q = blob + p.pal_off + 4 * coloridx;
+            px = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+        }
+        if (coloridx != p.key) px |= 0xff000000u;
+        *(uint32_t*)(outs[only >= 0 ? 0 : f] + (size_t)y * ostep + (size_t)x * 4) = px;
+    }
+}
+
+int launch_gif_compose(const uint8_t* blob, const GifPageDev* pages, uint8_t* const* outs, int npages, int cw, int ch,
+                       int ostep, int destructive, int only, hipStream_t s) {
+    const dim3 grid((unsigned)(((long long)cw * ch + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_gif_compose, grid, block, 0, s, blob, pages, outs, npages, cw, ch, ostep, destructive, only);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
 static GArgs gargs(const Frames& f) {
     return GArgs{f.src, f.src_stride, f.v.step, f.v.w, f.v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
 }

@@ -126,6 +126,9 @@ int launch_flip(const Frames& f, int mode, hipStream_t s);             // cvFlip
 int launch_rotate(const Frames& f, int amount, hipStream_t s);         // 90 / 270 (dw,dh = v.h,v.w), 180
 int launch_gray2bgr(const Frames& f, hipStream_t s);
 int launch_pack_fi(const View& v, int bpp, uint8_t* dst, int dpitch, hipStream_t s);   // IplToFI32/24: flip + repack
+struct GifPageDev { long long idx_off, pal_off; int w, h, pitch, left, top, dispose, key, pad; };   // offsets into one device blob
+int launch_gif_compose(const uint8_t* blob, const GifPageDev* pages, uint8_t* const* outs, int npages, int cw, int ch,
+                       int ostep, int destructive, int only, hipStream_t s);                 // LoadGIF's compositing loop
 // imp_pixel.hip
 int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int step, int count,
                          const PixelProgram& prog, hipStream_t s);

@@ -249,6 +249,30 @@ def batch_resize_rotate_watermark(src_ptr, src_stride, sw, sh, sstep, dst_ptr, d
         raise ImpError(rc, "impgpu_batch_resize_rotate_watermark")
 
 
+def gif_compose(pages, destructive=False, page=-1):
+    """LoadGIF's compositing loop (advancedio.c:204-247) on the device.  pages: dicts with `indices` (h x pitch uint8,
+    FreeImage scanline order), `width`, `left`, `top`, `dispose`, `key`, `palette` (256 x 4 uint8, B,G,R,reserved).
+    Returns (code, [Image ...]): every page, or just the requested one."""
+    from ._lib import CGifPage
+    keep = []
+    arr = (CGifPage * max(1, len(pages)))()
+    for i, p in enumerate(pages):
+        idx = np.ascontiguousarray(p["indices"], dtype=np.uint8)
+        pal = np.ascontiguousarray(p["palette"], dtype=np.uint8)
+        keep += [idx, pal]
+        arr[i].indices = idx.ctypes.data
+        arr[i].width = int(p["width"]); arr[i].height = idx.shape[0]; arr[i].pitch = idx.shape[1]
+        arr[i].left = int(p.get("left", 0)); arr[i].top = int(p.get("top", 0))
+        arr[i].dispose = int(p.get("dispose", 0)); arr[i].transparency_key = int(p.get("key", -1))
+        arr[i].palette = pal.ctypes.data
+    nout = 1 if page >= 0 else len(pages)
+    outs = (C.c_void_p * max(1, nout))()
+    rc = lib.impgpu_gif_compose(arr, len(pages), int(bool(destructive)), int(page), outs)
+    if rc:
+        return rc, []
+    return 0, [Image(handle=outs[i]) for i in range(nout)]
+
+
 def batch_filters(ptr, stride, w, h, c, step, count, filters, allow_experiments=1, stream=None):
     """Pointwise filter-* requests on every frame of a resident batch, one fused launch. Returns the IMP_* code."""
     arr = (C.c_char_p * max(1, len(filters)))(*[_b(f) for f in filters])

@@ -127,6 +127,21 @@ int orc_run_chain(orc_image** pointer, const orc_chain* chain, int* step);
 int orc_ipl_to_fi(const orc_image* img, int bpp, unsigned char* out, int pitch);
 orc_image* orc_fi32_to_ipl(const unsigned char* bits, int width, int height, int pitch);
 
+/* advancedio.c:103-262 LoadGIF, the compositing loop of :204-247.  A page is what FreeImage hands that loop:
+ * 8-bit palette indices in FreeImage scanline order (bottom-up, `pitch` bytes per row), the FrameLeft / FrameTop /
+ * DisposalMethod tags, the transparent index (-1 = none) and the 256-entry RGBQUAD palette (B,G,R,reserved).
+ * frames[i] receives page i composed on the first page's canvas (4 channels); with page >= 0 the walk stops at
+ * that page and only frames[0] (= that page) is returned, like advancedio.c:254-262. */
+typedef struct {
+    const unsigned char* indices;
+    int width, height, pitch;
+    int left, top;
+    int dispose;             /* 0 unspecified, 1 leave, 2 background, 3 previous (FreeImage GIF_DISPOSAL_*) */
+    int transparency_key;
+    const unsigned char* palette;
+} orc_gif_page;
+int orc_gif_compose(const orc_gif_page* pages, int count, int destructive, int page, orc_image** frames);
+
 /* bridge.c:304-372 request parsing + bridge.c:413-466 encoder choice. Strings point into `buffer`. */
 #define ORC_MAX_FILTERS 64
 typedef struct {

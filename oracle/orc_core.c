@@ -274,3 +274,61 @@ orc_image* orc_fi32_to_ipl(const unsigned char* bits, int width, int height, int
         memcpy(img->data + (size_t)(height - 1 - y) * img->step, bits + (size_t)y * pitch, (size_t)width * 4);
     return img;
 }
+
+/* ---- advancedio.c:103-262 LoadGIF: the per-pixel compositing loop (:204-247) ----
+ * Defined where the reference is undefined (the product defines the same):
+ *  - `x > left + w` lets x == left + w through, which reads row[w]: one byte past the frame's row.  Mirrored as the
+ *    same linear read (the pitch padding, or the next scanline's first byte); past the end of the page it is the key.
+ *  - an index < 0 (key -1 on a pixel outside the frame, or a never-written master entry) would index the palette
+ *    out of bounds: colour 0,0,0.  `master` starts at 0 (ngx_palloc does not clear it).
+ *  - page >= count: INVALID_ARGS (the reference would index Frames[] out of bounds). */
+int orc_gif_compose(const orc_gif_page* pages, int count, int destructive, int page, orc_image** frames) {
+    if (!pages || !frames || count <= 0 || page >= count) return ORC_ERROR_INVALID_ARGS;
+    const int cw = pages[0].width, ch = pages[0].height;          /* :133-136 canvas = first page */
+    if (cw <= 0 || ch <= 0) return ORC_ERROR_INVALID_ARGS;
+    int* master = destructive ? (int*)calloc((size_t)cw * ch, sizeof(int)) : NULL;   /* :195-200 */
+    if (destructive && !master) return ORC_ERROR_MALLOC_FAILED;
+    const int last = page >= 0 ? page : count - 1;
+    orc_image* kept = NULL;
+    for (int f = 0; f <= last; f++) {
+        const orc_gif_page* p = &pages[f];
+        const int w = p->width, h = p->height, left = p->left, top = p->top, key = p->transparency_key;
+        orc_image* img = orc_image_create(cw, ch, 4);
+        if (!img) { free(master); return ORC_ERROR_MALLOC_FAILED; }
+        for (int y = 0; y < ch; y++) {
+            const int rowidx = h + top - y - 1;                   /* :206 */
+            for (int x = 0; x < cw; x++) {
+                int coloridx;
+                if (rowidx < 0 || x < left || y < top || x > left + w || y > top + h) {   /* :213 */
+                    coloridx = key;
+                } else {
+                    const long long o = (long long)rowidx * p->pitch + (x - left);
+                    coloridx = o < (long long)p->pitch * h ? p->indices[o] : key;
+                }
+                if (destructive) {                                /* :219-240 */
+                    const size_t offset = (size_t)y * cw + x;
+                    if (p->dispose == 2) {                        /* GIF_DISPOSAL_BACKGROUND */
+                        if (coloridx == key) coloridx = 0;
+                        else master[offset] = coloridx;
+                    } else {
+                        if (coloridx == key && f > 0) coloridx = master[offset];
+                        else master[offset] = coloridx;
+                    }
+                }
+                unsigned char* d = img->data + (size_t)y * img->step + (size_t)x * 4;
+                if (coloridx >= 0 && coloridx < 256) {            /* :242-246 RGBQUAD = B,G,R,reserved */
+                    d[0] = p->palette[4 * coloridx]; d[1] = p->palette[4 * coloridx + 1]; d[2] = p->palette[4 * coloridx + 2];
+                } else {
+                    d[0] = d[1] = d[2] = 0;
+                }
+                d[3] = coloridx == key ? 0 : 255;
+            }
+        }
+        if (page < 0) frames[f] = img;
+        else if (f == page) kept = img;
+        else orc_image_free(img);
+    }
+    free(master);
+    if (page >= 0) frames[0] = kept;
+    return ORC_OK;
+}

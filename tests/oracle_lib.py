@@ -221,6 +221,35 @@ def ipl_to_fi(arr, bpp):
     return out
 
 
+class GifPage(C.Structure):
+    _fields_ = [("indices", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("pitch", C.c_int),
+                ("left", C.c_int), ("top", C.c_int), ("dispose", C.c_int), ("transparency_key", C.c_int),
+                ("palette", C.c_void_p)]
+
+
+def gif_compose(pages, destructive=False, page=-1):
+    """orc_gif_compose over the same page dicts as ngx_http_imgproc_amd.gif_compose -> (code, [ndarray ...])."""
+    keep = []
+    arr = (GifPage * max(1, len(pages)))()
+    for i, p in enumerate(pages):
+        idx = np.ascontiguousarray(p["indices"], dtype=np.uint8)
+        pal = np.ascontiguousarray(p["palette"], dtype=np.uint8)
+        keep += [idx, pal]
+        arr[i].indices = idx.ctypes.data
+        arr[i].width = int(p["width"]); arr[i].height = idx.shape[0]; arr[i].pitch = idx.shape[1]
+        arr[i].left = int(p.get("left", 0)); arr[i].top = int(p.get("top", 0))
+        arr[i].dispose = int(p.get("dispose", 0)); arr[i].transparency_key = int(p.get("key", -1))
+        arr[i].palette = pal.ctypes.data
+    nout = 1 if page >= 0 else len(pages)
+    outs = (C.c_void_p * max(1, nout))()
+    lib.orc_gif_compose.restype = C.c_int
+    lib.orc_gif_compose.argtypes = [C.POINTER(GifPage), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    rc = lib.orc_gif_compose(arr, len(pages), int(bool(destructive)), int(page), outs)
+    if rc:
+        return rc, []
+    return 0, [Img(handle=outs[i]).numpy() for i in range(nout)]
+
+
 def fi32_to_ipl(bits, w, h):
     bits = np.ascontiguousarray(bits, dtype=np.uint8)
     return Img(handle=lib.orc_fi32_to_ipl(bits.ctypes.data, w, h, w * 4)).numpy()
