@@ -360,17 +360,31 @@ template <int KS>
 __device__ __forceinline__ void hpass_px(const uint32_t* p, const short2_t* axp, int* h) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        int acc = 0;
+        int acc;
 #pragma unroll
         for (int j = 0; j < KS / 2; j++) {
             const uint32_t pr = __builtin_amdgcn_perm(p[2 * j + 1], p[2 * j], 0x0c040c00u + (c << 16) + c);
-            acc = __builtin_amdgcn_sdot2(as_short2(pr), axp[j], acc, false);
+            // the chain starts from a literal 0 in the three-operand form: the two-operand v_dot2c the compiler picks
+            // needs its accumulator zeroed by a v_mov first
+            if (j == 0) asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(acc) : "v"(pr), "v"(axp[0]));
+            else acc = __builtin_amdgcn_sdot2(as_short2(pr), axp[j], acc, false);
         }
         h[c] = acc;
     }
 }
 
 // vertical pass over the register ring at phase U of its period; returns the packed BGRA destination pixel
+// {sat_u8(v0 >> sh), sat_u8(v1 >> sh), sat_u8(v2 >> sh), sat_u8(v3 >> sh)} as bytes 0..3 in two instructions.
+// v_ashr_pk_u8_i32 writes ONE 16-bit half of its destination ({sat(S1 >> S2), sat(S0 >> S2)}) and leaves the other
+// half alone; op_sel:[0,0,0,1] selects the upper half.  Checked on hardware by tools/pk_probe.hip -- this is the
+// instruction hipcc itself mis-used (it assumes the other half is cleared; see shr_sat_u8).
+__device__ __forceinline__ uint32_t shr_sat_pack4(int v0, int v1, int v2, int v3, int sh) {
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v0), "v"(v1), "v"(sh));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(v2), "v"(v3), "v"(sh));
+    return r;
+}
+
 // a * b + c on the 24-bit multiplier as ONE instruction (hipcc otherwise splits it into v_mul_i32_i24 + v_add3_u32,
 // and every integer multiply form issues at half rate on gfx950: profiles/r01_valu_rates.txt)
 __device__ __forceinline__ int mad24(int a, int b, int c) {
@@ -379,11 +393,36 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
     return r;
 }
 
+// the same with the weight in a scalar register (wave-uniform row weights): no v_mov of it into a VGPR
+__device__ __forceinline__ int mad24s(int a, int b_uniform, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+
 // VSYM: the KS row weights are mirror-symmetric (host-checked; true at the half-pixel phase of an exact 2x scale),
 // so mirrored ring rows are added first (full-rate v_add_u32, exact) and the multiplies halve.
 template <int KS, int MODE, int U, bool VSYM = false>
 __device__ __forceinline__ uint32_t vpass_px(const int (*ring)[4], const int* b, int dx, int vec_end) {
     int out[4];
+    if constexpr (MODE == M_LANCZOS) {
+        int v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int hc[KS];
+#pragma unroll
+            for (int k = 0; k < KS; k++) hc[k] = ring[(k + 2 * U) % KS][c];
+            v[c] = 1 << 21;                                    // |hc| < 2^23: the 24-bit multiplier is exact
+            if constexpr (VSYM) {
+#pragma unroll
+                for (int k = 0; k < KS / 2; k++) v[c] = mad24s(hc[k] + hc[KS - 1 - k], b[k], v[c]);   // VSYM callers pass uniform weights
+            } else {
+#pragma unroll
+                for (int k = 0; k < KS; k++) v[c] = mad24(hc[k], b[k], v[c]);
+            }
+        }
+        return shr_sat_pack4(v[0], v[1], v[2], v[3], 22);
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         int hc[KS];
@@ -407,7 +446,7 @@ __device__ __forceinline__ uint32_t vpass_px(const int (*ring)[4], const int* b,
             int v = 1 << 21;                                   // |hc| < 2^23: the 24-bit multiplier is exact
             if constexpr (VSYM) {
 #pragma unroll
-                for (int k = 0; k < KS / 2; k++) v = mad24(hc[k] + hc[KS - 1 - k], b[k], v);
+                for (int k = 0; k < KS / 2; k++) v = mad24s(hc[k] + hc[KS - 1 - k], b[k], v);   // VSYM callers pass uniform weights
             } else {
 #pragma unroll
                 for (int k = 0; k < KS; k++) v = mad24(hc[k], b[k], v);
