@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void k_resize_2x_roll(RArgs a, const int* __re
 #define DMA_SLOT 576       // bytes per LDS row slot: (2 * 64 + KS + 3 rounded to 4) pixels = 34 lanes x 16 B, padded
 
 #ifndef DMA_WAVES
-#define DMA_WAVES 7
+#define DMA_WAVES 6
 #endif
 template <int KS, int MODE, int DEPTH, bool VSYM, int WPB>
 __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
@@ -577,7 +577,9 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
 
     // source row sy_first + r (clamped) -> slot r % R
     auto issue = [&](int r) {
-        const uint8_t* g = S + (size_t)clampi(sy_first + r, 0, a.sh - 1) * a.sstep + lane16;
+        // 32-bit offset from the scalar frame base (saddr + voffset addressing; a frame is < 4 GB, host-checked):
+        // the 64-bit form costs a v_mad_i64_i32 per address
+        const uint8_t* g = S + ((unsigned)clampi(sy_first + r, 0, a.sh - 1) * (unsigned)a.sstep + lane16);
         if (fetch)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)&lds[wv][r % R][0], 16, 0, 0);
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
                     hpass_px<KS>(q, axp, ring[(KS - 1 + 2 * u) % KS]);
                     asm volatile("" ::: "memory");             // the slots just read may be refilled from here on
                     const uint32_t px = vpass_px<KS, MODE, u, VSYM>(ring, by, dx, vec_end);
-                    if (!EDGE || live) *(uint32_t*)(D + (size_t)(dy0 + i) * a.dstep + lane4) = px;
+                    if (!EDGE || live) *(uint32_t*)(D + ((unsigned)(dy0 + i) * (unsigned)a.dstep + lane4)) = px;
                 }
             });
         }
@@ -1061,6 +1063,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             // prefetched (0 = off: the register-rolling kernel, which has no alignment demands)
             static const int dma_depth = std::getenv("IMPGPU_DMA_DEPTH") ? std::atoi(std::getenv("IMPGPU_DMA_DEPTH")) : 3;
             const bool dma_ok = dma_depth > 0 && interp != IMP_INTER_LINEAR && (a.sw & 3) == 0 &&
+                                (long long)a.sh * a.sstep < (1LL << 32) && (long long)a.dh * a.dstep < (1LL << 32) &&
                                 !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 15);
             const dim3 rgrid((a.dw + 255) / 256, nstrips, (unsigned)count);
             // waves of a block are independent (no barriers, private LDS rings): small blocks only shorten the tail
