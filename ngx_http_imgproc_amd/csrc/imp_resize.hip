@@ -908,6 +908,58 @@ __global__ __launch_bounds__(256) void k_resize_area_v3(RArgs a, AreaDev t, int 
     d[2] = (uint8_t)sat_u8(__float2int_rn(s2));
 }
 
+// k_resize_area_v3 with AREA_ROWS vertically adjacent outputs per lane (see k_resize_area_v4r)
+template <int NV>
+__global__ __launch_bounds__(256) void k_resize_area_v3r(RArgs a, AreaDev t, int bpf, int count) {
+    constexpr int R = AREA_ROWS;
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int ng = (a.dh + R - 1) / R;
+    const int idx = blk * 256 + threadIdx.x;
+    if (idx >= a.dw * ng) return;
+    const int g = idx / a.dw, dx = idx - g * a.dw;
+    const uint8_t* S = a.src + (long long)frame * a.src_stride;
+    const int xs = t.xstart_pad[dx];
+    float al[NV * 4];
+    __builtin_memcpy(al, __builtin_assume_aligned(t.xalpha_pad + (size_t)dx * (NV * 4), 16), NV * 16);
+    const int ys = t.ystart[g * R];
+    const float* yb = t.ybeta_grp + (size_t)g * t.nypg * R;
+    float s0[R], s1[R], s2[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) s0[k] = s1[k] = s2[k] = 0.f;
+    for (int j = 0; j < t.nypg; j++) {
+        const int sy = min(ys + j, a.sh - 1);
+        const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 3;
+        uint32_t w[NV * 3];
+        __builtin_memcpy(w, row, NV * 12);                    // byte-aligned vector loads
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV * 4; k++) {
+            const int o0 = 3 * k, o1 = 3 * k + 1, o2 = 3 * k + 2;
+            b0 = __fadd_rn(b0, __fmul_rn((float)((w[o0 >> 2] >> (8 * (o0 & 3))) & 0xff), al[k]));
+            b1 = __fadd_rn(b1, __fmul_rn((float)((w[o1 >> 2] >> (8 * (o1 & 3))) & 0xff), al[k]));
+            b2 = __fadd_rn(b2, __fmul_rn((float)((w[o2 >> 2] >> (8 * (o2 & 3))) & 0xff), al[k]));
+        }
+        float be[R];
+        __builtin_memcpy(be, __builtin_assume_aligned(yb + (size_t)j * R, 16), R * 4);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            s0[k] = __fadd_rn(s0[k], __fmul_rn(be[k], b0));
+            s1[k] = __fadd_rn(s1[k], __fmul_rn(be[k], b1));
+            s2[k] = __fadd_rn(s2[k], __fmul_rn(be[k], b2));
+        }
+    }
+    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)(g * R) * a.dstep + (size_t)dx * 3;
+#pragma unroll
+    for (int k = 0; k < R; k++)
+        if (g * R + k < a.dh) {
+            uint8_t* q = d + (size_t)k * a.dstep;
+            q[0] = (uint8_t)sat_u8(__float2int_rn(s0[k]));
+            q[1] = (uint8_t)sat_u8(__float2int_rn(s1[k]));
+            q[2] = (uint8_t)sat_u8(__float2int_rn(s2[k]));
+        }
+}
+
 // ------------------------------------------------------------------ per-geometry table cache
 struct TableSet {
     void* blob = nullptr;     // one device allocation
@@ -1036,11 +1088,18 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             const int ng = (a.dh + AREA_ROWS - 1) / AREA_ROWS;
             const int gbpf = (int)(((long long)a.dw * ng + 255) / 256);
             const dim3 ggrid((unsigned)gbpf, (unsigned)((count + 7) / 8 * 8));
-            const bool grp = CN == 4 && !no_grp && ts.area.nv >= 1 && ts.area.nv <= 4 && ts.area.nypg <= 96;
+            // (a lone frame keeps one output per lane: a quarter of the blocks would not fill 256 CUs)
+            const bool big = (long long)gbpf * count >= 1024;
+            const bool grp = CN == 4 && !no_grp && big && ts.area.nv >= 1 && ts.area.nv <= 4 && ts.area.nypg <= 96;
+            const bool grp3 = CN == 3 && !no_grp && big && ts.area.nv >= 1 && ts.area.nv <= 4 && ts.area.nypg <= 96;
             if (grp && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4r<1>), ggrid, block, 0, s, a, ts.area, gbpf, count);
             else if (grp && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4r<2>), ggrid, block, 0, s, a, ts.area, gbpf, count);
             else if (grp && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4r<3>), ggrid, block, 0, s, a, ts.area, gbpf, count);
             else if (grp && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v4r<4>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp3 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v3r<1>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp3 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v3r<2>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp3 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v3r<3>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp3 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v3r<4>), ggrid, block, 0, s, a, ts.area, gbpf, count);
             else if (CN == 4 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4<1>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else if (CN == 4 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4<2>), fgrid, block, 0, s, a, ts.area, bpf, count);
             else if (CN == 4 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4<3>), fgrid, block, 0, s, a, ts.area, bpf, count);

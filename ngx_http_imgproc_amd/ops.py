@@ -125,6 +125,11 @@ class Image:
     def device_ptr(self):
         return lib.impgpu_image_device_ptr(self.h)
 
+    @property
+    def step(self):
+        """Device row pitch in bytes (cvCreateImage's 4-byte alignment rule)."""
+        return lib.impgpu_image_step(self.h)
+
     def numpy(self):
         hh, ww, cc = self.shape
         out = np.empty((hh, ww, cc), dtype=np.uint8)

@@ -139,3 +139,20 @@ def test_exact_2x_dma_ring_shapes(gpu, interp, shape):
         want = orc.cv_resize(arr, sw // 2, sh // 2, interp)
         got = gpu_resize(gpu, arr, sw // 2, sh // 2, interp)
         assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
+
+
+@pytest.mark.parametrize("c", [3, 4])
+def test_area_row_groups_on_a_large_batch(gpu, c):
+    """Big launches take the row-grouped AREA kernels (four destination rows per lane): 137 frames (not a multiple of
+    the XCD group of 8), 75 destination rows (a partial last group of 3), fractional scales on both axes."""
+    n, sh, sw, dh, dw = 137, 241, 322, 75, 100
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (n, sh, sw, c), dtype=np.uint8)
+    src = gpu.Image(frames.reshape(n * sh, sw, c))
+    dst = gpu.Image(np.zeros((n * dh, dw, c), np.uint8))
+    sstep, dstep = src.step, dst.step
+    gpu.batch_cv_resize(src.device_ptr, sh * sstep, sw, sh, sstep, dst.device_ptr, dh * dstep, dw, dh, dstep, c, n, orc.INTER_AREA)
+    out = dst.numpy().reshape(n, dh, dw, c)
+    for i in list(range(0, n, 9)) + [n - 1]:
+        assert np.array_equal(out[i], orc.cv_resize(frames[i], dw, dh, orc.INTER_AREA)), i
+    src.release(); dst.release()
