@@ -44,6 +44,9 @@ WORKLOADS = {
               "batch 256 of 1920x1080 BGRA filter-gamma=2.2 in place (LUT)"),
     "chain": (1920, 1080, 540, 960, 1024, -1, 1920 * 1080 * 4 + 540 * 960 * 4,
               "batch 1024 of 1920x1080 BGRA resize(960x540)+rotate(90)+watermark alpha-blend chain"),
+    # SURVEY 8(d) cfg3's second variant: the same chain with resize=224,224 (general AREA kernel, then rotate, then blend)
+    "chain224": (1920, 1080, 224, 224, 1024, -1, 1920 * 1080 * 4 + 224 * 224 * 4,
+                 "batch 1024 of 1920x1080 BGRA resize(224x224)+rotate(90)+watermark alpha-blend chain"),
 }
 
 
@@ -280,7 +283,7 @@ def main():
     stream.wait_stream(torch.cuda.current_stream())
 
     cfg = None
-    if args.mode == "chain":
+    if args.mode in ("chain", "chain224"):
         ov = torch.randint(0, 256, (64, 256, 4), dtype=torch.uint8, generator=torch.Generator().manual_seed(0x1A4D00FF))
         ov[:, :, 3] = torch.linspace(0, 255, 256).to(torch.uint8)[None, :]
         cfg = imp.Config()
@@ -294,7 +297,7 @@ def main():
             return
         if cfg is not None:
             imp.batch_resize_rotate_watermark(src.data_ptr(), sh * sw * 4, sw, sh, sw * 4, dst.data_ptr(), dh * dw * 4, dw * 4,
-                                              960, 540, 90, cfg, 4, batch, stream=stream.cuda_stream)
+                                              dh, dw, 90, cfg, 4, batch, stream=stream.cuda_stream)   # resize to dh x dw, then the quarter turn
             return
         imp.batch_cv_resize(src.data_ptr(), sh * sw * 4, sw, sh, sw * 4, dst.data_ptr(), dh * dw * 4, dw, dh, dw * 4,
                             4, batch, interp, stream=stream.cuda_stream)

@@ -150,6 +150,26 @@ def test_cfg3_chain_batch(gpu):
     src.release(); dst.release(); cfg.release()
 
 
+def test_cfg3_chain_batch_224_variant(gpu):
+    """SURVEY 8(d) cfg3, second variant: resize=224,224 (general AREA) -> rotate 90 -> the 256x64 watermark, which is
+    wider than the 224-pixel target and gets clipped by the ROI rule (bridge.c:257-271)."""
+    n = 2
+    frames = [noise_image(1080, 1920, 4, 55 + i) for i in range(n)]
+    ov = noise_image(64, 256, 4, 0xFF)
+    ov[:, :, 3] = np.linspace(0, 255, 256).astype(np.uint8)[None, :]
+    cfg = gpu.Config()
+    assert cfg.prepare_watermark(ov, "r", "b", 16, 16, 60) == 0
+    src = gpu.Image(np.concatenate(frames, axis=0))
+    dst = gpu.Image(np.zeros((n * 224, 224, 4), np.uint8))
+    gpu.batch_resize_rotate_watermark(src.device_ptr, 1080 * 1920 * 4, 1920, 1080, 1920 * 4, dst.device_ptr,
+                                      224 * 224 * 4, 224 * 4, 224, 224, 90, cfg, 4, n)
+    out = dst.numpy().reshape(n, 224, 224, 4)
+    for i in range(n):
+        rc, step, want = oracle_chain(frames[i], resize="224,224", filters=["rotate=90"], overlay=ov, wm=("r", "b", 16, 16, 60))
+        assert rc == 0 and np.array_equal(out[i], want), i
+    src.release(); dst.release(); cfg.release()
+
+
 @pytest.mark.parametrize("rotate", [0, 90, 180, 270])
 @pytest.mark.parametrize("geom", [((96, 128), (64, 48)), ((96, 130), (64, 48)), ((70, 90), (45, 35)), ((66, 70), (35, 33))])
 def test_batch_resize_rotate_watermark_all_turns(gpu, rotate, geom):
