@@ -93,7 +93,9 @@ __device__ __forceinline__ int store_f(float v) {
 #define PIX_PER_THREAD 8
 
 // one stage on one pixel held in registers (c3 = alpha, untouched unless a table covers it)
-template <int CN>
+// VIG = false compiles the vignette stage out: its double-precision sqrt / cos inline to ~2000 instructions and
+// 130 VGPRs (3 waves per SIMD), which every other program would pay for (host picks the variant per program)
+template <int CN, bool VIG = true>
 __device__ __forceinline__ void apply_stage(const Stage& st, int& c0, int& c1, int& c2, int& c3, int x, int y, const uint8_t* lut) {
     {
         switch (st.kind) {
@@ -110,7 +112,7 @@ __device__ __forceinline__ void apply_stage(const Stage& st, int& c0, int& c1, i
                 const int off = ((c2 + c1 + c0) / 3) * 3;
                 c2 = t[off]; c1 = t[off + 1]; c0 = t[off + 2];
             } break;
-            case ST_VIGNETTE: {                     // filters.c:312-317 with the mask of :693-703 inline
+            case ST_VIGNETTE: if constexpr (VIG) {  // filters.c:312-317 with the mask of :693-703 inline
                 const double ddx = (double)(st.i0 - x), ddy = (double)(st.i1 - y);
                 const float dist = (float)sqrt(ddx * ddx + ddy * ddy);
                 const float raw = __fmul_rn(__fdiv_rn(dist, st.f0), st.f1);
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long 
 // the same program on the four pixels of one 16-byte group, stage by stage: the stage dispatch (wave-uniform
 // branches) is paid once per group and the 16 table reads of a LUT stage are in flight together instead of four
 // at a time behind each pixel's own wait.  Pixel k sits at (x0 + k, y0) carried into the next row at x == w.
+template <bool VIG>
 __device__ __forceinline__ void run_stages_x4(int (&c)[4][4], int x0, int y0, int w, const ProgDev& prog, const uint8_t* lut) {
     for (int si = 0; si < prog.n; si++) {
         const Stage& st = prog.st[si];
@@ -216,7 +219,7 @@ __device__ __forceinline__ void run_stages_x4(int (&c)[4][4], int x0, int y0, in
                 int x = x0, y = y0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    apply_stage<4>(st, c[k][0], c[k][1], c[k][2], c[k][3], x, y, lut);
+                    apply_stage<4, VIG>(st, c[k][0], c[k][1], c[k][2], c[k][3], x, y, lut);
                     if (++x == w) { x = 0; y++; }
                 }
             } break;
@@ -226,7 +229,7 @@ __device__ __forceinline__ void run_stages_x4(int (&c)[4][4], int x0, int y0, in
 
 // LUT_ONLY: the program is a single four-channel table (gamma, contrast, colorize and whatever the host composed
 // into one table): no stage loop at all, every lookup of the thread's groups is independent.
-template <int PV4_GROUPS, bool LUT_ONLY>      // 16-byte groups per thread: 4 for big batches (bytes in flight), 1 for a single frame (enough blocks)
+template <int PV4_GROUPS, bool LUT_ONLY, bool VIG>      // 16-byte groups per thread: 4 for big batches (bytes in flight), 1 for a single frame (enough blocks)
 __global__ __launch_bounds__(256) void k_pixel_program_v4(uint8_t* base, long long stride, int w, long long npix,
                                                           ProgDev prog, const uint8_t* __restrict__ tables, int need_xy) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[IMP_MAX_TABLE_BYTES];
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256) void k_pixel_program_v4(uint8_t* base, long lo
                 c[k][0] = t[c[k][0]]; c[k][1] = t[256 + c[k][1]]; c[k][2] = t[512 + c[k][2]]; c[k][3] = t[768 + c[k][3]];
             }
         } else {
-            run_stages_x4(c, x, y, w, prog, lut);
+            run_stages_x4<VIG>(c, x, y, w, prog, lut);
         }
         uint32_t o[4];
 #pragma unroll
@@ -290,15 +293,19 @@ int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int 
     bool need_xy = false;
     for (const Stage& st : prog.stages) need_xy = need_xy || st.kind == ST_VIGNETTE || st.kind == ST_SCANLINE;
     const bool lut_only = prog.stages.size() == 1 && prog.stages[0].kind == ST_LUT4;
+    bool has_vig = false;
+    for (const Stage& st : prog.stages) has_vig = has_vig || st.kind == ST_VIGNETTE;
     if (c == 4 && step == 4 * w && (npix & 3) == 0 && !(((uintptr_t)d | (uintptr_t)stride) & 15)) {
         if (npix * count >= (16LL << 20)) {
             const dim3 vgrid((unsigned)(((npix >> 2) + 256 * 4 - 1) / (256 * 4)), (unsigned)count);
-            if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<4, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, 0);
-            else hipLaunchKernelGGL((k_pixel_program_v4<4, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+            if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<4, true, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, 0);
+            else if (has_vig) hipLaunchKernelGGL((k_pixel_program_v4<4, false, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+            else hipLaunchKernelGGL((k_pixel_program_v4<4, false, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
         } else {        // a single frame or a small album: one group per thread keeps every CU busy
             const dim3 vgrid((unsigned)(((npix >> 2) + 255) / 256), (unsigned)count);
-            if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<1, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, 0);
-            else hipLaunchKernelGGL((k_pixel_program_v4<1, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+            if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<1, true, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, 0);
+            else if (has_vig) hipLaunchKernelGGL((k_pixel_program_v4<1, false, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
+            else hipLaunchKernelGGL((k_pixel_program_v4<1, false, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
         }
     } else if (c == 4) hipLaunchKernelGGL((k_pixel_program<4>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else if (c == 3) hipLaunchKernelGGL((k_pixel_program<3>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
