@@ -144,12 +144,12 @@ __device__ __forceinline__ void apply_stage(const Stage& st, int& c0, int& c1, i
 }
 
 // all stages of the program on one pixel
-template <int CN>
+template <int CN, bool VIG = true>
 __device__ __forceinline__ void run_stages(int& c0, int& c1, int& c2, int& c3, int x, int y, const ProgDev& prog, const uint8_t* lut) {
-    for (int si = 0; si < prog.n; si++) apply_stage<CN>(prog.st[si], c0, c1, c2, c3, x, y, lut);
+    for (int si = 0; si < prog.n; si++) apply_stage<CN, VIG>(prog.st[si], c0, c1, c2, c3, x, y, lut);
 }
 
-template <int CN>
+template <int CN, bool VIG>
 __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long stride, int w, int h, int step,
                                                        ProgDev prog, const uint8_t* __restrict__ tables) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[IMP_MAX_TABLE_BYTES];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long 
         } else {
             c0 = p[0]; c1 = c2 = 0;
         }
-        run_stages<CN>(c0, c1, c2, c3, x, y, prog, lut);
+        run_stages<CN, VIG>(c0, c1, c2, c3, x, y, prog, lut);
         if (CN == 4) *(uint32_t*)p = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16) | ((uint32_t)c3 << 24);
         else if (CN == 3) { p[0] = (uint8_t)c0; p[1] = (uint8_t)c1; p[2] = (uint8_t)c2; }
         else p[0] = (uint8_t)c0;
@@ -307,9 +307,11 @@ int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int 
             else if (has_vig) hipLaunchKernelGGL((k_pixel_program_v4<1, false, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
             else hipLaunchKernelGGL((k_pixel_program_v4<1, false, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
         }
-    } else if (c == 4) hipLaunchKernelGGL((k_pixel_program<4>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
-    else if (c == 3) hipLaunchKernelGGL((k_pixel_program<3>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
-    else hipLaunchKernelGGL((k_pixel_program<1>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    } else if (c == 4 && has_vig) hipLaunchKernelGGL((k_pixel_program<4, true>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    else if (c == 4) hipLaunchKernelGGL((k_pixel_program<4, false>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    else if (c == 3 && has_vig) hipLaunchKernelGGL((k_pixel_program<3, true>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    else if (c == 3) hipLaunchKernelGGL((k_pixel_program<3, false>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
+    else hipLaunchKernelGGL((k_pixel_program<1, false>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     e = hipGetLastError();
     // the table buffer goes back to the pool; on a foreign stream wait first, since pool reuse
     // is only ordered on the env stream
