@@ -215,8 +215,8 @@ def request_stream(imp, n_requests, n_threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)      # ~25 ms: past the clock ramp of a cold device
     ap.add_argument("--mode", default="cubic", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override frames per step (default: workload's)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
