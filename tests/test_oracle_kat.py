@@ -142,3 +142,80 @@ def test_brightness_float_accumulator_is_not_the_true_mean():
     # past 2^27 the float sum can only move in steps of 16, so each +100.0 lands as +96: -2.7 % on this frame
     assert abs(b / (100 / 255) - 1) > 0.02
     assert int(round(b * 100)) == 38 and int(round(100 / 255 * 100)) == 39    # the JSON integer percent differs too
+
+
+# ---- independent float cross-checks of the OpenCV-internal arithmetic the oracle restates from knowledge:
+# none of these share code or tables with oracle/*.c; they pin sample centres, kernels, border rules and rounding to
+# within the fixed-point error of OpenCV's 11-bit weights.
+def _separable_resize(arr, dw, dh, taps):
+    """Float reference: taps(frac) -> (first offset, weights); sample centre (d + 0.5) * scale - 0.5, replicate border."""
+    def axis_matrix(ssize, dsize):
+        scale = ssize / dsize
+        m = np.zeros((dsize, ssize))
+        for d in range(dsize):
+            f = (d + 0.5) * scale - 0.5
+            s = int(np.floor(f))
+            first, w = taps(f - s)
+            for k, wk in enumerate(w):
+                m[d, min(max(s + first + k, 0), ssize - 1)] += wk
+        return m
+    a = arr.astype(np.float64)
+    my, mx = axis_matrix(arr.shape[0], dh), axis_matrix(arr.shape[1], dw)
+    return np.einsum("ys,sxc->yxc", my, np.einsum("xs,ysc->yxc", mx, a))
+
+
+def test_linear_matches_float_bilinear_within_one():
+    import torch
+    import torch.nn.functional as F
+
+    for arr, size in ((smooth_image(120, 160, 4), (45, 77)), (noise_image(64, 48, 3, 11), (100, 90)), (noise_image(90, 70, 1, 12), (31, 29))):
+        got = orc.cv_resize(arr, size[1], size[0], orc.INTER_LINEAR).astype(np.float64)
+        t = torch.from_numpy(arr).permute(2, 0, 1)[None].double()
+        ref = F.interpolate(t, size=size, mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(got - np.clip(np.rint(ref), 0, 255)).max() <= 1
+
+
+def test_lanczos4_matches_windowed_sinc_within_two():
+    def taps(x):                      # Lanczos a = 4 sampled at the 8 integer offsets -3..4, normalised (imgwarp.cpp)
+        t = np.arange(-3, 5) - x
+        w = np.sinc(t) * np.sinc(t / 4.0)
+        return -3, w / w.sum()
+    for arr, (dw, dh) in ((smooth_image(90, 120, 4), (50, 40)), (noise_image(60, 80, 3, 13), (75, 95)), (noise_image(128, 128, 4, 14), (64, 64))):
+        got = orc.cv_resize(arr, dw, dh, orc.INTER_LANCZOS4).astype(np.float64)
+        ref = np.clip(np.rint(_separable_resize(arr, dw, dh, taps)), 0, 255)
+        d = np.abs(got - ref)
+        assert d.max() <= 2 and (d > 1).mean() < 0.002          # 11-bit weights on 8 taps: rarely 2, never more
+
+
+def test_area_matches_exact_overlap_average_within_one():
+    def overlap_matrix(ssize, dsize):
+        scale = ssize / dsize
+        m = np.zeros((dsize, ssize))
+        for d in range(dsize):
+            lo, hi = d * scale, (d + 1) * scale
+            for s in range(int(np.floor(lo)), min(int(np.ceil(hi)), ssize)):
+                m[d, s] = max(0.0, min(hi, s + 1) - max(lo, s)) / scale
+        return m
+    for arr, (dw, dh) in ((noise_image(108, 192, 4, 15), (22, 23)), (smooth_image(100, 100, 3), (33, 77)), (noise_image(50, 70, 1, 16), (7, 49))):
+        got = orc.cv_resize(arr, dw, dh, orc.INTER_AREA).astype(np.float64)
+        my, mx = overlap_matrix(arr.shape[0], dh), overlap_matrix(arr.shape[1], dw)
+        ref = np.einsum("ys,sxc->yxc", my, np.einsum("xs,ysc->yxc", mx, arr.astype(np.float64)))
+        assert np.abs(got - np.clip(np.rint(ref), 0, 255)).max() <= 1
+
+
+def test_gaussian_matches_float_convolution_within_one():
+    from scipy.ndimage import correlate1d
+
+    for sigma in (0.8, 2.0, 5.5):
+        n = orc.lib.orc_gaussian_ksize(sigma)
+        x = np.arange(n) - (n - 1) / 2
+        k = np.exp(-x * x / (2 * sigma * sigma))
+        k /= k.sum()                                            # getGaussianKernel, ksize = round(6 sigma + 1) | 1
+        # the 8-bit path converts each coefficient with convertTo(CV_32S, 256) and does NOT renormalise, so the kernel
+        # sums to 256 +- a few and the output carries that gain; the float reference uses the same rounded coefficients
+        kq = np.rint(k.astype(np.float32) * 256.0) / 256.0
+        a = noise_image(60, 70, 3, 17)
+        ref = correlate1d(correlate1d(a.astype(np.float64), kq, axis=1, mode="nearest"), kq, axis=0, mode="nearest")
+        got = orc.gaussian(a, sigma).astype(np.float64)
+        assert np.abs(got - np.clip(np.rint(ref), 0, 255)).max() <= 1
+        assert abs(kq.sum() - 1.0) < 0.05
