@@ -400,10 +400,12 @@ int launch_blend_paper(uint8_t* d, long long stride, int w, int h, int step, int
 //     the midpoint -- which, because (double)sum + t is itself rounded to 53 bits first, happens
 //     precisely when |r - u/2| <= 2^(e-53) (the midpoint is a double; rounding is monotone).  So
 //     inside a regime each term is a function of ONE bit of state, the parity of the sum's mantissa:
-//     parity -> (steps, parity').  Such functions compose associatively, so 4096 terms are folded
+//     parity -> (steps, parity').  Such functions compose associatively, so 16384 terms are folded
 //     by a block-wide scan; the scan also tells where the sum leaves the binade, and only that one
 //     term is added with the literal float/double sequence before the next regime starts.
-//   A 1080p frame needs ~530 block iterations instead of 2 million dependent add chains.
+//   A 1080p frame needs ~160 block iterations (127 chunks + one restart per binade) instead of 2 million dependent
+//   adds.  What bounds it now is one CU's double-precision rate (~40 DP ops per term): prefetching the next chunk
+//   measured slower (tools/brightness_probe.py); the next step would be chunk summaries computed by the whole GPU.
 template <int CN>
 __global__ __launch_bounds__(256) void k_brightness_terms(const uint8_t* __restrict__ src, int w, int h, int step,
                                                           double* __restrict__ terms) {
