@@ -318,18 +318,19 @@ __device__ __forceinline__ bool frame_block(int bpf, int count, int* frame, int*
 // When both scale factors are exactly 2 (4K -> 1080p, cfg4) the tap window of consecutive destination
 // rows advances by exactly two source rows.  A lane then owns one destination column and walks down a
 // strip of rows keeping the horizontal-pass results of its last KS source rows in a register ring: each
-// new destination row costs two horizontal passes (two wide non-temporal loads each) and one vertical
+// new destination row costs two horizontal passes (two wide loads each in this form) and one vertical
 // pass -- no LDS, no barriers, no halo recomputation except KS-2 rows at the top of a strip.  The ring
 // advances by two slots per row, so unrolling KS/2 rows makes every ring index a compile-time constant.
 // Weights still come from the per-geometry tables (nothing about their values is assumed); the host
 // only checks that the tap offsets are the arithmetic progressions 2*d + const.
 #define ROLL_STRIP 60      // destination rows per wave strip (a multiple of the ring period KS/2 = 1, 2, 4)
 
-// Measured alternatives that did NOT beat this form on cfg4 (0.96 ms / 64 frames): double-buffered and 4-deep
-// register prefetch of the windows (same time, fewer waves), and fetching each row segment once per wave into a
-// wave-private LDS row with ds_read_b64 windows (1.04-1.07 ms).  tools/valu_rate.hip explains the floor:
-// v_perm_b32 and v_dot2c_i32_i16 issue at half rate on gfx950 (3.8 cycles per wave-instruction against 2.3 for
-// v_mul_f32), so the 64 of them per destination pixel cost about as much as the HBM traffic of that pixel.
+// History (cfg4, 64 frames): this register form ran 0.96 ms; double-buffered and 4-deep register prefetch of the
+// windows measured the same (fewer waves), and copying each row segment through VGPRs into a wave-private LDS row was
+// slower (1.04-1.07 ms).  What it lacked was bytes in flight, which the asynchronous LDS-DMA ring of
+// k_resize_2x_dma below supplies without registers (0.62-0.69 ms); this form remains for pitches the DMA cannot take.
+// Instruction rates (tools/valu_rate2.hip): v_perm_b32 and v_dot2c_i32_i16 issue at half the rate of v_mul_f32, like
+// every other integer-multiply form, so the perm + dot2 pair is the cheapest exact H pass gfx950 offers.
 template <int KS>
 __device__ __forceinline__ void hpass_row(const uint8_t* row, int sxv, const int* sxk, bool interior,
                                           const short2_t* axp, int* h) {
