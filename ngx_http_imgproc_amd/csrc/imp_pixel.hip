@@ -184,10 +184,10 @@ __global__ __launch_bounds__(256) void k_pixel_program(uint8_t* base, long long 
 // BGRA frames whose rows are contiguous (step == 4*w) and 16-byte aligned: the frame is one linear run of pixels,
 // a lane moves four of them per 16-byte load / store (the coalescing sweet spot) and only derives (x, y) when a
 // stage of the program needs coordinates.
-// the same program on the four pixels of one 16-byte group, stage by stage: the stage dispatch (wave-uniform
-// branches) is paid once per group and the 16 table reads of a LUT stage are in flight together instead of four
-// at a time behind each pixel's own wait.  Pixel k sits at (x0 + k, y0) carried into the next row at x == w.
-template <bool VIG>
+// the same program on the four pixels of one group, stage by stage: the stage dispatch (wave-uniform branches) is
+// paid once per group and the table reads of a LUT stage are in flight together instead of behind each pixel's own
+// wait.  Pixel k sits at (x0 + k, y0) carried into the next row at x == w.  CN = 3: c[k][3] is a dummy.
+template <int CN, bool VIG>
 __device__ __forceinline__ void run_stages_x4(int (&c)[4][4], int x0, int y0, int w, const ProgDev& prog, const uint8_t* lut) {
     for (int si = 0; si < prog.n; si++) {
         const Stage& st = prog.st[si];
@@ -196,7 +196,8 @@ __device__ __forceinline__ void run_stages_x4(int (&c)[4][4], int x0, int y0, in
                 const uint8_t* t = lut + st.lut_off;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    c[k][0] = t[c[k][0]]; c[k][1] = t[256 + c[k][1]]; c[k][2] = t[512 + c[k][2]]; c[k][3] = t[768 + c[k][3]];
+                    c[k][0] = t[c[k][0]]; c[k][1] = t[256 + c[k][1]]; c[k][2] = t[512 + c[k][2]];
+                    if (CN == 4) c[k][3] = t[768 + c[k][3]];
                 }
             } break;
             case ST_GRADMAP: {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void run_stages_x4(int (&c)[4][4], int x0, int y0, in
                 int x = x0, y = y0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    apply_stage<4, VIG>(st, c[k][0], c[k][1], c[k][2], c[k][3], x, y, lut);
+                    apply_stage<CN, VIG>(st, c[k][0], c[k][1], c[k][2], c[k][3], x, y, lut);
                     if (++x == w) { x = 0; y++; }
                 }
             } break;
@@ -227,23 +228,26 @@ __device__ __forceinline__ void run_stages_x4(int (&c)[4][4], int x0, int y0, in
     }
 }
 
-// LUT_ONLY: the program is a single four-channel table (gamma, contrast, colorize and whatever the host composed
-// into one table): no stage loop at all, every lookup of the thread's groups is independent.
-template <int PV4_GROUPS, bool LUT_ONLY, bool VIG>      // 16-byte groups per thread: 4 for big batches (bytes in flight), 1 for a single frame (enough blocks)
+// Frames whose rows are contiguous (step == CN * w) are one linear run of pixels; a lane moves four of them per
+// group: 16 bytes (BGRA, one dwordx4) or 12 bytes (BGR -- what every JPEG decodes to -- one dwordx3 at a 4-byte
+// aligned address; every (pixel, channel) sits at a compile-time byte of the three dwords).
+// LUT_ONLY: the program is a single per-channel table (gamma, contrast, colorize and whatever the host composed into
+// one table): no stage loop at all, every lookup of the thread's groups is independent.
+template <int CN, int PV4_GROUPS, bool LUT_ONLY, bool VIG>   // groups per thread: 4 for big batches (bytes in flight), 1 for a single frame
 __global__ __launch_bounds__(256) void k_pixel_program_v4(uint8_t* base, long long stride, int w, long long npix,
                                                           ProgDev prog, const uint8_t* __restrict__ tables, int need_xy) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[IMP_MAX_TABLE_BYTES];
     for (int i = threadIdx.x * 4; i < prog.table_bytes; i += 256 * 4)
         *(uint32_t*)(lut + i) = *(const uint32_t*)(tables + i);
     __syncthreads();
-    uint4* img = (uint4*)(base + (long long)blockIdx.y * stride);
+    uint32_t* img = (uint32_t*)(base + (long long)blockIdx.y * stride);
     const long long ngroups = npix >> 2;                        // npix % 4 == 0 (launcher)
     const long long first = (long long)blockIdx.x * (256 * PV4_GROUPS) + threadIdx.x;
-    uint4 v[PV4_GROUPS];
+    uint32_t v[PV4_GROUPS][CN];
 #pragma unroll
     for (int it = 0; it < PV4_GROUPS; it++) {
         const long long gi = first + (long long)it * 256;
-        if (gi < ngroups) v[it] = img[gi];
+        if (gi < ngroups) __builtin_memcpy(v[it], __builtin_assume_aligned(img + gi * CN, CN == 4 ? 16 : 4), CN * 4);
     }
 #pragma unroll
     for (int it = 0; it < PV4_GROUPS; it++) {
@@ -251,23 +255,37 @@ __global__ __launch_bounds__(256) void k_pixel_program_v4(uint8_t* base, long lo
         if (gi >= ngroups) break;
         int x = 0, y = 0;
         if (need_xy) { const long long pix = gi * 4; y = (int)(pix / w); x = (int)(pix - (long long)y * w); }
-        const uint32_t u[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
         int c[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { c[k][0] = u[k] & 0xff; c[k][1] = (u[k] >> 8) & 0xff; c[k][2] = (u[k] >> 16) & 0xff; c[k][3] = u[k] >> 24; }
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+                const int o = k * CN + ch;                      // byte index inside the group
+                c[k][ch] = ch < CN ? (int)((v[it][o >> 2] >> (8 * (o & 3))) & 0xff) : 255;
+            }
+        }
         if constexpr (LUT_ONLY) {
             const uint8_t* t = lut + prog.st[0].lut_off;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                c[k][0] = t[c[k][0]]; c[k][1] = t[256 + c[k][1]]; c[k][2] = t[512 + c[k][2]]; c[k][3] = t[768 + c[k][3]];
+                c[k][0] = t[c[k][0]]; c[k][1] = t[256 + c[k][1]]; c[k][2] = t[512 + c[k][2]];
+                if (CN == 4) c[k][3] = t[768 + c[k][3]];
             }
         } else {
-            run_stages_x4<VIG>(c, x, y, w, prog, lut);
+            run_stages_x4<CN, VIG>(c, x, y, w, prog, lut);
         }
-        uint32_t o[4];
+        uint32_t o4[CN];
 #pragma unroll
-        for (int k = 0; k < 4; k++) o[k] = (uint32_t)c[k][0] | ((uint32_t)c[k][1] << 8) | ((uint32_t)c[k][2] << 16) | ((uint32_t)c[k][3] << 24);
-        img[gi] = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int d = 0; d < CN; d++) o4[d] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int ch = 0; ch < CN; ch++) {
+                const int o = k * CN + ch;
+                o4[o >> 2] |= (uint32_t)(c[k][ch] & 0xff) << (8 * (o & 3));
+            }
+        }
+        __builtin_memcpy(__builtin_assume_aligned(img + gi * CN, CN == 4 ? 16 : 4), o4, CN * 4);
     }
 }
 
@@ -295,18 +313,24 @@ int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int 
     const bool lut_only = prog.stages.size() == 1 && prog.stages[0].kind == ST_LUT4;
     bool has_vig = false;
     for (const Stage& st : prog.stages) has_vig = has_vig || st.kind == ST_VIGNETTE;
-    if (c == 4 && step == 4 * w && (npix & 3) == 0 && !(((uintptr_t)d | (uintptr_t)stride) & 15)) {
-        if (npix * count >= (16LL << 20)) {
-            const dim3 vgrid((unsigned)(((npix >> 2) + 256 * 4 - 1) / (256 * 4)), (unsigned)count);
-            if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<4, true, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, 0);
-            else if (has_vig) hipLaunchKernelGGL((k_pixel_program_v4<4, false, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
-            else hipLaunchKernelGGL((k_pixel_program_v4<4, false, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
-        } else {        // a single frame or a small album: one group per thread keeps every CU busy
-            const dim3 vgrid((unsigned)(((npix >> 2) + 255) / 256), (unsigned)count);
-            if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<1, true, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, 0);
-            else if (has_vig) hipLaunchKernelGGL((k_pixel_program_v4<1, false, true>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
-            else hipLaunchKernelGGL((k_pixel_program_v4<1, false, false>), vgrid, block, 0, s, d, stride, w, npix, pd, (const uint8_t*)dev_tables, need_xy ? 1 : 0);
-        }
+    const bool vec4 = c == 4 && step == 4 * w && (npix & 3) == 0 && !(((uintptr_t)d | (uintptr_t)stride) & 15);
+    const bool vec3 = c == 3 && step == 3 * w && (npix & 3) == 0 && !(((uintptr_t)d | (uintptr_t)stride) & 3);
+    if (vec4 || vec3) {
+        const bool big = npix * count >= (16LL << 20);
+        const int groups = big ? 4 : 1;                        // a single frame or a small album: one group per thread keeps every CU busy
+        const dim3 vgrid((unsigned)(((npix >> 2) + 256 * groups - 1) / (256 * groups)), (unsigned)count);
+        const uint8_t* tb_dev = (const uint8_t*)dev_tables;
+#define IMP_PV4(CN_, G_)                                                                                                 \
+    do {                                                                                                                 \
+        if (lut_only) hipLaunchKernelGGL((k_pixel_program_v4<CN_, G_, true, false>), vgrid, block, 0, s, d, stride, w, npix, pd, tb_dev, 0); \
+        else if (has_vig) hipLaunchKernelGGL((k_pixel_program_v4<CN_, G_, false, true>), vgrid, block, 0, s, d, stride, w, npix, pd, tb_dev, need_xy ? 1 : 0); \
+        else hipLaunchKernelGGL((k_pixel_program_v4<CN_, G_, false, false>), vgrid, block, 0, s, d, stride, w, npix, pd, tb_dev, need_xy ? 1 : 0); \
+    } while (0)
+        if (vec4 && big) IMP_PV4(4, 4);
+        else if (vec4) IMP_PV4(4, 1);
+        else if (big) IMP_PV4(3, 4);
+        else IMP_PV4(3, 1);
+#undef IMP_PV4
     } else if (c == 4 && has_vig) hipLaunchKernelGGL((k_pixel_program<4, true>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else if (c == 4) hipLaunchKernelGGL((k_pixel_program<4, false>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else if (c == 3 && has_vig) hipLaunchKernelGGL((k_pixel_program<3, true>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);

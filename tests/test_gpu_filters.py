@@ -223,3 +223,25 @@ def test_batch_filters_matches_per_frame(gpu):
     assert gpu.batch_filters(batch.device_ptr, h * w * 4, w, h, 4, w * 4, n, ["rotate=90"]) == 1       # not pointwise
     assert gpu.batch_filters(batch.device_ptr, h * w * 4, w, h, 4, w * 4, n, ["nosuch=1"]) == 52
     batch.release()
+
+
+@pytest.mark.parametrize("c", [3, 4])
+@pytest.mark.parametrize("filters", [["gamma=1.7"], ["gotham=1", "gamma=1.7"], ["scanline=0.6,0.4,3,2", "contrast=1.2"]],
+                         ids=["table-only", "hsv+tables", "needs-coordinates"])
+def test_batch_filters_vector_paths_big_batch(gpu, c, filters):
+    """Contiguous frames take the vectorised pixel program: 16-byte groups (BGRA) or 12-byte groups (BGR, every JPEG);
+    past 16 M pixels a thread carries four groups.  9 frames of 1080p cross that line; a 36 x 20 frame does not."""
+    for n, h, w in ((9, 1080, 1920), (3, 20, 36)):
+        rng = np.random.default_rng(700 + c)
+        frames = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)
+        batch = gpu.Image(frames.reshape(n * h, w, c))
+        assert batch.step == w * c
+        assert gpu.batch_filters(batch.device_ptr, h * w * c, w, h, c, w * c, n, filters) == 0
+        out = batch.numpy().reshape(n, h, w, c)
+        for i in (0, n // 2, n - 1):
+            cur = frames[i]
+            for f in filters:
+                rc, cur = orc.filter(cur, f)
+                assert rc == 0
+            assert np.array_equal(out[i], cur), (n, i)
+        batch.release()
