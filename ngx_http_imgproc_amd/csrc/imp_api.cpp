@@ -78,7 +78,7 @@ int apply_plan(Work& wk, const FilterPlan& plan) {
             return IMP_OK;
         }
         case FC_BLUR: {
-            if (wk.v.c == 4) {      // one-pass fused kernel into a fresh frame; falls through when it does not apply
+            if (wk.v.c == 4 || wk.v.c == 3) {      // one-pass fused kernel into a fresh frame; falls through when it does not apply
                 impgpu_image* out = nullptr;
                 if (int rc = image_new(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
                 int rc = launch_gaussian_fused(one_frame(wk.v, out), plan.sigma, env_stream());

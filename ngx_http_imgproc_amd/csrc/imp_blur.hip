@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_blur_col_any(const int* __restrict__ tm
     dst[(long long)blockIdx.y * stride + (size_t)y * step + e] = (uint8_t)out;
 }
 
-// ------------------------------------------------------------------ fused BGRA Gaussian (radius <= 16)
+// ------------------------------------------------------------------ fused BGRA / BGR Gaussian (radius <= 16)
 // One kernel, one read and one write of the frame: a 256-thread block owns a 64 x TH tile of the
 // output.  (0) its (64+2r) x (TH+2r) source footprint goes to LDS (edge-replicated, coalesced dword
 // loads, 12 in flight per lane); (1) the row pass runs once per (footprint row, column) out of
@@ -111,24 +111,28 @@ __global__ __launch_bounds__(256) void k_blur_col_any(const int* __restrict__ tm
 // host checks 255 * sum(kx) <= 65535); (2) the column pass is SymmColumnVec_32s8u's float sequence
 // on (row[+k] + row[-k]) read 8 bytes per lane from the plane, then a coalesced dword store.  Runs
 // out of place (a tile's halo belongs to its neighbours), which also materialises a cropped view.
+// CN = 3 (every JPEG): pixels are assembled from / scattered to three bytes, channel 3 is skipped, and the last
+// (3 w) % 4 elements of a row take SymmColumnVec's scalar tail, (sum + 2^15) >> 16 on integers, like the CPU.
 typedef short bl_short2 __attribute__((ext_vector_type(2)));
 
-template <int TH>
+template <int TH, int CN>
 __global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
                                                      uint8_t* __restrict__ dst, long long dstride, int dstep,
-                                                     const int* __restrict__ kxp, const float* __restrict__ kyf, int rx, int ry) {
+                                                     const int* __restrict__ kxp, const float* __restrict__ kyf,
+                                                     const int* __restrict__ kyi, int rx, int ry) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int SW = 64 + 2 * rx + 2, SH = TH + 2 * ry;         // +2: the padded last tap pair reads one dword further
     const int npair = rx + 1;                                 // 2*rx+1 taps -> rx+1 pairs, last one (tap, 0)
     uint32_t* s_kx = (uint32_t*)smem;                         // packed (k[2j], k[2j+1]) as 2 x i16
     float* s_ky = (float*)(s_kx + ((npair + 3) & ~3));
-    uint32_t* s_src = (uint32_t*)(s_ky + ((ry + 1 + 3) & ~3));
+    int* s_kyi = (int*)(s_ky + ((ry + 1 + 3) & ~3));
+    uint32_t* s_src = (uint32_t*)(s_kyi + ((ry + 1 + 3) & ~3));
     uint2* s_pl = (uint2*)(s_src + ((SW * SH + 3) & ~3));     // [SH][64] x 4 x u16
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * TH;
     const uint8_t* S = src + (long long)blockIdx.z * sstride;
     for (int i = tid; i < npair; i += 256) s_kx[i] = (uint32_t)kxp[i];
-    for (int i = tid; i <= ry; i += 256) s_ky[i] = kyf[i];
+    for (int i = tid; i <= ry; i += 256) { s_ky[i] = kyf[i]; s_kyi[i] = kyi[i]; }
 
     // (0) footprint -> LDS
     {
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             const int sx = tx0 - rx + lane + 64 * q;
-            sxc[q] = (sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx)) * 4;
+            sxc[q] = (sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx)) * CN;
         }
         for (int r0 = wv; r0 < SH; r0 += 16) {
             uint32_t v[4][3];
@@ -146,7 +150,14 @@ __global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__
                 const int sy = ty0 - ry + r;
                 const uint8_t* row = S + (size_t)(sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy)) * sstep;
 #pragma unroll
-                for (int q = 0; q < 3; q++) v[u][q] = (r < SH && lane + 64 * q < SW) ? *(const uint32_t*)(row + sxc[q]) : 0u;
+                for (int q = 0; q < 3; q++) {
+                    uint32_t px = 0u;
+                    if (r < SH && lane + 64 * q < SW) {
+                        if (CN == 4) px = *(const uint32_t*)(row + sxc[q]);
+                        else px = (uint32_t)row[sxc[q]] | ((uint32_t)row[sxc[q] + 1] << 8) | ((uint32_t)row[sxc[q] + 2] << 16);
+                    }
+                    v[u][q] = px;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__
             pr = __builtin_amdgcn_perm(p1, p0, 0x0c040c00u); __builtin_memcpy(&c, &pr, 4); a0 = __builtin_amdgcn_sdot2(c, kk, a0, false);
             pr = __builtin_amdgcn_perm(p1, p0, 0x0c050c01u); __builtin_memcpy(&c, &pr, 4); a1 = __builtin_amdgcn_sdot2(c, kk, a1, false);
             pr = __builtin_amdgcn_perm(p1, p0, 0x0c060c02u); __builtin_memcpy(&c, &pr, 4); a2 = __builtin_amdgcn_sdot2(c, kk, a2, false);
-            pr = __builtin_amdgcn_perm(p1, p0, 0x0c070c03u); __builtin_memcpy(&c, &pr, 4); a3 = __builtin_amdgcn_sdot2(c, kk, a3, false);
+            if (CN == 4) { pr = __builtin_amdgcn_perm(p1, p0, 0x0c070c03u); __builtin_memcpy(&c, &pr, 4); a3 = __builtin_amdgcn_sdot2(c, kk, a3, false); }
         }
         s_pl[r * 64 + lane] = make_uint2((uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16));
     }
@@ -198,9 +209,32 @@ __global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__
                 s2 = __fadd_rn(s2, __fmul_rn((float)((a.y & 0xffff) + (b.y & 0xffff)), f));
                 s3 = __fadd_rn(s3, __fmul_rn((float)((a.y >> 16) + (b.y >> 16)), f));
             }
-            const uint32_t o = (uint32_t)sat8(__float2int_rn(s0)) | ((uint32_t)sat8(__float2int_rn(s1)) << 8) |
-                               ((uint32_t)sat8(__float2int_rn(s2)) << 16) | ((uint32_t)sat8(__float2int_rn(s3)) << 24);
-            *(uint32_t*)(dst + (long long)blockIdx.z * dstride + (size_t)y * dstep + (size_t)x * 4) = o;
+            if (CN == 4) {
+                const uint32_t o = (uint32_t)sat8(__float2int_rn(s0)) | ((uint32_t)sat8(__float2int_rn(s1)) << 8) |
+                                   ((uint32_t)sat8(__float2int_rn(s2)) << 16) | ((uint32_t)sat8(__float2int_rn(s3)) << 24);
+                *(uint32_t*)(dst + (long long)blockIdx.z * dstride + (size_t)y * dstep + (size_t)x * 4) = o;
+            } else {
+                int o[3] = {sat8(__float2int_rn(s0)), sat8(__float2int_rn(s1)), sat8(__float2int_rn(s2))};
+                const int vec_end = (w * 3) & ~3;                   // SymmColumnVec_32s8u covers whole groups of 4 elements
+                if (x * 3 + 2 >= vec_end) {                         // this pixel holds tail elements: integer form for those
+                    int t0 = s_kyi[0] * (int)(c.x & 0xffff), t1 = s_kyi[0] * (int)(c.x >> 16), t2 = s_kyi[0] * (int)(c.y & 0xffff);
+                    for (int k = 1; k <= ry; k++) {
+                        const uint2 a = col[k * 64], b = col[-k * 64];
+                        const int fk = s_kyi[k];
+                        t0 += fk * (int)((a.x & 0xffff) + (b.x & 0xffff));
+                        t1 += fk * (int)((a.x >> 16) + (b.x >> 16));
+                        t2 += fk * (int)((a.y & 0xffff) + (b.y & 0xffff));
+                    }
+                    int ti[3] = {(t0 + (1 << 15)) >> 16, (t1 + (1 << 15)) >> 16, (t2 + (1 << 15)) >> 16};
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        asm volatile("" : "+v"(ti[ch]));            // keep shift and clamp apart (v_ashr_pk_u8_i32 hazard)
+                        if (x * 3 + ch >= vec_end) o[ch] = sat8(ti[ch]);
+                    }
+                }
+                uint8_t* q = dst + (long long)blockIdx.z * dstride + (size_t)y * dstep + (size_t)x * 3;
+                q[0] = (uint8_t)o[0]; q[1] = (uint8_t)o[1]; q[2] = (uint8_t)o[2];
+            }
         }
     }
 }
@@ -210,9 +244,9 @@ __global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__
 // launch_gaussian.  sigma must give ksize > 1.
 int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     const View& v = f.v;
-    if (v.c != 4 || f.count <= 0 || f.count > 65535 || f.dw != v.w || f.dh != v.h || v.w < 2 || v.h < 2) return IMP_ERROR_UNSUPPORTED;
+    if ((v.c != 4 && v.c != 3) || f.count <= 0 || f.count > 65535 || f.dw != v.w || f.dh != v.h || v.w < 2 || v.h < 2) return IMP_ERROR_UNSUPPORTED;
     if (f.src == f.dst) return IMP_ERROR_UNSUPPORTED;
-    if (((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)v.step | (uintptr_t)f.dstep | (uintptr_t)f.src_stride | (uintptr_t)f.dst_stride) & 3)
+    if (v.c == 4 && (((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)v.step | (uintptr_t)f.dstep | (uintptr_t)f.src_stride | (uintptr_t)f.dst_stride) & 3))
         return IMP_ERROR_UNSUPPORTED;
     const int ks = gaussian_ksize(sigma);
     const int r = ks / 2;
@@ -235,15 +269,21 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
         std::memcpy(&bits, &fk, 4);
         blob.push_back(bits);
     }
+    const size_t off_i = blob.size();
+    for (int k = 0; k <= r; k++) blob.push_back(ik[r + k]);
     void* dev_k = nullptr;
     if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
     const int TH = 32;
     const int SW = 64 + 2 * r + 2, SH = TH + 2 * r;
-    const size_t lds = (size_t)(((r + 1 + 3) & ~3) + ((r + 1 + 3) & ~3) + ((SW * SH + 3) & ~3)) * 4 + (size_t)SH * 64 * 8;
+    const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + ((SW * SH + 3) & ~3)) * 4 + (size_t)SH * 64 * 8;
     const dim3 grid((v.w + 63) / 64, (v.h + TH - 1) / TH, f.count), block(256);
     if (grid.y > 65535) { dev_free(dev_k); return IMP_ERROR_UNSUPPORTED; }
-    hipLaunchKernelGGL((k_blur_fused4<32>), grid, block, lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
-                       (const int*)dev_k, (const float*)((const int*)dev_k + off_f), r, r);
+    if (v.c == 4)
+        hipLaunchKernelGGL((k_blur_fused4<32, 4>), grid, block, lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
+                           (const int*)dev_k, (const float*)((const int*)dev_k + off_f), (const int*)dev_k + off_i, r, r);
+    else
+        hipLaunchKernelGGL((k_blur_fused4<32, 3>), grid, block, lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
+                           (const int*)dev_k, (const float*)((const int*)dev_k + off_f), (const int*)dev_k + off_i, r, r);
     hipError_t e = hipGetLastError();
     if (s != env_stream()) (void)hipStreamSynchronize(s);
     dev_free(dev_k);
