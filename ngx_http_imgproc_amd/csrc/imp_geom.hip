@@ -71,6 +71,65 @@ __global__ __launch_bounds__(256) void k_rotate_bgra(GArgs a, int amount) {
     }
 }
 
+// The same for 3-channel frames (every JPEG): a 32 x 32 pixel tile is 32 source row segments of 96 bytes.  Full,
+// dword-aligned tiles move as dwords on both sides (24 per row segment) and the quarter turn happens in the byte
+// gather out of LDS; border tiles and odd alignments take bytes on the global side.  LDS row pitch 100 bytes.
+__global__ __launch_bounds__(256) void k_rotate_bgr(GArgs a, int amount) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[32][100];
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;   // destination tile origin (x along dw = sh, y along dh = sw)
+    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
+    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride;
+    const int tid = threadIdx.y * 32 + threadIdx.x;
+    const bool full = tx0 + 32 <= a.dw && ty0 + 32 <= a.dh;
+    // source tile: rows srow0 .. srow0+31, columns scol0 .. scol0+31 (tile[r][3*c + ch])
+    const int srow0 = amount == 90 ? a.sh - 32 - tx0 : tx0;
+    const int scol0 = amount == 90 ? ty0 : a.sw - 32 - ty0;
+    const bool vec = full && !(((uintptr_t)S | (uintptr_t)D | (uintptr_t)a.sstep | (uintptr_t)a.dstep | (uintptr_t)(scol0 * 3)) & 3);
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int e = tid + 256 * q;                       // 768 dwords: 32 rows x 24
+            const int r = e / 24, d = e - r * 24;
+            *(uint32_t*)&tile[r][4 * d] = *(const uint32_t*)(S + (size_t)(srow0 + r) * a.sstep + (size_t)scol0 * 3 + 4 * d);
+        }
+    } else {
+        for (int e = tid; e < 32 * 32; e += 256) {
+            const int r = e >> 5, c = e & 31;
+            const int sr = srow0 + r, sc = scol0 + c;
+            if (sr >= 0 && sr < a.sh && sc >= 0 && sc < a.sw) {
+                const uint8_t* p = S + (size_t)sr * a.sstep + (size_t)sc * 3;
+                tile[r][3 * c] = p[0]; tile[r][3 * c + 1] = p[1]; tile[r][3 * c + 2] = p[2];
+            }
+        }
+    }
+    __syncthreads();
+    // destination pixel (row ty0 + li, column tx0 + lj) = tile[31 - lj][li] (90)  or  tile[lj][31 - li] (270)
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int e = tid + 256 * q;
+            const int li = e / 24, d = e - li * 24;
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int byte = 4 * d + b, lj = byte / 3, ch = byte - 3 * lj;
+                const uint8_t v = amount == 90 ? tile[31 - lj][3 * li + ch] : tile[lj][3 * (31 - li) + ch];
+                o |= (uint32_t)v << (8 * b);
+            }
+            *(uint32_t*)(D + (size_t)(ty0 + li) * a.dstep + (size_t)tx0 * 3 + 4 * d) = o;
+        }
+    } else {
+        for (int e = tid; e < 32 * 32; e += 256) {
+            const int li = e >> 5, lj = e & 31;
+            if (ty0 + li < a.dh && tx0 + lj < a.dw) {
+                const uint8_t* t = amount == 90 ? &tile[31 - lj][3 * li] : &tile[lj][3 * (31 - li)];
+                uint8_t* p = D + (size_t)(ty0 + li) * a.dstep + (size_t)(tx0 + lj) * 3;
+                p[0] = t[0]; p[1] = t[1]; p[2] = t[2];
+            }
+        }
+    }
+}
+
 template <int CN>
 __global__ __launch_bounds__(256) void k_rotate_any(GArgs a, int amount) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -214,6 +273,9 @@ int launch_rotate(const Frames& f, int amount, hipStream_t s) {
         const dim3 grid((f.dw + 31) / 32, (f.dh + 31) / 32, f.count), block(32, 8);
         if (grid.y > 65535) return IMP_ERROR_INVALID_ARGS;
         hipLaunchKernelGGL(k_rotate_bgra, grid, block, 0, s, a, amount);
+    } else if (f.v.c == 3 && (f.dh + 31) / 32 <= 65535) {
+        const dim3 grid((f.dw + 31) / 32, (f.dh + 31) / 32, f.count), block(32, 8);
+        hipLaunchKernelGGL(k_rotate_bgr, grid, block, 0, s, a, amount);
     } else {
         const dim3 grid(blocks_for((long long)f.dw * f.dh), f.count), block(256);
         if (f.v.c == 3) hipLaunchKernelGGL((k_rotate_any<3>), grid, block, 0, s, a, amount);

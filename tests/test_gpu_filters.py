@@ -246,3 +246,15 @@ def test_batch_filters_vector_paths_big_batch(gpu, c, filters):
                 assert rc == 0
             assert np.array_equal(out[i], cur), (n, i)
         batch.release()
+
+
+@pytest.mark.parametrize("amount", [90, 270])
+@pytest.mark.parametrize("shape", [(64, 96), (96, 64), (70, 130), (33, 32), (32, 33), (31, 31), (128, 36), (1, 40), (40, 1)])
+def test_rotate_bgr_tiles(gpu, amount, shape):
+    """3-channel quarter turns go through 32 x 32 LDS tiles: whole dword-aligned tiles (64 x 96 both ways), byte-path
+    borders, source columns that are not dword aligned for 270 (70 x 130), and images smaller than a tile."""
+    arr = noise_image(shape[0], shape[1], 3, 21)
+    rc, got = run_filter(gpu, arr, "rotate=%d" % amount)
+    assert rc == 0
+    assert np.array_equal(got, np.rot90(arr, k=-1 if amount == 90 else 1))
+    assert np.array_equal(got, orc.filter(arr, "rotate=%d" % amount)[1])
