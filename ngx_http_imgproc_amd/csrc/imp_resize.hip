@@ -115,6 +115,27 @@ __global__ __launch_bounds__(256) void k_resize_taps(RArgs a, const int* __restr
                 for (int k = 0; k < KS; k++) v += (int)((px[r][k] >> (8 * c)) & 0xff) * ax[k];
                 hs[r][c] = v;
             }
+    } else if (CN == 3 && interior && (KS * 3) % 4 == 0) {
+        // BGR (every JPEG): the KS taps of a row are KS*3 contiguous bytes at a byte-aligned address -- one unaligned
+        // dwordx3 (cubic) or two (lanczos) instead of KS*3 byte loads; tap k, channel c sits at the fixed byte 3k + c
+        uint32_t w[KS][KS * 3 / 4];
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+            const int sy = clampi(sy0 + r, 0, a.sh - 1);
+            __builtin_memcpy(w[r], S + (size_t)sy * a.sstep + (size_t)sx0 * 3, KS * 3);
+        }
+#pragma unroll
+        for (int r = 0; r < KS; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                int v = 0;
+#pragma unroll
+                for (int k = 0; k < KS; k++) {
+                    const int o = 3 * k + c;
+                    v += (int)((w[r][o >> 2] >> (8 * (o & 3))) & 0xff) * ax[k];
+                }
+                hs[r][c < CN ? c : 0] = v;
+            }
     } else {
         int sxk[KS];
 #pragma unroll
