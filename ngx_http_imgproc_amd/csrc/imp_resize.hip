@@ -887,6 +887,21 @@ __global__ __launch_bounds__(256) void k_resize_area_v4r(RArgs a, AreaDev t, int
                 ((uint32_t)sat_u8(__float2int_rn(s23[k].x)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s23[k].y)) << 24);
 }
 
+// N dwords starting at an arbitrary byte address, as 4-byte ALIGNED vector loads plus v_alignbyte_b32: a byte-
+// misaligned dwordx3/x4 is split by the texture addresser and measured 34 % slower in the BGR AREA kernel.  The one
+// extra dword is fetched only when it shares an aligned word with wanted bytes (shift != 0), so the read never
+// leaves the word -- and therefore the page -- the last wanted byte lives in.
+template <int N>
+__device__ __forceinline__ void load_bytes_aligned(uint32_t* w, const uint8_t* p) {
+    const unsigned sh = (unsigned)(uintptr_t)p & 3u;
+    const uint32_t* a = (const uint32_t*)(p - sh);
+    uint32_t t[N + 1];
+    __builtin_memcpy(t, __builtin_assume_aligned(a, 4), N * 4);
+    t[N] = a[sh ? N : N - 1];
+#pragma unroll
+    for (int i = 0; i < N; i++) w[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], sh);
+}
+
 // The same for 3-channel BGR frames -- what cvDecodeImage hands the reference for every JPEG, and the mode its
 // Resize() picks for every shrink.  A run of 4*NV pixels is 12*NV bytes at an arbitrary byte address; gfx950
 // takes unaligned vector loads, and every (pixel, channel) sits at a compile-time byte of the loaded dwords,
@@ -909,7 +924,7 @@ __global__ __launch_bounds__(256) void k_resize_area_v3(RArgs a, AreaDev t, int 
         const int sy = min(ys + j, a.sh - 1);
         const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 3;
         uint32_t w[NV * 3];
-        __builtin_memcpy(w, row, NV * 12);                    // byte-aligned vector loads
+        load_bytes_aligned<NV * 3>(w, row);
         float b0 = 0.f, b1 = 0.f, b2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NV * 4; k++) {
@@ -953,7 +968,7 @@ __global__ __launch_bounds__(256) void k_resize_area_v3r(RArgs a, AreaDev t, int
         const int sy = min(ys + j, a.sh - 1);
         const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 3;
         uint32_t w[NV * 3];
-        __builtin_memcpy(w, row, NV * 12);                    // byte-aligned vector loads
+        load_bytes_aligned<NV * 3>(w, row);
         float b0 = 0.f, b1 = 0.f, b2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NV * 4; k++) {
