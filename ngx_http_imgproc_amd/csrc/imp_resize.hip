@@ -79,6 +79,21 @@ __device__ __forceinline__ void load_stream(uint32_t* dst, const uint8_t* p) {
 // ------------------------------------------------------------------ LINEAR / CUBIC / LANCZOS4
 enum { M_LINEAR = 0, M_CUBIC = 1, M_LANCZOS = 2 };
 
+// N dwords starting at an arbitrary byte address, as 4-byte ALIGNED vector loads plus v_alignbyte_b32: a byte-
+// misaligned dwordx3/x4 is split by the texture addresser and measured 34 % slower in the BGR AREA kernel.  The one
+// extra dword is fetched only when it shares an aligned word with wanted bytes (shift != 0), so the read never
+// leaves the word -- and therefore the page -- the last wanted byte lives in.
+template <int N>
+__device__ __forceinline__ void load_bytes_aligned(uint32_t* w, const uint8_t* p) {
+    const unsigned sh = (unsigned)(uintptr_t)p & 3u;
+    const uint32_t* a = (const uint32_t*)(p - sh);
+    uint32_t t[N + 1];
+    __builtin_memcpy(t, __builtin_assume_aligned(a, 4), N * 4);
+    t[N] = a[sh ? N : N - 1];
+#pragma unroll
+    for (int i = 0; i < N; i++) w[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], sh);
+}
+
 template <int KS, int CN, int MODE>
 __global__ __launch_bounds__(256) void k_resize_taps(RArgs a, const int* __restrict__ xofs,
                                                      const short* __restrict__ xco,
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(256) void k_resize_taps(RArgs a, const int* __restr
 #pragma unroll
         for (int r = 0; r < KS; r++) {
             const int sy = clampi(sy0 + r, 0, a.sh - 1);
-            __builtin_memcpy(w[r], S + (size_t)sy * a.sstep + (size_t)sx0 * 3, KS * 3);
+            __builtin_memcpy(w[r], S + (size_t)sy * a.sstep + (size_t)sx0 * 3, KS * 3);   // (aligned + v_alignbyte measured 15 % slower here: one more dword of traffic)
         }
 #pragma unroll
         for (int r = 0; r < KS; r++)
@@ -885,21 +900,6 @@ __global__ __launch_bounds__(256) void k_resize_area_v4r(RArgs a, AreaDev t, int
             *(uint32_t*)(d + (size_t)k * a.dstep) =
                 (uint32_t)sat_u8(__float2int_rn(s01[k].x)) | ((uint32_t)sat_u8(__float2int_rn(s01[k].y)) << 8) |
                 ((uint32_t)sat_u8(__float2int_rn(s23[k].x)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s23[k].y)) << 24);
-}
-
-// N dwords starting at an arbitrary byte address, as 4-byte ALIGNED vector loads plus v_alignbyte_b32: a byte-
-// misaligned dwordx3/x4 is split by the texture addresser and measured 34 % slower in the BGR AREA kernel.  The one
-// extra dword is fetched only when it shares an aligned word with wanted bytes (shift != 0), so the read never
-// leaves the word -- and therefore the page -- the last wanted byte lives in.
-template <int N>
-__device__ __forceinline__ void load_bytes_aligned(uint32_t* w, const uint8_t* p) {
-    const unsigned sh = (unsigned)(uintptr_t)p & 3u;
-    const uint32_t* a = (const uint32_t*)(p - sh);
-    uint32_t t[N + 1];
-    __builtin_memcpy(t, __builtin_assume_aligned(a, 4), N * 4);
-    t[N] = a[sh ? N : N - 1];
-#pragma unroll
-    for (int i = 0; i < N; i++) w[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], sh);
 }
 
 // The same for 3-channel BGR frames -- what cvDecodeImage hands the reference for every JPEG, and the mode its
