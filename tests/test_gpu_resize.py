@@ -94,13 +94,14 @@ def test_batch_matches_single(gpu):
     src.release(); dst.release()
 
 
+@pytest.mark.parametrize("c", [3, 4])
 @pytest.mark.parametrize("interp", [orc.INTER_LINEAR, orc.INTER_CUBIC, orc.INTER_LANCZOS4], ids=lambda m: NAMES[m])
 @pytest.mark.parametrize("shape", [(16, 16), (122, 130), (240, 258), (2, 200), (300, 18), (64, 1000)])
-def test_exact_2x_decimation_rolling_kernel(gpu, interp, shape):
-    """Exact halves go through the register-rolling kernel (strips of 60 rows, 64 columns): strip seams, partial last
-    strips, partial column blocks and the clamped borders all sit inside these shapes."""
+def test_exact_2x_decimation_rolling_kernel(gpu, interp, shape, c):
+    """Exact halves go through the register-rolling kernels (strips of 60 rows, 64 columns; BGRA and BGR forms): strip
+    seams, partial last strips, partial column blocks and the clamped borders all sit inside these shapes."""
     sh, sw = shape
-    for arr in (noise_image(sh, sw, 4, 70), smooth_image(sh, sw, 4)):
+    for arr in (noise_image(sh, sw, c, 70), smooth_image(sh, sw, c)):
         want = orc.cv_resize(arr, sw // 2, sh // 2, interp)
         got = gpu_resize(gpu, arr, sw // 2, sh // 2, interp)
         assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
