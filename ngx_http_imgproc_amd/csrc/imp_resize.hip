@@ -807,6 +807,171 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
     else strip(std::false_type{});
 }
 
+// ------------------------------------------------------------------ exact 2x decimation, LDS-DMA row ring, 3 channels
+// k_resize_2x_dma for BGR frames.  Everything is counted in bytes: the strip's window starts at the 16-byte granule
+// holding byte 3 * (first tap) and spans (126 + KS) pixels = at most 27 granules; a lane's taps start 6 bytes after
+// its neighbour's, so it reads the aligned dwords around them and realigns with v_alignbyte_b32 (shift 0..3), then
+// runs the fixed-byte perm + dot2 pass of hpass_bgr.  Each row is three byte stores per lane, so once the pipeline is
+// full the wait counts 2 DEPTH fetches + 3 DEPTH stores younger than the rows it needs.
+#define DMA3_SLOT 448      // bytes per LDS row slot: 28 granules
+
+template <int KS, int MODE, int DEPTH, bool VSYM>
+__global__ __launch_bounds__(256, 5) void k_resize_2x_dma3(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                        const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end,
+                                                        int nbx, int bpf, int count) {
+    static_assert((KS * 3) % 4 == 0 && MODE != M_LINEAR, "cubic and lanczos only");
+    constexpr int R = 2 * DEPTH + 2, NDW = KS * 3 / 4;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][R][DMA3_SLOT];
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int bx = blk % nbx, byy = blk / nbx;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dx0 = (bx * 4 + wv) * 64;
+    if (dx0 >= a.dw) return;
+    const int sx00 = __builtin_amdgcn_readfirstlane(xofs[dx0]) - (KS / 2 - 1);   // first tap of the strip's first column
+    const int b00 = sx00 * 3;                                                    // ... as a byte offset in the row
+    const int wstart = b00 & ~15;                                                // window start byte, 16-byte aligned (may be < 0)
+    const int nl = (b00 - wstart + (126 + KS) * 3 + 15) >> 4;                    // granules that cover the window (<= 27)
+    const int rowbytes = a.sw * 3;                                               // a multiple of 16 (host-checked): no partial granule
+    const bool edge = wstart < 0 || wstart + nl * 16 > rowbytes || dx0 + 64 > a.dw;   // wave-uniform
+    const int dx = dx0 + lane;
+    const bool live = dx < a.dw;
+    const int dxc = live ? dx : a.dw - 1;
+    const int gb = wstart + 16 * lane;                                           // first byte of this lane's DMA granule
+    const bool fetch = lane < nl && gb >= 0 && gb + 16 <= rowbytes;
+    const int sx0e = xofs[dxc] - (KS / 2 - 1);
+    const int dy0 = byy * ROLL_STRIP;
+    const int dyn = min(ROLL_STRIP, a.dh - dy0);
+    const uint8_t* S = a.src + (long long)frame * a.src_stride + wstart;
+    uint8_t* D = a.dst + (long long)frame * a.dst_stride + (size_t)dx0 * 3;
+    const unsigned lane16 = lane * 16u, lane3 = lane * 3u;
+
+    short2_t axp[KS / 2];
+#pragma unroll
+    for (int j = 0; j < KS / 2; j++) { axp[j].x = xco[dxc * KS + 2 * j]; axp[j].y = xco[dxc * KS + 2 * j + 1]; }
+    int by[KS];
+#pragma unroll
+    for (int k = 0; k < KS; k++) by[k] = __builtin_amdgcn_readfirstlane((int)yco[dy0 * KS + k]);
+    const int lane_b = 6 * lane + (b00 - wstart);               // this lane's first tap byte inside a slot
+    const int sy_first = yofs[dy0] - (KS / 2 - 1);
+
+    auto issue = [&](int r) {
+        const uint8_t* g = S + ((unsigned)clampi(sy_first + r, 0, a.sh - 1) * (unsigned)a.sstep + lane16);
+        if (fetch)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)&lds[wv][r % R][0], 16, 0, 0);
+    };
+    auto strip = [&](auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        auto window = [&](int r, uint32_t* w) {
+            const uint8_t* slot = &lds[wv][r % R][0];
+            if constexpr (!EDGE) {
+                const uint32_t* q = (const uint32_t*)slot + (lane_b >> 2);
+                uint32_t t[NDW + 1];
+#pragma unroll
+                for (int i = 0; i <= NDW; i++) t[i] = q[i];
+#pragma unroll
+                for (int i = 0; i < NDW; i++) w[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], (unsigned)lane_b & 3u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NDW; i++) w[i] = 0;
+#pragma unroll
+                for (int k = 0; k < KS; k++) {
+                    const uint8_t* q = slot + (clampi(sx0e + k, 0, a.sw - 1) * 3 - wstart);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int o = 3 * k + c;
+                        w[o >> 2] |= (uint32_t)q[c] << (8 * (o & 3));
+                    }
+                }
+            }
+        };
+
+        static_assert(R >= KS - 2 && R <= KS - 2 + 2 * DEPTH, "ring too small for the prologue");
+        int ring[KS][3];
+#pragma unroll
+        for (int r = 0; r < R; r++) issue(r);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - (KS - 2)) : "memory");
+#pragma unroll
+        for (int k = 0; k < KS - 2; k++) {
+            uint32_t w[NDW];
+            window(k, w);
+            hpass_bgr<KS>(w, axp, ring[k]);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = R; r < KS - 2 + 2 * DEPTH; r++) issue(r);
+
+        constexpr int UN = KS / 2;
+        for (int i0 = 0; i0 < dyn; i0 += UN) {
+            static_for<UN>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int i = i0 + u;
+                if (i < dyn) {
+                    const int r0 = KS - 2 + 2 * i;
+                    if (i + DEPTH < dyn) {
+                        issue(r0 + 2 * DEPTH);
+                        issue(r0 + 2 * DEPTH + 1);
+                        // younger than this iteration's rows: 2 DEPTH fetches and, once DEPTH rows have been stored, their
+                        // 3 DEPTH byte stores (VMEM retires in order); before that the stricter count is simply safe
+                        if (i >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * DEPTH) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DEPTH) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    uint32_t p[NDW], q[NDW];
+                    window(r0, p);
+                    window(r0 + 1, q);
+                    hpass_bgr<KS>(p, axp, ring[(KS - 2 + 2 * u) % KS]);
+                    hpass_bgr<KS>(q, axp, ring[(KS - 1 + 2 * u) % KS]);
+                    asm volatile("" ::: "memory");
+                    int out[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        int hc[KS];
+#pragma unroll
+                        for (int k = 0; k < KS; k++) hc[k] = ring[(k + 2 * u) % KS][c];
+                        if constexpr (MODE == M_CUBIC) {
+                            if (dx * 3 + c < vec_end) {
+                                const float sc = 1.f / (2048.f * 2048.f);
+                                float s = __fmul_rn(__int2float_rn(hc[0]), __fmul_rn((float)by[0], sc));
+                                s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[1]), __fmul_rn((float)by[1], sc)));
+                                s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[2]), __fmul_rn((float)by[2], sc)));
+                                s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[3]), __fmul_rn((float)by[3], sc)));
+                                out[c] = sat_u8(__float2int_rn(s));
+                            } else {
+                                int v = __mul24(hc[0], by[0]) + __mul24(hc[1], by[1]) + __mul24(hc[2], by[2]) + __mul24(hc[3], by[3]);
+                                out[c] = shr_sat_u8(v + (1 << 21), 22);
+                            }
+                        } else {
+                            int v = 1 << 21;
+                            if constexpr (VSYM) {
+#pragma unroll
+                                for (int k = 0; k < KS / 2; k++) v = mad24s(hc[k] + hc[KS - 1 - k], by[k], v);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < KS; k++) v = mad24s(hc[k], by[k], v);
+                            }
+                            out[c] = v;
+                        }
+                    }
+                    if constexpr (MODE != M_CUBIC) {
+                        const uint32_t pk = shr_sat_pack4(out[0], out[1], out[2], 0, 22);
+                        out[0] = pk & 0xff; out[1] = (pk >> 8) & 0xff; out[2] = (pk >> 16) & 0xff;
+                    }
+                    // always three store instructions per iteration (the wait above counts them): idle lanes of a
+                    // partial strip are masked per lane, the instructions still issue
+                    uint8_t* o = D + ((unsigned)(dy0 + i) * (unsigned)a.dstep + lane3);
+                    if (!EDGE || live) { o[0] = (uint8_t)out[0]; o[1] = (uint8_t)out[1]; o[2] = (uint8_t)out[2]; }
+                }
+            });
+        }
+    };
+    if (edge) strip(std::true_type{});
+    else strip(std::false_type{});
+}
+
 // ------------------------------------------------------------------ NN
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_nn(RArgs a, double scale_x, double scale_y) {
@@ -1285,7 +1450,18 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             // exact 2x decimation of a 3-channel frame: register-rolling strips
             const int nstrips = (a.dh + ROLL_STRIP - 1) / ROLL_STRIP;
             const dim3 rgrid((a.dw + 255) / 256, nstrips, (unsigned)count);
-            if (interp == IMP_INTER_CUBIC)
+            static const bool no_dma3 = std::getenv("IMPGPU_NO_DMA3") != nullptr;
+            const bool dma3 = !no_dma3 && (a.sw & 15) == 0 && (long long)a.sh * a.sstep < (1LL << 32) && (long long)a.dh * a.dstep < (1LL << 32) &&
+                              !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 15);
+            const int nbx = (a.dw + 255) / 256, bpf = nbx * nstrips;
+            const dim3 dgrid((unsigned)(bpf * 8), (unsigned)((count + 7) / 8));
+            if (dma3 && interp == IMP_INTER_CUBIC)
+                hipLaunchKernelGGL((k_resize_2x_dma3<4, M_CUBIC, 3, false>), dgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, (a.dw * 3) & ~7, nbx, bpf, count);
+            else if (dma3 && ts.ysym)
+                hipLaunchKernelGGL((k_resize_2x_dma3<8, M_LANCZOS, 3, true>), dgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0, nbx, bpf, count);
+            else if (dma3)
+                hipLaunchKernelGGL((k_resize_2x_dma3<8, M_LANCZOS, 3, false>), dgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0, nbx, bpf, count);
+            else if (interp == IMP_INTER_CUBIC)
                 hipLaunchKernelGGL((k_resize_2x_roll3<4, M_CUBIC, false>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, (a.dw * 3) & ~7);
             else if (ts.ysym)
                 hipLaunchKernelGGL((k_resize_2x_roll3<8, M_LANCZOS, true>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);

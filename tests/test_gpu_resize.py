@@ -157,3 +157,38 @@ def test_area_row_groups_on_a_large_batch(gpu, c):
     for i in list(range(0, n, 9)) + [n - 1]:
         assert np.array_equal(out[i], orc.cv_resize(frames[i], dw, dh, orc.INTER_AREA)), i
     src.release(); dst.release()
+
+
+@pytest.mark.parametrize("interp", [orc.INTER_CUBIC, orc.INTER_LANCZOS4], ids=lambda m: NAMES[m])
+@pytest.mark.parametrize("shape", [(16, 16), (2, 32), (14, 144), (126, 128), (130, 272), (250, 528), (480, 640), (64, 1024)])
+def test_exact_2x_bgr_dma_ring_shapes(gpu, interp, shape):
+    """3-channel frames whose width is a multiple of 16 take the byte-granular DMA ring (k_resize_2x_dma3): one-strip
+    images, a partial last column strip (264 = 4 * 64 + 8), strip seams every 60 rows, windows clipped at both borders."""
+    sh, sw = shape
+    for arr in (noise_image(sh, sw, 3, 77), smooth_image(sh, sw, 3)):
+        want = orc.cv_resize(arr, sw // 2, sh // 2, interp)
+        got = gpu_resize(gpu, arr, sw // 2, sh // 2, interp)
+        assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
+
+
+@pytest.mark.parametrize("interp", [orc.INTER_CUBIC, orc.INTER_LANCZOS4], ids=lambda m: NAMES[m])
+@pytest.mark.parametrize("count", [1, 5, 9])
+@pytest.mark.parametrize("pad", [0, 16, 4], ids=["tight", "pitch+16", "pitch+4"])
+def test_exact_2x_bgr_batch(gpu, interp, count, pad):
+    """Resident 3-channel batches: the DMA ring with 16-byte aligned pitches (frame-per-XCD order around the group of
+    8), and the register-rolling fallback when the pitch is only 4-byte aligned."""
+    sh, sw = 126, 528
+    dh, dw = sh // 2, sw // 2
+    sstep = sw * 3 + pad
+    rng = np.random.default_rng(97)
+    frames = rng.integers(0, 256, (count, sh, sw, 3), dtype=np.uint8)
+    packed = np.zeros((count, sh, sstep), np.uint8)
+    packed[:, :, :sw * 3] = frames.reshape(count, sh, sw * 3)
+    src = gpu.Image(packed.reshape(count * sh, sstep // 4, 4))            # raw bytes; the batch call gives the real geometry
+    dst = gpu.Image(np.zeros((count * dh, dw, 3), np.uint8))
+    assert dst.step == dw * 3
+    gpu.batch_cv_resize(src.device_ptr, sh * sstep, sw, sh, sstep, dst.device_ptr, dh * dw * 3, dw, dh, dw * 3, 3, count, interp)
+    out = dst.numpy().reshape(count, dh, dw, 3)
+    for i in range(count):
+        assert np.array_equal(out[i], orc.cv_resize(frames[i], dw, dh, interp)), i
+    src.release(); dst.release()
