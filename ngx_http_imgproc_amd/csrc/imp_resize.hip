@@ -691,8 +691,10 @@ __global__ __launch_bounds__(256) void k_resize_2x_roll3(RArgs a, const int* __r
 // into registers costs the occupancy it buys.  Here each wave streams its row segments D iterations ahead with
 // global_load_lds_dwordx4 (global -> LDS DMA: no VGPRs, no ds_write) into a private ring of 2D+2 LDS row slots and
 // takes its tap windows from there.  Nothing is shared between waves, so there are no barriers: a wave orders its
-// own DMA against its own reads with s_waitcnt vmcnt(2D) (VMEM retires in order; the destination stores in the
-// queue only make the wait conservative).  In strips that touch the image border the granules outside the row are
+// own DMA against its own reads with s_waitcnt vmcnt(2D): fetches retire in order among themselves, so a row still
+// in flight would have the 2D younger fetches in flight behind it and the count could not be <= 2D -- the destination
+// stores in the queue can only make the wait stricter, in whatever order they retire (counting them too, vmcnt(3D),
+// assumes loads and stores retire in one order; the 3-channel kernel showed that assumption to be wrong).  In strips that touch the image border the granules outside the row are
 // masked off and the taps are read from LDS at clamped indices (a wave-uniform branch).
 #define DMA_SLOT 576       // bytes per LDS row slot: (2 * 64 + KS + 3 rounded to 4) pixels = 34 lanes x 16 B, padded
 
@@ -811,8 +813,7 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
 // k_resize_2x_dma for BGR frames.  Everything is counted in bytes: the strip's window starts at the 16-byte granule
 // holding byte 3 * (first tap) and spans (126 + KS) pixels = at most 27 granules; a lane's taps start 6 bytes after
 // its neighbour's, so it reads the aligned dwords around them and realigns with v_alignbyte_b32 (shift 0..3), then
-// runs the fixed-byte perm + dot2 pass of hpass_bgr.  Each row is three byte stores per lane, so once the pipeline is
-// full the wait counts 2 DEPTH fetches + 3 DEPTH stores younger than the rows it needs.
+// runs the fixed-byte perm + dot2 pass of hpass_bgr.  Each row is three byte stores per lane.
 #define DMA3_SLOT 448      // bytes per LDS row slot: 28 granules
 
 template <int KS, int MODE, int DEPTH, bool VSYM>
@@ -913,10 +914,11 @@ __global__ __launch_bounds__(256, 5) void k_resize_2x_dma3(RArgs a, const int* _
                     if (i + DEPTH < dyn) {
                         issue(r0 + 2 * DEPTH);
                         issue(r0 + 2 * DEPTH + 1);
-                        // younger than this iteration's rows: 2 DEPTH fetches and, once DEPTH rows have been stored, their
-                        // 3 DEPTH byte stores (VMEM retires in order); before that the stricter count is simply safe
-                        if (i >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * DEPTH) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DEPTH) : "memory");
+                        // vmcnt <= 2 DEPTH proves this iteration's rows have landed whatever the stores in the queue do:
+                        // fetches retire in order among themselves, so a row still in flight would have all 2 DEPTH younger
+                        // fetches in flight behind it.  (Counting the 3 DEPTH stores as well -- vmcnt(5 DEPTH) -- assumes
+                        // stores retire in order with loads; it gave intermittent wrong rows here, so they do not.)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DEPTH) : "memory");
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
