@@ -192,3 +192,14 @@ def test_exact_2x_bgr_batch(gpu, interp, count, pad):
     for i in range(count):
         assert np.array_equal(out[i], orc.cv_resize(frames[i], dw, dh, interp)), i
     src.release(); dst.release()
+
+
+@pytest.mark.parametrize("c", [3, 4])
+def test_dma_ring_results_do_not_depend_on_timing(gpu, c):
+    """The ring kernels order their own LDS DMA against their own reads with hand-written waits; a mistake there shows
+    as an occasional wrong row (profiles/r01_dma_stress.txt), so repeat the same resize and demand the same bytes."""
+    arr = noise_image(480, 1024, c, 99)
+    for interp in (orc.INTER_LANCZOS4, orc.INTER_CUBIC):
+        want = orc.cv_resize(arr, 512, 240, interp)
+        for rep in range(12):
+            assert np.array_equal(gpu_resize(gpu, arr, 512, 240, interp), want), (NAMES[interp], rep)
