@@ -27,6 +27,20 @@ def test_resize_any_geometry(gpu, sw, sh, dw, dh, c, interp, seed):
     assert np.array_equal(got, want), (sw, sh, dw, dh, c, interp)
 
 
+@settings(max_examples=80, **COMMON)
+@given(quarter_w=st.integers(1, 96), half_h=st.integers(1, 170), c=st.sampled_from([3, 4]), interp=st.sampled_from([2, 4]),
+       mult=st.sampled_from([4, 8, 16]), seed=st.integers(0, 100))
+def test_resize_exact_halves_ring_kernels(gpu, quarter_w, half_h, c, interp, mult, seed):
+    """Widths that are multiples of 4 (BGRA) / 16 (BGR) take the LDS-DMA ring kernels, the rest the register strips."""
+    sw = quarter_w * mult
+    arr = noise_image(2 * half_h, sw, c, seed)
+    want = orc.cv_resize(arr, sw // 2, half_h, interp)
+    im = gpu.Image(arr)
+    assert im.cv_resize(sw // 2, half_h, interp) == 0
+    assert np.array_equal(im.numpy(), want), (sw, 2 * half_h, c, interp)
+    im.release()
+
+
 @settings(max_examples=60, **COMMON)
 @given(half_w=st.integers(1, 200), half_h=st.integers(1, 150), interp=st.sampled_from([1, 2, 4]), seed=st.integers(0, 100))
 def test_resize_exact_halves(gpu, half_w, half_h, interp, seed):
