@@ -427,9 +427,12 @@ int launch_blend_paper(uint8_t* d, long long stride, int w, int h, int step, int
 //     parity -> (steps, parity').  Such functions compose associatively, so 16384 terms are folded
 //     by a block-wide scan; the scan also tells where the sum leaves the binade, and only that one
 //     term is added with the literal float/double sequence before the next regime starts.
-//   A 1080p frame needs ~160 block iterations (127 chunks + one restart per binade) instead of 2 million dependent
-//   adds.  What bounds it now is one CU's double-precision rate (~40 DP ops per term): prefetching the next chunk
-//   measured slower (tools/brightness_probe.py); the next step would be chunk summaries computed by the whole GPU.
+//   One block does ~10 us per 16384-term iteration (it is bound by one CU's double-precision rate), so a 1080p frame
+//   took 1.56 ms in that form.  The binades from 2^23 up hold almost all of the terms, and inside a binade the chunk
+//   functions do not depend on where the sum stands: k_brightness_summarize lets the whole GPU fold every remaining
+//   chunk for the accumulator's current exponent, and one block then only scans those summaries to the chunk in which
+//   the sum leaves the binade and replays that chunk exactly.  The host enqueues a (summarize, replay) pair for every
+//   exponent the frame can reach; a pair whose exponent is not the accumulator's returns at once.  0.42 ms at 1080p.
 template <int CN>
 __global__ __launch_bounds__(256) void k_brightness_terms(const uint8_t* __restrict__ src, int w, int h, int step,
                                                           double* __restrict__ terms) {
@@ -471,62 +474,154 @@ __device__ __forceinline__ ParityFn pf_shfl_up(const ParityFn& f, int d) {
 }
 
 #define BR_EPT 16
-__global__ __launch_bounds__(1024) void k_brightness_replay(const double* __restrict__ terms, long long n, float* out) {
+#define BR_CHUNK (1024 * BR_EPT)      // terms folded per block iteration, and the granularity of the chunk summaries
+
+struct BrState { float sum; int pad; long long pos; };        // the accumulator and the next term to add
+
+struct BrRegime {                     // everything a term's classification needs inside one binade
+    double u, invu, eps, mid;
+};
+__device__ __forceinline__ BrRegime br_regime(int e) {
+    return BrRegime{ldexp(1.0, e - 23), ldexp(1.0, 23 - e), ldexp(1.0, e - 53), 0.5 * ldexp(1.0, e - 23)};
+}
+// one term as a function of the mantissa parity (see the block comment above)
+__device__ __forceinline__ ParityFn br_classify(double t, const BrRegime& g) {
+    const double k = floor(t * g.invu);
+    const double diff = (t - k * g.u) - g.mid;                    // exact: both products are exact, the differences are small
+    ParityFn f;
+    if (fabs(diff) <= g.eps) {                                    // the double sum lands on the midpoint: ties-to-even
+        const int kp = (int)((long long)k & 1);
+        f.inc0 = k + (kp ? 1.0 : 0.0);
+        f.inc1 = k + (kp ? 0.0 : 1.0);
+        f.b0 = 0; f.b1 = 0;
+    } else {
+        const double r = k + (diff > 0.0 ? 1.0 : 0.0);
+        const int rp = (int)((long long)r & 1);
+        f.inc0 = r; f.inc1 = r;
+        f.b0 = rp; f.b1 = rp ^ 1;
+    }
+    return f;
+}
+// inclusive scan of one ParityFn per thread over a 1024-thread block (s_wave: 16 entries of shared scratch)
+__device__ __forceinline__ ParityFn br_block_scan(ParityFn f, ParityFn* s_wave) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const ParityFn prev = pf_shfl_up(f, d);
+        if (lane >= d) f = pf_compose(prev, f);
+    }
+    if (lane == 63) s_wave[wv] = f;
+    __syncthreads();
+    ParityFn pre = pf_identity();
+    for (int w2 = 0; w2 < wv; w2++) pre = pf_compose(pre, s_wave[w2]);
+    return pf_compose(pre, f);
+}
+
+// Chunk summaries for ONE binade, by the whole GPU: block c folds the terms of chunk c (aligned to BR_CHUNK) into
+// one ParityFn for the exponent the accumulator currently has.  Blocks of chunks that start before the accumulator's
+// position, or launched for an exponent the accumulator is not in, return at once.
+__global__ __launch_bounds__(1024) void k_brightness_summarize(const double* __restrict__ terms, long long n,
+                                                               const BrState* __restrict__ st, int e, ParityFn* __restrict__ summ) {
+    __shared__ ParityFn s_wave[16];
+    const float sum = st->sum;
+    const long long pos = st->pos;
+    if (pos >= n || sum == 0.f || (int)((__float_as_uint(sum) >> 23) & 0xff) - 127 != e) return;
+    const long long c0 = (long long)blockIdx.x * BR_CHUNK;
+    if (c0 < pos) return;
+    const BrRegime g = br_regime(e);
+    ParityFn f = pf_identity();
+#pragma unroll
+    for (int j = 0; j < BR_EPT; j++) {
+        const long long i = c0 + (long long)threadIdx.x * BR_EPT + j;
+        if (i < n) f = pf_compose(f, br_classify(terms[i], g));
+    }
+    f = br_block_scan(f, s_wave);
+    if (threadIdx.x == 1023) summ[blockIdx.x] = f;
+}
+
+// mode 0: from (0, 0) until the terms run out or the accumulator reaches binade stop_e.
+// mode 1: one binade, e_arg: (A) exact block iterations up to the next chunk boundary, (B) a scan over the chunk
+//         summaries of k_brightness_summarize to the chunk in which the sum leaves the binade (or to the end),
+//         (C) exact block iterations inside that chunk until it has left.  Returns at once when the accumulator is
+//         not in binade e_arg, so the host can enqueue the rounds for every possible exponent without looking.
+__global__ __launch_bounds__(1024) void k_brightness_replay(const double* __restrict__ terms, long long n, BrState* st, float* out,
+                                                            int mode, int e_arg, const ParityFn* __restrict__ summ) {
     __shared__ ParityFn s_wave[16];
     __shared__ int s_stop[16];
-    __shared__ double s_excl[1024 / 64 * 64];     // inclusive totals (steps) per thread for the chosen start parity
+    __shared__ double s_excl[1024];               // inclusive totals (steps) per thread for the chosen start parity
     __shared__ float s_sum;
     __shared__ long long s_pos;
+    __shared__ long long s_lim;                   // exact iterations read terms below this index only
+    __shared__ int s_phase;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { s_sum = 0.f; s_pos = 0; }
+    if (tid == 0) {
+        if (mode == 0) { s_sum = 0.f; s_pos = 0; }
+        else { s_sum = st->sum; s_pos = st->pos; }
+        const long long p = mode == 0 ? 0 : st->pos;
+        const long long boundary = (p + BR_CHUNK - 1) / BR_CHUNK * BR_CHUNK;
+        s_lim = mode == 0 ? n : (boundary < n ? boundary : n);
+        s_phase = 0;                               // mode 1: 0 = A, 1 = C
+    }
     __syncthreads();
+    const int stop_e = e_arg;
     for (;;) {
         const float sum = s_sum;
         const long long pos = s_pos;
+        const long long nlim = s_lim;
+        const int phase = s_phase;
         if (pos >= n) break;
         const unsigned sbits = __float_as_uint(sum);
         const bool zero = sum == 0.f;
         const int e = (int)((sbits >> 23) & 0xff) - 127;
+        if (mode == 0 && !zero && e >= stop_e) break;
+        if (mode == 1 && (zero || e != e_arg)) break;
         const int binit = (int)(sbits & 1u);
-        const double u = ldexp(1.0, e - 23), invu = ldexp(1.0, 23 - e), eps = ldexp(1.0, e - 53), mid = 0.5 * u;
         const double limit = (double)(0x800000u - (sbits & 0x7fffffu));     // steps until the binade ends
 
+        if (mode == 1 && phase == 0 && pos >= nlim) {
+            // ---- (B) whole chunks: scan their summaries, 1024 at a time
+            const long long cidx = pos / BR_CHUNK + tid;
+            ParityFn f = (cidx * BR_CHUNK < n) ? summ[cidx] : pf_identity();
+            f = br_block_scan(f, s_wave);
+            const double tot = binit ? f.inc1 : f.inc0;
+            const bool stop = tot >= limit;
+            const unsigned long long bal = __ballot(stop);
+            if (lane == 0) s_stop[wv] = bal ? (wv * 64 + (int)__builtin_ctzll(bal)) : 1 << 30;
+            s_excl[tid] = tot;
+            __syncthreads();
+            if (tid == 0) {
+                int first = 1 << 30;
+                for (int w2 = 0; w2 < 16; w2++) first = min(first, s_stop[w2]);
+                if (first >= 1024) {               // none of these chunks leaves the binade: take them all
+                    s_sum = __uint_as_float(sbits + (unsigned)(long long)s_excl[1023]);
+                    const long long np = pos + 1024LL * BR_CHUNK;
+                    s_pos = np < n ? np : n;
+                    s_lim = s_pos;                 // stay in (B)
+                } else {
+                    if (first > 0) s_sum = __uint_as_float(sbits + (unsigned)(long long)s_excl[first - 1]);
+                    s_pos = pos + (long long)first * BR_CHUNK;
+                    s_lim = n;                     // (C): exact iterations; the exponent test above ends them
+                    s_phase = 1;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+
+        // ---- exact block iteration over terms [pos, min(pos + BR_CHUNK, nlim))
+        const BrRegime g = br_regime(e);
         ParityFn f = pf_identity();
         bool nonzero = false;
 #pragma unroll
         for (int j = 0; j < BR_EPT; j++) {
             const long long i = pos + (long long)tid * BR_EPT + j;
-            if (i < n) {
+            if (i < nlim) {
                 const double t = terms[i];
                 if (zero) { nonzero |= (t != 0.0); continue; }
-                const double k = floor(t * invu);
-                const double diff = (t - k * u) - mid;            // exact: both products are exact, the differences are small
-                ParityFn g;
-                if (fabs(diff) <= eps) {                          // the double sum lands on the midpoint: ties-to-even
-                    const int kp = (int)((long long)k & 1);
-                    g.inc0 = k + (kp ? 1.0 : 0.0);
-                    g.inc1 = k + (kp ? 0.0 : 1.0);
-                    g.b0 = 0; g.b1 = 0;
-                } else {
-                    const double r = k + (diff > 0.0 ? 1.0 : 0.0);
-                    const int rp = (int)((long long)r & 1);
-                    g.inc0 = r; g.inc1 = r;
-                    g.b0 = rp; g.b1 = rp ^ 1;
-                }
-                f = pf_compose(f, g);
+                f = pf_compose(f, br_classify(t, g));
             }
         }
-        // inclusive scan of the per-thread functions: within the wave, then across the 16 waves
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const ParityFn prev = pf_shfl_up(f, d);
-            if (lane >= d) f = pf_compose(prev, f);
-        }
-        if (lane == 63) s_wave[wv] = f;
-        __syncthreads();
-        ParityFn pre = pf_identity();
-        for (int w2 = 0; w2 < wv; w2++) pre = pf_compose(pre, s_wave[w2]);
-        f = pf_compose(pre, f);
+        f = br_block_scan(f, s_wave);
         const double tot = binit ? f.inc1 : f.inc0;              // steps added by everything up to and including this thread
         const bool stop = zero ? nonzero : (tot >= limit);
         const unsigned long long bal = __ballot(stop);
@@ -538,40 +633,65 @@ __global__ __launch_bounds__(1024) void k_brightness_replay(const double* __rest
             for (int w2 = 0; w2 < 16; w2++) first = min(first, s_stop[w2]);
             float ns = sum;
             long long np;
-            if (first >= 1024) {                                  // the whole chunk stays inside the binade
+            if (first >= 1024) {                                  // everything offered stays inside the binade
                 if (!zero) ns = __uint_as_float(sbits + (unsigned)(long long)s_excl[1023]);
-                np = pos + 1024LL * BR_EPT;
+                np = pos + (long long)BR_CHUNK;
+                if (np > nlim) np = nlim;
             } else {
                 if (!zero && first > 0) ns = __uint_as_float(sbits + (unsigned)(long long)s_excl[first - 1]);
                 np = pos + (long long)first * BR_EPT;
                 // the thread's own terms hold the one that leaves the binade (or the first non-zero term): literal sequence
-                for (int j = 0; j < BR_EPT && np < n; j++, np++) ns = (float)__dadd_rn((double)ns, terms[np]);
+                for (int j = 0; j < BR_EPT && np < nlim; j++, np++) ns = (float)__dadd_rn((double)ns, terms[np]);
             }
             s_sum = ns;
-            s_pos = np < n ? np : n;
+            s_pos = np;
         }
         __syncthreads();
     }
-    if (tid == 0) *out = s_sum;
+    if (tid == 0) {
+        st->sum = s_sum;
+        st->pos = s_pos;
+        if (s_pos >= n) *out = s_sum;
+    }
 }
 
 int launch_brightness(const View& v, float* host_result, hipStream_t s) {
     const long long n = (long long)v.w * v.h;
-    void* terms = nullptr;
-    void* out = nullptr;
+    const long long nchunks = (n + BR_CHUNK - 1) / BR_CHUNK;
+    // big frames: the binades from 2^20 up hold almost all the terms, and their chunk summaries are work for the whole
+    // GPU; small frames (a thumbnail's Info request) are cheaper in the one-block form than the ~27 launches cost
+    const bool rounds = n >= (1LL << 19) && nchunks <= 0x7fffffff;
+    void *terms = nullptr, *out = nullptr, *st = nullptr, *summ = nullptr;
+    auto drop = [&]() { if (terms) dev_free(terms); if (out) dev_free(out); if (st) dev_free(st); if (summ) dev_free(summ); };
     if (int rc = dev_alloc((size_t)n * sizeof(double), &terms)) return rc;
-    if (int rc = dev_alloc(sizeof(float), &out)) { dev_free(terms); return rc; }
+    if (int rc = dev_alloc(sizeof(float), &out)) { drop(); return rc; }
+    if (int rc = dev_alloc(sizeof(BrState), &st)) { drop(); return rc; }
+    if (rounds) if (int rc = dev_alloc((size_t)nchunks * sizeof(ParityFn), &summ)) { drop(); return rc; }
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (v.c == 1) hipLaunchKernelGGL((k_brightness_terms<1>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
     else if (v.c == 3) hipLaunchKernelGGL((k_brightness_terms<3>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
     else hipLaunchKernelGGL((k_brightness_terms<4>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
-    hipLaunchKernelGGL(k_brightness_replay, dim3(1), dim3(1024), 0, s, (const double*)terms, n, (float*)out);
+    // a binade of T terms costs the one-block form about (T / 16384 + 1) x 10 us and a round about 37 us: rounds pay from
+    // 2^23 up (44 k terms at ~150 per term).  The sum cannot pass n * 255, nor (a term is at most 255, u / 2 = 256 there)
+    // leave binade 32.
+    const int first_round = 23;
+    int last_round = 0;
+    while (last_round < 32 && (double)n * 255.0 >= ldexp(1.0, last_round + 1)) last_round++;
+    hipLaunchKernelGGL(k_brightness_replay, dim3(1), dim3(1024), 0, s, (const double*)terms, n, (BrState*)st, (float*)out, 0,
+                       rounds ? first_round : 1000, (const ParityFn*)nullptr);
+    if (rounds) {
+        for (int e = first_round; e <= last_round; e++) {
+            hipLaunchKernelGGL(k_brightness_summarize, dim3((unsigned)nchunks), dim3(1024), 0, s, (const double*)terms, n,
+                               (const BrState*)st, e, (ParityFn*)summ);
+            hipLaunchKernelGGL(k_brightness_replay, dim3(1), dim3(1024), 0, s, (const double*)terms, n, (BrState*)st, (float*)out, 1, e,
+                               (const ParityFn*)summ);
+        }
+    }
     hipError_t e = hipGetLastError();
     float sum = 0.f;
     if (e == hipSuccess) e = hipMemcpyAsync(&sum, out, sizeof(float), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    dev_free(terms);
-    dev_free(out);
+    drop();
     if (e != hipSuccess) { set_error("brightness", e); return IMP_ERROR_DEVICE; }
     // filters.c:728: float / int -> float, then / 255.0 in double, returned as float
     const float mean = sum / (float)(v.w * v.h);

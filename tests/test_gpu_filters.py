@@ -199,7 +199,12 @@ def test_brightness_adversarial_exact(gpu):
     cases = [gray, gray[:, :, :1], zero_prefix, np.zeros((300, 300, 4), np.uint8), np.full((1080, 1920, 3), 255, np.uint8),
              np.full((1, 1, 3), 7, np.uint8), np.full((1, 5000, 1), 255, np.uint8), np.full((3000, 1, 1), 3, np.uint8),
              rng.integers(0, 256, size=(2160, 3840, 4), dtype=np.uint8),
-             np.full((2160, 3840, 1), 254, np.uint8), (np.arange(1500 * 1500) % 2 * 255).astype(np.uint8).reshape(1500, 1500, 1)]
+             np.full((2160, 3840, 1), 254, np.uint8), (np.arange(1500 * 1500) % 2 * 255).astype(np.uint8).reshape(1500, 1500, 1),
+             # the multi-kernel path (>= 2^19 pixels): a whole number of 16384-term chunks, the threshold itself and one
+             # past it, a dark frame that never reaches the first round's binade, a frame that is dark then bright
+             rng.integers(0, 256, size=(1024, 1024, 3), dtype=np.uint8), rng.integers(0, 256, size=(512, 1024, 1), dtype=np.uint8),
+             rng.integers(0, 256, size=(1, 524289, 1), dtype=np.uint8), rng.integers(0, 3, size=(800, 800, 3), dtype=np.uint8),
+             np.concatenate([rng.integers(0, 2, size=(900, 500, 3), dtype=np.uint8), rng.integers(200, 256, size=(900, 500, 3), dtype=np.uint8)], axis=1)]
     for arr in cases:
         im = gpu.Image(arr)
         got = im.calc_perceived_brightness()
