@@ -9,10 +9,14 @@ import oracle_lib as orc
 from conftest import noise_image
 
 pytestmark = pytest.mark.gpu
-COMMON = dict(deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+import os
+# IMP_FUZZ_RANDOM=1 draws fresh examples instead of the fixed derandomised set; IMP_FUZZ_SCALE=N multiplies their number
+COMMON = dict(deadline=None, derandomize=not os.environ.get("IMP_FUZZ_RANDOM"),
+              suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+SCALE = int(os.environ.get("IMP_FUZZ_SCALE", "1"))
 
 
-@settings(max_examples=250, **COMMON)
+@settings(max_examples=250 * SCALE, **COMMON)
 @given(sw=st.integers(1, 300), sh=st.integers(1, 200), dw=st.integers(1, 300), dh=st.integers(1, 200),
        c=st.sampled_from([1, 3, 4]), interp=st.integers(0, 4), seed=st.integers(0, 1000))
 def test_resize_any_geometry(gpu, sw, sh, dw, dh, c, interp, seed):
@@ -27,7 +31,7 @@ def test_resize_any_geometry(gpu, sw, sh, dw, dh, c, interp, seed):
     assert np.array_equal(got, want), (sw, sh, dw, dh, c, interp)
 
 
-@settings(max_examples=80, **COMMON)
+@settings(max_examples=80 * SCALE, **COMMON)
 @given(quarter_w=st.integers(1, 96), half_h=st.integers(1, 170), c=st.sampled_from([3, 4]), interp=st.sampled_from([2, 4]),
        mult=st.sampled_from([4, 8, 16]), seed=st.integers(0, 100))
 def test_resize_exact_halves_ring_kernels(gpu, quarter_w, half_h, c, interp, mult, seed):
@@ -41,7 +45,7 @@ def test_resize_exact_halves_ring_kernels(gpu, quarter_w, half_h, c, interp, mul
     im.release()
 
 
-@settings(max_examples=60, **COMMON)
+@settings(max_examples=60 * SCALE, **COMMON)
 @given(half_w=st.integers(1, 200), half_h=st.integers(1, 150), interp=st.sampled_from([1, 2, 4]), seed=st.integers(0, 100))
 def test_resize_exact_halves(gpu, half_w, half_h, interp, seed):
     arr = noise_image(2 * half_h, 2 * half_w, 4, seed)
@@ -82,7 +86,7 @@ def filter_chain(draw):
     return out
 
 
-@settings(max_examples=80, **COMMON)
+@settings(max_examples=80 * SCALE, **COMMON)
 @given(w=st.integers(2, 120), h=st.integers(2, 90), c=st.sampled_from([3, 4]), filters=filter_chain(), seed=st.integers(0, 100),
        crop=st.sampled_from([None, "1,1", "4,3,r,b", "2,1,l,t"]), resize=st.sampled_from([None, "40", "0,33", "50,20", "200,200,up"]))
 def test_run_ops_random_chain(gpu, w, h, c, filters, seed, crop, resize):
@@ -99,7 +103,7 @@ def test_run_ops_random_chain(gpu, w, h, c, filters, seed, crop, resize):
     im.release()
 
 
-@settings(max_examples=80, **COMMON)
+@settings(max_examples=80 * SCALE, **COMMON)
 @given(bw=st.integers(1, 90), bh=st.integers(1, 70), ow=st.integers(1, 60), oh=st.integers(1, 50), dc=st.sampled_from([3, 4]),
        sc=st.sampled_from([3, 4]), gx=st.sampled_from("lcr"), gy=st.sampled_from("tcb"), ox=st.integers(-40, 40),
        oy=st.integers(-40, 40), op=st.integers(1, 100), seed=st.integers(0, 50))
