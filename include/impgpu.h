@@ -189,7 +189,9 @@ int               impgpu_parse_request(const char* uri, const char* extension, c
 const impgpu_job* impgpu_request_job(const impgpu_request* request);
 const char*       impgpu_request_quality(const impgpu_request* request);    /* value of quality= or NULL */
 const char*       impgpu_request_format(const impgpu_request* request);     /* value of format= or NULL */
-int               impgpu_request_page(const impgpu_request* request);       /* -1 when absent (bridge.c:324) */
+/* the page LoadGIF gets (DecodeRequest.Page, bridge.c:563): the page= value; when absent, 0 for every encoder that
+ * takes one frame and -1 (= all pages) only for GIF output and the json exit (bridge.c:324, :433-435, :448-450) */
+int               impgpu_request_page(const impgpu_request* request);
 int               impgpu_request_mime(const impgpu_request* request);       /* IMP_MIME_* of required.h:57-62 */
 int               impgpu_request_destructive(const impgpu_request* request); /* CheckDestructive over the filters */
 void              impgpu_request_free(impgpu_request** request);
@@ -200,8 +202,9 @@ void              impgpu_request_free(impgpu_request** request);
  *      is destructive (advancedio.c:195-240), the RGBQUAD palette lookup into a 4-channel frame (:242-246) -- runs
  *      on the device.  A page is what FreeImage hands that loop: 8-bit indices in scanline order (bottom-up,
  *      `pitch` bytes per row; FreeImage_ConvertTo8Bits first when the page is not 8-bit, :181-185).
- *      frames[i] = page i (all `count` of them) when page < 0; with page >= 0 the walk stops there and frames[0]
- *      is that page alone (advancedio.c:249-262).  Returns IMP_ERROR_INVALID_ARGS for page >= count. ---- */
+ *      frames[i] = page i (all `count` of them) when page == -1.  With page >= 0 the walk is always destructive, a
+ *      page past the last one means page 0 (advancedio.c:111-116), the walk stops at that page and frames[0] is
+ *      that page alone (advancedio.c:256-273).  page < -1 returns IMP_ERROR_INVALID_ARGS (undefined in the reference). ---- */
 #define IMP_GIF_DISPOSAL_UNSPECIFIED 0
 #define IMP_GIF_DISPOSAL_LEAVE       1
 #define IMP_GIF_DISPOSAL_BACKGROUND  2

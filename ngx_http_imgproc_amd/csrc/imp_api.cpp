@@ -220,7 +220,11 @@ int impgpu_blend_with_paper(impgpu_image* image) {
 }
 
 int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** frames) {
-    if (!pages || !frames || count <= 0 || page >= count) return IMP_ERROR_INVALID_ARGS;
+    if (!pages || !frames || count <= 0 || page < -1) return IMP_ERROR_INVALID_ARGS;   // page < -1: the reference reads Frames[page] below the array
+    if (page != -1) {                                              // advancedio.c:111-116: a page request is always a
+        destructive = 1;                                           // destructive walk, and a page past the end is page 0
+        if (page > count - 1) page = 0;
+    }
     if (int rc = need_env()) return rc;
     const int cw = pages[0].width, ch = pages[0].height;           // advancedio.c:133-136: canvas = first page
     if (cw <= 0 || ch <= 0) return IMP_ERROR_INVALID_ARGS;
@@ -459,7 +463,7 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
 
 int impgpu_batch_filters(void* frames, long long frame_stride, int width, int height, int channels, int step, int count,
                          const char* const* filters, int filter_count, int allow_experiments, void* stream) {
-    if (!frames || !filters || filter_count < 0 || (channels != 3 && channels != 4) || step < width * channels) return IMP_ERROR_INVALID_ARGS;
+    if (!frames || !filters || filter_count < 0 || (channels != 3 && channels != 4) || (long long)step < (long long)width * channels) return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;
     PixelProgram prog;
     for (int i = 0; i < filter_count; i++) {

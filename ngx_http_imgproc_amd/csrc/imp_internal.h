@@ -31,6 +31,11 @@ inline View view_sub(const View& v, int x, int y, int w, int h) {
     return View{v.d + (size_t)y * v.step + (size_t)x * v.c, w, h, v.c, v.step};
 }
 inline int aligned_step(int w, int c) { return (w * c + 3) & ~3; }
+// what the kernels' 32-bit pixel / byte indexing can address (see image_new)
+inline bool frame_fits(int w, int h, int c) {
+    const long long step = ((long long)w * c + 3) & ~3LL;
+    return (long long)w * h <= (1LL << 30) && step * h <= 0xffffffffLL && step <= 0x7fffffffLL;
+}
 
 // ---------------------------------------------------------------- runtime (imp_runtime.hip)
 void set_error(const char* what, hipError_t e);

@@ -293,7 +293,26 @@ int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int 
                          const PixelProgram& prog, hipStream_t s) {
     if (prog.empty() || count <= 0) return IMP_OK;
     if (count > 65535) return IMP_ERROR_INVALID_ARGS;
-    if (prog.stages.size() > IMP_MAX_STAGES || prog.tables.size() > IMP_MAX_TABLE_BYTES) return IMP_ERROR_TOO_MUCH_FILTERS;
+    if (prog.stages.size() > IMP_MAX_STAGES || prog.tables.size() > IMP_MAX_TABLE_BYTES) {
+        // a long run of pointwise filters (a raised imgproc_max_filters): the reference just runs them one after another,
+        // so cut the program into launches that fit.  Exact anywhere: every stage already rounds to 8 bits per channel,
+        // which is all a frame in HBM holds between two launches.
+        PixelProgram part;
+        for (const Stage& st : prog.stages) {
+            const size_t tb = st.kind == ST_LUT4 ? 1024 : (st.kind == ST_GRADMAP ? 768 : 0);
+            if (part.stages.size() + 1 > IMP_MAX_STAGES || part.tables.size() + tb > IMP_MAX_TABLE_BYTES) {
+                if (int rc = launch_pixel_program(d, stride, w, h, c, step, count, part, s)) return rc;
+                part.clear();
+            }
+            Stage cp = st;
+            if (tb) {
+                cp.lut_off = (int)part.tables.size();
+                part.tables.insert(part.tables.end(), prog.tables.begin() + st.lut_off, prog.tables.begin() + st.lut_off + tb);
+            }
+            part.stages.push_back(cp);
+        }
+        return launch_pixel_program(d, stride, w, h, c, step, count, part, s);
+    }
     if (c == 4 && (((uintptr_t)d | (uintptr_t)step | (uintptr_t)stride) & 3)) return IMP_ERROR_INVALID_ARGS;
     ProgDev pd{};
     pd.n = (int)prog.stages.size();

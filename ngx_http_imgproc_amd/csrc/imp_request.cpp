@@ -121,6 +121,21 @@ int impgpu_parse_request(const char* uri, const char* extension, const impgpu_co
         if (cls == F_UNKNOWN || cls == F_NOT_IMPL) return IMP_ERROR_UNSUPPORTED; // bridge.c:441-444
         r->mime = -4;
     }
+    // bridge.c:433-435, :448-450: every encoder but GIF (and the json exit) takes one page, so an absent page= means
+    // page 0 -- which also makes LoadGIF's walk destructive (advancedio.c:111-113)
+    if (r->page == -1 && r->mime != -3 && cls != F_GIF) r->page = 0;
+    if (r->quality && (r->mime == -1 || r->mime == -2)) {               // bridge.c:475-500: jpg 0..100, png 0..9
+        const long qv = std::strtol(r->quality, nullptr, 10);
+        if (qv < 0 || qv > (r->mime == -1 ? 100 : 9)) return IMP_ERROR_INVALID_ARGS;
+    }
+    if (r->quality && r->mime == -4) {                                  // bridge.c:511-519: FIF_J2K / FIF_JP2 / FIF_WEBP 0..512
+        const char* e = format;
+        if (const char* dot = std::strrchr(e, '.')) e = dot + 1;
+        if (ieq(e, "j2k") || ieq(e, "j2c") || ieq(e, "jp2") || ieq(e, "webp")) {
+            const long qv = std::strtol(r->quality, nullptr, 10);
+            if (qv < 0 || qv > 512) return IMP_ERROR_INVALID_ARGS;
+        }
+    }
     r->job.simple = cls == F_GIF;                                        // bridge.c:594
     r->job.need_flatten = r->mime == -1 || (r->mime == -4 && cls == F_NO_ALPHA);   // bridge.c:643-647
     return IMP_OK;

@@ -150,6 +150,9 @@ void dev_free(void* p) {
 
 int image_new(int w, int h, int c, impgpu_image** out) {
     if (w <= 0 || h <= 0 || (c != 1 && c != 3 && c != 4)) return IMP_ERROR_INVALID_ARGS;
+    // the kernels index pixels and row bytes in 32 bits: a frame is at most 2^30 pixels and 4 GiB - 1 of rows.  Larger
+    // requests (resize=2000000000,1,up with the size watchdog off) end like a failed cvCreateImage, not in a wrapped pitch.
+    if (!frame_fits(w, h, c)) { t_error = "frame too large"; return IMP_ERROR_MALLOC_FAILED; }
     impgpu_image* im = new impgpu_image();
     im->w = w; im->h = h; im->c = c;
     im->step = aligned_step(w, c);
@@ -289,7 +292,7 @@ int impgpu_image_create(int width, int height, int channels, impgpu_image** out)
 
 int impgpu_image_upload(const unsigned char* data, int width, int height, int channels, int step,
                         impgpu_image** out) {
-    if (!data || !out || step < width * channels) return IMP_ERROR_INVALID_ARGS;
+    if (!data || !out || (long long)step < (long long)width * channels) return IMP_ERROR_INVALID_ARGS;
     Lane* L = lane();
     if (!L) return no_env();
     impgpu_image* im = nullptr;
@@ -328,7 +331,7 @@ void impgpu_host_free(void* p) {
 
 int impgpu_image_upload_pinned(const unsigned char* data, int width, int height, int channels, int step,
                                impgpu_image** out) {
-    if (!data || !out || step < width * channels) return IMP_ERROR_INVALID_ARGS;
+    if (!data || !out || (long long)step < (long long)width * channels) return IMP_ERROR_INVALID_ARGS;
     Lane* L = lane();
     if (!L) return no_env();
     impgpu_image* im = nullptr;
@@ -397,7 +400,8 @@ int impgpu_image_download_fi(const impgpu_image* im, int bpp, unsigned char* bit
 
 int impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int step, impgpu_image** out) {
     if (!device_ptr || !out || width <= 0 || height <= 0 || (channels != 1 && channels != 3 && channels != 4) ||
-        step < width * channels)
+        (long long)step < (long long)width * channels || !frame_fits(width, height, channels) ||
+        (long long)step * height > 0xffffffffLL)
         return IMP_ERROR_INVALID_ARGS;
     impgpu_image* im = new impgpu_image();
     im->d = (uint8_t*)device_ptr;

@@ -55,9 +55,9 @@ void build_tap_axis(int ssize, int dsize, double scale, int interp, bool is_x, T
         float f = (float)((d + 0.5) * scale - 0.5);
         int s = (int)std::floor(f);
         f -= s;
-        if (is_x && interp == IMP_INTER_LINEAR) {   // the x-only edge rule of the linear branch
-            if (s < 0) { f = 0; s = 0; }
-            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        if (is_x) {     // cv::resize's xofs loop, OpenCV 2.4.9: unconditional for every generic mode (the CUBIC /
+            if (s < 0) { f = 0; s = 0; }                    // LANCZOS4 exemption only arrived in 3.x), x axis only:
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }   // an enlargement's edge columns copy src[0] / src[w-1]
         }
         out->ofs[d] = s;
         if (interp == IMP_INTER_CUBIC) weights_cubic(f, w);

@@ -281,9 +281,15 @@ orc_image* orc_fi32_to_ipl(const unsigned char* bits, int width, int height, int
  *    same linear read (the pitch padding, or the next scanline's first byte); past the end of the page it is the key.
  *  - an index < 0 (key -1 on a pixel outside the frame, or a never-written master entry) would index the palette
  *    out of bounds: colour 0,0,0.  `master` starts at 0 (ngx_palloc does not clear it).
- *  - page >= count: INVALID_ARGS (the reference would index Frames[] out of bounds). */
+ *  - page < -1: INVALID_ARGS (the reference walks every page and then indexes Frames[page] below the array).
+ * A page request (page != -1) forces the destructive walk and a page past the last one means page 0
+ * (advancedio.c:111-116): `isdestructive = 1; if (page > framecount - 1) page = 0;`. */
 int orc_gif_compose(const orc_gif_page* pages, int count, int destructive, int page, orc_image** frames) {
-    if (!pages || !frames || count <= 0 || page >= count) return ORC_ERROR_INVALID_ARGS;
+    if (!pages || !frames || count <= 0 || page < -1) return ORC_ERROR_INVALID_ARGS;
+    if (page != -1) {                                             /* :111-116 */
+        destructive = 1;
+        if (page > count - 1) page = 0;
+    }
     const int cw = pages[0].width, ch = pages[0].height;          /* :133-136 canvas = first page */
     if (cw <= 0 || ch <= 0) return ORC_ERROR_INVALID_ARGS;
     int* master = destructive ? (int*)calloc((size_t)cw * ch, sizeof(int)) : NULL;   /* :195-200 */

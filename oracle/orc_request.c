@@ -10,6 +10,7 @@
 #define _GNU_SOURCE
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include "imp_oracle.h"
 
 enum { F_UNKNOWN = 0, F_ALPHA_OK, F_NO_ALPHA, F_GIF, F_NOT_IMPL };
@@ -100,6 +101,18 @@ int orc_parse_request(const char* uri, const char* exten, int max_filters, orc_r
         cls = fif_class(format);
         if (cls == F_UNKNOWN || cls == F_NOT_IMPL) return ORC_ERROR_UNSUPPORTED;   /* bridge.c:441-444 */
         r->mime = -4;
+    }
+    if (r->page == -1 && r->mime != -3 && cls != F_GIF) r->page = 0;  /* bridge.c:433-435, :448-450 */
+    if (r->quality && (r->mime == -1 || r->mime == -2)) {             /* bridge.c:475-500 */
+        long qv = strtol(r->quality, NULL, 10);
+        if (qv < 0 || qv > (r->mime == -1 ? 100 : 9)) return ORC_ERROR_INVALID_ARGS;
+    }
+    if (r->quality && r->mime == -4) {                                /* bridge.c:511-519 */
+        const char* e = strrchr(format, '.') ? strrchr(format, '.') + 1 : format;
+        if (!strcasecmp(e, "j2k") || !strcasecmp(e, "j2c") || !strcasecmp(e, "jp2") || !strcasecmp(e, "webp")) {
+            long qv = strtol(r->quality, NULL, 10);
+            if (qv < 0 || qv > 512) return ORC_ERROR_INVALID_ARGS;
+        }
     }
     r->simple = cls == F_GIF;                                         /* bridge.c:594 */
     r->need_flatten = r->mime == -1 || (r->mime == -4 && cls == F_NO_ALPHA);   /* bridge.c:643-647 (if the frame has alpha) */

@@ -64,7 +64,7 @@ static void lanczos4_coeffs(float x, float* c) {
 
 /* One axis of the coefficient tables of cv::resize's generic branch.
  * ofs[d] = first-tap-centre source index (may be out of range; taps are clamped when read),
- * coef[d*ksize + k] = fixed-point weights. is_x selects the x-only linear edge rule. */
+ * coef[d*ksize + k] = fixed-point weights. is_x selects the x-only edge rule. */
 static void build_axis(int ssize, int dsize, double scale, int interp, int is_x, int* ofs, short* coef) {
     int ksize = interp == ORC_INTER_LINEAR ? 2 : interp == ORC_INTER_CUBIC ? 4 : 8;
     float cbuf[8];
@@ -72,7 +72,10 @@ static void build_axis(int ssize, int dsize, double scale, int interp, int is_x,
         float f = (float)((d + 0.5) * scale - 0.5);
         int s = (int)floor(f);
         f -= s;
-        if (is_x && interp == ORC_INTER_LINEAR) {
+        /* imgwarp.cpp (2.4.9) cv::resize, xofs loop: `if( sx < 0 ) fx = 0, sx = 0;` and
+         * `if( sx >= ssize.width-1 ) fx = 0, sx = ssize.width-1;` apply to LINEAR, CUBIC and LANCZOS4 alike
+         * (3.x exempted CUBIC / LANCZOS4 later); the yofs loop has no such rule. */
+        if (is_x) {
             if (s < 0) { f = 0; s = 0; }
             if (s >= ssize - 1) { f = 0; s = ssize - 1; }
         }

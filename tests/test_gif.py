@@ -91,7 +91,23 @@ def test_requested_page_stops_the_walk_and_is_returned_alone():
     rc, frames = orc.gif_compose(pages, destructive=True, page=2)
     assert rc == 0 and len(frames) == 1
     assert np.array_equal(frames[0], expect(pal, np.full((2, 2), 3), 0))
-    assert orc.gif_compose(pages, page=4)[0] == 50      # IMP_ERROR_INVALID_ARGS (required.h:31)
+    # advancedio.c:114-116: a page past the last one is page 0, not an error
+    rc, frames = orc.gif_compose(pages, page=4)
+    assert rc == 0 and len(frames) == 1 and np.array_equal(frames[0], expect(pal, np.full((2, 2), 1), 0))
+    assert orc.gif_compose(pages, page=-2)[0] == 50     # undefined in the reference (Frames[-2]); INVALID_ARGS here
+
+
+def test_page_request_forces_the_destructive_walk():
+    """advancedio.c:111-113: `if (page != -1) { ...; isdestructive = 1; }` -- whatever the filters said.  Page 1 is fully
+    transparent with DISPOSAL_LEAVE, so it shows page 0 through the master canvas only when the walk is destructive."""
+    pal = palette(3)
+    p0 = np.array([[5, 6], [7, 8]], np.uint8)
+    p1 = np.full((2, 2), 99, np.uint8)
+    pages = [page(p0, dispose=1, key=99, pal=pal), page(p1, dispose=1, key=99, pal=pal)]
+    rc, alone = orc.gif_compose(pages, destructive=False, page=1)
+    assert rc == 0 and np.array_equal(alone[0], expect(pal, p0.astype(int), 99))
+    rc, album = orc.gif_compose(pages, destructive=False)           # page == -1 keeps the caller's flag
+    assert rc == 0 and (album[1][:, :, 3] == 0).all()
 
 
 # ------------------------------------------------------------------ GPU parity
@@ -132,8 +148,20 @@ def test_gif_compose_matches_oracle(gpu, destructive, seed, n, cw, ch):
 @pytest.mark.gpu
 def test_gif_compose_rejects_bad_arguments(gpu):
     pages = random_album(9, 2, 8, 8)
-    assert gpu.gif_compose(pages, page=2)[0] == gpu.IMP_ERROR_INVALID_ARGS
+    assert gpu.gif_compose(pages, page=-2)[0] == gpu.IMP_ERROR_INVALID_ARGS
     assert gpu.gif_compose([], page=-1)[0] == gpu.IMP_ERROR_INVALID_ARGS
+
+
+@pytest.mark.gpu
+def test_gif_page_past_the_end_is_page_zero_and_always_destructive(gpu):
+    pages = random_album(10, 3, 12, 9)
+    for destructive in (False, True):
+        rc, got = gpu.gif_compose(pages, destructive, page=7)       # advancedio.c:114-116 -> page 0
+        rc_o, want = orc.gif_compose(pages, True, page=0)
+        assert rc == rc_o == 0 and np.array_equal(got[0].numpy(), want[0])
+        rc, got = gpu.gif_compose(pages, destructive, page=2)       # advancedio.c:113 -> destructive whatever the flag
+        rc_o, want = orc.gif_compose(pages, True, page=2)
+        assert rc == rc_o == 0 and np.array_equal(got[0].numpy(), want[0])
 
 
 @pytest.mark.gpu

@@ -75,8 +75,45 @@ def test_cubic_matches_float_bicubic_within_one():
         t = torch.from_numpy(arr).permute(2, 0, 1)[None].double()
         ref = F.interpolate(t, size=size, mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
         d = np.abs(got - np.clip(np.rint(ref), 0, 255))
+        # OpenCV 2.4.9's x-edge rule (sx < 0 -> src[0], sx >= w-1 -> src[w-1]; see test_cubic_upscale_edge_columns...)
+        # pins the outermost columns of an enlargement; torch has no such rule, so those columns are checked there
+        sx = np.floor((np.arange(size[1]) + 0.5) * (arr.shape[1] / size[1]) - 0.5)
+        inner = (sx >= 0) & (sx < arr.shape[1] - 1)
+        d = d[:, inner]
         assert d.max() <= 1        # 11-bit fixed-point weights vs float: never more than one LSB
         assert (d > 0).mean() < 0.08
+
+
+def test_cubic_upscale_edge_columns_hand_derived():
+    """OpenCV 2.4.9 cv::resize, xofs loop: `if( sx < 0 ) fx = 0, sx = 0;` and `if( sx >= ssize.width-1 ) fx = 0,
+    sx = ssize.width-1;` for EVERY generic mode (3.x later exempted CUBIC / LANCZOS4).  The reference dispatches CUBIC only
+    when enlarging (bridge.c:190), where dx = 0 always has sx = -1: the edge columns are copies of src[0] / src[w-1].
+    Row [10 20 30 40] -> 8 wide, worked by hand with the 11-bit weights of interpolateCubic (A = -0.75):
+      x = .25 -> (-216, 1800, 536, -72) / 2048,  x = .75 -> (-72, 536, 1800, -216) / 2048
+      dx=1: taps 10,10,20,30 -> 24400 / 2048 = 11.91 -> 12      dx=2: 10,10,20,30 @.75 -> 34160 / 2048 = 16.68 -> 17
+      dx=3: 10,20,30,40 @.25 -> 47040 / 2048 = 22.97 -> 23      dx=4: 10,20,30,40 @.75 -> 55360 / 2048 = 27.03 -> 27
+      dx=5: 20,30,40,40 @.25 -> 68240 / 2048 = 33.32 -> 33      dx=6: 20,30,40,40 @.75 -> 78000 / 2048 = 38.09 -> 38
+    and dx=0 -> src[0] = 10, dx=7 -> src[3] = 40 (blending clamped taps instead would give 9 and 41)."""
+    w25, w75 = (-216, 1800, 536, -72), (-72, 536, 1800, -216)
+    src = [10, 20, 30, 40]
+    tap = lambda i: src[min(max(i, 0), 3)]
+    want = [10]
+    for dx in range(1, 7):
+        f = (dx + 0.5) * 0.5 - 0.5
+        s0 = int(np.floor(f))
+        wts = w25 if f - s0 == 0.25 else w75
+        want.append(int(np.rint(sum(tap(s0 - 1 + k) * wts[k] for k in range(4)) / 2048.0)))
+    want.append(40)
+    assert want == [10, 12, 17, 23, 27, 33, 38, 40]
+    for c in (1, 3, 4):
+        a = np.repeat(np.array(src, np.uint8)[None, :, None], c, axis=2)
+        assert orc.cv_resize(a, 8, 1, orc.INTER_CUBIC)[0, :, 0].tolist() == want, c
+        tall = np.repeat(a, 5, axis=0)                      # constant columns: the y pass must not change them
+        assert (orc.cv_resize(tall, 8, 11, orc.INTER_CUBIC)[:, :, 0] == np.array(want)[None, :]).all()
+    # LANCZOS4 and LINEAR follow the same x rule; the y axis has no such rule (rows blend clamped taps)
+    col = np.array(src, np.uint8)[:, None, None]
+    assert orc.cv_resize(np.array(src, np.uint8)[None, :, None], 8, 1, orc.INTER_LANCZOS4)[0, [0, 7], 0].tolist() == [10, 40]
+    assert orc.cv_resize(col, 1, 8, orc.INTER_CUBIC)[[0, 7], 0, 0].tolist() == [9, 41]
 
 
 def test_cubic_simd_and_scalar_vertical_paths_differ_by_at_most_one():
@@ -148,19 +185,24 @@ def test_brightness_float_accumulator_is_not_the_true_mean():
 # none of these share code or tables with oracle/*.c; they pin sample centres, kernels, border rules and rounding to
 # within the fixed-point error of OpenCV's 11-bit weights.
 def _separable_resize(arr, dw, dh, taps):
-    """Float reference: taps(frac) -> (first offset, weights); sample centre (d + 0.5) * scale - 0.5, replicate border."""
-    def axis_matrix(ssize, dsize):
+    """Float reference: taps(frac) -> (first offset, weights); sample centre (d + 0.5) * scale - 0.5, replicate border;
+    on the x axis OpenCV 2.4.9's edge rule: a centre left of pixel 0 or at / right of the last pixel snaps onto it."""
+    def axis_matrix(ssize, dsize, is_x):
         scale = ssize / dsize
         m = np.zeros((dsize, ssize))
         for d in range(dsize):
             f = (d + 0.5) * scale - 0.5
             s = int(np.floor(f))
+            if is_x and s < 0:
+                f, s = 0.0, 0
+            if is_x and s >= ssize - 1:
+                f, s = float(ssize - 1), ssize - 1
             first, w = taps(f - s)
             for k, wk in enumerate(w):
                 m[d, min(max(s + first + k, 0), ssize - 1)] += wk
         return m
     a = arr.astype(np.float64)
-    my, mx = axis_matrix(arr.shape[0], dh), axis_matrix(arr.shape[1], dw)
+    my, mx = axis_matrix(arr.shape[0], dh, False), axis_matrix(arr.shape[1], dw, True)
     return np.einsum("ys,sxc->yxc", my, np.einsum("xs,ysc->yxc", mx, a))
 
 

@@ -36,6 +36,8 @@ EDGE_URIS = [
     ("/a.jpg?format=bmp", "jpg"), ("/a.jpg?format=tiff&quality=lzw", "jpg"), ("/a.jpg?format=jpeg", "jpg"),
     ("/a.jpg?format=jp2", "jpg"), ("/a.jpg?format=ico", "jpg"), ("/a.jpg?format=nonsense", "jpg"), ("/a.xyz?resize=1", "xyz"),
     ("/a.PNG?resize=1", "PNG"), ("/a.jpg?gravity=r,b&crop=1,1", "jpg"), ("/a.jpg?page=3&page=x", "jpg"),
+    ("/a.gif?format=png", "gif"), ("/a.gif?format=json", "gif"), ("/a.jpg?format=gif", "jpg"), ("/a.jpg?quality=101", "jpg"),
+    ("/a.png?quality=10", "png"), ("/a.png?quality=9", "png"), ("/a.jpg?format=text", "jpg"),
 ]
 
 
@@ -58,6 +60,25 @@ def test_parse_details():
     r = imp.Request("/x.gif?resize=5", "gif")
     assert (r.code, r.simple, r.mime) == (0, 1, -4)
     assert imp.Request("/x.jpg", "jpg").code == 50 and imp.Request("/x.ico?resize=1", "ico").code == 1
+
+
+def test_page_defaults_follow_the_encoder():
+    """bridge.c:433-435 and :448-450, stated here without the oracle: an absent page= is page 0 for every one-frame
+    encoder (jpg, png, text, every FreeImage format but GIF) and stays -1 (all pages) only for GIF output and json."""
+    want = {("jpg", None): 0, ("png", None): 0, ("jpg", "text"): 0, ("jpg", "json"): -1, ("gif", None): -1,
+            ("gif", "png"): 0, ("jpg", "gif"): -1, ("jpg", "webp"): 0, ("jpg", "bmp"): 0, ("gif", "json"): -1}
+    for (ext, fmt), page in want.items():
+        r = imp.Request("/a.%s?resize=10%s" % (ext, "&format=" + fmt if fmt else ""), ext)
+        assert (r.code, r.page) == (0, page), (ext, fmt)
+    assert imp.Request("/a.gif?page=3", "gif").page == 3 and imp.Request("/a.jpg?page=3", "jpg").page == 3
+
+
+def test_quality_ranges_of_the_basic_encoders():
+    """bridge.c:475-500: jpg quality 0..100, png compression 0..9, else IMP_ERROR_INVALID_ARGS; :511-519: j2k / jp2 / webp 0..512."""
+    codes = {("jpg", "0"): 0, ("jpg", "100"): 0, ("jpg", "101"): 50, ("jpg", "-1"): 50, ("png", "9"): 0, ("png", "10"): 50,
+             ("jpg", "abc"): 0, ("webp", "512"): 0, ("webp", "700"): 50, ("jp2", "-3"): 50, ("bmp", "700"): 0}
+    for (fmt, q), code in codes.items():
+        assert imp.Request("/a.jpg?format=%s&quality=%s" % (fmt, q), "jpg").code == code, (fmt, q)
 
 
 @pytest.mark.gpu
