@@ -146,70 +146,89 @@ def cpu_baseline(seconds_budget=12.0):
     }
 
 
-def request_stream(imp, n_requests, n_threads):
-    """BASELINE configs[4] on one GPU: mixed-size request stream (long side log-uniform in [256, 3840], aspect in
-    {1:1, 4:3, 3:2, 16:9}, orientation coin flip, seed 0x1A4D0005), each request = upload (pinned) -> resize=224,0
-    (keep aspect; AREA, what the reference runs) -> download, n_threads host threads each on its own HIP stream."""
+def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, world=1):
+    """BASELINE configs[4]: mixed-size request stream (ngx_http_imgproc_amd.workloads.mixed_sizes), each request =
+    upload (pinned) -> resize=224,0 (keep aspect; AREA, what the reference runs, bridge.c:588-604 on whatever size
+    arrives) -> download.  Requests shard round-robin over ranks (request i -> rank i mod world, no collective); on a
+    rank they wait in a queue of `queue_depth` entries from which `n_threads` host threads -- each with its own lane
+    = HIP stream -- pull; a thread keeps up to `inflight` requests enqueued on its stream before it waits for them."""
     import ctypes as C
+    import queue
     import threading
     import numpy as np
+    from ngx_http_imgproc_amd.shard import round_robin
+    from ngx_http_imgproc_amd.workloads import MIXED_RESIZE, mixed_sizes
 
-    rng = np.random.Generator(np.random.PCG64(0x1A4D0005))
-    aspects = [(1, 1), (4, 3), (3, 2), (16, 9)]
-    sizes = []
-    for _ in range(n_requests):
-        long_side = int(round(np.exp(rng.uniform(np.log(256), np.log(3840)))))
-        a, b = aspects[rng.integers(0, 4)]
-        short = max(1, int(round(long_side * b / a)))
-        sizes.append((long_side, short) if rng.integers(0, 2) else (short, long_side))
+    all_sizes = mixed_sizes(n_requests)
+    mine = [all_sizes[i] for i in round_robin(n_requests, rank, world)]
     lib = imp.lib
     # one pinned source buffer (largest frame) filled with noise: every request reads its w*h*4 prefix
-    maxpx = max(w * h for w, h in sizes)
+    maxpx = max(w * h for w, h in all_sizes)
     hsrc = lib.impgpu_host_alloc(maxpx * 4)
+    rng = np.random.Generator(np.random.PCG64(0x1A4D0005))
     noise = rng.integers(0, 256, size=maxpx * 4, dtype=np.uint8)
     C.memmove(hsrc, noise.ctypes.data, noise.nbytes)
     cfg = imp.Config()
-    counter = {"i": 0}
-    lock = threading.Lock()
+    pending = queue.Queue(maxsize=max(1, queue_depth))
     errors = []
+    out_bytes = 224 * 224 * 4 * 4          # the short side is at most 224 * 16/9
+
+    def feeder():
+        for item in mine:
+            pending.put(item)
+        for _ in range(n_threads):
+            pending.put(None)
 
     def worker():
-        hdst = lib.impgpu_host_alloc(224 * 224 * 4 * 4)
-        while True:
-            with lock:
-                i = counter["i"]
-                counter["i"] += 1
-            if i >= n_requests:
-                break
-            w, h = sizes[i]
-            img = C.c_void_p()
-            rc = lib.impgpu_image_upload_pinned(hsrc, w, h, 4, w * 4, C.byref(img))
-            if rc == 0:
-                rc = lib.impgpu_resize(C.byref(img), b"224,0", C.byref(cfg.c), 0)
-            if rc == 0:
-                ow = lib.impgpu_image_width(img)
-                rc = lib.impgpu_image_download_pinned(img, hdst, ow * 4) or lib.impgpu_sync()
-            lib.impgpu_image_release(C.byref(img))
-            if rc:
-                errors.append((i, rc))
-                break
-        lib.impgpu_sync()
+        hdst = lib.impgpu_host_alloc(out_bytes * inflight)
+        live = []
+        done = False
+        while not done:
+            item = pending.get()
+            if item is None:
+                done = True
+            else:
+                w, h = item
+                img = C.c_void_p()
+                rc = lib.impgpu_image_upload_pinned(hsrc, w, h, 4, w * 4, C.byref(img))
+                if rc == 0:
+                    rc = lib.impgpu_resize(C.byref(img), MIXED_RESIZE, C.byref(cfg.c), 0)
+                if rc == 0:
+                    ow = lib.impgpu_image_width(img)
+                    rc = lib.impgpu_image_download_pinned(img, hdst + out_bytes * len(live), ow * 4)
+                live.append(img)
+                if rc:
+                    errors.append((item, rc))
+                    done = True
+            if live and (done or len(live) >= inflight):
+                if lib.impgpu_sync():
+                    errors.append(("sync", 90))
+                    done = True
+                for img in live:
+                    lib.impgpu_image_release(C.byref(img))
+                live = []
         lib.impgpu_host_free(hdst)
 
-    t0 = time.perf_counter()
     threads = [threading.Thread(target=worker) for _ in range(n_threads)]
+    feed = threading.Thread(target=feeder)
+    t0 = time.perf_counter()
+    feed.start()
     for t in threads:
         t.start()
     for t in threads:
         t.join()
     dt = time.perf_counter() - t0
+    if errors:      # unblock the feeder before failing
+        try:
+            while True:
+                pending.get_nowait()
+        except queue.Empty:
+            pass
+    feed.join(timeout=5)
     lib.impgpu_host_free(hsrc)
     if errors:
         raise SystemExit("request_stream failed: %r" % errors[:3])
-    src_bytes = sum(w * h * 4 for w, h in sizes)
-    return {"metric": "mixed-size request stream (256px-4K), resize=224,0, per-thread HIP stream, PCIe-inclusive",
-            "requests": n_requests, "threads": n_threads, "images_per_sec": round(n_requests / dt, 1),
-            "source_MB_per_sec": round(src_bytes / dt / 1e6, 1), "seconds": round(dt, 3)}
+    return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * 4 for w, h in mine)}
 
 
 def main():
@@ -224,6 +243,8 @@ def main():
     ap.add_argument("--stream", type=int, default=0, metavar="N",
                     help="instead of the headline, run N mixed-size PCIe-inclusive requests (cfg5) over --threads host threads")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--queue-depth", type=int, default=4096, help="--stream: requests waiting in the rank's queue")
+    ap.add_argument("--inflight", type=int, default=4, help="--stream: requests a thread enqueues before it waits")
     ap.add_argument("--e2e", type=int, default=0, metavar="N",
                     help="instead of the headline, time N PCIe-inclusive requests (upload + resize + download) and exit")
     args = ap.parse_args()
@@ -260,8 +281,34 @@ def main():
 
     imp.env_start(local_rank)
     if args.stream:
-        print(json.dumps(request_stream(imp, args.stream, args.threads)), flush=True)
+        # warm this rank's lanes / pools / clocks on a short untimed prefix, then the timed stream
+        request_stream(imp, min(args.stream, 64 * args.threads), args.threads, args.queue_depth, args.inflight, rank, world)
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+        r = request_stream(imp, args.stream, args.threads, args.queue_depth, args.inflight, rank, world)
+        torch.cuda.synchronize()
+        t = torch.tensor([r["seconds"], float(r["requests"]), float(r["source_bytes"])], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t[0] = tmax[0]
+        secs, nreq, nbytes = float(t[0]), float(t[1]), float(t[2])
+        if rank == 0:
+            print(json.dumps({
+                "metric": "requests/sec, mixed-size request stream (256px-4K) resize=224,0, PCIe-inclusive",
+                "value": round(nreq / secs, 1), "unit": "requests/sec", "n_gpus": world, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+                "data": "synthetic (seeded sizes, noise BGRA frames in pinned host memory)",
+                "source_MB_per_sec": round(nbytes / secs / 1e6, 1), "seconds": round(secs, 3),
+                "config": {"workload": "BASELINE configs[4]: %d requests, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % int(nreq),
+                           "threads_per_gpu": args.threads, "queue_depth": args.queue_depth, "inflight_per_thread": args.inflight,
+                           "sharding": "request i -> rank i mod N, no collective"}}), flush=True)
         imp.env_destroy()
+        if use_dist:
+            dist.destroy_process_group()
         return
     if args.e2e:
         res = {"metric": "PCIe-inclusive requests/sec: upload 1920x1080 BGRA + INTER_CUBIC ->224x224 + download, one stream",

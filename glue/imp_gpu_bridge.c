@@ -1,0 +1,154 @@
+/*
+ * imp_gpu_bridge.c -- see imp_gpu_bridge.h.  C (gnu99) like the module it is compiled into.
+ */
+#include "required.h"
+#include "helpers.h"
+#include "imp_gpu_bridge.h"
+
+void ImpGpuEnvStart(int worker) {
+    /* HIP is initialised here, in the worker, never in the master before fork.  A failure is not fatal for nginx:
+     * every later call then answers IMP_ERROR_DEVICE, which BodyFilter maps to 500 (module.c:305). */
+    if (impgpu_env_start(worker) != IMP_OK) {
+        fprintf(stderr, "imp::no usable GPU for worker %d: %s\n", worker, impgpu_last_error());
+    }
+}
+
+void ImpGpuEnvDestroy(void) {
+    impgpu_env_destroy();
+}
+
+/* The Config fields the operators read (required.h:108-118) in the ABI's plain struct.  The overlay is uploaded by the
+ * first request that needs it in this worker: PrepareWatermark ran in the master (module.c:159) and parked the decoded
+ * pixels in the conf pool, which every forked worker inherits; the device handle is per worker AND per location --
+ * each location's Config is its own object (OnConfigMerge, module.c:130-190) -- so it lives in that Config. */
+static int FillConfig(Config* config, impgpu_config* g) {
+    memset(g, 0, sizeof(*g));
+    g->max_target_w      = config->MaxTargetDimensions->W;
+    g->max_target_h      = config->MaxTargetDimensions->H;
+    g->max_filters_count = (int)config->MaxFiltersCount;
+    g->allow_experiments = (int)config->AllowExperiments;
+    if (config->WatermarkInfo) {
+        if (!config->WatermarkDevice) {
+            RecoverInfo* inf = config->WatermarkInfo;
+            impgpu_config once;
+            memset(&once, 0, sizeof(once));
+            int rc = impgpu_prepare_watermark(&once, inf->Pointer, inf->Size.width, inf->Size.height, inf->Channels, inf->Step);
+            if (rc) {
+                return rc;
+            }
+            config->WatermarkDevice = once.watermark;
+        }
+        g->watermark           = (impgpu_image*)config->WatermarkDevice;
+        g->watermark_opacity   = (int)config->WatermarkOpacity;
+        g->watermark_gravity_x = config->WatermarkPosition->GravityX;
+        g->watermark_gravity_y = config->WatermarkPosition->GravityY;
+        g->watermark_offset_x  = config->WatermarkPosition->OffsetX;
+        g->watermark_offset_y  = config->WatermarkPosition->OffsetY;
+    }
+    return IMP_OK;
+}
+
+int ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* crop, char* gravity, char* resize, int simple,
+                    char** filters, int filterCount, int lacksAlpha, Config* config, int* step) {
+    impgpu_config gcfg;
+    impgpu_job job;
+    int fid;
+
+    gpu->Count = 0;
+    gpu->Frames = ngx_pcalloc(pool, album->Count * sizeof(impgpu_image*));
+    if (!gpu->Frames) {
+        return IMP_ERROR_MALLOC_FAILED;
+    }
+
+    *step = IMP_STEP_WATERMARK;
+    int rc = FillConfig(config, &gcfg);
+    if (rc) {
+        return rc;
+    }
+
+    job.crop         = crop;
+    job.gravity      = gravity;
+    job.resize       = resize;
+    job.simple       = simple;
+    job.filters      = (const char* const*)filters;
+    job.filter_count = filterCount;
+    job.need_flatten = lacksAlpha;      /* applied only to 4-channel frames, like bridge.c:642-656 */
+
+    /* every frame is enqueued before any is waited for: uploads, kernels and the next frame's upload overlap */
+    for (fid = 0; fid < album->Count; fid++) {
+        IplImage* image = album->Frames[fid].Image;
+        *step = IMP_STEP_DECODE;
+        rc = impgpu_image_upload((unsigned char*)image->imageData, image->width, image->height, image->nChannels,
+                                 image->widthStep, &gpu->Frames[fid]);
+        if (rc) {
+            return rc;
+        }
+        gpu->Count = fid + 1;
+        rc = impgpu_run_ops(&gpu->Frames[fid], &job, &gcfg, step);
+        if (rc) {
+            return rc;
+        }
+    }
+    return IMP_OK;
+}
+
+u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool) {
+    float brightness = 0;
+    u_char* json = ngx_palloc(pool, 256 * sizeof(u_char));
+    impgpu_calc_perceived_brightness(gpu->Frames[0], &brightness);
+    sprintf(
+        (char*)json,
+        "{"
+            "\"width\":%d,"
+            "\"height\":%d,"
+            "\"brightness\":%d,"
+            "\"count\":%d"
+        "}",
+        impgpu_image_width(gpu->Frames[0]),
+        impgpu_image_height(gpu->Frames[0]),
+        (int)round(brightness * 100),
+        album->Count
+    );
+    return json;
+}
+
+Memory ImpGpuASCII(ImpGpuAlbum* gpu, char* args, ngx_pool_t* pool) {
+    Memory result;
+    impgpu_image* image = gpu->Frames[0];
+    long buflen = (long)(impgpu_image_width(image) + 1) * impgpu_image_height(image) - 1;
+    result.Buffer = ngx_palloc(pool, buflen > 0 ? buflen : 1);
+    result.Length = 0;
+    result.Error  = result.Buffer ? impgpu_ascii(image, args, result.Buffer, buflen, &result.Length) : IMP_ERROR_MALLOC_FAILED;
+    return result;
+}
+
+int ImpGpuDownload(ImpGpuAlbum* gpu, Album* album) {
+    int fid;
+    for (fid = 0; fid < gpu->Count; fid++) {
+        impgpu_image* frame = gpu->Frames[fid];
+        IplImage* old = album->Frames[fid].Image;
+        /* same header rules as every cvCreateImage in bridge.c: 8-bit, rows padded to 4 bytes -- the layout the
+         * device frame already has, so cvEncodeImage / IplToFI32 / IplToFI24 read it unchanged */
+        IplImage* fresh = cvCreateImage(cvSize(impgpu_image_width(frame), impgpu_image_height(frame)), IPL_DEPTH_8U,
+                                        impgpu_image_channels(frame));
+        if (!fresh || !fresh->imageData) {
+            return IMP_ERROR_MALLOC_FAILED;
+        }
+        int rc = impgpu_image_download(frame, (unsigned char*)fresh->imageData, fresh->widthStep);
+        if (rc) {
+            cvReleaseImage(&fresh);
+            return rc;
+        }
+        cvReleaseImage(&old);
+        album->Frames[fid].Image = fresh;
+    }
+    return IMP_OK;
+}
+
+void ImpGpuRelease(ImpGpuAlbum* gpu) {
+    int fid;
+    for (fid = 0; fid < gpu->Count; fid++) {
+        impgpu_image_release(&gpu->Frames[fid]);
+    }
+    gpu->Count = 0;
+}

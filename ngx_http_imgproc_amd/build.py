@@ -46,28 +46,49 @@ def _hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+OBJ = os.path.join(HERE, "_obj")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS + [os.path.join("..", "build.py")]:
-        if os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return False
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _common_deps():
+    return [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+
+
+def needs_build():
+    return _stale(LIB, [os.path.join(CSRC, f) for f in SOURCES] + _common_deps())
 
 
 def build_library(force=False, verbose=False):
+    """One object per source (compiled in parallel, only when stale), then one link."""
     if not force and not needs_build():
         return LIB
-    srcs = []
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJ, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"] + ["-c", "-I", os.path.join(HERE, "..", "include")]
+    jobs = []
     for f in SOURCES:
-        path = os.path.join(CSRC, f)
-        # .cpp files hold host code only but share headers with the kernels: compile all as HIP
-        srcs += ["-x", "hip", path]
-    cmd = [_hipcc()] + FLAGS + ["-I", os.path.join(HERE, "..", "include")] + srcs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f + ".o")
+        if force or _stale(obj, [src] + _common_deps()):
+            # .cpp files hold host code only but share headers with the kernels: compile all as HIP
+            jobs.append([_hipcc()] + compile_flags + ["-x", "hip", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as pool:
+        list(pool.map(run, jobs))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, f + ".o") for f in SOURCES] + ["-o", LIB]
+    run(link)
     return LIB
 
 

@@ -269,6 +269,8 @@ int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive,
 int impgpu_calc_perceived_brightness(const impgpu_image* image, float* brightness) {
     if (!image || !brightness) return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;
+    TraceRange tr("IMP_STEP_INFO");                                    // bridge.c:659-666
+    IMP_FAULT_POINT(IMP_STEP_INFO);
     return launch_brightness(view_of(image), brightness, env_stream());
 }
 
@@ -338,6 +340,8 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
 
     *step = IMP_STEP_CROP;                                             // bridge.c:575-586
     if (job->crop) {
+        TraceRange tr("IMP_STEP_CROP");
+        if (fault_hit(IMP_STEP_CROP)) { rc = IMP_ERROR_DEVICE; goto done; }
         int x, y, w, h;
         rc = crop_geometry(wk.v.w, wk.v.h, job->crop, job->gravity, &x, &y, &w, &h);
         if (rc) goto done;
@@ -345,6 +349,8 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
     }
     *step = IMP_STEP_RESIZE;                                           // bridge.c:588-604
     if (job->resize) {
+        TraceRange tr("IMP_STEP_RESIZE");
+        if (fault_hit(IMP_STEP_RESIZE)) { rc = IMP_ERROR_DEVICE; goto done; }
         int w, h, interp;
         rc = resize_geometry(wk.v.w, wk.v.h, job->resize, config->max_target_w, config->max_target_h, job->simple, &w, &h, &interp);
         if (rc) goto done;
@@ -352,22 +358,24 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
         if (rc) goto done;
     }
     *step = IMP_STEP_FILTERING;                                        // bridge.c:606-627
+    trace_push("IMP_STEP_FILTERING");
+    if ((wk.v.c == 1 || job->filter_count > 0) && fault_hit(IMP_STEP_FILTERING)) { rc = IMP_ERROR_DEVICE; trace_pop(); goto done; }
     if (wk.v.c == 1) {
         impgpu_image* out = nullptr;
         rc = image_new(wk.v.w, wk.v.h, 3, &out);
-        if (rc) goto done;
+        if (rc) { trace_pop(); goto done; }
         rc = launch_gray2bgr(one_frame(wk.v, out), env_stream());
-        if (rc) { image_delete(out); goto done; }
+        if (rc) { image_delete(out); trace_pop(); goto done; }
         wk.adopt(out);
     }
-    for (int i = 0; i < job->filter_count; i++) {
-        rc = do_filter(wk, job->filters[i], config->allow_experiments, prog);
-        if (rc) goto done;
-    }
-    rc = flush_program(wk, prog);
+    for (int i = 0; i < job->filter_count && !rc; i++) rc = do_filter(wk, job->filters[i], config->allow_experiments, prog);
+    if (!rc) rc = flush_program(wk, prog);
+    trace_pop();
     if (rc) goto done;
     *step = IMP_STEP_WATERMARK;                                        // bridge.c:629-640
     if (config->watermark) {
+        TraceRange tr("IMP_STEP_WATERMARK");
+        if (fault_hit(IMP_STEP_WATERMARK)) { rc = IMP_ERROR_DEVICE; goto done; }
         rc = do_watermark(wk, config);
         if (rc) goto done;
     }
@@ -432,7 +440,7 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
     } else {
         const int mstep = aligned_step(resize_width, channels);
         const long long mstride = ((long long)mstep * resize_height + 15) & ~15LL;
-        rc = dev_alloc((size_t)mstride * count + 16, &mid);
+        rc = dev_alloc_on((size_t)mstride * count + 16, &mid, s);
         if (rc) return rc;
         rs.dst = (uint8_t*)mid; rs.dst_stride = mstride; rs.dstep = mstep;
         rc = launch_cv_resize(rs, interp, s);
@@ -454,10 +462,7 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
                                    rx, ry, maxcol, maxrow, 1 - opacity, s);
         }
     }
-    if (mid) {
-        if (s != env_stream()) (void)hipStreamSynchronize(s);
-        dev_free(mid);
-    }
+    if (mid) dev_free_on(mid, s);       // no host wait: parked behind an event when `s` is the caller's stream
     return rc;
 }
 

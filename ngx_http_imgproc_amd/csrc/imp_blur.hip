@@ -277,7 +277,7 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     const int SW = 64 + 2 * r + 2, SH = TH + 2 * r;
     const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + ((SW * SH + 3) & ~3)) * 4 + (size_t)SH * 64 * 8;
     const dim3 grid((v.w + 63) / 64, (v.h + TH - 1) / TH, f.count), block(256);
-    if (grid.y > 65535) { dev_free(dev_k); return IMP_ERROR_UNSUPPORTED; }
+    if (grid.y > 65535) { dev_free_on(dev_k, s); return IMP_ERROR_UNSUPPORTED; }
     if (v.c == 4)
         hipLaunchKernelGGL((k_blur_fused4<32, 4>), grid, block, lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
                            (const int*)dev_k, (const float*)((const int*)dev_k + off_f), (const int*)dev_k + off_i, r, r);
@@ -285,8 +285,7 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
         hipLaunchKernelGGL((k_blur_fused4<32, 3>), grid, block, lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
                            (const int*)dev_k, (const float*)((const int*)dev_k + off_f), (const int*)dev_k + off_i, r, r);
     hipError_t e = hipGetLastError();
-    if (s != env_stream()) (void)hipStreamSynchronize(s);
-    dev_free(dev_k);
+    dev_free_on(dev_k, s);
     if (e != hipSuccess) { set_error("k_blur_fused4", e); return IMP_ERROR_DEVICE; }
     return IMP_OK;
 }
@@ -327,7 +326,7 @@ int launch_gaussian(uint8_t* d, long long stride, int w, int h, int c, int step,
     if (chunk > count) chunk = count;
     if (chunk > 65535) chunk = 65535;
     void* tmp = nullptr;
-    if (int rc = dev_alloc(per_frame * chunk, &tmp)) { dev_free(dev_k); return rc; }
+    if (int rc = dev_alloc_on(per_frame * chunk, &tmp, s)) { dev_free_on(dev_k, s); return rc; }
     int rc = IMP_OK;
     for (int f0 = 0; f0 < count && rc == IMP_OK; f0 += chunk) {
         const int n = count - f0 < chunk ? count - f0 : chunk;
@@ -343,9 +342,8 @@ int launch_gaussian(uint8_t* d, long long stride, int w, int h, int c, int step,
         }
         if (hipGetLastError() != hipSuccess) rc = IMP_ERROR_DEVICE;
     }
-    if (s != env_stream()) (void)hipStreamSynchronize(s);
-    dev_free(tmp);
-    dev_free(dev_k);
+    dev_free_on(tmp, s);
+    dev_free_on(dev_k, s);
     return rc;
 }
 

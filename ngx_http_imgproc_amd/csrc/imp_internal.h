@@ -47,6 +47,37 @@ int  image_new(int w, int h, int c, impgpu_image** out);
 void image_delete(impgpu_image* im);
 // Copy a small host blob (tables, taps) into pool memory through the pinned ring, ordered on `s`.
 int  upload_small(const void* host, size_t bytes, void** dev, hipStream_t s);
+// Pool memory and caller-supplied ("foreign") streams -- the batch entry points.  The pool recycles blocks in the order
+// of the lane's own stream; these keep that sound without a host wait:
+void dev_free_on(void* p, hipStream_t s);                  // free once the work enqueued on `s` so far is done
+int  dev_alloc_on(size_t bytes, void** out, hipStream_t s); // dev_alloc + make `s` wait for the lane stream's tail
+int  stream_join(hipStream_t s);                           // `s` waits for everything the lane stream holds now
+int  stream_join_back(hipStream_t s);                      // the lane stream waits for everything `s` holds now
+bool lane_stream_idle();
+bool on_lane_stream(hipStream_t s);
+// Per-lane caches (resize tables): owned by the lane, dropped with it (impgpu_env_destroy), no lock.
+struct LaneCache { virtual ~LaneCache() {} };
+constexpr int LANE_CACHE_SLOTS = 2;
+LaneCache** lane_cache_slot(int which);
+// rocTX ranges named after the reference's step codes (required.h:46-54) around each stage of a request, so a
+// `rocprofv3 --marker-trace` timeline reads like JobResult.Step.  Resolved with dlopen at impgpu_env_start: no link-time
+// dependency, nothing emitted unless a profiler's rocTX library is already in the process or IMPGPU_ROCTX=1.
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange {
+    explicit TraceRange(const char* name) { trace_push(name); }
+    ~TraceRange() { trace_pop(); }
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
+// Fault injection: IMPGPU_FAULT=<step>[:<n>] read at impgpu_env_start makes the n-th (default first) entry into
+// that IMP_STEP_* behave as if its first HIP call had failed: IMP_ERROR_DEVICE, impgpu_last_error() says so, the failing
+// step is reported like any other -- the path a lost device takes, testable without losing one.
+bool fault_hit(int step);
+#define IMP_FAULT_POINT(step)                                     \
+    do {                                                          \
+        if (imp::fault_hit(step)) return IMP_ERROR_DEVICE;        \
+    } while (0)
 #define IMP_HIP(call)                                             \
     do {                                                          \
         hipError_t _e = (call);                                   \

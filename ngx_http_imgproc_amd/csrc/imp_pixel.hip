@@ -356,10 +356,8 @@ int launch_pixel_program(uint8_t* d, long long stride, int w, int h, int c, int 
     else if (c == 3) hipLaunchKernelGGL((k_pixel_program<3, false>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     else hipLaunchKernelGGL((k_pixel_program<1, false>), grid, block, 0, s, d, stride, w, h, step, pd, (const uint8_t*)dev_tables);
     e = hipGetLastError();
-    // the table buffer goes back to the pool; on a foreign stream wait first, since pool reuse
-    // is only ordered on the env stream
-    if (s != env_stream()) (void)hipStreamSynchronize(s);
-    dev_free(dev_tables);
+    // the table buffer goes back to the pool: at once in lane-stream order, or behind an event of a caller's stream
+    dev_free_on(dev_tables, s);
     if (e != hipSuccess) { set_error("k_pixel_program", e); return IMP_ERROR_DEVICE; }
     return IMP_OK;
 }

@@ -1303,8 +1303,23 @@ struct TableSet {
     AreaDev area{};
 };
 using Key = std::tuple<int, int, int, int, int>;
-static std::map<Key, TableSet> g_tables;
-static std::mutex g_tables_mu;
+
+// One cache per lane (= per calling thread), owned by the lane and dropped with it: no lock, no shared state, nothing
+// survives impgpu_env_destroy.  A miss builds the tables on the calling thread and sends them through the lane's
+// pinned ring with hipMemcpyAsync; the blob is pool memory.  A mixed-size request stream (BASELINE configs[4]) misses
+// on almost every request, so a miss must cost no lock, no hipMalloc and no device-wide wait.  Least-recently-used
+// entries are evicted one at a time; their memory goes back to the pool in stream order.
+struct TableEntry {
+    TableSet ts;
+    unsigned long long tick = 0;
+    bool settled = false;                   // the upload is known to have completed
+    std::vector<hipStream_t> foreign;       // caller-supplied streams that have read the blob (batch entry points)
+};
+struct TableCache : LaneCache {
+    std::map<Key, TableEntry> m;
+    unsigned long long tick = 0;
+};
+constexpr size_t TABLE_CACHE_ENTRIES = 256;
 
 template <class T>
 static size_t put(std::vector<uint8_t>& blob, const std::vector<T>& v) {
@@ -1315,15 +1330,37 @@ static size_t put(std::vector<uint8_t>& blob, const std::vector<T>& v) {
     return off;
 }
 
-static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x, double scale_y, TableSet* out) {
-    std::lock_guard<std::mutex> lk(g_tables_mu);
+static int table_use(TableEntry& e, hipStream_t s) {     // order `s` behind the entry's upload
+    if (on_lane_stream(s)) return IMP_OK;                // the upload rode the lane stream: already ordered
+    bool seen = false;
+    for (hipStream_t f : e.foreign) seen = seen || f == s;
+    if (!seen) e.foreign.push_back(s);
+    if (e.settled) return IMP_OK;
+    if (lane_stream_idle()) { e.settled = true; return IMP_OK; }
+    return stream_join(s);
+}
+
+static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x, double scale_y, hipStream_t s, TableSet* out) {
+    LaneCache** slot = lane_cache_slot(0);
+    if (!slot) { set_error("impgpu_env_start has not been called", hipErrorNotInitialized); return IMP_ERROR_DEVICE; }
+    if (!*slot) *slot = new TableCache();
+    TableCache& C = *static_cast<TableCache*>(*slot);
     Key key{interp, sw, sh, dw, dh};
-    auto it = g_tables.find(key);
-    if (it != g_tables.end()) { *out = it->second; return IMP_OK; }
-    if (g_tables.size() >= 512) {   // bound the cache: drop everything once nothing can still be reading it
-        IMP_HIP(hipDeviceSynchronize());
-        for (auto& kv : g_tables) (void)hipFree(kv.second.blob);
-        g_tables.clear();
+    auto it = C.m.find(key);
+    if (it != C.m.end()) {
+        it->second.tick = ++C.tick;
+        if (int rc = table_use(it->second, s)) return rc;
+        *out = it->second.ts;
+        return IMP_OK;
+    }
+    if (C.m.size() >= TABLE_CACHE_ENTRIES) {             // evict the least recently used geometry
+        auto victim = C.m.begin();
+        for (auto j = C.m.begin(); j != C.m.end(); ++j)
+            if (j->second.tick < victim->second.tick) victim = j;
+        for (hipStream_t f : victim->second.foreign)     // kernels on caller-supplied streams may still read it
+            if (int rc = stream_join_back(f)) return rc;
+        dev_free(victim->second.ts.blob);                // lane-stream order from here on
+        C.m.erase(victim);
     }
     std::vector<uint8_t> blob;
     TableSet ts;
@@ -1375,10 +1412,9 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         ts.ysym = ts.step2;
         for (int k = 0; k < ty.ksize && ts.ysym; k++) ts.ysym = ty.coef[k] == ty.coef[ty.ksize - 1 - k];
     }
-    uint8_t* dev = nullptr;
-    IMP_HIP(hipMalloc((void**)&dev, blob.size()));
-    hipError_t e = hipMemcpy(dev, blob.data(), blob.size(), hipMemcpyHostToDevice);   // blocking: visible to every stream
-    if (e != hipSuccess) { set_error("hipMemcpy(tables)", e); (void)hipFree(dev); return IMP_ERROR_DEVICE; }
+    void* devp = nullptr;
+    if (int rc = upload_small(blob.data(), blob.size(), &devp, s)) return rc;     // asynchronous, ordered before later work on `s`
+    uint8_t* dev = (uint8_t*)devp;
     ts.blob = dev;
     if (interp == IMP_INTER_AREA) {
         ts.area.xstart = (const int*)(dev + o[0]); ts.area.xcount = (const int*)(dev + o[1]);
@@ -1396,7 +1432,10 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         ts.xofs = (const int*)(dev + o[0]); ts.xco = (const short*)(dev + o[1]);
         ts.yofs = (const int*)(dev + o[2]); ts.yco = (const short*)(dev + o[3]);
     }
-    g_tables[key] = ts;
+    TableEntry& e = C.m[key];
+    e.ts = ts;
+    e.tick = ++C.tick;
+    if (!on_lane_stream(s)) e.foreign.push_back(s);
     *out = ts;
     return IMP_OK;
 }
@@ -1413,7 +1452,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             hipLaunchKernelGGL((k_resize_area_int<CN>), grid, block, 0, s, a, isx, isy);
         } else {
             TableSet ts;
-            if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, &ts)) return rc;
+            if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, s, &ts)) return rc;
             const int bpf = (int)grid.x;                       // blocks per frame
             const dim3 fgrid(grid.x, (unsigned)((count + 7) / 8 * 8));   // whole groups of 8 frames (frame-per-XCD order)
             // BGRA: row groups share their source-row walk unless a group would walk a very long run (tiny outputs)
@@ -1445,7 +1484,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
         }
     } else {
         TableSet ts;
-        if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, &ts)) return rc;
+        if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, s, &ts)) return rc;
         // both scales <= 2: neighbouring outputs share taps -> LDS-tiled separable kernel (BGRA)
         static const bool no_roll = std::getenv("IMPGPU_NO_ROLL") != nullptr;
         if (CN == 3 && ts.step2 && a.sw >= 8 && !no_roll && interp != IMP_INTER_LINEAR) {

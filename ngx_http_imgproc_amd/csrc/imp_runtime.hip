@@ -9,8 +9,17 @@
 // can be handed to the next without a device sync (stream order is the only ordering needed), and
 // requests driven from different threads overlap their H2D copies, kernels and D2H copies with no
 // shared lock on the hot path.  A frame belongs to the lane (thread) that created it.
+//
+// Nothing on the per-request path waits for the device except the call that hands pixels back to the
+// host: pool reuse is ordered by the lane's stream; memory that a caller-supplied ("foreign") stream
+// still reads is parked behind an event and taken back when the event has fired (dev_free_on); the
+// pinned ring for small tables is cut into segments, each fenced by its own event, so a wrap waits
+// only for copies issued a whole ring ago; frame staging alternates between two pinned buffers, so
+// the host copy of request N+1 overlaps the H2D DMA of request N.
+#include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -18,17 +27,38 @@
 
 namespace imp {
 
+constexpr int    RING_SEGS = 8;
+constexpr size_t RING_SEG_BYTES = size_t(128) << 10;   // blobs above this take a one-off pinned buffer
+constexpr int    N_STAGE = 2;
+
+struct Staging {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+struct Parked {             // a pool block waiting for an event of a foreign stream
+    hipEvent_t ev;
+    void* dev;
+};
+
 struct Lane {
     hipStream_t stream = nullptr;
     std::mutex mu;                              // guards the pool: frees may come from other threads
     std::multimap<size_t, void*> free_list;     // bucket size -> buffer
     std::map<void*, size_t> live;               // buffer -> bucket size
-    uint8_t* stage = nullptr;                   // pinned staging for pageable upload / download
-    size_t stage_cap = 0;
-    hipEvent_t stage_done = nullptr;
-    bool stage_busy = false;
-    uint8_t* ring = nullptr;                    // pinned ring for per-launch tables (LUTs, Gaussian taps)
-    size_t ring_cap = 0, ring_pos = 0;
+    Staging stage[N_STAGE];                     // pinned staging for pageable upload / download, used alternately
+    int stage_next = 0;
+    uint8_t* ring = nullptr;                    // pinned ring for per-launch tables (LUTs, Gaussian taps, resize tables)
+    int seg = 0;                                // segment being filled
+    size_t seg_pos = 0;
+    hipEvent_t seg_done[RING_SEGS] = {};        // recorded on the lane stream when a segment is left
+    bool seg_busy[RING_SEGS] = {};
+    hipEvent_t join_ev = nullptr;               // lane stream -> foreign stream ordering
+    std::vector<hipEvent_t> ev_pool;
+    std::deque<Parked> parked;
+    LaneCache* caches[LANE_CACHE_SLOTS] = {};
 };
 
 struct Env {
@@ -38,11 +68,60 @@ struct Env {
     std::vector<Lane*> lanes;
 };
 
+static void lane_destroy(Lane* L);
 static Env* g_env = nullptr;
 static unsigned long long g_generation = 0;
 static thread_local Lane* t_lane = nullptr;
 static thread_local unsigned long long t_lane_gen = 0;
 static thread_local std::string t_error;
+
+// ---- rocTX (optional) and fault injection
+static void (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static int g_fault_step = -1;
+static long g_fault_countdown = 0;
+static std::mutex g_fault_mu;
+
+static void trace_init() {
+    g_roctx_push = nullptr;
+    g_roctx_pop = nullptr;
+    const bool want = std::getenv("IMPGPU_ROCTX") != nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);            // a profiler already brought it in
+        if (!h && want) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        auto push = (void (*)(const char*))dlsym(h, "roctxRangePushA");
+        auto pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) { g_roctx_push = push; g_roctx_pop = pop; return; }
+    }
+}
+void trace_push(const char* name) { if (g_roctx_push) g_roctx_push(name); }
+void trace_pop() { if (g_roctx_pop) (void)g_roctx_pop(); }
+
+static void fault_init() {
+    std::lock_guard<std::mutex> lk(g_fault_mu);
+    g_fault_step = -1;
+    g_fault_countdown = 0;
+    const char* s = std::getenv("IMPGPU_FAULT");
+    if (!s || !*s) return;
+    char* end = nullptr;
+    const long step = std::strtol(s, &end, 10);
+    if (end == s || step < IMP_STEP_START || step > IMP_STEP_ENCODE) return;
+    g_fault_step = (int)step;
+    g_fault_countdown = (*end == ':') ? std::strtol(end + 1, nullptr, 10) : 1;
+    if (g_fault_countdown < 1) g_fault_countdown = 1;
+}
+
+void set_error(const char* what, hipError_t e);
+bool fault_hit(int step) {
+    if (g_fault_step < 0) return false;                            // the only cost when not armed
+    std::lock_guard<std::mutex> lk(g_fault_mu);
+    if (step != g_fault_step || g_fault_countdown <= 0) return false;
+    if (--g_fault_countdown > 0) return false;
+    g_fault_step = -1;
+    set_error("injected fault (IMPGPU_FAULT)", hipErrorUnknown);
+    return true;
+}
 
 void set_error(const char* what, hipError_t e) {
     t_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -61,9 +140,13 @@ static Lane* lane() {
     if (t_lane && t_lane_gen == E->generation) return t_lane;
     if (hipSetDevice(E->device) != hipSuccess) return nullptr;
     Lane* L = new Lane();
-    if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&L->stage_done, hipEventDisableTiming) != hipSuccess) {
-        delete L;
+    bool ok = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&L->join_ev, hipEventDisableTiming) == hipSuccess &&
+              hipHostMalloc((void**)&L->ring, RING_SEGS * RING_SEG_BYTES, hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < N_STAGE; i++) ok = hipEventCreateWithFlags(&L->stage[i].done, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < RING_SEGS; i++) ok = hipEventCreateWithFlags(&L->seg_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        lane_destroy(L);
         return nullptr;
     }
     {
@@ -91,9 +174,38 @@ static size_t bucket_of(size_t bytes) {
     return b;
 }
 
+static bool lane_take_back(Lane* L, void* p);
+
+// Take back whatever the parked events have released (front to back: a stream's events fire in order, and a few
+// unfinished entries of another stream in front only delay the ones behind them until the next call).
+static void reap(Lane* L, bool wait) {
+    while (!L->parked.empty()) {
+        Parked& k = L->parked.front();
+        if (wait) (void)hipEventSynchronize(k.ev);
+        else if (hipEventQuery(k.ev) != hipSuccess) break;
+        lane_take_back(L, k.dev);
+        L->ev_pool.push_back(k.ev);
+        L->parked.pop_front();
+    }
+}
+
+static void park(Lane* L, void* dev, hipStream_t s) {
+    hipEvent_t ev = nullptr;
+    if (!L->ev_pool.empty()) { ev = L->ev_pool.back(); L->ev_pool.pop_back(); }
+    else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (!ev || hipEventRecord(ev, s) != hipSuccess) {       // cannot fence it: wait now rather than hand it out early
+        (void)hipStreamSynchronize(s);
+        if (ev) L->ev_pool.push_back(ev);
+        lane_take_back(L, dev);
+        return;
+    }
+    L->parked.push_back(Parked{ev, dev});
+}
+
 int dev_alloc(size_t bytes, void** out) {
     Lane* L = lane();
     if (!L) return no_env();
+    if (!L->parked.empty()) reap(L, false);
     const size_t b = bucket_of(bytes ? bytes : 1);
     {
         std::lock_guard<std::mutex> lk(L->mu);
@@ -109,6 +221,7 @@ int dev_alloc(size_t bytes, void** out) {
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
         // drop this lane's cache and retry once
+        reap(L, true);
         {
             std::lock_guard<std::mutex> lk(L->mu);
             (void)hipStreamSynchronize(L->stream);
@@ -148,6 +261,64 @@ void dev_free(void* p) {
         if (L != mine && lane_take_back(L, p)) return;
 }
 
+// Free `p` once everything enqueued on `s` so far is done.  On the lane's own stream that is plain stream order (the
+// next user of the block is enqueued behind it); a foreign stream's work is fenced with an event, no host wait.
+void dev_free_on(void* p, hipStream_t s) {
+    Lane* L = lane();
+    if (!p || !L) return;
+    if (s == L->stream) { dev_free(p); return; }
+    bool mine;
+    {
+        std::lock_guard<std::mutex> lk(L->mu);
+        mine = L->live.count(p) != 0;
+    }
+    if (mine) { park(L, p, s); return; }        // stays in `live` until the event has fired
+    (void)hipStreamSynchronize(s);              // another lane's block: its owner cannot see our event
+    dev_free(p);
+}
+
+// Make the foreign stream `s` wait for what the lane's stream holds right now: pool blocks are recycled in lane-stream
+// order, so a block about to be used on `s` may still be read by an earlier lane-stream kernel.
+int stream_join(hipStream_t s) {
+    Lane* L = lane();
+    if (!L) return no_env();
+    if (s == L->stream) return IMP_OK;
+    IMP_HIP(hipEventRecord(L->join_ev, L->stream));
+    IMP_HIP(hipStreamWaitEvent(s, L->join_ev, 0));
+    return IMP_OK;
+}
+
+// The other direction: the lane's stream waits for what `s` holds now (before a block `s` was reading is recycled).
+int stream_join_back(hipStream_t s) {
+    Lane* L = lane();
+    if (!L) return no_env();
+    if (s == L->stream) return IMP_OK;
+    IMP_HIP(hipEventRecord(L->join_ev, s));
+    IMP_HIP(hipStreamWaitEvent(L->stream, L->join_ev, 0));
+    return IMP_OK;
+}
+
+bool lane_stream_idle() {
+    Lane* L = lane();
+    return L && hipStreamQuery(L->stream) == hipSuccess;
+}
+
+int dev_alloc_on(size_t bytes, void** out, hipStream_t s) {
+    if (int rc = dev_alloc(bytes, out)) return rc;
+    if (int rc = stream_join(s)) { dev_free(*out); *out = nullptr; return rc; }
+    return IMP_OK;
+}
+
+bool on_lane_stream(hipStream_t s) {
+    Lane* L = lane();
+    return L && s == L->stream;
+}
+
+LaneCache** lane_cache_slot(int which) {
+    Lane* L = lane();
+    return (L && which >= 0 && which < LANE_CACHE_SLOTS) ? &L->caches[which] : nullptr;
+}
+
 int image_new(int w, int h, int c, impgpu_image** out) {
     if (w <= 0 || h <= 0 || (c != 1 && c != 3 && c != 4)) return IMP_ERROR_INVALID_ARGS;
     // the kernels index pixels and row bytes in 32 bits: a frame is at most 2^30 pixels and 4 GiB - 1 of rows.  Larger
@@ -172,6 +343,30 @@ void image_delete(impgpu_image* im) {
     delete im;
 }
 
+// The next staging buffer, free to overwrite and at least `bytes` large.  Two buffers alternate: while the DMA of
+// one request still reads buffer A the host fills buffer B for the next.
+static int stage_reserve(Lane* L, size_t bytes, Staging** out) {
+    Staging* S = &L->stage[L->stage_next];
+    L->stage_next = (L->stage_next + 1) % N_STAGE;
+    if (S->busy) {
+        IMP_HIP(hipEventSynchronize(S->done));
+        S->busy = false;
+    }
+    if (S->cap < bytes) {
+        if (S->p) IMP_HIP(hipHostFree(S->p));
+        S->p = nullptr;
+        S->cap = 0;
+        // (hipHostFree above waits for the device: start at a 1080p frame so the common sizes never regrow)
+        const size_t cap = bucket_of(bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes);
+        IMP_HIP(hipHostMalloc((void**)&S->p, cap, hipHostMallocDefault));
+        S->cap = cap;
+    }
+    *out = S;
+    return IMP_OK;
+}
+
+// Small host blob -> pool memory, visible to work enqueued on `s` afterwards.  The copy itself always rides the lane's
+// stream (so ONE event per ring segment fences every copy out of it); a foreign `s` is made to wait for it.
 int upload_small(const void* host, size_t bytes, void** dev, hipStream_t s) {
     Lane* L = lane();
     if (!L) return no_env();
@@ -179,53 +374,56 @@ int upload_small(const void* host, size_t bytes, void** dev, hipStream_t s) {
     int rc = dev_alloc(bytes, &p);
     if (rc) return rc;
     const size_t need = (bytes + 63) & ~size_t(63);
-    if (need > L->ring_cap) {       // first use, or a blob larger than the ring
-        (void)hipDeviceSynchronize();
-        if (L->ring) (void)hipHostFree(L->ring);
-        L->ring = nullptr;
-        L->ring_cap = 0;
-        const size_t cap = need * 2 > (size_t(1) << 20) ? need * 2 : (size_t(1) << 20);
-        hipError_t e = hipHostMalloc((void**)&L->ring, cap, hipHostMallocDefault);
-        if (e != hipSuccess) { set_error("hipHostMalloc(ring)", e); dev_free(p); return IMP_ERROR_DEVICE; }
-        L->ring_cap = cap;
-        L->ring_pos = 0;
+    hipError_t e;
+    if (need > RING_SEG_BYTES) {            // GIF albums and the like: through the frame staging buffers
+        Staging* S = nullptr;
+        rc = stage_reserve(L, bytes, &S);
+        if (rc) { dev_free(p); return rc; }
+        std::memcpy(S->p, host, bytes);
+        e = hipMemcpyAsync(p, S->p, bytes, hipMemcpyHostToDevice, L->stream);
+        if (e == hipSuccess) e = hipEventRecord(S->done, L->stream);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync(upload)", e); (void)hipStreamSynchronize(L->stream); dev_free(p); return IMP_ERROR_DEVICE; }
+        S->busy = true;
+    } else {
+        if (L->seg_pos + need > RING_SEG_BYTES) {             // leave this segment: fence its copies, enter the next one
+            if (hipEventRecord(L->seg_done[L->seg], L->stream) == hipSuccess) L->seg_busy[L->seg] = true;
+            else (void)hipStreamSynchronize(L->stream);
+            L->seg = (L->seg + 1) % RING_SEGS;
+            L->seg_pos = 0;
+            if (L->seg_busy[L->seg]) {                        // copies issued a whole ring ago: long done in practice
+                (void)hipEventSynchronize(L->seg_done[L->seg]);
+                L->seg_busy[L->seg] = false;
+            }
+        }
+        uint8_t* slot = L->ring + (size_t)L->seg * RING_SEG_BYTES + L->seg_pos;
+        L->seg_pos += need;
+        std::memcpy(slot, host, bytes);
+        e = hipMemcpyAsync(p, slot, bytes, hipMemcpyHostToDevice, L->stream);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync(small)", e); dev_free(p); return IMP_ERROR_DEVICE; }
     }
-    if (L->ring_pos + need > L->ring_cap) {   // wrap: everything that read the ring must be done
-        (void)hipDeviceSynchronize();         // (device-wide: a batch call may have used a foreign stream)
-        L->ring_pos = 0;
+    if (s != L->stream) {
+        rc = stream_join(s);
+        if (rc) { dev_free(p); return rc; }
     }
-    uint8_t* slot = L->ring + L->ring_pos;
-    L->ring_pos += need;
-    std::memcpy(slot, host, bytes);
-    hipError_t e = hipMemcpyAsync(p, slot, bytes, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) { set_error("hipMemcpyAsync(small)", e); dev_free(p); return IMP_ERROR_DEVICE; }
     *dev = p;
     return IMP_OK;
 }
 
-static int stage_reserve(Lane* L, size_t bytes) {
-    if (L->stage_busy) {
-        IMP_HIP(hipEventSynchronize(L->stage_done));
-        L->stage_busy = false;
-    }
-    if (L->stage_cap >= bytes) return IMP_OK;
-    if (L->stage) IMP_HIP(hipHostFree(L->stage));
-    L->stage = nullptr;
-    L->stage_cap = 0;
-    const size_t cap = bucket_of(bytes);
-    IMP_HIP(hipHostMalloc((void**)&L->stage, cap, hipHostMallocDefault));
-    L->stage_cap = cap;
-    return IMP_OK;
-}
-
 static void lane_destroy(Lane* L) {
-    (void)hipStreamSynchronize(L->stream);
+    if (L->stream) (void)hipStreamSynchronize(L->stream);
+    reap(L, true);
+    for (LaneCache*& c : L->caches) { delete c; c = nullptr; }       // host side only: their device blocks are in `live`
     for (auto& kv : L->free_list) (void)hipFree(kv.second);
     for (auto& kv : L->live) (void)hipFree(kv.first);
-    if (L->stage) (void)hipHostFree(L->stage);
+    for (Staging& S : L->stage) {
+        if (S.p) (void)hipHostFree(S.p);
+        if (S.done) (void)hipEventDestroy(S.done);
+    }
     if (L->ring) (void)hipHostFree(L->ring);
-    (void)hipEventDestroy(L->stage_done);
-    (void)hipStreamDestroy(L->stream);
+    for (hipEvent_t ev : L->seg_done) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : L->ev_pool) (void)hipEventDestroy(ev);
+    if (L->join_ev) (void)hipEventDestroy(L->join_ev);
+    if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
 }
 
@@ -251,6 +449,8 @@ int impgpu_env_start(int device) {
     }
     device %= n;    // round-robin of workers over the node's GPUs
     IMP_HIP(hipSetDevice(device));
+    trace_init();
+    fault_init();
     Env* E = new Env();
     E->device = device;
     E->generation = ++g_generation;
@@ -295,24 +495,27 @@ int impgpu_image_upload(const unsigned char* data, int width, int height, int ch
     if (!data || !out || (long long)step < (long long)width * channels) return IMP_ERROR_INVALID_ARGS;
     Lane* L = lane();
     if (!L) return no_env();
+    TraceRange tr("IMP_STEP_DECODE");                       // the decoded frame's hand-over (bridge.c:541-572)
+    IMP_FAULT_POINT(IMP_STEP_DECODE);
     impgpu_image* im = nullptr;
     int rc = image_new(width, height, channels, &im);
     if (rc) return rc;
     const size_t bytes = (size_t)im->step * height;
-    rc = stage_reserve(L, bytes);
+    Staging* S = nullptr;
+    rc = stage_reserve(L, bytes, &S);
     if (rc) { image_delete(im); return rc; }
     // repack into the device row pitch (cvCreateImage alignment) inside pinned memory
     const size_t rowbytes = (size_t)width * channels;
     if ((size_t)step == (size_t)im->step) {
-        std::memcpy(L->stage, data, bytes - (im->step - rowbytes));
+        std::memcpy(S->p, data, bytes - (im->step - rowbytes));
     } else {
         for (int y = 0; y < height; y++)
-            std::memcpy(L->stage + (size_t)y * im->step, data + (size_t)y * step, rowbytes);
+            std::memcpy(S->p + (size_t)y * im->step, data + (size_t)y * step, rowbytes);
     }
-    hipError_t e = hipMemcpyAsync(im->d, L->stage, bytes, hipMemcpyHostToDevice, L->stream);
-    if (e == hipSuccess) e = hipEventRecord(L->stage_done, L->stream);
-    if (e != hipSuccess) { set_error("hipMemcpyAsync(upload)", e); image_delete(im); return IMP_ERROR_DEVICE; }
-    L->stage_busy = true;
+    hipError_t e = hipMemcpyAsync(im->d, S->p, bytes, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess) e = hipEventRecord(S->done, L->stream);
+    if (e != hipSuccess) { set_error("hipMemcpyAsync(upload)", e); (void)hipStreamSynchronize(L->stream); image_delete(im); return IMP_ERROR_DEVICE; }
+    S->busy = true;
     *out = im;
     return IMP_OK;
 }
@@ -337,9 +540,12 @@ int impgpu_image_upload_pinned(const unsigned char* data, int width, int height,
     impgpu_image* im = nullptr;
     int rc = image_new(width, height, channels, &im);
     if (rc) return rc;
-    // straight from the caller's pinned frame: no staging pass.  hipMemcpy2DAsync repacks the row pitch.
-    hipError_t e = hipMemcpy2DAsync(im->d, (size_t)im->step, data, (size_t)step, (size_t)width * channels, (size_t)height,
-                                    hipMemcpyHostToDevice, L->stream);
+    // straight from the caller's pinned frame: no staging pass.  Equal pitches (every BGRA frame) are one linear DMA;
+    // otherwise hipMemcpy2DAsync repacks the row pitch.
+    hipError_t e;
+    if (step == im->step) e = hipMemcpyAsync(im->d, data, (size_t)step * height, hipMemcpyHostToDevice, L->stream);
+    else e = hipMemcpy2DAsync(im->d, (size_t)im->step, data, (size_t)step, (size_t)width * channels, (size_t)height,
+                              hipMemcpyHostToDevice, L->stream);
     if (e != hipSuccess) { set_error("hipMemcpy2DAsync(upload_pinned)", e); image_delete(im); return IMP_ERROR_DEVICE; }
     *out = im;
     return IMP_OK;
@@ -349,8 +555,9 @@ int impgpu_image_download_pinned(const impgpu_image* im, unsigned char* data, in
     if (!im || !data || step < im->w * im->c) return IMP_ERROR_INVALID_ARGS;
     Lane* L = lane();
     if (!L) return no_env();
-    IMP_HIP(hipMemcpy2DAsync(data, (size_t)step, im->d, (size_t)im->step, (size_t)im->w * im->c, (size_t)im->h,
-                             hipMemcpyDeviceToHost, L->stream));
+    if (step == im->step) IMP_HIP(hipMemcpyAsync(data, im->d, (size_t)step * im->h, hipMemcpyDeviceToHost, L->stream));
+    else IMP_HIP(hipMemcpy2DAsync(data, (size_t)step, im->d, (size_t)im->step, (size_t)im->w * im->c, (size_t)im->h,
+                                  hipMemcpyDeviceToHost, L->stream));
     return IMP_OK;
 }
 
@@ -362,15 +569,16 @@ int impgpu_image_upload_fi32(const unsigned char* bits, int width, int height, i
     int rc = image_new(width, height, 4, &im);
     if (rc) return rc;
     const size_t bytes = (size_t)im->step * height;
-    rc = stage_reserve(L, bytes);
+    Staging* S = nullptr;
+    rc = stage_reserve(L, bytes, &S);
     if (rc) { image_delete(im); return rc; }
     // LoadSingle (advancedio.c:310-318): FreeImage rows are bottom-up; the flip rides on the staging copy
     for (int y = 0; y < height; y++)
-        std::memcpy(L->stage + (size_t)(height - 1 - y) * im->step, bits + (size_t)y * pitch, (size_t)width * 4);
-    hipError_t e = hipMemcpyAsync(im->d, L->stage, bytes, hipMemcpyHostToDevice, L->stream);
-    if (e == hipSuccess) e = hipEventRecord(L->stage_done, L->stream);
-    if (e != hipSuccess) { set_error("hipMemcpyAsync(upload_fi32)", e); image_delete(im); return IMP_ERROR_DEVICE; }
-    L->stage_busy = true;
+        std::memcpy(S->p + (size_t)(height - 1 - y) * im->step, bits + (size_t)y * pitch, (size_t)width * 4);
+    hipError_t e = hipMemcpyAsync(im->d, S->p, bytes, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess) e = hipEventRecord(S->done, L->stream);
+    if (e != hipSuccess) { set_error("hipMemcpyAsync(upload_fi32)", e); (void)hipStreamSynchronize(L->stream); image_delete(im); return IMP_ERROR_DEVICE; }
+    S->busy = true;
     *out = im;
     return IMP_OK;
 }
@@ -385,16 +593,17 @@ int impgpu_image_download_fi(const impgpu_image* im, int bpp, unsigned char* bit
     int rc = dev_alloc(bytes, &tmp);
     if (rc) return rc;
     rc = launch_pack_fi(view_of(im), bpp, (uint8_t*)tmp, dpitch, L->stream);
-    if (!rc) rc = stage_reserve(L, bytes);
+    Staging* S = nullptr;
+    if (!rc) rc = stage_reserve(L, bytes, &S);
     if (!rc) {
-        hipError_t e = hipMemcpyAsync(L->stage, tmp, bytes, hipMemcpyDeviceToHost, L->stream);
+        hipError_t e = hipMemcpyAsync(S->p, tmp, bytes, hipMemcpyDeviceToHost, L->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
         if (e != hipSuccess) { set_error("download_fi", e); rc = IMP_ERROR_DEVICE; }
     }
     dev_free(tmp);
     if (rc) return rc;
     const size_t rowbytes = (size_t)im->w * (bpp / 8);
-    for (int y = 0; y < im->h; y++) std::memcpy(bits + (size_t)y * pitch, L->stage + (size_t)y * dpitch, rowbytes);
+    for (int y = 0; y < im->h; y++) std::memcpy(bits + (size_t)y * pitch, S->p + (size_t)y * dpitch, rowbytes);
     return IMP_OK;
 }
 
@@ -416,14 +625,17 @@ int impgpu_image_download(const impgpu_image* im, unsigned char* data, int step)
     if (!im || !data || step < im->w * im->c) return IMP_ERROR_INVALID_ARGS;
     Lane* L = lane();
     if (!L) return no_env();
+    TraceRange tr("IMP_STEP_ENCODE");                       // the encoder's hand-over (bridge.c:680-710)
+    IMP_FAULT_POINT(IMP_STEP_ENCODE);
     const size_t bytes = (size_t)im->step * im->h;
-    int rc = stage_reserve(L, bytes);
+    Staging* S = nullptr;
+    int rc = stage_reserve(L, bytes, &S);
     if (rc) return rc;
-    IMP_HIP(hipMemcpyAsync(L->stage, im->d, bytes, hipMemcpyDeviceToHost, L->stream));
+    IMP_HIP(hipMemcpyAsync(S->p, im->d, bytes, hipMemcpyDeviceToHost, L->stream));
     IMP_HIP(hipStreamSynchronize(L->stream));
     const size_t rowbytes = (size_t)im->w * im->c;
     for (int y = 0; y < im->h; y++)
-        std::memcpy(data + (size_t)y * step, L->stage + (size_t)y * im->step, rowbytes);
+        std::memcpy(data + (size_t)y * step, S->p + (size_t)y * im->step, rowbytes);
     return IMP_OK;
 }
 

@@ -1,0 +1,121 @@
+// fuzz_host.cpp -- driver for the AddressSanitizer + UBSan build of the host-side grammar (imp_args.cpp,
+// imp_request.cpp, imp_tables.cpp): the code that parses attacker-controlled query strings before anything reaches
+// the GPU.  CPU only (sanitizers cannot run on the GPU box).  The reference's own parser has over-runs of exactly this
+// class (RewindArgs walks past the terminator when the separator is missing, helpers.c:18-23; strtok on NULL).
+//
+// stdin: one case per line, fields separated by one space, strings hex-encoded ("-" = NULL pointer):
+//   crop <w> <h> <args> <gravity>        -> rc x y w h
+//   resize <w> <h> <args> <maxw> <maxh> <simple> -> rc w h interp
+//   filter <request> <allow> <channels> <w> <h>  -> rc class stages table_bytes
+//   destructive <request>                -> flag
+//   request <uri> <ext> <max_filters>    -> rc mime page simple flatten nfilters destructive
+//   taps <ssize> <dsize> <interp> <is_x> -> checksum of the table
+//   area <ssize> <dsize>                 -> checksum of the table
+//   gauss <sigma as text>                -> ksize checksum
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include "../../ngx_http_imgproc_amd/csrc/imp_internal.h"
+
+static bool unhex(const std::string& h, std::string* out) {
+    out->clear();
+    if (h == "-") return false;
+    if (h == "=") return true;      // empty string
+    for (size_t i = 0; i + 1 < h.size(); i += 2) out->push_back((char)std::strtol(h.substr(i, 2).c_str(), nullptr, 16));
+    return true;
+}
+
+int main() {
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        std::istringstream in(line);
+        std::string kind;
+        in >> kind;
+        if (kind == "crop") {
+            int w, h; std::string a, g, sa, sg;
+            in >> w >> h >> a >> g;
+            const bool ha = unhex(a, &sa), hg = unhex(g, &sg);
+            int x = 0, y = 0, ow = 0, oh = 0;
+            int rc = ha ? imp::crop_geometry(w, h, sa.c_str(), hg ? sg.c_str() : nullptr, &x, &y, &ow, &oh) : IMP_ERROR_INVALID_ARGS;
+            if (rc) x = y = ow = oh = 0;
+            std::printf("%d %d %d %d %d\n", rc, x, y, ow, oh);
+        } else if (kind == "resize") {
+            int w, h, simple; unsigned mw, mh; std::string a, sa;
+            in >> w >> h >> a >> mw >> mh >> simple;
+            unhex(a, &sa);
+            int ow = 0, oh = 0, interp = 0;
+            int rc = imp::resize_geometry(w, h, sa.c_str(), mw, mh, simple, &ow, &oh, &interp);
+            if (rc) ow = oh = interp = 0;
+            std::printf("%d %d %d %d\n", rc, ow, oh, interp);
+        } else if (kind == "filter") {
+            std::string r, sr; int allow, c, w, h;
+            in >> r >> allow >> c >> w >> h;
+            unhex(r, &sr);
+            imp::FilterPlan plan;
+            imp::PixelProgram prog;
+            int rc = imp::filter_plan(sr.c_str(), allow, c, w, h, &plan, &prog);
+            std::printf("%d %d %zu %zu\n", rc, rc ? -1 : plan.cls, prog.stages.size(), prog.tables.size());
+        } else if (kind == "destructive") {
+            std::string r, sr;
+            in >> r;
+            unhex(r, &sr);
+            std::printf("%d\n", imp::check_destructive(sr.c_str()));
+        } else if (kind == "request") {
+            std::string u, e, su, se; int maxf;
+            in >> u >> e >> maxf;
+            unhex(u, &su);
+            const bool he = unhex(e, &se);
+            impgpu_config cfg{};
+            cfg.max_filters_count = maxf;
+            impgpu_request* rq = nullptr;
+            int rc = impgpu_parse_request(su.c_str(), he ? se.c_str() : nullptr, &cfg, &rq);
+            const impgpu_job* j = impgpu_request_job(rq);
+            size_t touched = 0;     // read every string the job points at: they must be valid C strings
+            if (!rc && j) {
+                for (const char* s : {j->crop, j->gravity, j->resize, impgpu_request_quality(rq), impgpu_request_format(rq)})
+                    if (s) touched += std::strlen(s);
+                for (int i = 0; i < j->filter_count; i++) touched += std::strlen(j->filters[i]);
+            }
+            std::printf("%d %d %d %d %d %d %d %zu\n", rc, impgpu_request_mime(rq), rc ? 0 : impgpu_request_page(rq), (j && !rc) ? j->simple : 0,
+                        (j && !rc) ? j->need_flatten : 0, (j && !rc) ? j->filter_count : 0, rc ? 0 : impgpu_request_destructive(rq), touched);
+            impgpu_request_free(&rq);
+        } else if (kind == "taps") {
+            int ss, ds, interp, isx;
+            in >> ss >> ds >> interp >> isx;
+            imp::TapAxis t;
+            imp::build_tap_axis(ss, ds, 1. / ((double)ds / ss), interp, isx != 0, &t);
+            long long sum = 0;
+            for (size_t i = 0; i < t.ofs.size(); i++) sum += t.ofs[i] * 31LL;
+            for (size_t i = 0; i < t.coef.size(); i++) sum += t.coef[i] * (long long)(i % 7 + 1);
+            std::printf("%lld\n", sum);
+        } else if (kind == "area") {
+            int ss, ds;
+            in >> ss >> ds;
+            imp::AreaAxis a;
+            imp::build_area_axis(ss, ds, 1. / ((double)ds / ss), &a);
+            double sum = 0;
+            for (size_t d = 0; d < a.start.size(); d++) {
+                if (a.start[d] < 0 || a.start[d] + a.count[d] > ss) { std::printf("out-of-range run\n"); return 1; }
+                for (int k = 0; k < a.count[d]; k++) sum += a.alpha[a.aoff[d] + k];
+            }
+            std::printf("%.3f %d\n", sum, a.max_count);
+        } else if (kind == "gauss") {
+            double sigma;
+            in >> sigma;
+            const int n = imp::gaussian_ksize(sigma);
+            long long sum = 0;
+            if (n > 0 && n < 4096) {
+                std::vector<int> k;
+                imp::gaussian_kernel_fixed(n, sigma, &k);
+                for (int v : k) sum += v;
+            }
+            std::printf("%d %lld\n", n, sum);
+        } else {
+            std::printf("?\n");
+        }
+    }
+    return 0;
+}

@@ -3,6 +3,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- FIRST: torch bundles its own HIP/HSA runtime; if libimpgpu.so's /opt/rocm copy is mapped before
+#                              it, torch.cuda finds no device in this process (bench.py imports in the same order)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

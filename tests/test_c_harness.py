@@ -1,0 +1,145 @@
+"""The boundary exercised from the reference's own language: tests/c/runjob_harness.c is plain C99 that includes only
+<impgpu.h> and walks RunJob's path (bridge.c:302-724) -- env start, PrepareWatermark, request parse, upload, the operator
+segment, then the json / text / encoder exits.  Everything it writes is compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import ROOT, noise_image, smooth_image
+
+HARNESS = os.path.join(ROOT, "tests", "c", "_build", "runjob_harness")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+    return HARNESS
+
+
+def run(tmp_path, frame, uri, ext, overlay=None, pos=None, env=None):
+    h, w, c = frame.shape
+    src, out = tmp_path / "frame.raw", tmp_path / "out.raw"
+    frame.tofile(src)
+    cmd = [build(), str(src), str(w), str(h), str(c), uri, ext, str(out)]
+    if overlay is not None:
+        ov = tmp_path / "overlay.raw"
+        overlay.tofile(ov)
+        oh, ow, oc = overlay.shape
+        cmd += [str(ov), str(ow), str(oh), str(oc)] + [str(v) for v in pos]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, **(env or {})))
+    fields = dict(kv.split("=") for kv in p.stdout.split()) if p.returncode == 0 else {}
+    data = np.fromfile(out, dtype=np.uint8) if out.exists() else None
+    return p, {k: int(v) for k, v in fields.items()}, data
+
+
+def test_harness_is_c99_and_fails_loudly_without_a_device(tmp_path):
+    """Compiles with -std=c99 -pedantic against include/impgpu.h alone; with no usable device the very first call
+    (OnEnvStart) reports IMP_ERROR_DEVICE -- there is no CPU path behind the ABI."""
+    import torch
+
+    assert os.path.exists(build())
+    env = {"HIP_VISIBLE_DEVICES": "-1", "ROCR_VISIBLE_DEVICES": "-1"} if torch.cuda.is_available() else {}
+    p, fields, data = run(tmp_path, noise_image(8, 8, 3, 1), "/a.png?resize=4", "png", env=env)
+    assert p.returncode == 3 and "impgpu_env_start" in p.stderr and data is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("uri,ext,c", [
+    ("/cat.jpg?crop=1,1,c,c&resize=120&filter-gotham=1", "jpg", 3),
+    ("/a.png?resize=0,90&filter-rotate=90&filter-blur=1.5", "png", 4),
+    ("/a.png?crop=16,9&filter-flip=10&format=jpg", "png", 4),          # 4-channel frame to a jpg encoder: flattened on white
+    ("/a.jpg?resize=500,0,up&filter-modulate=30,150,100", "jpg", 3),     # enlargement: INTER_CUBIC
+    ("/a.gif?resize=64&filter-gamma=1.7", "gif", 4),                    # GIF output: nearest-neighbour
+])
+def test_encoder_exit_matches_oracle(tmp_path, uri, ext, c):
+    from test_gpu_chain import oracle_chain
+
+    frame = smooth_image(240, 320, c)
+    p, f, data = run(tmp_path, frame, uri, ext)
+    assert p.returncode == 0, p.stderr
+    rc_o, q = orc.parse_request(uri, ext, 5)
+    rc_w, step_w, want = oracle_chain(frame, crop=q["crop"], gravity=q["gravity"], resize=q["resize"], simple=q["simple"],
+                                      filters=q["filters"], flatten=q["need_flatten"])
+    assert rc_o == 0 and f["code"] == rc_w == 0 and f["step"] == 8 and f["mime"] == q["mime"]
+    assert (f["h"], f["w"], f["c"]) == want.shape
+    assert np.array_equal(data.reshape(want.shape), want)
+
+
+@pytest.mark.gpu
+def test_watermark_json_and_text_exits_match_oracle(tmp_path):
+    from test_gpu_chain import oracle_chain
+
+    frame = noise_image(150, 200, 4, 31)
+    overlay = noise_image(20, 30, 4, 32)
+    overlay[:, :, 3] = np.linspace(0, 255, 30).astype(np.uint8)[None, :]
+    pos = ("r", "b", 5, 7, 60)
+    # configured watermark + encoder exit
+    p, f, data = run(tmp_path, frame, "/a.png?resize=100", "png", overlay, pos)
+    rc_w, step_w, want = oracle_chain(frame, resize="100", overlay=overlay, wm=pos)
+    assert p.returncode == 0 and f["code"] == rc_w == 0 and np.array_equal(data.reshape(want.shape), want)
+    # json exit: Info()'s integer percent (bridge.c:296) of the float-accumulator brightness
+    p, f, data = run(tmp_path, frame, "/a.png?resize=100&format=json", "png")
+    rc_w, step_w, want = oracle_chain(frame, resize="100")
+    assert p.returncode == 0 and f["code"] == 0 and f["mime"] == -3
+    assert f["brightness"] == int(round(orc.brightness(want) * 100))
+    # text exit: ASCII() with quality= as the table name (bridge.c:670)
+    for table in ("wide", "narrow"):
+        p, f, data = run(tmp_path, frame, "/a.png?resize=60&format=text&quality=%s" % table, "png")
+        rc_w, step_w, want = oracle_chain(frame, resize="60")
+        text = orc.ascii_art(want, table)
+        assert p.returncode == 0 and f["code"] == 0 and f["mime"] == -5 and f["bytes"] == len(text)
+        assert bytes(data) == text
+
+
+@pytest.mark.gpu
+def test_error_codes_and_steps_reach_the_c_caller(tmp_path):
+    frame = noise_image(60, 80, 3, 33)
+    for uri, code, step in (("/a.jpg?crop=0,0,320,240", 50, 3), ("/a.jpg?resize=0,0", 50, 4), ("/a.jpg?filter-nope=1", 52, 5),
+                            ("/a.jpg?resize=3000,10,up", 54, 4), ("/a.jpg", 50, 0), ("/a.ico?resize=5", 1, 0)):
+        p, f, data = run(tmp_path, frame, uri, uri.split("?")[0].rsplit(".", 1)[1])
+        assert p.returncode == 0 and (f["code"], f["step"]) == (code, step), uri
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fault,uri,step", [("2", "/a.png?resize=10", 2), ("3", "/a.png?crop=1,1", 3), ("4", "/a.png?crop=1,1&resize=10", 4),
+                                            ("5", "/a.png?filter-gamma=2", 5), ("7", "/a.png?resize=10&format=json", 7),
+                                            ("8", "/a.png?resize=10", 8)])
+def test_injected_device_fault_reaches_the_c_caller_with_its_step(tmp_path, fault, uri, step):
+    """IMPGPU_FAULT=<step>: that stage behaves as if its HIP call had failed -> IMP_ERROR_DEVICE (90) and JobResult.Step,
+    which BodyFilter turns into `Job failed at step %d with code %d` + HTTP 500 (module.c:305, :326-329)."""
+    p, f, data = run(tmp_path, noise_image(40, 60, 4, 34), uri, "png", env={"IMPGPU_FAULT": fault})
+    assert p.returncode == 0 and (f["code"], f["step"]) == (90, step) and data is None
+
+
+@pytest.mark.gpu
+def test_a_worker_survives_an_injected_fault(tmp_path):
+    """The n-th entry fails, the requests before and after it succeed on the same env: a failed request leaves the lane,
+    its pool and the frame handle usable (the reference's `goto finalize` equivalent)."""
+    import sys
+
+    script = r'''
+import ctypes as C, sys
+import numpy as np
+import torch  # first (see tests/conftest.py)
+import ngx_http_imgproc_amd as imp
+imp.env_start(0)
+cfg = imp.Config()
+frame = np.random.default_rng(5).integers(0, 256, (50, 70, 3), dtype=np.uint8)
+codes = []
+for i in range(4):
+    im = imp.Image(frame)
+    rc, step = imp.run_ops(im, cfg, resize="20")
+    codes.append((rc, step, imp.lib.impgpu_last_error().decode() if rc else "", im.shape))
+    im.release()
+imp.env_destroy()
+print(repr(codes))
+'''
+    import os
+    p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env=dict(os.environ, IMPGPU_FAULT="4:2", PYTHONPATH=ROOT))
+    assert p.returncode == 0, p.stderr[-2000:]
+    codes = eval(p.stdout.strip().split("\n")[-1])
+    assert [c[0] for c in codes] == [0, 90, 0, 0] and codes[1][1] == 4 and "injected fault" in codes[1][2]
+    assert codes[0][3] == codes[2][3] == (14, 20, 3) and codes[1][3] == (50, 70, 3)      # the failed request's frame is intact

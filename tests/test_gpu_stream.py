@@ -1,0 +1,176 @@
+"""BASELINE configs[4] on the device: a mixed-size request stream (256 px - 4K) driven from several host threads, each
+with its own lane (HIP stream, pool, table cache), every output compared with the oracle.  This is the shape of the
+reference's per-frame Resize loop on whatever sizes arrive (bridge.c:588-604) under `worker_processes N`.
+
+Also here: the per-lane resize-table cache under eviction pressure (more geometries than it holds, from several
+threads at once) and the batch entry points on a caller's stream with no host wait in between.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import noise_image
+from ngx_http_imgproc_amd.workloads import MIXED_RESIZE, mixed_sizes
+
+pytestmark = pytest.mark.gpu
+
+
+def run_threads(n_threads, items, work):
+    """Deal `items` to n_threads workers; returns the list of (item, failure text)."""
+    failures = []
+    lock = threading.Lock()
+    it = iter(list(enumerate(items)))
+
+    def worker():
+        while True:
+            with lock:
+                nxt = next(it, None)
+            if nxt is None:
+                return
+            try:
+                msg = work(*nxt)
+            except Exception as exc:  # noqa: BLE001  (reported through the assertion below)
+                msg = repr(exc)
+            if msg:
+                failures.append((nxt[1], msg))
+
+    ts = [threading.Thread(target=worker) for _ in range(n_threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return failures
+
+
+def test_mixed_size_request_stream_matches_oracle(gpu):
+    """64 seeded requests of bench.py --stream's generator, with one 256 px and one 3840x2160 frame forced in,
+    4 host threads, resize=224,0: upload -> Resize() -> download, bit-exact against the oracle's Resize()."""
+    sizes = mixed_sizes(64)
+    sizes[5] = (256, 144)
+    sizes[17] = (3840, 2160)
+    sizes[40] = (2160, 3840)
+    cfg = gpu.Config()
+
+    def one(i, wh):
+        w, h = wh
+        rng = np.random.Generator(np.random.PCG64(0x1A4D5000 + i))
+        frame = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        im = gpu.Image(frame)
+        rc = gpu.lib.impgpu_resize(C.byref(im.h), MIXED_RESIZE, C.byref(cfg.c), 0)
+        rc_o, want = orc.resize(frame, MIXED_RESIZE.decode())
+        if rc != rc_o:
+            return "codes %d / %d" % (rc, rc_o)
+        got = im.numpy()
+        im.release()
+        if got.shape != want.shape or not np.array_equal(got, want):
+            return "pixels differ (%r vs %r)" % (got.shape, want.shape)
+        return None
+
+    assert run_threads(4, sizes, one) == []
+
+
+def test_mixed_sizes_through_pinned_uploads_keep_several_requests_in_flight(gpu):
+    """The bench loop's own shape: pinned source, `inflight` requests enqueued per thread before one impgpu_sync."""
+    sizes = mixed_sizes(48, seed=0x1A4D0A05)
+    lib = gpu.lib
+    maxpx = max(w * h for w, h in sizes)
+    rng = np.random.Generator(np.random.PCG64(77))
+    noise = rng.integers(0, 256, size=maxpx * 4, dtype=np.uint8)
+    hsrc = lib.impgpu_host_alloc(noise.nbytes)
+    C.memmove(hsrc, noise.ctypes.data, noise.nbytes)
+    cfg = gpu.Config()
+    out_bytes = 224 * 224 * 4 * 4
+    groups = [sizes[i:i + 4] for i in range(0, len(sizes), 4)]
+
+    def one(_, group):
+        hdst = lib.impgpu_host_alloc(out_bytes * len(group))
+        live, shapes = [], []
+        for k, (w, h) in enumerate(group):
+            img = C.c_void_p()
+            assert lib.impgpu_image_upload_pinned(hsrc, w, h, 4, w * 4, C.byref(img)) == 0
+            assert lib.impgpu_resize(C.byref(img), MIXED_RESIZE, C.byref(cfg.c), 0) == 0
+            ow, oh = lib.impgpu_image_width(img), lib.impgpu_image_height(img)
+            assert lib.impgpu_image_download_pinned(img, hdst + out_bytes * k, ow * 4) == 0
+            live.append(img)
+            shapes.append((oh, ow))
+        assert lib.impgpu_sync() == 0
+        bad = None
+        for k, (w, h) in enumerate(group):
+            oh, ow = shapes[k]
+            got = np.ctypeslib.as_array((C.c_uint8 * (oh * ow * 4)).from_address(hdst + out_bytes * k)).reshape(oh, ow, 4)
+            rc_o, want = orc.resize(noise[:w * h * 4].reshape(h, w, 4), MIXED_RESIZE.decode())
+            if rc_o != 0 or not np.array_equal(got, want):
+                bad = "request %dx%d differs" % (w, h)
+        for img in live:
+            lib.impgpu_image_release(C.byref(img))
+        lib.impgpu_host_free(hdst)
+        return bad
+
+    failures = run_threads(3, groups, one)
+    lib.impgpu_host_free(hsrc)
+    assert failures == []
+
+
+def test_table_cache_eviction_under_threads(gpu):
+    """More distinct geometries than a lane's table cache holds (256), from three threads at once: evicted tables go
+    back to the pool in stream order, so no launch may ever read a recycled table (round 1's cache freed tables that a
+    kernel about to be enqueued still pointed at)."""
+    geoms = [(40 + (i % 37), 30 + (i // 37) % 29, 9 + i % 7) for i in range(700)]     # (w, h, target w): 700 distinct keys
+    assert len(set(geoms)) == 700
+    cfg = gpu.Config()
+
+    def one(i, g):
+        w, h, tw = g
+        frame = noise_image(h, w, 4 if i % 2 else 3, 3000 + i)
+        modes = [("%d,0" % tw, 0), ("%d,0,up" % (w + tw), 0), ("%d,0" % tw, 1)]     # AREA, CUBIC (enlarging), NN
+        args, simple = modes[i % 3]
+        im = gpu.Image(frame)
+        rc = gpu.lib.impgpu_resize(C.byref(im.h), args.encode(), C.byref(cfg.c), simple)
+        rc_o, want = orc.resize(frame, args, simple=simple)
+        got = im.numpy()
+        im.release()
+        return None if (rc == rc_o == 0 and np.array_equal(got, want)) else "geometry %r differs" % (g,)
+
+    assert run_threads(3, geoms, one) == []
+
+
+def test_batch_calls_on_a_callers_stream_need_no_host_wait(gpu):
+    """The batch entry points take a hipStream_t and return after enqueue (impgpu.h): temporary blocks are parked
+    behind an event of that stream instead of a hipStreamSynchronize.  Many back-to-back calls with different
+    geometries and LUTs, one sync at the end, everything compared with the oracle."""
+    import torch
+
+    stream = torch.cuda.Stream()
+    n = 6
+    src_np = np.stack([noise_image(96, 128, 4, 4100 + i) for i in range(n)])
+    src = torch.from_numpy(src_np).cuda()
+    cfg = gpu.Config(allow_experiments=True)
+    ov = noise_image(8, 12, 4, 4200)
+    assert cfg.prepare_watermark(ov, "r", "b", 2, 2, 60) == 0
+    outs = []
+    torch.cuda.synchronize()
+    for k, (rw, rh) in enumerate([(64, 48), (50, 40), (64, 48), (33, 21), (70, 60), (50, 40)]):
+        dst = torch.zeros((n, rw, rh, 4), dtype=torch.uint8, device="cuda")       # rotated: rh wide, rw tall
+        gpu.batch_resize_rotate_watermark(src.data_ptr(), 96 * 128 * 4, 128, 96, 128 * 4, dst.data_ptr(), rw * rh * 4, rh * 4,
+                                          rw, rh, 90, cfg, 4, n, stream=stream.cuda_stream)
+        fl = torch.from_numpy(src_np.copy()).cuda()
+        torch.cuda.current_stream().synchronize()
+        stream.wait_stream(torch.cuda.current_stream())
+        assert gpu.batch_filters(fl.data_ptr(), 96 * 128 * 4, 128, 96, 4, 128 * 4, n, ["gamma=%s" % (1.2 + 0.1 * k), "kelvin=1"],
+                                 stream=stream.cuda_stream) == 0
+        outs.append(((rw, rh), dst, fl, 1.2 + 0.1 * k))
+    stream.synchronize()
+    for (rw, rh), dst, fl, gamma in outs:
+        got, gotf = dst.cpu().numpy(), fl.cpu().numpy()
+        for i in range(n):
+            rc, o = orc.resize(src_np[i], "%d,%d" % (rw, rh))
+            rc, o = orc.filter(o, "rotate=90")
+            rc, o = orc.watermark(o, ov, "r", "b", 2, 2, 60)
+            assert np.array_equal(got[i], o), (rw, rh, i)
+            rc, f = orc.filter(src_np[i], "gamma=%s" % gamma)
+            rc, f = orc.filter(f, "kelvin=1", 1)
+            assert np.array_equal(gotf[i], f), (gamma, i)
+    cfg.release()

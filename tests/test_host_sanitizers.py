@@ -1,0 +1,125 @@
+"""The host-side grammar under AddressSanitizer + UBSan (SURVEY 5 "race detection / sanitizers").
+
+imp_args.cpp / imp_request.cpp / imp_tables.cpp parse attacker-controlled query strings before anything reaches the
+GPU; the reference's own parser over-runs on some of them (RewindArgs without its separator, helpers.c:18-23; strtok on
+NULL in Scanline, filters.c:408-409).  tests/c/fuzz_host.cpp links those three sources built with
+`g++ -fsanitize=address,undefined -fno-sanitize-recover` and replays fuzzed cases; every answer must also equal what the
+regular (unsanitized, hipcc-built) library returns through the C ABI, so nothing depends on undefined behaviour.
+CPU only: sanitizers are not available on the GPU box.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import ngx_http_imgproc_amd as imp
+from conftest import ROOT
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ with libasan / libubsan")
+DRIVER = os.path.join(ROOT, "tests", "c", "_build", "fuzz_host_asan")
+
+
+def hx(s):
+    if s is None:
+        return "-"
+    b = s if isinstance(s, bytes) else s.encode("utf-8", "surrogatepass")
+    return b.hex() if b else "="
+
+
+def drive(lines):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), DRIVER])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([DRIVER], input="\n".join(lines) + "\n", capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-3000:]
+    out = p.stdout.strip().split("\n")
+    assert len(out) == len(lines)
+    return out
+
+
+# grammar-shaped fragments so the fuzz spends its time near the parsers' decisions, plus raw text
+TOKENS = ["", "0", "1", "16", "9", "320px", "-5px", "px", "l", "r", "c", "t", "b", "up", ",", ",,", "4294967296", "-1", "1e9", "0x10",
+          "99999999999999999999", "ff8000", "zzzzzz", "0.5", "nan", "inf", "-inf", "full", "pale", "=", "&", "?", "%", "%3", "%zz", "\x7f", "é"]
+frag = st.one_of(st.sampled_from(TOKENS), st.text(alphabet=st.characters(blacklist_characters="\x00\n\r", blacklist_categories=("Cs",)), max_size=6))
+args_text = st.lists(frag, max_size=6).map(",".join)
+FILTER_NAMES = ["flip", "rotate", "modulate", "colorize", "blur", "gamma", "contrast", "gradmap", "vignette", "gotham", "lomo",
+                "kelvin", "rainbow", "scanline", "cartoon", "", "blurry", "FLIP"]
+filter_req = st.one_of(st.builds(lambda n, a: n + "=" + a, st.sampled_from(FILTER_NAMES), args_text),
+                       st.builds(lambda n, a, b: n + "=" + a + "=" + b, st.sampled_from(FILTER_NAMES), args_text, args_text),
+                       st.sampled_from(FILTER_NAMES), args_text)
+KEYS = ["crop", "gravity", "resize", "quality", "format", "page", "filter-", "filter", "cropx", "unknown", ""]
+FORMATS = ["jpg", "png", "json", "text", "gif", "webp", "jp2", "bmp", "ico", "tiff", "JPG", "x.y.jpeg", ""]
+param = st.one_of(st.builds(lambda k, v: k + "=" + v, st.sampled_from(KEYS), st.one_of(args_text, filter_req, st.sampled_from(FORMATS))),
+                  st.builds(lambda k, v: k + v, st.sampled_from(KEYS), filter_req), st.sampled_from(KEYS))
+uri = st.builds(lambda path, q, ps: path + q + "&".join(ps), st.sampled_from(["/a.jpg", "", "/a%20b.png", "?", "/x?y"]),
+                st.sampled_from(["?", "", "??", "?&"]), st.lists(param, max_size=9))
+dims = st.integers(min_value=1, max_value=5000)
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(st.lists(st.tuples(dims, dims, args_text, st.one_of(st.none(), args_text)), min_size=20, max_size=40))
+def test_crop_grammar_under_sanitizers(cases):
+    out = drive(["crop %d %d %s %s" % (w, h, hx(a), hx(g)) for w, h, a, g in cases])
+    for (w, h, a, g), line in zip(cases, out):
+        x, y, ow, oh = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rc = imp.lib.impgpu_crop_geometry(w, h, a.encode(), None if g is None else g.encode(), x, y, ow, oh)
+        want = [rc] + ([x.value, y.value, ow.value, oh.value] if rc == 0 else [0, 0, 0, 0])
+        assert [int(v) for v in line.split()] == want, (w, h, a, g)
+        if rc == 0:
+            assert 0 <= x.value and 0 <= y.value and x.value + ow.value <= w and y.value + oh.value <= h and ow.value > 0 and oh.value > 0
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(st.lists(st.tuples(dims, dims, args_text, st.sampled_from([0, 1, 2000, 100000]), st.sampled_from([0, 1, 2000]), st.booleans()),
+                min_size=20, max_size=40))
+def test_resize_grammar_under_sanitizers(cases):
+    out = drive(["resize %d %d %s %d %d %d" % (w, h, hx(a), mw, mh, int(s)) for w, h, a, mw, mh, s in cases])
+    for (w, h, a, mw, mh, s), line in zip(cases, out):
+        cfg = imp.Config(max_w=mw, max_h=mh)
+        ow, oh, ip = C.c_int(), C.c_int(), C.c_int()
+        rc = imp.lib.impgpu_resize_geometry(w, h, a.encode(), C.byref(cfg.c), int(s), ow, oh, ip)
+        want = [rc] + ([ow.value, oh.value, ip.value] if rc == 0 else [0, 0, 0])
+        assert [int(v) for v in line.split()] == want, (w, h, a)
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(st.lists(st.tuples(filter_req, st.booleans()), min_size=20, max_size=40))
+def test_filter_grammar_under_sanitizers(cases):
+    out = drive(["filter %s %d 4 64 64" % (hx(r), int(al)) for r, al in cases] + ["destructive %s" % hx(r) for r, _ in cases])
+    for i, (r, al) in enumerate(cases):
+        assert int(out[i].split()[0]) == imp.lib.impgpu_filter_check(r.encode(), int(al)), r
+        assert int(out[len(cases) + i]) == imp.lib.impgpu_check_destructive(r.encode()), r
+
+
+@settings(max_examples=200, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(st.lists(st.tuples(uri, st.one_of(st.none(), st.sampled_from(FORMATS)), st.sampled_from([0, 1, 5, 9])), min_size=20, max_size=40))
+def test_request_parser_under_sanitizers(cases):
+    out = drive(["request %s %s %d" % (hx(u), hx(e), mf) for u, e, mf in cases])
+    for (u, e, mf), line in zip(cases, out):
+        r = imp.Request(u, e, imp.Config(max_filters=mf)) if e is not None else None
+        if r is None:
+            continue
+        got = [int(v) for v in line.split()]
+        assert got[0] == r.code, (u, e)
+        if r.code == 0:
+            assert got[1:7] == [r.mime, r.page, int(r.simple), int(r.need_flatten), len(r.filters), int(r.destructive)], (u, e)
+
+
+def test_table_builders_under_sanitizers():
+    """Every (source, destination) size pair up to 40 plus the benchmark geometries: run tables stay inside the row."""
+    lines = []
+    for s in range(1, 41):
+        for d in range(1, 41):
+            lines += ["taps %d %d %d 1" % (s, d, m) for m in (1, 2, 4)]
+            if d <= s:
+                lines.append("area %d %d" % (s, d))
+    lines += ["area 1920 224", "area 1080 224", "area 3840 224", "taps 3840 1920 4 1", "taps 1920 224 2 1", "taps 480 1920 2 1"]
+    lines += ["gauss %s" % v for v in ("0", "-1", "0.01", "0.1", "0.5", "2", "5.5", "25", "600", "1e9", "nan", "inf")]
+    out = drive(lines)
+    assert not any("out-of-range" in o for o in out)
+    for line, o in zip(lines, out):
+        if line.startswith("area"):
+            s, d = map(int, line.split()[1:])
+            assert abs(float(o.split()[0]) - d) < 1e-2 * d      # every run's weights sum to 1
