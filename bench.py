@@ -36,6 +36,12 @@ WORKLOADS = {
              "batch 1024 of 1920x1080 BGRA resize->224x224 INTER_AREA (what the reference's Resize() dispatches)"),
     "lanczos": (3840, 2160, 1920, 1080, 64, 4, 3840 * 2160 * 4 + 1920 * 1080 * 4,
                 "batch 64 of 3840x2160 BGRA resize->1920x1080 INTER_LANCZOS4"),
+    # the reference's only CUBIC dispatch is an enlargement (bridge.c:190): 480x270 -> 1920x1080 `up`; output-dominated
+    "upscale": (480, 270, 1920, 1080, 512, 2, 480 * 270 * 4 + 1920 * 1080 * 4,
+                "batch 512 of 480x270 BGRA resize->1920x1080 INTER_CUBIC (enlargement: what Resize() sends to CUBIC)"),
+    # the simplest shrink: exact 2x2 box (cfg3's resize=960,540 on its own)
+    "area2x": (1920, 1080, 960, 540, 256, 3, 1920 * 1080 * 4 + 960 * 540 * 4,
+               "batch 256 of 1920x1080 BGRA resize->960x540 INTER_AREA (exact 2x2 box)"),
     # BASELINE configs[2]: resize=960,540 (AREA, exact 2x2) -> filter-rotate=90 -> configured watermark 256x64 r,b,16,16 @60
     # a GIF-album style batch: filter-gotham (HSV modulate + colorize + gamma + contrast, 6 CPU sweeps) fused, in place
     "gotham": (1920, 1080, 1920, 1080, 256, -2, 2 * 1920 * 1080 * 4,
@@ -411,6 +417,9 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
+                # NOT measured in this run: the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_probe.py,
+                # separate passes, gfx950 FETCH x2 correction) is its own profiled run whose result is committed
+                "traffic_source": ("profiles/traffic_%s.json" % args.mode) if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes * batch,
                 "kernel_ms_per_launch": round(launch_ms, 4),
             },

@@ -410,6 +410,179 @@ __device__ __forceinline__ void hpass_px(const uint32_t* p, const short2_t* axp,
     }
 }
 
+// ------------------------------------------------------------------ CUBIC enlargement (the reference's only CUBIC dispatch)
+// Resize() asks for CV_INTER_CUBIC exactly when an axis grows (bridge.c:190).  Enlarging, the destination is the big side:
+// 1920x1080 from 480x270 writes 16 bytes for every byte it reads, every source row feeds ~4 / scale destination rows, and
+// instructions per destination pixel -- then the store stream -- set the pace, not the reads.
+//
+// A WAVE owns 64 destination columns and walks a chunk of rows down the frame, alone: no LDS, no barriers, nothing
+// shared with the other waves of its block (an earlier block-wide form with the H sums in an LDS ring stalled every tile
+// on its global loads -- table rows, source rows -- behind two barriers: 0.25 of the roofline).  All lanes of a wave
+// work on the same destination row, so the row's four footprint rows are wave-uniform and the horizontal sums of the
+// current footprint live in REGISTERS (four rows x four channels, already converted to float: exact, |sum| < 2^24, and
+// VResizeCubicVec_32s8u's vertical pass is float).  When the footprint advances -- every 1/scale_y rows -- the ring
+// shifts by one row and ONE new source row is reduced (one 16-byte window per lane, perm + dot2), its pixels having
+// been requested one advance earlier.  The vertical pass is then four packed multiplies and three packed adds per
+// channel pair with the row's weights in scalar registers: a row's constants (first footprint row, the four weights as
+// the floats b * 2^-22, tabulated on the host) are wave-uniform, so they come by scalar loads, the next row's in flight;
+// v_cvt_pk_u8_f32 rounds to nearest even, saturates and packs in one instruction per channel.
+typedef float float2v_t __attribute__((ext_vector_type(2)));
+#define UP_ROWS 128        // destination rows per wave chunk, at most
+#define UP_CAP_PX 1536     // source pixels a wave stages in LDS (6 KB per wave, 28 KB per block with the store patch)
+
+__device__ __forceinline__ uint32_t cvt_pk_u8(float x, uint32_t acc, int byte) {
+    // v_cvt_pk_u8_f32: byte `byte` of acc <- saturate_u8(round-half-even(x)) -- exactly saturate_cast<uchar>(cvRound(x))
+    // (checked on hardware over ties, negatives and > 255: tools/cvt_probe.hip)
+    uint32_t r;
+    asm("v_cvt_pk_u8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(byte), "v"(acc));
+    return r;
+}
+
+// per destination row, 32 bytes: how far the footprint moves before this row, then the four weights b * 2^-22
+struct UpRow { int adv; float bf[4]; int first; int pad[2]; };      // first = first footprint row (yofs - 1); adv = first - previous row's first
+
+__global__ __launch_bounds__(256) void k_resize_up_cubic4(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                          const short* __restrict__ yco, const UpRow* __restrict__ rows,
+                                                          int vec_end, int nbx, int rows_per_wave) {
+    // a wave's own 4 rows x 64 pixels, used only to turn four row-wise dword results per lane into one 16-byte store per lane
+    __shared__ __attribute__((aligned(16))) uint32_t s_tr[4][4][64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_src[4][UP_CAP_PX];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cy = blockIdx.x / nbx, bx = blockIdx.x - cy * nbx;
+    const int tx0 = (bx * 4 + wv) * 64;
+    if (tx0 >= a.dw) return;                                   // waves are independent: no barrier follows
+    const int txn = min(64, a.dw - tx0);
+    const bool live = lane < txn;
+    const int dx = tx0 + min(lane, txn - 1);                   // idle lanes of a partial strip shadow its last column
+    const int row0 = cy * rows_per_wave, row_end = min(a.dh, row0 + rows_per_wave);
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride;
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride;   // wave-uniform base; lanes add a 32-bit offset
+
+    short2_t axp[2];
+    axp[0].x = xco[dx * 4]; axp[0].y = xco[dx * 4 + 1]; axp[1].x = xco[dx * 4 + 2]; axp[1].y = xco[dx * 4 + 3];
+
+    // The source pixels this wave will ever touch -- its strip's columns x its chunk's footprint rows, a few KB because an
+    // enlargement re-reads every source pixel many times -- are copied into the wave's own LDS patch ONCE, already
+    // replicated at the image borders (clamped row and column indices), before the row loop starts.  The steady state
+    // then holds no global load at all.  That matters more than the bytes: loads and stores share one counter (vmcnt),
+    // so a wave that waits for a prefetched window also waits for every store it has issued since, i.e. for the full
+    // HBM write latency once per footprint advance.
+    const int sxmin = __builtin_amdgcn_readfirstlane(xofs[tx0]) - 1;
+    const int W = __builtin_amdgcn_readfirstlane(xofs[tx0 + txn - 1]) + 2 - sxmin + 1;        // strip's source columns
+    const int f0 = rows[row0].first;
+    const int NR = rows[row_end - 1].first + 3 - f0 + 1;                                         // chunk's footprint rows
+    if (NR * W > UP_CAP_PX) return;        // cannot happen: the launcher sizes chunks from the same bounds; keeps LDS sound
+    for (int i = lane; i < NR * W; i += 64) {
+        const int r = i / W, c = i - r * W;
+        s_src[wv][i] = *(const uint32_t*)(S + (size_t)clampi(f0 + r, 0, a.sh - 1) * a.sstep + (size_t)clampi(sxmin + c, 0, a.sw - 1) * 4);
+    }
+    const int lx = xofs[dx] - 1 - sxmin;                       // this lane's window start inside a patch row
+    const int last = f0 + NR - 1;
+    // (indexed through s_src itself: a pointer variable here loses its LDS address space and the reads become flat_load)
+    auto fetch = [&](int vy, uint32_t* p) {                    // the 4-pixel window of footprint row vy
+        const int o = (min(vy, last) - f0) * W + lx;
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k] = s_src[wv][o + k];
+    };
+
+    float2v_t hxy[4], hzw[4];                                  // H sums of footprint rows cur .. cur + 3, channel pairs (B,G) (R,A)
+    uint32_t pn[4];                                            // pixels of footprint row cur + 4, requested one advance early
+    int cur = f0 - 4;
+    fetch(cur + 4, pn);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { hxy[k] = float2v_t{0.f, 0.f}; hzw[k] = float2v_t{0.f, 0.f}; }
+
+    auto advance = [&]() {                                     // the footprint moves down one source row
+        int h[4];
+        // perm + dot2 like hpass_px, written with the builtin only: with hpass_px's inline-asm first dot2 hipcc 7.2
+        // allocated a perm's destination on top of its own source pixel inside this kernel's unrolled row loop
+        // (v_perm_b32 v2, v3, v2, ... followed by a second perm reading v2), i.e. wrong sums for every tap but one
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t sel = 0x0c040c00u + ((uint32_t)c << 16) + (uint32_t)c;
+            int acc = __builtin_amdgcn_sdot2(as_short2(__builtin_amdgcn_perm(pn[1], pn[0], sel)), axp[0], 0, false);
+            h[c] = __builtin_amdgcn_sdot2(as_short2(__builtin_amdgcn_perm(pn[3], pn[2], sel)), axp[1], acc, false);
+        }
+        cur++;
+        fetch(cur + 4, pn);                                    // needed at the NEXT advance
+        hxy[0] = hxy[1]; hxy[1] = hxy[2]; hxy[2] = hxy[3];
+        hzw[0] = hzw[1]; hzw[1] = hzw[2]; hzw[2] = hzw[3];
+        hxy[3] = float2v_t{__int2float_rn(h[0]), __int2float_rn(h[1])};
+        hzw[3] = float2v_t{__int2float_rn(h[2]), __int2float_rn(h[3])};
+    };
+    // channels ride in pairs (v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar ops; contraction is off): the
+    // SSE2 sequence s = x0*b0; s += x1*b1; s += x2*b2; s += x3*b3, then v_cvt_pk_u8_f32 = round to nearest even + saturate
+    auto vpass = [&](const float* bf) -> uint32_t {
+        float2v_t sxy = hxy[0] * bf[0], szw = hzw[0] * bf[0];
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            sxy = sxy + hxy[k] * bf[k];
+            szw = szw + hzw[k] * bf[k];
+        }
+        uint32_t px = cvt_pk_u8(sxy.x, 0u, 0);
+        px = cvt_pk_u8(sxy.y, px, 1);
+        px = cvt_pk_u8(szw.x, px, 2);
+        return cvt_pk_u8(szw.y, px, 3);
+    };
+    for (int k = 0; k < 4; k++) advance();                     // the first row's footprint
+    int dy = row0;
+
+    // Fast path (wave-uniform): a full 64-column strip, 16-byte aligned destination, whole groups of four rows.  A full
+    // strip never holds the row's scalar-tail pixel (that is the last pixel of an odd-width row, and a strip is full
+    // only left of it).  Four rows are parked in the wave's LDS patch and leave as ONE 16-byte store per lane
+    // (4 rows x 256 B per instruction).  Per row the scalar side does one pointer bump, one 32-byte constant row (the
+    // table carries a sentinel row past the last one, so the look-ahead needs no bound) and one compare-and-branch for
+    // the footprint advance (0 or 1: scale_y <= 1).
+    if (txn == 64 && !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & 15)) {
+        const unsigned voff = (unsigned)(lane >> 4) * (unsigned)a.dstep + (unsigned)(tx0 + (lane & 15) * 4) * 4u;
+        uint32_t* park = &s_tr[wv][0][lane];
+        const u32x4_t* pick = (const u32x4_t*)&s_tr[wv][lane >> 4][(lane & 15) * 4];
+        const UpRow* rq = rows + row0;
+        UpRow rc = *rq;
+        rc.adv = 0;                                            // the first row's footprint is already in place
+        uint8_t* Dg = D + (size_t)dy * a.dstep;
+        const size_t group_bytes = (size_t)a.dstep * 4;
+        for (; dy + 4 <= row_end; dy += 4, Dg += group_bytes) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const UpRow rn = *++rq;                        // next row's constants, in flight
+                if (rc.adv) advance();
+                park[r * 64] = vpass(rc.bf);
+                rc = rn;
+            }
+            // the same wave wrote the patch and LDS serves a wave in order; the compiler must not move the 16-byte read
+            // across the four dword writes either
+            asm volatile("" ::: "memory");
+            const u32x4_t q = *pick;
+            asm volatile("" ::: "memory");
+            *(u32x4_t*)(Dg + voff) = q;
+        }
+    }
+
+    // Generic path: partial strips, unaligned destinations, the last (rows % 4) rows of a chunk
+    const bool tail = dx * 4 + 3 >= vec_end;                   // this pixel holds bytes of the row's scalar tail
+    const unsigned lane_off = (unsigned)dx * 4u;
+    for (; dy < row_end; dy++) {
+        const UpRow rc = rows[dy];
+        while (cur < rc.first) advance();
+        uint32_t px = vpass(rc.bf);
+        if (tail) {
+            const float hc[4][4] = {{hxy[0].x, hxy[1].x, hxy[2].x, hxy[3].x}, {hxy[0].y, hxy[1].y, hxy[2].y, hxy[3].y},
+                                    {hzw[0].x, hzw[1].x, hzw[2].x, hzw[3].x}, {hzw[0].y, hzw[1].y, hzw[2].y, hzw[3].y}};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (dx * 4 + c >= vec_end) {
+                    int v = 1 << 21;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v += __mul24((int)hc[c][k], (int)yco[dy * 4 + k]);
+                    px = (px & ~(0xffu << (8 * c))) | ((uint32_t)shr_sat_u8(v, 22) << (8 * c));
+                }
+        }
+        if (live) *(uint32_t*)(D + ((unsigned)dy * (unsigned)a.dstep + lane_off)) = px;
+    }
+}
+
 // vertical pass over the register ring at phase U of its period; returns the packed BGRA destination pixel
 // {sat_u8(v0 >> sh), sat_u8(v1 >> sh), sat_u8(v2 >> sh), sat_u8(v3 >> sh)} as bytes 0..3 in two instructions.
 // v_ashr_pk_u8_i32 writes ONE 16-bit half of its destination ({sat(S1 >> S2), sat(S0 >> S2)}) and leaves the other
@@ -1031,6 +1204,81 @@ __global__ __launch_bounds__(256) void k_resize_area_int(RArgs a, int isx, int i
     }
 }
 
+// ------------------------------------------------------------------ AREA, exact 2x2 box, streaming form
+// resizeAreaFast_ with both scales 2: (a + b + c + d + 2) >> 2 per channel -- a pure stream (every source byte read
+// once, a quarter as many written), so it is written like a copy: a lane owns FOUR neighbouring destination pixels of a
+// row = 32 source bytes in each of two rows (two 16-byte non-temporal loads per row, all four in flight before the first
+// use) and one 16-byte store; a wave reads two 2 KB runs and writes one 1 KB run.  The four channels of a pixel are
+// summed two at a time in 16-bit halves of a dword (1022 fits).  The per-pixel k_resize_area_int it replaces issued
+// four dword loads and one dword store per lane and reached 0.49 of the HBM roofline.
+__device__ __forceinline__ uint32_t box4_swar(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t M = 0x00ff00ffu;
+    const uint32_t e = (a & M) + (b & M) + (c & M) + (d & M) + 0x00020002u;
+    const uint32_t o = ((a >> 8) & M) + ((b >> 8) & M) + ((c >> 8) & M) + ((d >> 8) & M) + 0x00020002u;
+    return ((e >> 2) & M) | (((o >> 2) & M) << 8);
+}
+
+__global__ __launch_bounds__(256) void k_area2x2_v4(RArgs a, int qpr) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= qpr * a.dh) return;
+    const int dy = idx / qpr, q = idx - dy * qpr;
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride + (size_t)(2 * dy) * a.sstep + (size_t)q * 32;
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep + (size_t)q * 16;
+    const int n = min(4, a.dw - 4 * q);
+    if (n == 4) {
+        uint32_t r0[8], r1[8];
+        load_stream<8>(r0, S);
+        load_stream<8>(r1, S + a.sstep);
+        u32x4_t o;
+        o.x = box4_swar(r0[0], r0[1], r1[0], r1[1]);
+        o.y = box4_swar(r0[2], r0[3], r1[2], r1[3]);
+        o.z = box4_swar(r0[4], r0[5], r1[4], r1[5]);
+        o.w = box4_swar(r0[6], r0[7], r1[6], r1[7]);
+        __builtin_nontemporal_store(o, (u32x4_t*)D);
+    } else {
+        for (int j = 0; j < n; j++) {
+            const uint32_t* p0 = (const uint32_t*)(S + 8 * j);
+            const uint32_t* p1 = (const uint32_t*)(S + a.sstep + 8 * j);
+            *(uint32_t*)(D + 4 * j) = box4_swar(p0[0], p0[1], p1[0], p1[1]);
+        }
+    }
+}
+
+// The same for 3-channel frames (every JPEG): four destination pixels = 12 bytes out, 24 bytes in from each of two rows
+// (dwordx4 + dwordx2, 4-byte aligned because 24 q is); source byte 6 j + c (+3 for the right neighbour) of each row.
+__global__ __launch_bounds__(256) void k_area2x2_v3(RArgs a, int qpr) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= qpr * a.dh) return;
+    const int dy = idx / qpr, q = idx - dy * qpr;
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride + (size_t)(2 * dy) * a.sstep + (size_t)q * 24;
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep + (size_t)q * 12;
+    const int n = min(4, a.dw - 4 * q);
+    if (n == 4) {
+        uint32_t r0[6], r1[6];
+        load_stream<6>(r0, S);
+        load_stream<6>(r1, S + a.sstep);
+        uint32_t o[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int i0 = 6 * j + c, i1 = i0 + 3, ob = 3 * j + c;
+                const uint32_t sum = ((r0[i0 >> 2] >> (8 * (i0 & 3))) & 0xff) + ((r0[i1 >> 2] >> (8 * (i1 & 3))) & 0xff) +
+                                     ((r1[i0 >> 2] >> (8 * (i0 & 3))) & 0xff) + ((r1[i1 >> 2] >> (8 * (i1 & 3))) & 0xff) + 2;
+                o[ob >> 2] |= (sum >> 2) << (8 * (ob & 3));
+            }
+        typedef unsigned int u32x3_t __attribute__((ext_vector_type(3), aligned(4)));
+        const u32x3_t ov = {o[0], o[1], o[2]};
+        *(u32x3_t*)D = ov;
+    } else {
+        const uint8_t* p0 = S;
+        const uint8_t* p1 = S + a.sstep;
+        for (int j = 0; j < n; j++)
+            for (int c = 0; c < 3; c++)
+                D[3 * j + c] = (uint8_t)((p0[6 * j + c] + p0[6 * j + 3 + c] + p1[6 * j + c] + p1[6 * j + 3 + c] + 2) >> 2);
+    }
+}
+
 // ------------------------------------------------------------------ AREA, general (float tables)
 struct AreaDev {
     const int *xstart, *xcount, *xaoff; const float* xalpha;
@@ -1298,6 +1546,7 @@ struct TableSet {
     void* blob = nullptr;     // one device allocation
     const int *xofs = nullptr, *yofs = nullptr;
     const short *xco = nullptr, *yco = nullptr;
+    const void* yrows = nullptr;  // CUBIC: per destination row {footprint advance, yco * 2^-22 as floats, first footprint row} (UpRow)
     bool ysym = false;        // step2 and the one set of row weights is mirror-symmetric (vpass_px's VSYM form)
     bool step2 = false;       // xofs[d] = xofs[0] + 2d and yofs[d] = yofs[0] + 2d: k_resize_2x_roll applies
     AreaDev area{};
@@ -1404,6 +1653,20 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         build_tap_axis(sw, dw, scale_x, interp, true, &tx);
         build_tap_axis(sh, dh, scale_y, interp, false, &ty);
         o[0] = put(blob, tx.ofs); o[1] = put(blob, tx.coef); o[2] = put(blob, ty.ofs); o[3] = put(blob, ty.coef);
+        if (interp == IMP_INTER_CUBIC) {
+            std::vector<UpRow> yr((size_t)dh + 1);          // + a sentinel the kernel's one-row look-ahead may read
+            for (int d = 0; d < dh; d++) {
+                yr[d].first = ty.ofs[d] - 1;
+                yr[d].adv = d ? ty.ofs[d] - ty.ofs[d - 1] : 0;
+                for (int k = 0; k < 4; k++)     // the constants of VResizeCubicVec_32s8u's multiplies: one IEEE multiply each
+                    yr[d].bf[k] = (float)ty.coef[(size_t)d * 4 + k] * (1.f / (2048.f * 2048.f));
+                yr[d].pad[0] = yr[d].pad[1] = 0;
+            }
+            yr[dh] = yr[dh - 1];
+            yr[dh].adv = 0;
+            while (blob.size() % 32) blob.push_back(0);
+            o[4] = put(blob, yr);
+        }
         ts.step2 = true;
         for (int d = 1; d < dw && ts.step2; d++) ts.step2 = tx.ofs[d] == tx.ofs[0] + 2 * d;
         for (int d = 1; d < dh && ts.step2; d++) ts.step2 = ty.ofs[d] == ty.ofs[0] + 2 * d;
@@ -1431,6 +1694,7 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
     } else {
         ts.xofs = (const int*)(dev + o[0]); ts.xco = (const short*)(dev + o[1]);
         ts.yofs = (const int*)(dev + o[2]); ts.yco = (const short*)(dev + o[3]);
+        ts.yrows = interp == IMP_INTER_CUBIC ? (const void*)(dev + o[4]) : nullptr;
     }
     TableEntry& e = C.m[key];
     e.ts = ts;
@@ -1449,7 +1713,15 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
     } else if (interp == IMP_INTER_AREA) {
         const int isx = (int)std::lrint(scale_x), isy = (int)std::lrint(scale_y);
         if (std::fabs(scale_x - isx) < 2.220446049250313e-16 && std::fabs(scale_y - isy) < 2.220446049250313e-16) {
-            hipLaunchKernelGGL((k_resize_area_int<CN>), grid, block, 0, s, a, isx, isy);
+            const bool rows4 = !(((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.sstep | (uintptr_t)a.dstep |
+                                  (uintptr_t)a.src_stride | (uintptr_t)a.dst_stride) & 3);
+            if (isx == 2 && isy == 2 && (CN == 4 || CN == 3) && rows4 && a.sw == 2 * a.dw && a.sh >= 2 * a.dh) {
+                const int qpr = (a.dw + 3) / 4;                  // lanes per destination row
+                const dim3 qgrid((unsigned)(((long long)qpr * a.dh + 255) / 256), (unsigned)count);
+                if (CN == 4) hipLaunchKernelGGL(k_area2x2_v4, qgrid, block, 0, s, a, qpr);
+                else hipLaunchKernelGGL(k_area2x2_v3, qgrid, block, 0, s, a, qpr);
+            } else
+                hipLaunchKernelGGL((k_resize_area_int<CN>), grid, block, 0, s, a, isx, isy);
         } else {
             TableSet ts;
             if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, s, &ts)) return rc;
@@ -1545,6 +1817,22 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                 hipLaunchKernelGGL((k_resize_2x_roll<4, M_CUBIC>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, (a.dw * 4) & ~7);
             else
                 hipLaunchKernelGGL((k_resize_2x_roll<8, M_LANCZOS>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
+        } else if (CN == 4 && interp == IMP_INTER_CUBIC && scale_y <= 1.0 && scale_x <= 2.0 && a.sw >= 4 &&
+                   (long long)a.dh * a.dstep < (1LL << 32) && !std::getenv("IMPGPU_NO_UP")) {
+            // enlargement (bridge.c:190's CUBIC case): wave-private strips, float H sums in a register ring
+            const int nbx = (a.dw + 255) / 256;                 // four 64-column strips per block, one per wave
+            // few frames: shorter row chunks so that every CU still gets waves
+            static const int up_rows = std::getenv("IMPGPU_UP_ROWS") ? std::atoi(std::getenv("IMPGPU_UP_ROWS")) : UP_ROWS;
+            // rows per wave chunk: as many as keep the chunk's source footprint (strip columns x footprint rows, from the
+            // bound floor(n * scale) + 1 on how far n + 1 sample positions spread, + 3 taps + 1) inside the wave's LDS
+            // patch, at most UP_ROWS; fewer when there are too few frames to fill the chip otherwise
+            const int wmax = (int)std::floor(63 * scale_x) + 6;
+            int rpw = std::max(4, std::min(up_rows, 512)) & ~3;
+            while (rpw > 4 && ((int)std::floor((rpw - 1) * scale_y) + 6) * wmax > UP_CAP_PX) rpw -= 4;
+            while (rpw > 16 && (long long)nbx * 4 * ((a.dh + rpw - 1) / rpw) * count < 8192) rpw -= rpw > 64 ? 64 : 16;
+            const int ncy = (a.dh + rpw - 1) / rpw;
+            hipLaunchKernelGGL(k_resize_up_cubic4, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
+                               ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
         } else if (CN == 4 && scale_x <= 2.0 && scale_y <= 2.0 && a.sw >= 8) {
             static const int th = std::getenv("IMPGPU_TILE_TH") ? std::atoi(std::getenv("IMPGPU_TILE_TH")) : 8;
             const int ntx = (a.dw + TL_TW - 1) / TL_TW, nty = (a.dh + th - 1) / th;

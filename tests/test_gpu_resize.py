@@ -203,3 +203,45 @@ def test_dma_ring_results_do_not_depend_on_timing(gpu, c):
         want = orc.cv_resize(arr, 512, 240, interp)
         for rep in range(12):
             assert np.array_equal(gpu_resize(gpu, arr, 512, 240, interp), want), (NAMES[interp], rep)
+
+
+@pytest.mark.parametrize("shape", [((270, 480), (1080, 1920)), ((100, 161), (333, 515)), ((64, 4), (200, 9)), ((50, 100), (200, 80)),
+                                   ((37, 41), (37, 123)), ((90, 7), (91, 8)), ((33, 200), (1000, 230))])
+def test_cubic_enlargement_kernel_bit_exact(gpu, shape):
+    """The reference's only CUBIC dispatch (bridge.c:190: an axis grows): k_resize_up_cubic4 -- float H sums in LDS, scalar
+    row weights.  Full 480x270 -> 1080p, odd widths (a scalar tail pixel in every row), 4-pixel-wide sources, x shrinking
+    while y grows, and the edge columns the 2.4.9 x rule pins to src[0] / src[w-1]."""
+    (sh, sw), (dh, dw) = shape
+    for arr in (noise_image(sh, sw, 4, 21), smooth_image(sh, sw, 4)):
+        want = orc.cv_resize(arr, dw, dh, orc.INTER_CUBIC)
+        got = gpu_resize(gpu, arr, dw, dh, orc.INTER_CUBIC)
+        assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
+        if dw > sw:     # OpenCV 2.4.9's x-edge rule: the outermost columns are the source's, resampled vertically only
+            col = orc.cv_resize(arr[:, :1], 1, dh, orc.INTER_CUBIC)          # (a 1-pixel row takes the integer vertical form,
+            assert np.abs(got[:, :1].astype(int) - col).max() <= 1          #  a wide one the SSE2 float form: within one LSB)
+
+
+@pytest.mark.parametrize("c", [3, 4])
+@pytest.mark.parametrize("shape", [(540, 960), (64, 64), (33, 45), (7, 3), (1, 1), (100, 2), (12, 1023)])
+def test_area_2x2_streaming_kernel_bit_exact(gpu, c, shape):
+    """k_area2x2_v4 / _v3: (a+b+c+d+2)>>2 with four destination pixels per lane; widths that leave a partial quad."""
+    dh, dw = shape
+    arr = noise_image(2 * dh, 2 * dw, c, 22)
+    box = (arr[0::2, 0::2].astype(int) + arr[0::2, 1::2] + arr[1::2, 0::2] + arr[1::2, 1::2] + 2) >> 2
+    got = gpu_resize(gpu, arr, dw, dh, orc.INTER_AREA)
+    assert np.array_equal(got, box.astype(np.uint8)) and np.array_equal(got, orc.cv_resize(arr, dw, dh, orc.INTER_AREA))
+
+
+def test_area_2x2_on_a_cropped_view_and_batch(gpu):
+    """Crop folded into the box filter's source view (unaligned 16-byte loads) and a batch through the batch entry point."""
+    arr = noise_image(200, 300, 4, 23)
+    im = gpu.Image(arr)
+    cfg = gpu.Config()
+    rc, step = gpu.run_ops(im, cfg, crop="101px,66px,7px,5px", resize="50,33")       # (101, 66) -> clamp -> AREA general, not 2x
+    assert rc == 0
+    im.release()
+    im = gpu.Image(arr)
+    rc, step = gpu.run_ops(im, cfg, crop="100px,66px,7px,5px", resize="50,33")       # exact 2x of the 100 x 66 window at (7, 5)
+    want = orc.resize(orc.crop(arr, "100px,66px,7px,5px")[1], "50,33")[1]
+    assert rc == 0 and np.array_equal(im.numpy(), want)
+    im.release()

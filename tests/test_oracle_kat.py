@@ -261,3 +261,233 @@ def test_gaussian_matches_float_convolution_within_one():
         got = orc.gaussian(a, sigma).astype(np.float64)
         assert np.abs(got - np.clip(np.rint(ref), 0, 255)).max() <= 1
         assert abs(kq.sum() - 1.0) < 0.05
+
+
+# ---- independent pins for the hand-written filters (filters.c:524-729, helpers.c:70-176).  The product's host code
+# (imp_args.cpp) and the oracle (oracle/orc_filters.c) were written from the same reading of the reference, so a shared
+# misreading would pass every product-vs-oracle test.  Each check below restates the DOCUMENTED behaviour in float64
+# numpy (docs/03 - Usage.md, the textbook colour maths) or as a closed form, shares no code or table with oracle/, and
+# states its tolerance: the reference truncates where the textbook rounds, so +-1 is the usual bound.
+def _textbook_hsv(bgr):
+    """OpenCV-convention 8-bit HSV in float64: H in [0, 180), S and V in [0, 255]."""
+    b, g, r = [bgr[..., i].astype(np.float64) for i in range(3)]
+    v = np.maximum(np.maximum(r, g), b)
+    mn = np.minimum(np.minimum(r, g), b)
+    d = v - mn
+    s = np.where(v > 0, 255.0 * d / np.maximum(v, 1), 0.0)
+    dd = np.maximum(d, 1e-12)
+    h = np.where(v == r, 30.0 * (g - b) / dd, np.where(v == g, 60.0 + 30.0 * (b - r) / dd, 120.0 + 30.0 * (r - g) / dd))
+    h = np.where(d == 0, 0.0, h)
+    h = np.where(h < 0, h + 180.0, h)
+    return h, s, v
+
+
+def _textbook_hsv_to_bgr(h, s, v):
+    """Sector formula on float64 (h in half-degrees)."""
+    hh = (h * 2.0) / 60.0
+    i = np.floor(hh)
+    f = hh - i
+    s1 = s / 255.0
+    p, q, t = v * (1 - s1), v * (1 - s1 * f), v * (1 - s1 * (1 - f))
+    i = i.astype(int) % 6
+    r = np.choose(i, [v, q, p, p, t, v])
+    g = np.choose(i, [t, v, v, q, p, p])
+    b = np.choose(i, [p, p, t, v, v, q])
+    return np.stack([b, g, r], axis=-1)
+
+
+def test_pin_a9_rgb2hsv_against_textbook_within_one():
+    a = noise_image(64, 64, 3, 40)
+    got = orc.rgb2hsv(a).astype(np.float64)
+    h, s, v = _textbook_hsv(a)
+    assert np.array_equal(got[..., 2], v)                            # value is the exact maximum
+    # the reference truncates the integer quotients toward zero (helpers.c:89-97): within one unit below the real value
+    assert np.all(np.abs(got[..., 1] - s) < 1.0 + 1e-9)
+    dh = np.abs(got[..., 0] - h)
+    dh = np.minimum(dh, 180.0 - dh)
+    assert np.all(dh[s >= 1.0] < 1.0 + 1e-9)                         # (s < 1 truncates to 0, where the reference skips the hue)
+
+
+def test_pin_a9_hsv2rgb_against_sector_formula_within_one():
+    rng = np.random.Generator(np.random.PCG64(41))
+    hsv = np.stack([rng.integers(0, 180, (48, 48)), rng.integers(0, 256, (48, 48)), rng.integers(0, 256, (48, 48))], axis=-1).astype(np.uint8)
+    got = orc.hsv2rgb(hsv).astype(np.float64)
+    want = _textbook_hsv_to_bgr(hsv[..., 0].astype(np.float64), hsv[..., 1].astype(np.float64), hsv[..., 2].astype(np.float64))
+    # p, q, t are truncated to int (helpers.c:132-134) from float32 products: never above the real value, less than 1 below
+    d = want - got
+    assert d.min() > -1e-3 and d.max() < 1.0 + 1e-3
+
+
+def test_pin_a10_modulate_closed_forms():
+    a = noise_image(40, 50, 3, 42)
+    # saturation 0: every pixel becomes its own maximum on all channels, exactly (HSV2RGB's s == 0 branch)
+    rc, out = orc.filter(a, "modulate=0,0,100")
+    assert rc == 0 and np.array_equal(out, np.repeat(a.max(axis=2, keepdims=True), 3, axis=2))
+    # brightness 50 %: value halves (docs/03: "brightness ... percent"), so does every channel -- up to the 8-bit HSV trip:
+    # the hue is an integer count of half-degrees, worth chroma / 30 per unit, plus the truncations of S, p, q, t
+    rc, out = orc.filter(a, "modulate=0,100,50")
+    chroma = (a.max(axis=2, keepdims=True).astype(float) - a.min(axis=2, keepdims=True)) * 0.5
+    assert (np.abs(out.astype(float) - a.astype(float) * 0.5) <= chroma / 30.0 + 2.5).all()
+    assert np.array_equal(out.max(axis=2), a.max(axis=2) // 2)                 # the value channel itself is exact
+    # hue +90 half-degrees = 180 degrees: primaries turn into their complements exactly
+    prim = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0], [0, 255, 255]]], np.uint8)          # B,G,R: red, green, blue, yellow
+    rc, out = orc.filter(prim, "modulate=90,100,100")
+    assert out[0].tolist() == [[255, 255, 0], [255, 0, 255], [0, 255, 255], [255, 0, 0]]        # cyan, magenta, yellow, blue
+    # documented argument ranges (filters.c:148-153)
+    assert orc.filter(a, "modulate=181,100,100")[0] == 50 and orc.filter(a, "modulate=0,100,0")[0] == 50
+
+
+def test_pin_a11_colorize_is_a_weighted_average_within_one():
+    a = noise_image(30, 40, 4, 43)
+    for color, op in (("ff8000", 0.3), ("102030", 0.5), ("00ff00", 0.85)):
+        rc, out = orc.filter(a, "colorize=%s,%s" % (color, op))
+        rgb = [int(color[i:i + 2], 16) for i in (0, 2, 4)]
+        want = (1 - op) * a[..., :3].astype(np.float64) + np.array(rgb[::-1]) * op      # memory order is B,G,R
+        d = want - out[..., :3].astype(np.float64)
+        assert rc == 0 and d.min() > -0.01 and d.max() < 1.01                           # truncated, float32 arithmetic
+        assert np.array_equal(out[..., 3], a[..., 3])                                   # alpha untouched (filters.c:613)
+    assert np.array_equal(orc.filter(a, "colorize=123456,0")[1], a)
+    solid = orc.filter(a, "colorize=123456,1")[1]
+    assert (solid[..., 0] == 0x56).all() and (solid[..., 1] == 0x34).all() and (solid[..., 2] == 0x12).all()
+
+
+def test_pin_a12_gamma_closed_form():
+    a = noise_image(30, 40, 4, 44)
+    assert np.array_equal(orc.filter(a, "gamma=1")[1], a)
+    for g in (2.2, 0.45, 1.6):
+        want = np.floor(255.0 * (a.astype(np.float64) / 255.0) ** (1.0 / g) + 1e-9)
+        out = orc.filter(a, "gamma=%s" % g)[1].astype(np.float64)
+        assert np.abs(out - want).max() <= 1          # 1/g is a float in the reference (filters.c:562); alpha included (:554)
+        assert (out[a == 0] == 0).all() and (out[a == 255] == 255).all()
+
+
+def test_pin_a13_contrast_closed_form():
+    a = noise_image(30, 40, 4, 45)
+    assert np.array_equal(orc.filter(a, "contrast=1")[1], a)
+    out = orc.filter(a, "contrast=2")[1]
+    assert np.array_equal(out[..., :3], np.minimum(a[..., :3].astype(int) * 2, 255).astype(np.uint8))     # exact in float32
+    assert np.array_equal(out[..., 3], a[..., 3])                                                         # channels < 3 only (filters.c:599)
+    half = orc.filter(a, "contrast=0.5")[1]
+    assert np.array_equal(half[..., :3], a[..., :3] // 2)
+    assert orc.filter(a, "contrast=0")[0] == 50 and orc.filter(a, "contrast=-1")[0] == 50
+
+
+def test_pin_a14_gradmap_endpoints_and_midpoints():
+    gray = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)              # (R+G+B)/3 = the level itself
+    lvl = np.arange(256, dtype=np.float64)
+    rc, out = orc.filter(gray, "gradmap=000000,ffffff")
+    # 256 steps from the first colour towards (never reaching) the second: level i -> round(255 i / 256) (filters.c:583-586)
+    assert rc == 0 and np.array_equal(out[0, :, 0], np.floor(lvl * 255 / 256 + 0.5).astype(np.uint8)) and out[0, 255, 0] == 254
+    assert (out[..., 0] == out[..., 1]).all() and (out[..., 1] == out[..., 2]).all()
+    rc, out = orc.filter(gray, "gradmap=ff0000,0000ff")                                     # colours are R,G,B; memory is B,G,R
+    assert np.array_equal(out[0, :, 2], np.floor(255 - lvl * 255 / 256 + 0.5).astype(np.uint8))    # red falls ...
+    assert np.array_equal(out[0, :, 0], np.floor(lvl * 255 / 256 + 0.5).astype(np.uint8))          # ... blue rises, green stays 0
+    assert (out[0, :, 1] == 0).all()
+    rc, out = orc.filter(gray, "gradmap=000000,ff0000,ffffff")                              # three colours: two segments of 128
+    assert out[0, 0].tolist() == [0, 0, 0] and out[0, 128].tolist() == [0, 0, 255] and out[0, 64].tolist() == [0, 0, 128]
+    assert out[0, 192].tolist() == [128, 128, 255]
+    # a colourful pixel is indexed by its integer mean (filters.c:267-271)
+    px = np.array([[[10, 20, 40]]], np.uint8)
+    assert orc.filter(px, "gradmap=000000,ffffff")[1][0, 0].tolist() == [23, 23, 23]         # (10+20+40)/3 = 23 -> round(22.9)
+
+
+def test_pin_a16_vignette_on_gray_follows_cos4():
+    h, w = 61, 81
+    a = np.full((h, w, 3), 200, np.uint8)
+    intensity, radius = 0.8, 1.0
+    rc, out = orc.filter(a, "vignette=%s,%s" % (intensity, radius))
+    cx, cy = w // 2, h // 2
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = np.sqrt((xx - cx) ** 2.0 + (yy - cy) ** 2.0)
+    maxd = max(np.hypot(cx, cy), np.hypot(w - cx, cy), np.hypot(cx, h - cy), np.hypot(w - cx, h - cy))    # corners at (w, h): helpers.c:52-55
+    want = 200.0 * np.cos(d / (radius * maxd) * intensity) ** 4
+    # gray stays gray (S = 0) and V is truncated (filters.c:316): +-1 covers float32 vs float64
+    assert rc == 0 and (out[..., 0] == out[..., 1]).all() and (out[..., 1] == out[..., 2]).all()
+    diff = want - out[..., 0].astype(np.float64)
+    assert diff.min() > -1.0 and diff.max() < 1.0 + 1e-6
+    assert out[cy, cx, 0] == 200
+
+
+def test_pin_a17_lomo_kelvin_gotham():
+    a = noise_image(30, 40, 4, 46)
+    lomo = orc.filter(a, "lomo=1")[1]
+    want = np.clip(np.trunc(a[..., 1:3].astype(np.float64) * 1.5 - 50), 0, 255)             # G and R only (filters.c:340)
+    assert np.array_equal(lomo[..., 1:3], want.astype(np.uint8)) and np.array_equal(lomo[..., [0, 3]], a[..., [0, 3]])
+    # Kelvin and Gotham are fixed chains of the public filters (filters.c:325-354): the same bytes as spelling them out
+    k = orc.filter(orc.filter(a, "modulate=120,50,100")[1], "colorize=ff9900,0.5")[1]
+    assert np.array_equal(orc.filter(a, "kelvin=1")[1], k)
+    g = orc.filter(orc.filter(orc.filter(a, "modulate=120,5,100")[1], "colorize=111b5d,0.15")[1], "gamma=0.3")[1]
+    # last stage: brightness -0.07, contrast 1.5 -> trunc(1.5 v - 17.85) clamped, channels B,G,R (no public spelling)
+    want = np.clip(np.trunc(1.5 * g[..., :3].astype(np.float64) + np.float32(-0.07) * np.float32(255)), 0, 255)
+    got = orc.filter(a, "gotham=1")[1]
+    assert np.abs(got[..., :3].astype(np.float64) - want).max() <= 1 and np.array_equal(got[..., 3], g[..., 3])
+
+
+def test_pin_a18_rainbow_bands():
+    # one pixel per documented band centre (filters.c:375-394), value 200: the band's hue at full saturation
+    def pure(hue_deg, v=200):
+        return _textbook_hsv_to_bgr(np.array([[hue_deg / 2.0]]), np.array([[255.0]]), np.array([[float(v)]]))[0, 0]
+    cases = {0: 0, 20: 30, 50: 60, 100: 120, 170: 195, 230: 225, 300: 285, 350: 0}
+    for hue_in, hue_out in cases.items():
+        px = np.rint(pure(hue_in)).astype(np.uint8)[None, None, :]
+        got = orc.filter(px, "rainbow=full")[1][0, 0].astype(np.float64)
+        want = pure((hue_out // 2) * 2)                                                     # the stored hue is an integer half-degree count
+        assert np.abs(got - want).max() <= 1.0, (hue_in, got, want)
+    dark = np.array([[[5, 10, 15]]], np.uint8)
+    assert orc.filter(dark, "rainbow=full")[1][0, 0].tolist() == [0, 0, 0]                  # V < 20 -> black
+    white = np.array([[[255, 255, 255]]], np.uint8)
+    assert orc.filter(white, "rainbow=mid")[1][0, 0].tolist() == [255, 255, 255]            # V > 254 -> unsaturated
+    assert orc.filter(white, "rainbow=sepia")[0] == 50
+
+
+def test_pin_a6_alpha_blend_is_porter_duff_over_with_subtracted_opacity():
+    rng = np.random.Generator(np.random.PCG64(47))
+    base = rng.integers(0, 256, (40, 60, 4), dtype=np.uint8)
+    ov = rng.integers(0, 256, (16, 24, 4), dtype=np.uint8)
+    for opacity in (100, 60, 25):
+        rc, out = orc.watermark(base, ov, "l", "t", 3, 5, opacity)
+        sa = np.maximum(ov[..., 3] / 255.0 - (1 - opacity / 100.0), 0.0)                    # opacity SUBTRACTS from alpha (filters.c:620,642)
+        da = base[5:21, 3:27, 3] / 255.0
+        ta = sa + da * (1 - sa)
+        num = ov[..., :3] * sa[..., None] + base[5:21, 3:27, :3] * (da * (1 - sa))[..., None]
+        want = np.where(ta[..., None] > 0, num / np.maximum(ta[..., None], 1e-30), 0.0)
+        region = out[5:21, 3:27].astype(np.float64)
+        d = want - region[..., :3]
+        assert rc == 0 and d.min() > -1.01 and d.max() < 1.01                                # truncation + float32
+        assert np.abs(ta * 255.0 - region[..., 3]).max() < 1.01
+        untouched = out.copy()
+        untouched[5:21, 3:27] = base[5:21, 3:27]
+        assert np.array_equal(untouched, base)                                              # nothing outside the overlay rectangle
+    # 3-channel destination: destination alpha is 1, no alpha written
+    rc, out = orc.watermark(base[..., :3].copy(), ov, "r", "b", 0, 0, 100)
+    sa = ov[..., 3] / 255.0
+    want = ov[..., :3] * sa[..., None] + base[-16:, -24:, :3] * (1 - sa)[..., None]
+    d = want - out[-16:, -24:].astype(np.float64)
+    assert rc == 0 and d.min() > -1.01 and d.max() < 1.01
+
+
+def test_pin_a8_flatten_on_white_paper():
+    a = noise_image(30, 40, 4, 48)
+    out = orc.blend_with_paper(a)
+    al = a[..., 3:4].astype(np.float64) / 255.0
+    want = 255.0 * (1 - al) + a[..., :3] * al                                               # white paper under the pixel
+    d = want - out[..., :3].astype(np.float64)
+    assert d.min() > -0.01 and d.max() < 1.01 and (out[..., 3] == 255).all()
+    opaque = a.copy()
+    opaque[..., 3] = 255
+    assert np.array_equal(orc.blend_with_paper(opaque), opaque)
+    clear = a.copy()
+    clear[..., 3] = 0
+    assert (orc.blend_with_paper(clear)[..., :3] == 255).all()
+
+
+def test_pin_a19_brightness_is_the_weighted_rms_mean():
+    for c, seed in ((3, 49), (4, 50)):
+        a = noise_image(48, 64, c, seed)                                                    # small: the float accumulator is still exact to 1e-6
+        b, g, r = [a[..., i].astype(np.float64) for i in range(3)]
+        want = np.sqrt(0.241 * r * r + 0.691 * g * g + 0.068 * b * b).mean() / 255.0
+        got = orc.brightness(a)
+        assert abs(got - want) < 1e-4 and int(round(got * 100)) == int(round(want * 100))  # Info() reports the integer percent
+    gray = noise_image(20, 30, 1, 51)
+    assert abs(orc.brightness(gray) - gray.mean() / 255.0) < 1e-5
+    assert orc.brightness(np.full((8, 8, 3), 255, np.uint8)) == pytest.approx(1.0, abs=1e-6)
