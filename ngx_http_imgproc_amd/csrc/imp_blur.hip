@@ -239,6 +239,120 @@ __global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ large radii: column strips with an LDS ring
+// radius 17 .. 60 (sigma up to 20; `docs/03 - Usage.md:224`: "execution time is proportional to sigma").  The two-pass
+// fallback parks an int32 plane in HBM and re-reads it 2r+1 times through L2 (sigma = 8: 147 us per 1080p frame, 1.4 % of
+// the roofline).  Here the row sums never leave the CU: a 256-thread block owns 64 columns and walks down a strip of rows,
+// four source rows per step (one per wave):
+//   (a) a wave copies its source row's segment (64 + 2r pixels, edge-replicated) into LDS -- the pixels were requested
+//       one step earlier, and the previous step's output pixel is stored right after that wait and BEFORE the next
+//       request, so the wait (loads and stores share vmcnt) never covers a store younger than one whole step;
+//   (b) row pass out of that segment: lane i reads dwords i .. i+2r, two taps per v_dot2_i32_i16 after v_perm_b32 pairs
+//       the channel bytes (exact integers), and parks the four sums AS FLOATS (exact: < 2^16) in ring row (y mod RH);
+//   (c) one barrier; then each wave runs SymmColumnVec_32s8u's float sequence for the output row whose last tap row
+//       was just written: s = f0*c; s += f_k * (row[+k] + row[-k]) for k = 1..r -- the integer add of the SSE2 code is
+//       exact in float too (< 2^17) -- channel pairs in packed FP32, then round-half-even + saturate (v_cvt_pk_u8_f32).
+// The ring holds RH >= 2r + 8 rows (a power of two), so the rows a fast wave writes in the next step are never rows a
+// slower wave still reads in this one: one barrier per step is enough.
+typedef float bl_float2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t bl_cvt_pk_u8(float x, uint32_t acc, int byte) {   // saturate_u8(round-half-even(x)) into one byte
+    uint32_t r;
+    asm("v_cvt_pk_u8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(byte), "v"(acc));
+    return r;
+}
+
+template <int RH>
+__global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
+                                                     uint8_t* __restrict__ dst, long long dstride, int dstep,
+                                                     const int* __restrict__ kxp, const float* __restrict__ kyf, int r, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int npair = r + 1;                                   // 2r+1 taps -> r+1 pairs, the last one (tap, 0)
+    const int SEGW = (64 + 2 * r + 2 + 3) & ~3;                // +2: the padded last pair reads one dword further
+    uint32_t* s_kx = (uint32_t*)smem;                          // packed (k[2j], k[2j+1]) as 2 x i16
+    float* s_ky = (float*)(s_kx + ((npair + 3) & ~3));
+    uint32_t* s_seg = (uint32_t*)(s_ky + ((r + 1 + 3) & ~3));  // [4][SEGW]
+    float4* s_ring = (float4*)(s_seg + 4 * SEGW);              // [RH][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * 64;
+    const int y0 = blockIdx.y * rows_per_block, y1 = min(h, y0 + rows_per_block);
+    const uint8_t* S = src + (long long)blockIdx.z * sstride;
+    uint8_t* D = dst + (long long)blockIdx.z * dstride + (size_t)min(x0 + lane, w - 1) * 4;
+    const bool live = x0 + lane < w;
+    for (int i = tid; i < npair; i += 256) s_kx[i] = (uint32_t)kxp[i];
+    for (int i = tid; i <= r; i += 256) s_ky[i] = kyf[i];
+
+    // this lane's (up to four) columns of a segment, clamped into the row
+    int sxc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) sxc[q] = min(max(x0 - r + lane + 64 * q, 0), w - 1) * 4;
+    const int nq = (SEGW + 63) / 64;                           // dwords per lane per segment (<= 4 for r <= 60)
+    uint32_t* seg = s_seg + wv * SEGW;
+    auto request = [&](int ys, uint32_t* v) {
+        const uint8_t* row = S + (size_t)min(max(ys, 0), h - 1) * sstep;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < nq) v[q] = *(const uint32_t*)(row + sxc[q]);
+    };
+
+    uint32_t cur[4], out_px = 0;
+    int out_y = -1;                                            // output row whose pixel waits in out_px
+    int ys = y0 - r + wv;                                      // this wave's source row of the step
+    request(ys, cur);
+    __syncthreads();                                           // taps are in LDS
+    for (; ys - wv <= y1 - 1 + r; ys += 4) {
+        // (a) the segment of row ys -> LDS; last step's pixel out; next row in flight
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < nq && lane + 64 * q < SEGW) seg[lane + 64 * q] = cur[q];
+        if (out_y >= 0 && live) *(uint32_t*)(D + (size_t)out_y * dstep) = out_px;
+        out_y = -1;
+        request(ys + 4, cur);
+        // (b) row pass
+        {
+            const uint32_t* win = seg + lane;
+            int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int j = 0; j < npair; j++) {
+                const uint32_t p0 = win[2 * j], p1 = win[2 * j + 1];
+                bl_short2 kk;
+                const uint32_t kw = s_kx[j];
+                __builtin_memcpy(&kk, &kw, 4);
+                bl_short2 c;
+                uint32_t pr;
+                pr = __builtin_amdgcn_perm(p1, p0, 0x0c040c00u); __builtin_memcpy(&c, &pr, 4); a0 = __builtin_amdgcn_sdot2(c, kk, a0, false);
+                pr = __builtin_amdgcn_perm(p1, p0, 0x0c050c01u); __builtin_memcpy(&c, &pr, 4); a1 = __builtin_amdgcn_sdot2(c, kk, a1, false);
+                pr = __builtin_amdgcn_perm(p1, p0, 0x0c060c02u); __builtin_memcpy(&c, &pr, 4); a2 = __builtin_amdgcn_sdot2(c, kk, a2, false);
+                pr = __builtin_amdgcn_perm(p1, p0, 0x0c070c03u); __builtin_memcpy(&c, &pr, 4); a3 = __builtin_amdgcn_sdot2(c, kk, a3, false);
+            }
+            s_ring[(ys & (RH - 1)) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+        }
+        __syncthreads();
+        // (c) column pass for the row centred r rows above
+        const int yo = ys - r;
+        if (yo >= y0 && yo < y1) {                             // wave-uniform
+            const float4 c = s_ring[(yo & (RH - 1)) * 64 + lane];
+            const float f0 = s_ky[0];
+            bl_float2 sxy = bl_float2{c.x, c.y} * f0 + 0.f, szw = bl_float2{c.z, c.w} * f0 + 0.f;
+            for (int k = 1; k <= r; k++) {
+                // rows replicate at the frame's edges exactly like the CPU's BORDER_REPLICATE: clamp the ROW index, whose
+                // sums are in the ring whenever the clamped row lies inside this block's source range
+                const int ya = min(yo + k, h - 1), yb = max(yo - k, 0);
+                const float4 pa = s_ring[(ya & (RH - 1)) * 64 + lane], pb = s_ring[(yb & (RH - 1)) * 64 + lane];
+                const float f = s_ky[k];
+                sxy = sxy + (bl_float2{pa.x, pa.y} + bl_float2{pb.x, pb.y}) * f;
+                szw = szw + (bl_float2{pa.z, pa.w} + bl_float2{pb.z, pb.w}) * f;
+            }
+            uint32_t px = bl_cvt_pk_u8(sxy.x, 0u, 0);
+            px = bl_cvt_pk_u8(sxy.y, px, 1);
+            px = bl_cvt_pk_u8(szw.x, px, 2);
+            out_px = bl_cvt_pk_u8(szw.y, px, 3);
+            out_y = yo;
+        }
+    }
+    if (out_y >= 0 && live) *(uint32_t*)(D + (size_t)out_y * dstep) = out_px;
+}
+
 // src view -> dst (same size, BGRA, separate buffers).  IMP_ERROR_UNSUPPORTED when the fused form does not apply
 // (other channel counts, radius > 16, fixed-point taps summing above 257, 1-pixel axes): callers fall back to
 // launch_gaussian.  sigma must give ksize > 1.
@@ -248,14 +362,24 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     if (f.src == f.dst) return IMP_ERROR_UNSUPPORTED;
     if (v.c == 4 && (((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)v.step | (uintptr_t)f.dstep | (uintptr_t)f.src_stride | (uintptr_t)f.dst_stride) & 3))
         return IMP_ERROR_UNSUPPORTED;
-    const int ks = gaussian_ksize(sigma);
-    const int r = ks / 2;
-    if (ks <= 1 || r > 16) return IMP_ERROR_UNSUPPORTED;
+    const int ks0 = gaussian_ksize(sigma);
+    if (ks0 <= 1 || ks0 > 4096) return IMP_ERROR_UNSUPPORTED;
     std::vector<int> ik;
-    gaussian_kernel_fixed(ks, sigma, &ik);
+    gaussian_kernel_fixed(ks0, sigma, &ik);
     long long sum = 0;
     for (int k : ik) sum += k;
     if (sum > 257) return IMP_ERROR_UNSUPPORTED;              // row sums must fit 16 bits
+    // The 8-bit fixed-point taps of a wide Gaussian are ZERO towards both ends (sigma = 8: 49 taps, the outer 4 + 4 round
+    // to 0/256).  A zero tap adds 0 to the integer row sum and +0.0f to the non-negative float column sum -- both exact
+    // no-ops -- and a replicated border pixel under a zero tap is irrelevant, so the kernels run on the non-zero core only.
+    int r = ks0 / 2;
+    {
+        const int r0 = r;
+        while (r > 1 && ik[r0 + r] == 0 && ik[r0 - r] == 0) r--;
+        ik = std::vector<int>(ik.begin() + (r0 - r), ik.begin() + (r0 + r + 1));
+    }
+    const int ks = 2 * r + 1;
+    if (r > 60 || (r > 16 && v.c != 4)) return IMP_ERROR_UNSUPPORTED;
     std::vector<int> blob;
     for (int j = 0; j <= r; j++) {                           // pairs (k[2j], k[2j+1]); the pair past the end is (k[2r], 0)
         const int lo = ik[2 * j], hi = (2 * j + 1 < ks) ? ik[2 * j + 1] : 0;
@@ -273,6 +397,31 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     for (int k = 0; k <= r; k++) blob.push_back(ik[r + k]);
     void* dev_k = nullptr;
     if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
+    if (r > 16) {       // column strips with an LDS ring (k_blur_strip4)
+        const int RH = 2 * r + 8 <= 64 ? 64 : 128;
+        const int SEGW = (64 + 2 * r + 2 + 3) & ~3;
+        const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 2 + 4 * SEGW) * 4 + (size_t)RH * 64 * 16;
+        const int nbx = (v.w + 63) / 64;
+        int rpb = 256;                                         // taller strips recompute fewer halo rows; shorter ones fill the chip
+        while (rpb > 64 && (long long)nbx * ((v.h + rpb - 1) / rpb) * f.count < 1024) rpb /= 2;
+        const dim3 sgrid((unsigned)nbx, (unsigned)((v.h + rpb - 1) / rpb), (unsigned)f.count);
+        hipError_t e = hipSuccess;
+        if (RH == 64) {
+            e = hipFuncSetAttribute((const void*)k_blur_strip4<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL((k_blur_strip4<64>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
+                               (const int*)dev_k, (const float*)((const int*)dev_k + off_f), r, rpb);
+        } else {
+            e = hipFuncSetAttribute((const void*)k_blur_strip4<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL((k_blur_strip4<128>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
+                                   (const int*)dev_k, (const float*)((const int*)dev_k + off_f), r, rpb);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        dev_free_on(dev_k, s);
+        if (e != hipSuccess) { set_error("k_blur_strip4", e); return IMP_ERROR_DEVICE; }
+        return IMP_OK;
+    }
     const int TH = 32;
     const int SW = 64 + 2 * r + 2, SH = TH + 2 * r;
     const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + ((SW * SH + 3) & ~3)) * 4 + (size_t)SH * 64 * 8;

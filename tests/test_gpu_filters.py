@@ -77,6 +77,31 @@ def test_blur_large_sigma_and_thin_images(gpu):
         assert rc == 0 and np.array_equal(got, orc.gaussian(a, 2.0)), shape
 
 
+@pytest.mark.parametrize("sigma", ["2.8", "3", "4.5", "4.7", "8", "9.9", "12", "20"])    # radii 17, 18, 27, 28 (ring 64), 29.., 60 (ring 128)
+def test_blur_large_radius_strip_kernel_bit_exact(gpu, sigma):
+    """k_blur_strip4: radius 17..60 on BGRA -- column strips with the row sums in an LDS ring.  Frames narrower than a strip,
+    shorter than the radius (every tap row clamps), taller than one block's strip, and widths that are no multiple of 64."""
+    for shape in [(70, 130), (300, 67), (9, 200), (131, 64), (64, 1), (2, 3)]:
+        arr = noise_image(shape[0], shape[1], 4, 14) if shape[0] % 2 else smooth_image(shape[0], shape[1], 4)
+        want = orc.gaussian(arr, float(np.float32(sigma)))
+        rc, got = run_filter(gpu, arr, "blur=" + sigma)
+        assert rc == 0
+        assert np.array_equal(got, want), "sigma %s %r: max diff %d" % (sigma, shape, np.abs(got.astype(int) - want.astype(int)).max())
+
+
+def test_blur_sigma8_full_hd_and_after_crop(gpu):
+    arr = noise_image(1080, 1920, 4, 15)
+    rc, got = run_filter(gpu, arr, "blur=8")
+    assert rc == 0 and np.array_equal(got, orc.gaussian(arr, 8.0))
+    # a cropped view as the source (unaligned window, pitch of the uncropped frame)
+    im = gpu.Image(arr[:300, :400].copy())
+    cfg = gpu.Config()
+    rc, step = gpu.run_ops(im, cfg, crop="301px,177px,13px,9px", filters=["blur=6"])
+    want = orc.gaussian(orc.crop(arr[:300, :400].copy(), "301px,177px,13px,9px")[1], 6.0)
+    assert rc == 0 and np.array_equal(im.numpy(), want)
+    im.release()
+
+
 def test_filter_error_codes_match(gpu):
     arr = noise_image(16, 16, 4, 13)
     for req, allow in [("nosuch=1", 1), ("flip", 1), ("flip=2", 1), ("flip=101", 1), ("rotate=45", 1), ("modulate=1,2", 1),
