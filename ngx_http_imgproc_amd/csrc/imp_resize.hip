@@ -583,6 +583,151 @@ __global__ __launch_bounds__(256) void k_resize_up_cubic4(RArgs a, const int* __
     }
 }
 
+// The same for 3-channel frames -- what cvDecodeImage hands Resize() for every JPEG, so every JPEG enlargement
+// (k_resize_taps<4,3> re-did the whole 4 x 4 footprint per output pixel: 0.056 of the roofline).  Differences from the
+// BGRA kernel: the LDS patch holds the strip's source bytes (3 per pixel, rows padded to dwords); a lane's window is the
+// 12 bytes at byte 3 * (first tap), taken as four aligned dwords + v_alignbyte_b32 and reduced by hpass_bgr's fixed-byte
+// perm + dot2; the ring keeps (B,G) as a packed pair and R alone; four finished rows (4 x 192 bytes) leave the patch as
+// three dword stores per lane.  The scalar tail of a row ((3 dw) % 8 bytes, up to the last three pixels) again lies only
+// in the last, partial strip, which takes the generic path.
+template <int KS>
+__device__ __forceinline__ void hpass_bgr(const uint32_t* w, const short2_t* axp, int* h);
+
+#define UP_CAP3_BYTES 6144   // bytes of source a wave stages in LDS
+
+__global__ __launch_bounds__(256) void k_resize_up_cubic3(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                          const short* __restrict__ yco, const UpRow* __restrict__ rows,
+                                                          int vec_end, int nbx, int rows_per_wave) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tr[4][4 * 192];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[4][UP_CAP3_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cy = blockIdx.x / nbx, bx = blockIdx.x - cy * nbx;
+    const int tx0 = (bx * 4 + wv) * 64;
+    if (tx0 >= a.dw) return;                                   // waves are independent: no barrier follows
+    const int txn = min(64, a.dw - tx0);
+    const bool live = lane < txn;
+    const int dx = tx0 + min(lane, txn - 1);                   // idle lanes of a partial strip shadow its last column
+    const int row0 = cy * rows_per_wave, row_end = min(a.dh, row0 + rows_per_wave);
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride;
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride;
+
+    short2_t axp[2];
+    axp[0].x = xco[dx * 4]; axp[0].y = xco[dx * 4 + 1]; axp[1].x = xco[dx * 4 + 2]; axp[1].y = xco[dx * 4 + 3];
+
+    const int sxmin = __builtin_amdgcn_readfirstlane(xofs[tx0]) - 1;
+    const int W = __builtin_amdgcn_readfirstlane(xofs[tx0 + txn - 1]) + 2 - sxmin + 1;        // strip's source columns
+    const int WB = ((W * 3 + 3) & ~3) + 4;                     // patch row pitch: dword-aligned, + the extra dword a window may touch
+    const int f0 = rows[row0].first;
+    const int NR = rows[row_end - 1].first + 3 - f0 + 1;       // chunk's footprint rows
+    if (NR * WB > UP_CAP3_BYTES) return;   // cannot happen: the launcher sizes chunks from the same bounds; keeps LDS sound
+    for (int i = lane; i < NR * W; i += 64) {                  // border replication happens here, once: clamped row / column
+        const int r = i / W, c = i - r * W;
+        const uint8_t* q = S + (size_t)clampi(f0 + r, 0, a.sh - 1) * a.sstep + (size_t)clampi(sxmin + c, 0, a.sw - 1) * 3;
+        uint8_t* o = &s_src[wv][r * WB + c * 3];
+        o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+    }
+    const int lb = (xofs[dx] - 1 - sxmin) * 3;                 // this lane's first tap byte inside a patch row
+    const int last = f0 + NR - 1;
+    auto fetch = [&](int vy, uint32_t* t) {                    // the four aligned dwords around the 12-byte window of row vy
+        const int o = ((min(vy, last) - f0) * WB + lb) >> 2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) t[k] = ((const uint32_t*)&s_src[wv][0])[o + k];
+    };
+
+    float2v_t hxy[4];                                          // H sums of footprint rows cur .. cur + 3: (B,G) pairs ...
+    float hz[4];                                               // ... and R
+    uint32_t tn[4];                                            // dwords of footprint row cur + 4, requested one advance early
+    int cur = f0 - 4;
+    fetch(cur + 4, tn);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { hxy[k] = float2v_t{0.f, 0.f}; hz[k] = 0.f; }
+    const unsigned sh8 = (unsigned)lb & 3u;
+
+    auto advance = [&]() {
+        uint32_t w[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) w[i] = __builtin_amdgcn_alignbyte(tn[i + 1], tn[i], sh8);
+        int h[3];
+        hpass_bgr<4>(w, axp, h);
+        cur++;
+        fetch(cur + 4, tn);
+        hxy[0] = hxy[1]; hxy[1] = hxy[2]; hxy[2] = hxy[3];
+        hz[0] = hz[1]; hz[1] = hz[2]; hz[2] = hz[3];
+        hxy[3] = float2v_t{__int2float_rn(h[0]), __int2float_rn(h[1])};
+        hz[3] = __int2float_rn(h[2]);
+    };
+    auto vpass = [&](const float* bf) -> uint32_t {            // B | G << 8 | R << 16
+        float2v_t sxy = hxy[0] * bf[0];
+        float sz = __fmul_rn(hz[0], bf[0]);
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            sxy = sxy + hxy[k] * bf[k];
+            sz = __fadd_rn(sz, __fmul_rn(hz[k], bf[k]));
+        }
+        uint32_t px = cvt_pk_u8(sxy.x, 0u, 0);
+        px = cvt_pk_u8(sxy.y, px, 1);
+        return cvt_pk_u8(sz, px, 2);
+    };
+    for (int k = 0; k < 4; k++) advance();
+    int dy = row0;
+
+    if (txn == 64 && !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & 3)) {
+        uint8_t* park = &s_tr[wv][lane * 3];
+        const UpRow* rq = rows + row0;
+        UpRow rc = *rq;
+        rc.adv = 0;
+        uint8_t* Dg = D + (size_t)dy * a.dstep + (size_t)tx0 * 3;
+        const size_t group_bytes = (size_t)a.dstep * 4;
+        // the 4 x 48 dwords of a group go out as three dword stores per lane: dword n = lane + 64 j -> row n / 48, column n % 48
+        unsigned voff[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int n = lane + 64 * j;
+            voff[j] = (unsigned)(n / 48) * (unsigned)a.dstep + (unsigned)(n % 48) * 4u;
+        }
+        for (; dy + 4 <= row_end; dy += 4, Dg += group_bytes) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const UpRow rn = *++rq;
+                if (rc.adv) advance();
+                const uint32_t px = vpass(rc.bf);
+                park[r * 192] = (uint8_t)px; park[r * 192 + 1] = (uint8_t)(px >> 8); park[r * 192 + 2] = (uint8_t)(px >> 16);
+                rc = rn;
+            }
+            asm volatile("" ::: "memory");                     // the compiler must not move the dword reads across the byte writes
+            uint32_t q[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) q[j] = ((const uint32_t*)&s_tr[wv][0])[lane + 64 * j];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 3; j++) *(uint32_t*)(Dg + voff[j]) = q[j];
+        }
+    }
+
+    const bool tail = dx * 3 + 2 >= vec_end;
+    for (; dy < row_end; dy++) {
+        const UpRow rc = rows[dy];
+        while (cur < rc.first) advance();
+        uint32_t px = vpass(rc.bf);
+        if (tail) {
+            const float hc[3][4] = {{hxy[0].x, hxy[1].x, hxy[2].x, hxy[3].x}, {hxy[0].y, hxy[1].y, hxy[2].y, hxy[3].y}, {hz[0], hz[1], hz[2], hz[3]}};
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (dx * 3 + c >= vec_end) {
+                    int v = 1 << 21;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v += __mul24((int)hc[c][k], (int)yco[dy * 4 + k]);
+                    px = (px & ~(0xffu << (8 * c))) | ((uint32_t)shr_sat_u8(v, 22) << (8 * c));
+                }
+        }
+        if (live) {
+            uint8_t* o = D + (size_t)dy * a.dstep + (size_t)dx * 3;
+            o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16);
+        }
+    }
+}
+
 // vertical pass over the register ring at phase U of its period; returns the packed BGRA destination pixel
 // {sat_u8(v0 >> sh), sat_u8(v1 >> sh), sat_u8(v2 >> sh), sat_u8(v3 >> sh)} as bytes 0..3 in two instructions.
 // v_ashr_pk_u8_i32 writes ONE 16-bit half of its destination ({sat(S1 >> S2), sat(S0 >> S2)}) and leaves the other
@@ -880,6 +1025,11 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
                                                        int nbx, int bpf, int count) {
     constexpr int R = 2 * DEPTH + 2;
     __shared__ __attribute__((aligned(16))) uint8_t lds[WPB][R][DMA_SLOT];
+    // four finished rows of a wave's 64 columns, parked only to leave as ONE 16-byte store per lane (4 rows x 256 B per
+    // instruction) instead of four dword stores: stores sit in the same vmcnt queue as the DMA fetches, so every store
+    // still in flight takes one of the 2*DEPTH places the prefetch is allowed to hold -- a store per row and a write
+    // latency of several iterations cut the effective prefetch depth to a fraction of DEPTH
+    __shared__ __attribute__((aligned(16))) uint32_t s_tr[WPB][4][64];
     // one frame per XCD at a time, its blocks in row-major order: an XCD then streams whole source rows (DRAM page
     // runs of 15 KB instead of one 2 KB column band of every frame) and the strips' shared halo rows meet in its L2
     int frame, blk;
@@ -953,7 +1103,11 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
         for (int r = R; r < KS - 2 + 2 * DEPTH; r++) issue(r);
 
         constexpr int UN = KS / 2;
+        // whole groups of four rows of a full strip with a 16-byte aligned destination leave through the LDS patch
+        const bool wide = !EDGE && UN == 4 && !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & 15);
+        const unsigned voff4 = (unsigned)(lane >> 4) * (unsigned)a.dstep + (unsigned)(lane & 15) * 16u;
         for (int i0 = 0; i0 < dyn; i0 += UN) {
+            const bool park = wide && i0 + UN <= dyn;          // wave-uniform
             static_for<UN>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const int i = i0 + u;
@@ -973,9 +1127,16 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
                     hpass_px<KS>(q, axp, ring[(KS - 1 + 2 * u) % KS]);
                     asm volatile("" ::: "memory");             // the slots just read may be refilled from here on
                     const uint32_t px = vpass_px<KS, MODE, u, VSYM>(ring, by, dx, vec_end);
-                    if (!EDGE || live) *(uint32_t*)(D + ((unsigned)(dy0 + i) * (unsigned)a.dstep + lane4)) = px;
+                    if (park) s_tr[wv][u & 3][lane] = px;
+                    else if (!EDGE || live) *(uint32_t*)(D + ((unsigned)(dy0 + i) * (unsigned)a.dstep + lane4)) = px;
                 }
             });
+            if (park) {
+                asm volatile("" ::: "memory");                 // the compiler must not move the 16-byte read across the dword writes
+                const u32x4_t q = *(const u32x4_t*)&s_tr[wv][lane >> 4][(lane & 15) * 4];
+                asm volatile("" ::: "memory");
+                *(u32x4_t*)(D + ((unsigned)(dy0 + i0) * (unsigned)a.dstep + voff4)) = q;
+            }
         }
     };
     if (edge) strip(std::true_type{});
@@ -1817,6 +1978,17 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                 hipLaunchKernelGGL((k_resize_2x_roll<4, M_CUBIC>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, (a.dw * 4) & ~7);
             else
                 hipLaunchKernelGGL((k_resize_2x_roll<8, M_LANCZOS>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
+        } else if (CN == 3 && interp == IMP_INTER_CUBIC && scale_y <= 1.0 && scale_x <= 2.0 && a.sw >= 4 &&
+                   (long long)a.dh * a.dstep < (1LL << 32) && !std::getenv("IMPGPU_NO_UP")) {
+            // enlargement of a 3-channel frame (every JPEG): the BGRA kernel's structure on bytes
+            const int nbx = (a.dw + 255) / 256;
+            const int wbmax = ((((int)std::floor(63 * scale_x) + 6) * 3 + 3) & ~3) + 4;
+            int rpw = UP_ROWS;
+            while (rpw > 4 && ((int)std::floor((rpw - 1) * scale_y) + 6) * wbmax > UP_CAP3_BYTES) rpw -= 4;
+            while (rpw > 16 && (long long)nbx * 4 * ((a.dh + rpw - 1) / rpw) * count < 8192) rpw -= rpw > 64 ? 64 : 16;
+            const int ncy = (a.dh + rpw - 1) / rpw;
+            hipLaunchKernelGGL(k_resize_up_cubic3, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
+                               ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 3) & ~7, nbx, rpw);
         } else if (CN == 4 && interp == IMP_INTER_CUBIC && scale_y <= 1.0 && scale_x <= 2.0 && a.sw >= 4 &&
                    (long long)a.dh * a.dstep < (1LL << 32) && !std::getenv("IMPGPU_NO_UP")) {
             // enlargement (bridge.c:190's CUBIC case): wave-private strips, float H sums in a register ring
@@ -1878,7 +2050,7 @@ __device__ __forceinline__ uint32_t box2x2(uint32_t a, uint32_t b, uint32_t c, u
     return o;
 }
 
-template <int TX, int TY>      // tile of the halved image: TX columns x TY rows, TX * TY == 4096
+template <int TX, int TY>      // tile of the halved image: TX columns x TY rows, 4096 pixels or a multiple
 __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount, int rw, int rh, int ntx, int nty, int count, int order) {
     __shared__ uint32_t tile[TY][TX + 1];                     // odd pitch: the transposed read is bank-conflict free
     // Block order: a group of 8 frames is dealt one frame per XCD (linear id mod 8), and inside a frame the tiles of
@@ -1897,30 +2069,36 @@ __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount
     const int rx0 = bx * TX, ry0 = by * TY;                   // tile origin in the halved (pre-rotation) image
     const int tid = threadIdx.x;
     {   // (1) each thread averages two neighbouring outputs per row from two 16-byte loads.  Addresses are clamped into
-        // the frame so all loads issue back to back with no branch between them; only the LDS stores are predicated.
+        // the frame so all loads of a batch issue back to back with no branch between them; only the LDS stores are
+        // predicated.  Tiles of more than 4096 pixels take the rows in batches of eight passes (register budget).
         constexpr int LPR = TX / 2;                           // lanes per tile row
         constexpr int RPP = 256 / LPR;                        // rows per pass
-        constexpr int NP = TY / RPP;                          // passes (8 for every shape)
+        constexpr int NPT = TY / RPP;                         // passes in all
+        constexpr int NP = NPT < 8 ? NPT : 8;                 // passes per batch
+        static_assert(NPT % NP == 0, "tile rows must split into whole batches");
         const int lx = (tid % LPR) * 2, ty = tid / LPR;
         const int rx = rx0 + lx;
         const int rxc = min(rx, rw - 2);                      // launcher guarantees rw >= 2
-        uint32_t t0[NP][4], t1[NP][4];
+#pragma unroll 1
+        for (int b0 = 0; b0 < NPT; b0 += NP) {
+            uint32_t t0[NP][4], t1[NP][4];
 #pragma unroll
-        for (int r = 0; r < NP; r++) {
-            const int ryc = min(ry0 + ty + RPP * r, rh - 1);
-            const uint8_t* p = S + (size_t)(2 * ryc) * a.sstep + (size_t)rxc * 8;
-            load_stream<4>(t0[r], p);
-            load_stream<4>(t1[r], p + a.sstep);
-        }
+            for (int r = 0; r < NP; r++) {
+                const int ryc = min(ry0 + ty + RPP * (b0 + r), rh - 1);
+                const uint8_t* p = S + (size_t)(2 * ryc) * a.sstep + (size_t)rxc * 8;
+                load_stream<4>(t0[r], p);
+                load_stream<4>(t1[r], p + a.sstep);
+            }
 #pragma unroll
-        for (int r = 0; r < NP; r++) {
-            const int ly = ty + RPP * r;
-            if (ry0 + ly < rh) {
-                if (rx + 1 < rw) {
-                    tile[ly][lx] = box2x2(t0[r][0], t0[r][1], t1[r][0], t1[r][1]);
-                    tile[ly][lx + 1] = box2x2(t0[r][2], t0[r][3], t1[r][2], t1[r][3]);
-                } else if (rx < rw) {                          // odd rw: the clamped window ends on this pixel
-                    tile[ly][lx] = box2x2(t0[r][2], t0[r][3], t1[r][2], t1[r][3]);
+            for (int r = 0; r < NP; r++) {
+                const int ly = ty + RPP * (b0 + r);
+                if (ry0 + ly < rh) {
+                    if (rx + 1 < rw) {
+                        tile[ly][lx] = box2x2(t0[r][0], t0[r][1], t1[r][0], t1[r][1]);
+                        tile[ly][lx + 1] = box2x2(t0[r][2], t0[r][3], t1[r][2], t1[r][3]);
+                    } else if (rx < rw) {                      // odd rw: the clamped window ends on this pixel
+                        tile[ly][lx] = box2x2(t0[r][2], t0[r][3], t1[r][2], t1[r][3]);
+                    }
                 }
             }
         }
@@ -1976,11 +2154,17 @@ int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s) {
     if (((uintptr_t)f.dst | (uintptr_t)f.dstep | (uintptr_t)f.dst_stride) & 3) return IMP_ERROR_UNSUPPORTED;
     RArgs a{f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
     const dim3 block(256);
-    const int tx = shape, ty = 4096 / shape;
+    static const int shape_y = std::getenv("IMPGPU_CHAIN_TILE_Y") ? std::atoi(std::getenv("IMPGPU_CHAIN_TILE_Y")) : 0;
+    const int tx = shape, ty = shape_y ? shape_y : 4096 / shape;
     const int ntx = (rw + tx - 1) / tx, nty = (rh + ty - 1) / ty;
     static const int order = std::getenv("IMPGPU_CHAIN_ORDER") ? std::atoi(std::getenv("IMPGPU_CHAIN_ORDER")) : 0;
     const dim3 grid((unsigned)(ntx * nty), (unsigned)((f.count + 7) / 8 * 8));
-    if (tx == 16) hipLaunchKernelGGL((k_area2x2_rotate_bgra<16, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    if (tx == 64 && ty == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else if (tx == 128 && ty == 64) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else if (tx == 64 && ty == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else if (tx == 32 && ty == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else if (tx == 128 && ty == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    else if (tx == 16) hipLaunchKernelGGL((k_area2x2_rotate_bgra<16, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
     else if (tx == 32) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
     else if (tx == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 32>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
     else if (tx == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<256, 16>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);

@@ -206,13 +206,15 @@ def test_dma_ring_results_do_not_depend_on_timing(gpu, c):
 
 
 @pytest.mark.parametrize("shape", [((270, 480), (1080, 1920)), ((100, 161), (333, 515)), ((64, 4), (200, 9)), ((50, 100), (200, 80)),
-                                   ((37, 41), (37, 123)), ((90, 7), (91, 8)), ((33, 200), (1000, 230))])
-def test_cubic_enlargement_kernel_bit_exact(gpu, shape):
-    """The reference's only CUBIC dispatch (bridge.c:190: an axis grows): k_resize_up_cubic4 -- float H sums in LDS, scalar
-    row weights.  Full 480x270 -> 1080p, odd widths (a scalar tail pixel in every row), 4-pixel-wide sources, x shrinking
-    while y grows, and the edge columns the 2.4.9 x rule pins to src[0] / src[w-1]."""
+                                   ((37, 41), (37, 123)), ((90, 7), (91, 8)), ((33, 200), (1000, 230)), ((50, 100), (200, 128)),
+                                   ((60, 40), (61, 256)), ((30, 70), (90, 64))])
+@pytest.mark.parametrize("c", [3, 4])
+def test_cubic_enlargement_kernel_bit_exact(gpu, shape, c):
+    """The reference's only CUBIC dispatch (bridge.c:190: an axis grows): k_resize_up_cubic4 / _cubic3 -- wave-private strips,
+    float H sums in a register ring, scalar row weights.  Full 480x270 -> 1080p, odd widths (a scalar tail in every row),
+    4-pixel-wide sources, x shrinking while y grows, and the edge columns the 2.4.9 x rule pins to src[0] / src[w-1]."""
     (sh, sw), (dh, dw) = shape
-    for arr in (noise_image(sh, sw, 4, 21), smooth_image(sh, sw, 4)):
+    for arr in (noise_image(sh, sw, c, 21), smooth_image(sh, sw, c)):
         want = orc.cv_resize(arr, dw, dh, orc.INTER_CUBIC)
         got = gpu_resize(gpu, arr, dw, dh, orc.INTER_CUBIC)
         assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
