@@ -51,6 +51,18 @@ with torch.cuda.stream(stream):
     for _ in range(reps):
         imp.batch_cv_resize(src4.data_ptr(), 2160 * 3840 * 4, 3840, 2160, 3840 * 4, dst4.data_ptr(), 1080 * 1920 * 4,
                             1920, 1080, 1920 * 4, 4, n4, imp.INTER_LANCZOS4, stream=stream.cuda_stream)
+    # round 2: the CUBIC enlargement (bridge.c:190's only CUBIC dispatch) on batch/2 frames, the streaming 2x2 box on batch/4
+    nu = max(1, batch // 2)
+    srcu = src.view(-1)[: nu * 270 * 480 * 4]
+    dstu = torch.zeros((nu, 1080, 1920, 4), dtype=torch.uint8, device="cuda")
+    for _ in range(reps):
+        imp.batch_cv_resize(srcu.data_ptr(), 270 * 480 * 4, 480, 270, 480 * 4, dstu.data_ptr(), 1080 * 1920 * 4,
+                            1920, 1080, 1920 * 4, 4, nu, imp.INTER_CUBIC, stream=stream.cuda_stream)
+    na = max(1, batch // 4)
+    dsta = torch.zeros((na, 540, 960, 4), dtype=torch.uint8, device="cuda")
+    for _ in range(reps):
+        imp.batch_cv_resize(src.data_ptr(), 1080 * 1920 * 4, 1920, 1080, 1920 * 4, dsta.data_ptr(), 540 * 960 * 4,
+                            960, 540, 960 * 4, 4, na, imp.INTER_AREA, stream=stream.cuda_stream)
 torch.cuda.synchronize()
 print("probe done: batch", batch, "reps", reps)
 imp.env_destroy()

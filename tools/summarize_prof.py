@@ -23,7 +23,10 @@ PROF = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_v4r<3>": "area", "k_resize_nn<4>": "nn",
-         "k_resize_taps<2, 4, 0>": "linear", "k_resize_2x_dma<8, 2": "lanczos", "k_area2x2_rotate_bgra": "chain"}
+         "k_resize_taps<2, 4, 0>": "linear", "k_resize_2x_dma<8, 2": "lanczos", "k_area2x2_rotate_bgra": "chain",
+         "k_resize_up_cubic4": "upscale", "k_area2x2_v4": "area2x"}
+# frames per launch in tools/pmc_probe.py, as a divisor of PROBE_BATCH
+BATCH_DIV = {"lanczos": 16, "upscale": 2, "area2x": 4}
 
 
 def counter_means(kind):
@@ -67,7 +70,7 @@ def main():
         for pat, mode in MODES.items():
             if pat in k and entry["hbm_bytes_per_launch"]:
                 with open(os.path.join(PROF, "traffic_%s.json" % mode), "w") as fh:
-                    json.dump({"kernel": k, "round": tag, "batch": batch // 16 if mode == "lanczos" else batch,
+                    json.dump({"kernel": k, "round": tag, "batch": batch // BATCH_DIV.get(mode, 1),
                                "hbm_bytes_per_launch": round(entry["hbm_bytes_per_launch"]),
                                "read_bytes": round(f * 2), "write_bytes": round(w),
                                "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
