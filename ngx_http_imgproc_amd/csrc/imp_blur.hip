@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_blur_fused4(const uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------ large radii: column strips with an LDS ring
-// radius 17 .. 60 (sigma up to 20; `docs/03 - Usage.md:224`: "execution time is proportional to sigma").  The two-pass
+// radius 17 .. 60 after trimming zero taps (sigma up to ~25; `docs/03 - Usage.md:224`: "execution time is proportional to sigma").  The two-pass
 // fallback parks an int32 plane in HBM and re-reads it 2r+1 times through L2 (sigma = 8: 147 us per 1080p frame, 1.4 % of
 // the roofline).  Here the row sums never leave the CU: a 256-thread block owns 64 columns and walks down a strip of rows,
 // four source rows per step (one per wave):
@@ -262,39 +262,52 @@ __device__ __forceinline__ uint32_t bl_cvt_pk_u8(float x, uint32_t acc, int byte
     return r;
 }
 
-template <int RH>
+// CN = 3 (every JPEG): pixels are assembled from / scattered to three bytes, channel 3 is not computed, and the last
+// (3 w) % 4 elements of a row take SymmColumnVec's scalar tail, (sum + 2^15) >> 16 on integers, like the CPU.
+template <int RH, int CN>
 __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
                                                      uint8_t* __restrict__ dst, long long dstride, int dstep,
-                                                     const int* __restrict__ kxp, const float* __restrict__ kyf, int r, int rows_per_block) {
+                                                     const int* __restrict__ kxp, const float* __restrict__ kyf,
+                                                     const int* __restrict__ kyi, int r, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int npair = r + 1;                                   // 2r+1 taps -> r+1 pairs, the last one (tap, 0)
     const int SEGW = (64 + 2 * r + 2 + 3) & ~3;                // +2: the padded last pair reads one dword further
     uint32_t* s_kx = (uint32_t*)smem;                          // packed (k[2j], k[2j+1]) as 2 x i16
     float* s_ky = (float*)(s_kx + ((npair + 3) & ~3));
-    uint32_t* s_seg = (uint32_t*)(s_ky + ((r + 1 + 3) & ~3));  // [4][SEGW]
+    int* s_kyi = (int*)(s_ky + ((r + 1 + 3) & ~3));
+    uint32_t* s_seg = (uint32_t*)(s_kyi + ((r + 1 + 3) & ~3));  // [4][SEGW]
     float4* s_ring = (float4*)(s_seg + 4 * SEGW);              // [RH][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * 64;
     const int y0 = blockIdx.y * rows_per_block, y1 = min(h, y0 + rows_per_block);
     const uint8_t* S = src + (long long)blockIdx.z * sstride;
-    uint8_t* D = dst + (long long)blockIdx.z * dstride + (size_t)min(x0 + lane, w - 1) * 4;
+    uint8_t* D = dst + (long long)blockIdx.z * dstride + (size_t)min(x0 + lane, w - 1) * CN;
     const bool live = x0 + lane < w;
     for (int i = tid; i < npair; i += 256) s_kx[i] = (uint32_t)kxp[i];
-    for (int i = tid; i <= r; i += 256) s_ky[i] = kyf[i];
+    for (int i = tid; i <= r; i += 256) { s_ky[i] = kyf[i]; s_kyi[i] = kyi[i]; }
 
     // this lane's (up to four) columns of a segment, clamped into the row
     int sxc[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) sxc[q] = min(max(x0 - r + lane + 64 * q, 0), w - 1) * 4;
+    for (int q = 0; q < 4; q++) sxc[q] = min(max(x0 - r + lane + 64 * q, 0), w - 1) * CN;
     const int nq = (SEGW + 63) / 64;                           // dwords per lane per segment (<= 4 for r <= 60)
     uint32_t* seg = s_seg + wv * SEGW;
     auto request = [&](int ys, uint32_t* v) {
         const uint8_t* row = S + (size_t)min(max(ys, 0), h - 1) * sstep;
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            if (q < nq) v[q] = *(const uint32_t*)(row + sxc[q]);
+            if (q < nq) {
+                if (CN == 4) v[q] = *(const uint32_t*)(row + sxc[q]);
+                else v[q] = (uint32_t)row[sxc[q]] | ((uint32_t)row[sxc[q] + 1] << 8) | ((uint32_t)row[sxc[q] + 2] << 16);
+            }
     };
+    auto emit = [&](int y, uint32_t px) {
+        if (CN == 4) *(uint32_t*)(D + (size_t)y * dstep) = px;
+        else { uint8_t* o = D + (size_t)y * dstep; o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16); }
+    };
+    const int vec_end = CN == 3 ? (w * 3) & ~3 : 0;            // SymmColumnVec_32s8u covers whole groups of 4 row elements
+    const bool tail = CN == 3 && (x0 + lane) * 3 + 2 >= vec_end;
 
     uint32_t cur[4], out_px = 0;
     int out_y = -1;                                            // output row whose pixel waits in out_px
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (q < nq && lane + 64 * q < SEGW) seg[lane + 64 * q] = cur[q];
-        if (out_y >= 0 && live) *(uint32_t*)(D + (size_t)out_y * dstep) = out_px;
+        if (out_y >= 0 && live) emit(out_y, out_px);
         out_y = -1;
         request(ys + 4, cur);
         // (b) row pass
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
                 pr = __builtin_amdgcn_perm(p1, p0, 0x0c040c00u); __builtin_memcpy(&c, &pr, 4); a0 = __builtin_amdgcn_sdot2(c, kk, a0, false);
                 pr = __builtin_amdgcn_perm(p1, p0, 0x0c050c01u); __builtin_memcpy(&c, &pr, 4); a1 = __builtin_amdgcn_sdot2(c, kk, a1, false);
                 pr = __builtin_amdgcn_perm(p1, p0, 0x0c060c02u); __builtin_memcpy(&c, &pr, 4); a2 = __builtin_amdgcn_sdot2(c, kk, a2, false);
-                pr = __builtin_amdgcn_perm(p1, p0, 0x0c070c03u); __builtin_memcpy(&c, &pr, 4); a3 = __builtin_amdgcn_sdot2(c, kk, a3, false);
+                if (CN == 4) { pr = __builtin_amdgcn_perm(p1, p0, 0x0c070c03u); __builtin_memcpy(&c, &pr, 4); a3 = __builtin_amdgcn_sdot2(c, kk, a3, false); }
             }
             s_ring[(ys & (RH - 1)) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
         }
@@ -346,11 +359,27 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
             uint32_t px = bl_cvt_pk_u8(sxy.x, 0u, 0);
             px = bl_cvt_pk_u8(sxy.y, px, 1);
             px = bl_cvt_pk_u8(szw.x, px, 2);
-            out_px = bl_cvt_pk_u8(szw.y, px, 3);
+            if (CN == 4) px = bl_cvt_pk_u8(szw.y, px, 3);
+            if (tail) {                                        // this pixel holds elements of the row's scalar tail: integer form for those
+                int t[3] = {s_kyi[0] * (int)c.x, s_kyi[0] * (int)c.y, s_kyi[0] * (int)c.z};
+                for (int k = 1; k <= r; k++) {
+                    const int ya = min(yo + k, h - 1), yb = max(yo - k, 0);
+                    const float4 pa = s_ring[(ya & (RH - 1)) * 64 + lane], pb = s_ring[(yb & (RH - 1)) * 64 + lane];
+                    const int fk = s_kyi[k];
+                    t[0] += fk * ((int)pa.x + (int)pb.x); t[1] += fk * ((int)pa.y + (int)pb.y); t[2] += fk * ((int)pa.z + (int)pb.z);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    int ti = (t[ch] + (1 << 15)) >> 16;
+                    asm volatile("" : "+v"(ti));                // keep shift and clamp apart (v_ashr_pk_u8_i32 hazard)
+                    if ((x0 + lane) * 3 + ch >= vec_end) px = (px & ~(0xffu << (8 * ch))) | ((uint32_t)sat8(ti) << (8 * ch));
+                }
+            }
+            out_px = px;
             out_y = yo;
         }
     }
-    if (out_y >= 0 && live) *(uint32_t*)(D + (size_t)out_y * dstep) = out_px;
+    if (out_y >= 0 && live) emit(out_y, out_px);
 }
 
 // src view -> dst (same size, BGRA, separate buffers).  IMP_ERROR_UNSUPPORTED when the fused form does not apply
@@ -379,7 +408,7 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
         ik = std::vector<int>(ik.begin() + (r0 - r), ik.begin() + (r0 + r + 1));
     }
     const int ks = 2 * r + 1;
-    if (r > 60 || (r > 16 && v.c != 4)) return IMP_ERROR_UNSUPPORTED;
+    if (r > 60) return IMP_ERROR_UNSUPPORTED;
     std::vector<int> blob;
     for (int j = 0; j <= r; j++) {                           // pairs (k[2j], k[2j+1]); the pair past the end is (k[2r], 0)
         const int lo = ik[2 * j], hi = (2 * j + 1 < ks) ? ik[2 * j + 1] : 0;
@@ -400,23 +429,25 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     if (r > 16) {       // column strips with an LDS ring (k_blur_strip4)
         const int RH = 2 * r + 8 <= 64 ? 64 : 128;
         const int SEGW = (64 + 2 * r + 2 + 3) & ~3;
-        const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 2 + 4 * SEGW) * 4 + (size_t)RH * 64 * 16;
+        const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + 4 * SEGW) * 4 + (size_t)RH * 64 * 16;
         const int nbx = (v.w + 63) / 64;
         int rpb = 256;                                         // taller strips recompute fewer halo rows; shorter ones fill the chip
         while (rpb > 64 && (long long)nbx * ((v.h + rpb - 1) / rpb) * f.count < 1024) rpb /= 2;
         const dim3 sgrid((unsigned)nbx, (unsigned)((v.h + rpb - 1) / rpb), (unsigned)f.count);
         hipError_t e = hipSuccess;
-        if (RH == 64) {
-            e = hipFuncSetAttribute((const void*)k_blur_strip4<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess)
-                hipLaunchKernelGGL((k_blur_strip4<64>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
-                               (const int*)dev_k, (const float*)((const int*)dev_k + off_f), r, rpb);
-        } else {
-            e = hipFuncSetAttribute((const void*)k_blur_strip4<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess)
-                hipLaunchKernelGGL((k_blur_strip4<128>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep,
-                                   (const int*)dev_k, (const float*)((const int*)dev_k + off_f), r, rpb);
-        }
+#define IMP_BLUR_STRIP(RH_, CN_)                                                                                                   \
+    do {                                                                                                                           \
+        e = hipFuncSetAttribute((const void*)k_blur_strip4<RH_, CN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        if (e == hipSuccess)                                                                                                       \
+            hipLaunchKernelGGL((k_blur_strip4<RH_, CN_>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst,   \
+                               f.dst_stride, f.dstep, (const int*)dev_k, (const float*)((const int*)dev_k + off_f),                 \
+                               (const int*)dev_k + off_i, r, rpb);                                                                  \
+    } while (0)
+        if (RH == 64 && v.c == 4) IMP_BLUR_STRIP(64, 4);
+        else if (RH == 64) IMP_BLUR_STRIP(64, 3);
+        else if (v.c == 4) IMP_BLUR_STRIP(128, 4);
+        else IMP_BLUR_STRIP(128, 3);
+#undef IMP_BLUR_STRIP
         if (e == hipSuccess) e = hipGetLastError();
         dev_free_on(dev_k, s);
         if (e != hipSuccess) { set_error("k_blur_strip4", e); return IMP_ERROR_DEVICE; }

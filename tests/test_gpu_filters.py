@@ -77,12 +77,14 @@ def test_blur_large_sigma_and_thin_images(gpu):
         assert rc == 0 and np.array_equal(got, orc.gaussian(a, 2.0)), shape
 
 
-@pytest.mark.parametrize("sigma", ["2.8", "3", "4.5", "4.7", "8", "9.9", "12", "20"])    # radii 17, 18, 27, 28 (ring 64), 29.., 60 (ring 128)
-def test_blur_large_radius_strip_kernel_bit_exact(gpu, sigma):
-    """k_blur_strip4: radius 17..60 on BGRA -- column strips with the row sums in an LDS ring.  Frames narrower than a strip,
-    shorter than the radius (every tap row clamps), taller than one block's strip, and widths that are no multiple of 64."""
-    for shape in [(70, 130), (300, 67), (9, 200), (131, 64), (64, 1), (2, 3)]:
-        arr = noise_image(shape[0], shape[1], 4, 14) if shape[0] % 2 else smooth_image(shape[0], shape[1], 4)
+@pytest.mark.parametrize("c", [3, 4])
+@pytest.mark.parametrize("sigma", ["3.4", "4", "5.5", "8", "9.9", "12", "20", "25", "31"])    # non-zero radii 17 .. 60 (ring 64 / 128), 31: two-pass
+def test_blur_large_radius_strip_kernel_bit_exact(gpu, sigma, c):
+    """k_blur_strip4: radius 17..60 (after the zero taps are trimmed) on BGRA and BGR -- column strips with the row sums in
+    an LDS ring.  Frames narrower than a strip, shorter than the radius (every tap row clamps), taller than one block's
+    strip, widths that are no multiple of 64 and, for BGR, rows whose last 1..3 elements take the integer tail."""
+    for shape in [(70, 130), (300, 67), (9, 200), (131, 64), (64, 1), (2, 3), (40, 65), (33, 66)]:
+        arr = noise_image(shape[0], shape[1], c, 14) if shape[0] % 2 else smooth_image(shape[0], shape[1], c)
         want = orc.gaussian(arr, float(np.float32(sigma)))
         rc, got = run_filter(gpu, arr, "blur=" + sigma)
         assert rc == 0
