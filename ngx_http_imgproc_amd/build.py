@@ -72,6 +72,7 @@ def build_library(force=False, verbose=False):
 
     os.makedirs(OBJ, exist_ok=True)
     compile_flags = [f for f in FLAGS if f != "-shared"] + ["-c", "-I", os.path.join(HERE, "..", "include")]
+    compile_flags += os.environ.get("IMPGPU_EXTRA_FLAGS", "").split()      # A/B builds: -DNAME=value (pair with IMPGPU_LIB)
     jobs = []
     for f in SOURCES:
         src = os.path.join(CSRC, f)

@@ -426,11 +426,23 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
     void* mid = nullptr;
     int rc;
     rc = IMP_ERROR_UNSUPPORTED;
+    bool watermark_done = false;
     if (interp == IMP_INTER_AREA && swap && resize_width * 2 == src_width && resize_height * 2 == src_height) {
-        // exact 2x2 box + quarter turn: one pass, the half-size intermediate never reaches HBM
+        // exact 2x2 box + quarter turn: one pass, the half-size intermediate never reaches HBM -- and with a BGRA overlay
+        // (4-byte aligned rows) the Watermark step rides on the same kernel's stores
         Frames fz = rs;
         fz.dst = (uint8_t*)dst; fz.dst_stride = dst_frame_stride; fz.dstep = dst_step; fz.dw = fw; fz.dh = fh;
-        rc = launch_area2x2_rotate(fz, rotate, s);
+        OverlayArgs wm{};
+        const impgpu_image* ov = config->watermark;
+        const bool fuse = ov && channels == 4 && ov->c == 4 && !(((uintptr_t)ov->d | (uintptr_t)ov->step) & 3);
+        if (fuse) {
+            rc = watermark_rect(fw, fh, ov->w, ov->h, config, &wm.rx, &wm.ry, &wm.maxcol, &wm.maxrow);
+            if (rc) return rc;
+            wm.ov = ov->d; wm.ostep = ov->step;
+            wm.alpha = 1 - (float)(config->watermark_opacity / 100.0);     // bridge.c:275, filters.c:620
+        }
+        rc = launch_area2x2_rotate(fz, rotate, fuse ? &wm : nullptr, s);
+        watermark_done = fuse && rc == IMP_OK;
     }
     if (rc != IMP_ERROR_UNSUPPORTED) {
         // fused path taken (or failed with a device error)
@@ -453,7 +465,7 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
             rc = launch_rotate(rt, rotate, s);
         }
     }
-    if (!rc && config->watermark) {
+    if (!rc && config->watermark && !watermark_done) {
         int rx, ry, maxcol, maxrow;
         rc = watermark_rect(fw, fh, config->watermark->w, config->watermark->h, config, &rx, &ry, &maxcol, &maxrow);
         if (!rc) {

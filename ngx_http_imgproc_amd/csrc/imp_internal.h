@@ -84,6 +84,28 @@ bool fault_hit(int step);
         if (_e != hipSuccess) { imp::set_error(#call, _e); return IMP_ERROR_DEVICE; } \
     } while (0)
 
+// ---------------------------------------------------------------- AlphaBlendOver on one BGRA pixel pair (filters.c:633-659)
+// Shared by k_blend_over (imp_pixel.hip) and the fused resize + rotate + watermark kernel (imp_resize.hip): the float
+// sequence of the reference, one operation per rounding (`alpha` = 1 - opacity, filters.c:620).
+__device__ __forceinline__ uint32_t blend_over_bgra(uint32_t d, uint32_t s, float alpha) {
+    const int dB = d & 0xff, dG = (d >> 8) & 0xff, dR = (d >> 16) & 0xff;
+    const float dA = (float)((double)(d >> 24) / 255.0);
+    const int sB = s & 0xff, sG = (s >> 8) & 0xff, sR = (s >> 16) & 0xff;
+    float sA = (float)((double)(s >> 24) / 255.0);
+    sA = (float)fmax((double)__fsub_rn(sA, alpha), 0.0);
+    const float inv = __fsub_rn(1.f, sA);
+    const float tA = __fadd_rn(sA, __fmul_rn(dA, inv));
+    int tB = 0, tG = 0, tR = 0;
+    if (tA != 0.f) {
+        tB = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sB, sA), __fmul_rn(__fmul_rn((float)dB, dA), inv)), tA);
+        tG = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sG, sA), __fmul_rn(__fmul_rn((float)dG, dA), inv)), tA);
+        tR = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sR, sA), __fmul_rn(__fmul_rn((float)dR, dA), inv)), tA);
+    }
+    const float a255 = __fmul_rn(tA, 255.f);
+    const int tAi = (a255 > -2147483904.f && a255 < 2147483648.f) ? (int)a255 : (int)0x80000000;
+    return (uint32_t)(tB & 0xff) | ((uint32_t)(tG & 0xff) << 8) | ((uint32_t)(tR & 0xff) << 16) | ((uint32_t)(tAi & 0xff) << 24);
+}
+
 // ---------------------------------------------------------------- host grammar (imp_args.cpp)
 int crop_geometry(int col, int row, const char* args, const char* gravity, int* x, int* y, int* w, int* h);
 int resize_geometry(int col, int row, const char* args, unsigned max_w, unsigned max_h, int simple,
@@ -154,8 +176,10 @@ struct Frames {             // `count` frames of one geometry
 };
 // imp_resize.hip
 int launch_cv_resize(const Frames& f, int interp, hipStream_t s);
-// exact-2x AREA + rotate 90/270 of BGRA in one pass; IMP_ERROR_UNSUPPORTED when the geometry does not qualify
-int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s);
+// exact-2x AREA + rotate 90/270 of BGRA in one pass; IMP_ERROR_UNSUPPORTED when the geometry does not qualify.
+// With a 4-channel overlay the Watermark step (bridge.c:629-640) rides on the store phase of the same kernel.
+struct OverlayArgs { const uint8_t* ov; int ostep, rx, ry, maxcol, maxrow; float alpha; };
+int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s);
 // imp_geom.hip
 int launch_copy(const Frames& f, hipStream_t s);                       // crop copy / clone (dw,dh = v.w,v.h)
 int launch_flip(const Frames& f, int mode, hipStream_t s);             // cvFlip

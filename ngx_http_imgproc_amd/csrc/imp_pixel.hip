@@ -372,6 +372,10 @@ __global__ __launch_bounds__(256) void k_blend_over(uint8_t* base, long long str
     const int row = idx / maxcol, col = idx - row * maxcol;
     uint8_t* d = base + (long long)blockIdx.y * stride + (size_t)(row + ry) * step + (size_t)(col + rx) * DC;
     const uint8_t* sp = ov + (size_t)row * ostep + (size_t)col * SC;
+    if (DC == 4 && SC == 4 && !(((uintptr_t)d | (uintptr_t)sp) & 3)) {     // the common pair: one dword in, one dword out
+        *(uint32_t*)d = blend_over_bgra(*(const uint32_t*)d, *(const uint32_t*)sp, alpha);
+        return;
+    }
     const int dB = d[0], dG = d[1], dR = d[2];
     const float dA = DC == 4 ? (float)((double)d[3] / 255.0) : 1.f;
     const int sB = sp[0], sG = sp[1], sR = sp[2];

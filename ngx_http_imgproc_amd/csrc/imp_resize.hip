@@ -2051,7 +2051,8 @@ __device__ __forceinline__ uint32_t box2x2(uint32_t a, uint32_t b, uint32_t c, u
 }
 
 template <int TX, int TY>      // tile of the halved image: TX columns x TY rows, 4096 pixels or a multiple
-__global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount, int rw, int rh, int ntx, int nty, int count, int order) {
+__global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount, int rw, int rh, int ntx, int nty, int count, int order,
+                                                             OverlayArgs wm) {
     __shared__ uint32_t tile[TY][TX + 1];                     // odd pitch: the transposed read is bank-conflict free
     // Block order: a group of 8 frames is dealt one frame per XCD (linear id mod 8), and inside a frame the tiles of
     // one tile column are walked top to bottom back to back.  Vertically adjacent tiles store neighbouring column
@@ -2074,7 +2075,10 @@ __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount
         constexpr int LPR = TX / 2;                           // lanes per tile row
         constexpr int RPP = 256 / LPR;                        // rows per pass
         constexpr int NPT = TY / RPP;                         // passes in all
-        constexpr int NP = NPT < 8 ? NPT : 8;                 // passes per batch
+#ifndef CHAIN_NP
+#define CHAIN_NP 8
+#endif
+        constexpr int NP = NPT < CHAIN_NP ? NPT : CHAIN_NP;   // passes per batch
         static_assert(NPT % NP == 0, "tile rows must split into whole batches");
         const int lx = (tid % LPR) * 2, ty = tid / LPR;
         const int rx = rx0 + lx;
@@ -2124,17 +2128,29 @@ __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount
             const int dy = amount == 90 ? rx : rw - 1 - rx;
             uint8_t* drow = D + (size_t)dy * a.dstep;
             if (ryb + 3 < rh) {
-                if (amount == 90) {     // dx = rh-1-ry descends: reverse the four
-                    const u32x4_t o = {v[3], v[2], v[1], v[0]};
-                    *(u32x4_t*)(drow + (size_t)(rh - 1 - (ryb + 3)) * 4) = o;
-                } else {
-                    const u32x4_t o = {v[0], v[1], v[2], v[3]};
-                    *(u32x4_t*)(drow + (size_t)ryb * 4) = o;
+                uint32_t o4[4];
+                const int dx0 = amount == 90 ? rh - 1 - (ryb + 3) : ryb;      // dx = rh-1-ry descends for 90: reverse the four
+#pragma unroll
+                for (int j = 0; j < 4; j++) o4[j] = amount == 90 ? v[3 - j] : v[j];
+                // Watermark (bridge.c:629-640, AlphaBlendOver filters.c:619-662) on the way out: the few tiles under the
+                // overlay rectangle blend their pixels before the store; everyone else pays one wave-uniform-ish test
+                if (wm.ov && dy >= wm.ry && dy < wm.ry + wm.maxrow && dx0 + 3 >= wm.rx && dx0 < wm.rx + wm.maxcol) {
+                    const uint8_t* orow = wm.ov + (size_t)(dy - wm.ry) * wm.ostep;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int ox = dx0 + j - wm.rx;
+                        if (ox >= 0 && ox < wm.maxcol) o4[j] = blend_over_bgra(o4[j], *(const uint32_t*)(orow + (size_t)ox * 4), wm.alpha);
+                    }
                 }
+                const u32x4_t o = {o4[0], o4[1], o4[2], o4[3]};
+                *(u32x4_t*)(drow + (size_t)dx0 * 4) = o;
             } else {
                 for (int j = 0; j < 4 && ryb + j < rh; j++) {
                     const int dx = amount == 90 ? rh - 1 - (ryb + j) : ryb + j;
-                    *(uint32_t*)(drow + (size_t)dx * 4) = v[j];
+                    uint32_t px = v[j];
+                    if (wm.ov && dy >= wm.ry && dy < wm.ry + wm.maxrow && dx >= wm.rx && dx < wm.rx + wm.maxcol)
+                        px = blend_over_bgra(px, *(const uint32_t*)(wm.ov + (size_t)(dy - wm.ry) * wm.ostep + (size_t)(dx - wm.rx) * 4), wm.alpha);
+                    *(uint32_t*)(drow + (size_t)dx * 4) = px;
                 }
             }
         }
@@ -2143,7 +2159,7 @@ __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount
 
 // src: sw x sh BGRA with sw = 2*rw, sh = 2*rh; dst: rh x rw (rotated).  Returns IMP_ERROR_UNSUPPORTED when the
 // geometry is not the exact-2x BGRA case so the caller can fall back to resize + rotate.
-int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s) {
+int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s) {
     const View& v = f.v;
     static const int shape = std::getenv("IMPGPU_CHAIN_TILE") ? std::atoi(std::getenv("IMPGPU_CHAIN_TILE")) : 64;   // measured (profiles/r01_chain_tiles.txt): 64x64 with the column walk
     if (v.c != 4 || (amount != 90 && amount != 270) || (v.w & 1) || (v.h & 1)) return IMP_ERROR_UNSUPPORTED;
@@ -2159,16 +2175,18 @@ int launch_area2x2_rotate(const Frames& f, int amount, hipStream_t s) {
     const int ntx = (rw + tx - 1) / tx, nty = (rh + ty - 1) / ty;
     static const int order = std::getenv("IMPGPU_CHAIN_ORDER") ? std::atoi(std::getenv("IMPGPU_CHAIN_ORDER")) : 0;
     const dim3 grid((unsigned)(ntx * nty), (unsigned)((f.count + 7) / 8 * 8));
-    if (tx == 64 && ty == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else if (tx == 128 && ty == 64) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else if (tx == 64 && ty == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else if (tx == 32 && ty == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else if (tx == 128 && ty == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else if (tx == 16) hipLaunchKernelGGL((k_area2x2_rotate_bgra<16, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else if (tx == 32) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else if (tx == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 32>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else if (tx == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<256, 16>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
-    else hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order);
+    OverlayArgs wm{};
+    if (overlay) wm = *overlay;
+    if (tx == 64 && ty == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else if (tx == 128 && ty == 64) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else if (tx == 64 && ty == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else if (tx == 32 && ty == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else if (tx == 128 && ty == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else if (tx == 16) hipLaunchKernelGGL((k_area2x2_rotate_bgra<16, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else if (tx == 32) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else if (tx == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 32>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else if (tx == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<256, 16>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }
