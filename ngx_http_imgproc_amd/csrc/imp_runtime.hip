@@ -66,6 +66,7 @@ struct Env {
     unsigned long long generation = 0;
     std::mutex mu;
     std::vector<Lane*> lanes;
+    std::vector<Lane*> idle;                    // lanes whose thread has exited: the next new thread takes one over
 };
 
 static void lane_destroy(Lane* L);
@@ -73,6 +74,18 @@ static Env* g_env = nullptr;
 static unsigned long long g_generation = 0;
 static thread_local Lane* t_lane = nullptr;
 static thread_local unsigned long long t_lane_gen = 0;
+
+// A thread that ends hands its lane (stream, pool, staging, caches) back instead of leaking it: a server that churns
+// threads would otherwise collect a stream and tens of MB of pinned memory per dead thread until impgpu_env_destroy.
+struct LaneReturn {
+    ~LaneReturn() {
+        Env* E = g_env;
+        if (!E || !t_lane || t_lane_gen != E->generation) return;
+        std::lock_guard<std::mutex> lk(E->mu);
+        E->idle.push_back(t_lane);
+    }
+};
+static thread_local LaneReturn t_lane_return;
 static thread_local std::string t_error;
 
 // ---- rocTX (optional) and fault injection
@@ -139,6 +152,16 @@ static Lane* lane() {
     if (!E) return nullptr;
     if (t_lane && t_lane_gen == E->generation) return t_lane;
     if (hipSetDevice(E->device) != hipSuccess) return nullptr;
+    (void)&t_lane_return;                       // instantiate this thread's returner
+    {
+        std::lock_guard<std::mutex> lk(E->mu);
+        if (!E->idle.empty()) {                 // everything the previous owner enqueued is ordered on the lane's stream
+            t_lane = E->idle.back();
+            E->idle.pop_back();
+            t_lane_gen = E->generation;
+            return t_lane;
+        }
+    }
     Lane* L = new Lane();
     bool ok = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&L->join_ev, hipEventDisableTiming) == hipSuccess &&

@@ -228,13 +228,26 @@ def test_threads_have_independent_streams_and_pools(gpu):
     assert not errs, errs
     for i in range(len(jobs)):
         assert np.array_equal(got[i], want[i]), i
-    # distinct threads really got distinct streams
-    streams = []
-    ts = [threading.Thread(target=lambda: streams.append(gpu.lib.impgpu_env_stream())) for _ in range(3)]
+    # threads alive at the same time really have distinct streams ...
+    streams, gate = [], threading.Barrier(3)
+
+    def grab():
+        streams.append(gpu.lib.impgpu_env_stream())
+        gate.wait()
+
+    ts = [threading.Thread(target=grab) for _ in range(3)]
     for t in ts:
         t.start()
+    for t in ts:
         t.join()
     assert len(set(streams + [gpu.lib.impgpu_env_stream()])) == 4
+    # ... and a thread that has ended hands its lane to the next new thread instead of leaking a stream per thread
+    later = []
+    for _ in range(6):
+        t = threading.Thread(target=lambda: later.append(gpu.lib.impgpu_env_stream()))
+        t.start()
+        t.join()
+    assert len(set(later)) == 1 and gpu.lib.impgpu_env_stream() not in later
 
 
 @pytest.mark.parametrize("c", [3, 4])
