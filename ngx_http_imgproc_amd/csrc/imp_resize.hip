@@ -1440,6 +1440,102 @@ __global__ __launch_bounds__(256) void k_area2x2_v3(RArgs a, int qpr) {
     }
 }
 
+// ------------------------------------------------------------------ AREA, other integer scales (3x3, 4x4, 4x3 ...), streaming form
+// resizeAreaFast_ for integer scales: the box sum is exact integer work and the mean is saturate(cvRound(sum * (1.f/area))).
+// Like k_area2x2_v4 a lane owns FOUR neighbouring destination pixels of a row: ISX 16-byte loads per source row, ISY rows,
+// the 4 * ISX source pixels of a row landing on their destination pixel at compile time; two channels per add in the
+// 16-bit halves of a dword (ISX * ISY * 255 fits 16 bits up to 257 source pixels per box), one 16-byte store.  The per-pixel
+// k_resize_area_int it replaces issued one dword load per source pixel: 0.45 (4x4) and 0.27 (8x8) of the roofline.
+template <int ISX>
+__global__ __launch_bounds__(256) void k_area_box4(RArgs a, int isy, int qpr, float scale) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= qpr * a.dh) return;
+    const int dy = idx / qpr, q = idx - dy * qpr;
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride + (size_t)(dy * isy) * a.sstep + (size_t)q * (16 * ISX);
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep + (size_t)q * 16;
+    const int n = min(4, a.dw - 4 * q);
+    const uint32_t M = 0x00ff00ffu;
+    uint32_t e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};        // (B,R) and (G,A) sums of the four boxes
+    if (n == 4) {
+        for (int ky = 0; ky < isy; ky++) {
+            uint32_t p[4 * ISX];
+            load_stream<4 * ISX>(p, S + (size_t)ky * a.sstep);
+#pragma unroll
+            for (int i = 0; i < 4 * ISX; i++) {
+                e[i / ISX] += p[i] & M;
+                o[i / ISX] += (p[i] >> 8) & M;
+            }
+        }
+    } else {
+        for (int ky = 0; ky < isy; ky++)
+            for (int i = 0; i < n * ISX; i++) {
+                const uint32_t p = *(const uint32_t*)(S + (size_t)ky * a.sstep + 4 * i);
+                e[i / ISX] += p & M;
+                o[i / ISX] += (p >> 8) & M;
+            }
+    }
+    uint32_t out[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {      // v_cvt_pk_u8_f32 = saturate(round-half-even(x)) = saturate_cast<uchar>(cvRound(x))
+        uint32_t px = cvt_pk_u8(__fmul_rn((float)(e[j] & 0xffff), scale), 0u, 0);
+        px = cvt_pk_u8(__fmul_rn((float)(o[j] & 0xffff), scale), px, 1);
+        px = cvt_pk_u8(__fmul_rn((float)(e[j] >> 16), scale), px, 2);
+        out[j] = cvt_pk_u8(__fmul_rn((float)(o[j] >> 16), scale), px, 3);
+    }
+    if (n == 4) {
+        const u32x4_t ov = {out[0], out[1], out[2], out[3]};
+        __builtin_nontemporal_store(ov, (u32x4_t*)D);
+    } else {
+        for (int j = 0; j < n; j++) *(uint32_t*)(D + 4 * j) = out[j];
+    }
+}
+
+// Power-of-two widths (1/4 and 1/8 thumbnails): here every wave-instruction reads 1 KB CONTIGUOUS (lane l takes pixels
+// 4 l .. 4 l + 3 of the j-th 256-pixel piece), so a 16-byte granule is one whole box column group (ISX = 4) or half of one
+// (ISX = 8, the two halves meet through one DPP exchange at the end).  k_area_box4 above gives each lane ISX adjacent
+// granules -- 64 or 128 bytes apart between lanes -- and every 128-byte line is then fetched by four to eight different
+// instructions (0.49 / 0.29 of the roofline against 0.57 for ISX = 3).
+template <int ISX>
+__global__ __launch_bounds__(256) void k_area_boxc(RArgs a, int isy, int cpr, float scale) {
+    static_assert(ISX == 4 || ISX == 8, "16-byte granules must tile a box row");
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave = one 1024-pixel chunk of one destination row
+    if (gw >= cpr * a.dh) return;
+    const int dy = gw / cpr, ch = gw - dy * cpr;
+    const int px0 = ch * 1024 + lane * 4;
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride + (size_t)(dy * isy) * a.sstep;
+    const uint32_t M = 0x00ff00ffu;
+    uint32_t e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+    for (int ky = 0; ky < isy; ky++) {
+        const uint8_t* row = S + (size_t)ky * a.sstep;
+        uint32_t p[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (px0 + 256 * j < a.sw) load_stream<4>(p[j], row + (size_t)(px0 + 256 * j) * 4);     // sw is a multiple of 4 here
+            else p[j][0] = p[j][1] = p[j][2] = p[j][3] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { e[j] += p[j][k] & M; o[j] += (p[j][k] >> 8) & M; }
+    }
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t ee = e[j], oo = o[j];
+        if (ISX == 8) {                                       // the other half of the box sits in the neighbouring lane
+            ee += (uint32_t)__shfl_xor((int)ee, 1);
+            oo += (uint32_t)__shfl_xor((int)oo, 1);
+        }
+        uint32_t px = cvt_pk_u8(__fmul_rn((float)(ee & 0xffff), scale), 0u, 0);
+        px = cvt_pk_u8(__fmul_rn((float)(oo & 0xffff), scale), px, 1);
+        px = cvt_pk_u8(__fmul_rn((float)(ee >> 16), scale), px, 2);
+        px = cvt_pk_u8(__fmul_rn((float)(oo >> 16), scale), px, 3);
+        const int sp = px0 + 256 * j;
+        if (sp < a.sw && (ISX == 4 || !(lane & 1))) *(uint32_t*)(D + (size_t)(sp / ISX) * 4) = px;
+    }
+}
+
 // ------------------------------------------------------------------ AREA, general (float tables)
 struct AreaDev {
     const int *xstart, *xcount, *xaoff; const float* xalpha;
@@ -1881,6 +1977,21 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                 const dim3 qgrid((unsigned)(((long long)qpr * a.dh + 255) / 256), (unsigned)count);
                 if (CN == 4) hipLaunchKernelGGL(k_area2x2_v4, qgrid, block, 0, s, a, qpr);
                 else hipLaunchKernelGGL(k_area2x2_v3, qgrid, block, 0, s, a, qpr);
+            } else if (CN == 4 && rows4 && isx >= 3 && isx <= 8 && isy >= 1 && isx * isy <= 257 && a.sw == isx * a.dw && a.sh >= isy * a.dh) {
+                const int qpr = (a.dw + 3) / 4;
+                const dim3 qgrid((unsigned)(((long long)qpr * a.dh + 255) / 256), (unsigned)count);
+                const float scale = 1.f / (float)(isx * isy);
+                const int cpr = (a.sw + 1023) / 1024;             // 1024-pixel chunks per source row (k_area_boxc)
+                const dim3 cgrid((unsigned)(((long long)cpr * a.dh + 3) / 4), (unsigned)count);
+                switch (isx) {
+                    case 3: hipLaunchKernelGGL((k_area_box4<3>), qgrid, block, 0, s, a, isy, qpr, scale); break;
+                    case 4: hipLaunchKernelGGL((k_area_boxc<4>), cgrid, block, 0, s, a, isy, cpr, scale); break;
+                    case 8: hipLaunchKernelGGL((k_area_boxc<8>), cgrid, block, 0, s, a, isy, cpr, scale); break;
+                    case 5: hipLaunchKernelGGL((k_area_box4<5>), qgrid, block, 0, s, a, isy, qpr, scale); break;
+                    case 6: hipLaunchKernelGGL((k_area_box4<6>), qgrid, block, 0, s, a, isy, qpr, scale); break;
+                    case 7: hipLaunchKernelGGL((k_area_box4<7>), qgrid, block, 0, s, a, isy, qpr, scale); break;
+                    default: hipLaunchKernelGGL((k_area_box4<8>), qgrid, block, 0, s, a, isy, qpr, scale); break;
+                }
             } else
                 hipLaunchKernelGGL((k_resize_area_int<CN>), grid, block, 0, s, a, isx, isy);
         } else {
