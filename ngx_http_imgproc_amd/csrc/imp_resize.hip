@@ -1490,28 +1490,36 @@ __global__ __launch_bounds__(256) void k_area_box4(RArgs a, int isy, int qpr, fl
     }
 }
 
-// Power-of-two widths (1/4 and 1/8 thumbnails): here every wave-instruction reads 1 KB CONTIGUOUS (lane l takes pixels
-// 4 l .. 4 l + 3 of the j-th 256-pixel piece), so a 16-byte granule is one whole box column group (ISX = 4) or half of one
+// Power-of-two widths (1/4 and 1/8 thumbnails): here every wave-instruction reads 1 KB CONTIGUOUS (lane l takes the l-th
+// 16-byte granule of the j-th 1 KB piece), so a 16-byte granule is one whole box column group (ISX = 4) or half of one
 // (ISX = 8, the two halves meet through one DPP exchange at the end).  k_area_box4 above gives each lane ISX adjacent
 // granules -- 64 or 128 bytes apart between lanes -- and every 128-byte line is then fetched by four to eight different
 // instructions (0.49 / 0.29 of the roofline against 0.57 for ISX = 3).
 template <int ISX>
-__global__ __launch_bounds__(256) void k_area_boxc(RArgs a, int isy, int cpr, float scale) {
+__global__ __launch_bounds__(256) void k_area_boxc(RArgs a, int isy, int gpr, float scale) {
     static_assert(ISX == 4 || ISX == 8, "16-byte granules must tile a box row");
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave = one 1024-pixel chunk of one destination row
-    if (gw >= cpr * a.dh) return;
-    const int dy = gw / cpr, ch = gw - dy * cpr;
-    const int px0 = ch * 1024 + lane * 4;
-    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride + (size_t)(dy * isy) * a.sstep;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // granules (16 bytes = 4 source pixels) are numbered along a band of ISY source rows, then band by band: a wave takes
+    // 4 x 64 consecutive ones, so a band's end does not leave lanes idle (gpr = granules per source row)
+    const int total = gpr * a.dh;
+    int gx[4], dy[4];
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int gid = (gw * 4 + j) * 64 + lane;
+        dy[j] = gid / gpr;
+        gx[j] = gid - dy[j] * gpr;
+        if (gid >= total) dy[j] = -1;
+    }
+    if (dy[0] < 0) return;                                     // lanes past the end only ever trail a wave (ISX = 8 pairs stay whole: gpr is even)
     const uint32_t M = 0x00ff00ffu;
     uint32_t e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
     for (int ky = 0; ky < isy; ky++) {
-        const uint8_t* row = S + (size_t)ky * a.sstep;
         uint32_t p[4][4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (px0 + 256 * j < a.sw) load_stream<4>(p[j], row + (size_t)(px0 + 256 * j) * 4);     // sw is a multiple of 4 here
+            if (dy[j] >= 0) load_stream<4>(p[j], S + (size_t)(dy[j] * isy + ky) * a.sstep + (size_t)gx[j] * 16);
             else p[j][0] = p[j][1] = p[j][2] = p[j][3] = 0;
         }
 #pragma unroll
@@ -1519,7 +1527,7 @@ __global__ __launch_bounds__(256) void k_area_boxc(RArgs a, int isy, int cpr, fl
 #pragma unroll
             for (int k = 0; k < 4; k++) { e[j] += p[j][k] & M; o[j] += (p[j][k] >> 8) & M; }
     }
-    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep;
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         uint32_t ee = e[j], oo = o[j];
@@ -1531,9 +1539,39 @@ __global__ __launch_bounds__(256) void k_area_boxc(RArgs a, int isy, int cpr, fl
         px = cvt_pk_u8(__fmul_rn((float)(oo & 0xffff), scale), px, 1);
         px = cvt_pk_u8(__fmul_rn((float)(ee >> 16), scale), px, 2);
         px = cvt_pk_u8(__fmul_rn((float)(oo >> 16), scale), px, 3);
-        const int sp = px0 + 256 * j;
-        if (sp < a.sw && (ISX == 4 || !(lane & 1))) *(uint32_t*)(D + (size_t)(sp / ISX) * 4) = px;
+        if (dy[j] >= 0 && (ISX == 4 || !(lane & 1))) *(uint32_t*)(D + (size_t)dy[j] * a.dstep + (size_t)(gx[j] * 4 / ISX) * 4) = px;
     }
+}
+
+// 2x2 in the same contiguous form (even destination widths): a granule is two destination pixels, a wave reads 2 x 1 KB
+// runs of each of its two source rows and writes 2 x 512 bytes.
+__global__ __launch_bounds__(256) void k_area2x2_c4(RArgs a, int gpr) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total = gpr * a.dh;
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride;
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride;
+    uint32_t r0[2][4], r1[2][4];
+    int gx[2], dy[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int gid = (gw * 2 + j) * 64 + lane;
+        dy[j] = gid / gpr;
+        gx[j] = gid - dy[j] * gpr;
+        if (gid >= total) dy[j] = -1;
+        if (dy[j] >= 0) {
+            const uint8_t* row = S + (size_t)(2 * dy[j]) * a.sstep + (size_t)gx[j] * 16;
+            load_stream<4>(r0[j], row);
+            load_stream<4>(r1[j], row + a.sstep);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+        if (dy[j] >= 0) {
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t o = {box4_swar(r0[j][0], r0[j][1], r1[j][0], r1[j][1]), box4_swar(r0[j][2], r0[j][3], r1[j][2], r1[j][3])};
+            __builtin_nontemporal_store(o, (u32x2_t*)(D + (size_t)dy[j] * a.dstep + (size_t)gx[j] * 8));
+        }
 }
 
 // ------------------------------------------------------------------ AREA, general (float tables)
@@ -1975,14 +2013,18 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             if (isx == 2 && isy == 2 && (CN == 4 || CN == 3) && rows4 && a.sw == 2 * a.dw && a.sh >= 2 * a.dh) {
                 const int qpr = (a.dw + 3) / 4;                  // lanes per destination row
                 const dim3 qgrid((unsigned)(((long long)qpr * a.dh + 255) / 256), (unsigned)count);
-                if (CN == 4) hipLaunchKernelGGL(k_area2x2_v4, qgrid, block, 0, s, a, qpr);
+                const int gpr2 = a.sw / 4;
+                const dim3 cgrid2((unsigned)(((long long)gpr2 * a.dh + 511) / 512), (unsigned)count);
+                static const bool no_c4 = std::getenv("IMPGPU_NO_C4") != nullptr;
+                if (CN == 4 && !(a.dw & 1) && !no_c4) hipLaunchKernelGGL(k_area2x2_c4, cgrid2, block, 0, s, a, gpr2);
+                else if (CN == 4) hipLaunchKernelGGL(k_area2x2_v4, qgrid, block, 0, s, a, qpr);
                 else hipLaunchKernelGGL(k_area2x2_v3, qgrid, block, 0, s, a, qpr);
             } else if (CN == 4 && rows4 && isx >= 3 && isx <= 8 && isy >= 1 && isx * isy <= 257 && a.sw == isx * a.dw && a.sh >= isy * a.dh) {
                 const int qpr = (a.dw + 3) / 4;
                 const dim3 qgrid((unsigned)(((long long)qpr * a.dh + 255) / 256), (unsigned)count);
                 const float scale = 1.f / (float)(isx * isy);
-                const int cpr = (a.sw + 1023) / 1024;             // 1024-pixel chunks per source row (k_area_boxc)
-                const dim3 cgrid((unsigned)(((long long)cpr * a.dh + 3) / 4), (unsigned)count);
+                const int cpr = a.sw / 4;                         // 16-byte granules per source row (k_area_boxc)
+                const dim3 cgrid((unsigned)(((long long)cpr * a.dh + 1023) / 1024), (unsigned)count);
                 switch (isx) {
                     case 3: hipLaunchKernelGGL((k_area_box4<3>), qgrid, block, 0, s, a, isy, qpr, scale); break;
                     case 4: hipLaunchKernelGGL((k_area_boxc<4>), cgrid, block, 0, s, a, isy, cpr, scale); break;

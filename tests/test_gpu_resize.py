@@ -224,9 +224,10 @@ def test_cubic_enlargement_kernel_bit_exact(gpu, shape, c):
 
 
 @pytest.mark.parametrize("c", [3, 4])
-@pytest.mark.parametrize("shape", [(540, 960), (64, 64), (33, 45), (7, 3), (1, 1), (100, 2), (12, 1023)])
+@pytest.mark.parametrize("shape", [(540, 960), (64, 64), (33, 45), (7, 3), (1, 1), (100, 2), (12, 1023), (300, 10), (9, 6)])
 def test_area_2x2_streaming_kernel_bit_exact(gpu, c, shape):
-    """k_area2x2_v4 / _v3: (a+b+c+d+2)>>2 with four destination pixels per lane; widths that leave a partial quad."""
+    """(a+b+c+d+2)>>2: k_area2x2_c4 (BGRA, even widths: contiguous granules, short rows wrap inside a wave's run),
+    k_area2x2_v4 / _v3 (four destination pixels per lane; widths that leave a partial quad)."""
     dh, dw = shape
     arr = noise_image(2 * dh, 2 * dw, c, 22)
     box = (arr[0::2, 0::2].astype(int) + arr[0::2, 1::2] + arr[1::2, 0::2] + arr[1::2, 1::2] + 2) >> 2
@@ -252,8 +253,9 @@ def test_area_2x2_on_a_cropped_view_and_batch(gpu):
 @pytest.mark.parametrize("scale", [(3, 3), (4, 4), (4, 3), (3, 5), (5, 2), (6, 6), (7, 1), (8, 8), (8, 16), (2, 3), (9, 9), (16, 16)])
 @pytest.mark.parametrize("dims", [(270, 480), (33, 45), (5, 3), (1, 1), (17, 130)])
 def test_area_integer_scales_streaming_kernel_bit_exact(gpu, scale, dims):
-    """resizeAreaFast_ at integer scales other than 2x2: k_area_box4<ISX> (ISX 3..8, any ISY with ISX*ISY <= 257) and the
-    per-pixel fallback beyond; widths that leave a partial quad; saturate(cvRound(sum * (1.f / area)))."""
+    """resizeAreaFast_ at integer scales other than 2x2: k_area_boxc<4|8> (contiguous granules, rows shorter than a wave's
+    run wrap inside it), k_area_box4<ISX> for 3, 5, 6, 7 (any ISY with ISX*ISY <= 257) and the per-pixel fallback beyond;
+    widths that leave a partial quad; saturate(cvRound(sum * (1.f / area)))."""
     isx, isy = scale
     dh, dw = dims
     if dh * isy * dw * isx > 6_000_000:
