@@ -56,6 +56,61 @@ WORKLOADS = {
 }
 
 
+def mixed_resident(imp, n, steps, warmup, rank, world):
+    """BASELINE configs[4] without PCIe: this rank's share of n mixed-size BGRA frames (workloads.mixed_sizes) resident in
+    HBM, every one resized to 224 wide (INTER_AREA, bridge.c:190).  A step = all of them once: (a) one
+    impgpu_batch_resize_mixed call, (b) one impgpu_batch_cv_resize launch per frame from one thread."""
+    import torch
+    from ngx_http_imgproc_amd.workloads import MIXED_RESIZE, mixed_sizes
+
+    sizes = mixed_sizes(n)[rank::world]
+    cfg = imp.Config()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x1A4D0005 + rank)
+    srcs, dsts, items, alg = [], [], [], 0
+    for w, h in sizes:
+        rc, (dw, dh, _) = imp.resize_geometry(w, h, MIXED_RESIZE.decode(), cfg)
+        assert rc == 0
+        srcs.append(torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda", generator=g))
+        dsts.append(torch.zeros((dh, dw, 4), dtype=torch.uint8, device="cuda"))
+        items.append((srcs[-1].data_ptr(), w, h, w * 4, dsts[-1].data_ptr(), dw, dh, dw * 4))
+        alg += w * h * 4 + dw * dh * 4
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    arr = (imp.ResizeItem * len(items))(*[imp.ResizeItem(*it) for it in items])
+
+    def gathered():
+        assert imp.lib.impgpu_batch_resize_mixed(arr, len(items), 4, 0, stream.cuda_stream) == 0
+
+    def per_frame():
+        for sp, w, h, ss, dp, dw, dh, ds in items:
+            imp.batch_cv_resize(sp, 0, w, h, ss, dp, 0, dw, dh, ds, 4, 1, imp.INTER_AREA, stream=stream.cuda_stream)
+
+    res = {}
+    for name, fn in (("one_call", gathered), ("launch_per_frame", per_frame)):
+        for _ in range(max(1, warmup // 10)):
+            fn()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(steps):
+            fn()
+        ev1.record(stream)
+        host = time.perf_counter() - t0            # the calls return after enqueue: what the host spent issuing them
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        secs = max(wall, ev0.elapsed_time(ev1) / 1e3)
+        res[name] = {"host_ms_per_step": round(host / steps * 1e3, 3),"images_per_sec": round(len(items) * steps / secs, 1), "ms_per_step": round(secs / steps * 1e3, 3),
+                     "alg_GBps": round(alg * steps / secs / 1e9, 1), "frac_of_8TBps": round(alg * steps / secs / 1e9 / HBM_PEAK_GBPS, 4),
+                     "device_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 3)}
+    return {"metric": "images/sec mixed-size resident stream resize=224,0", "unit": "images/sec", "value": res["one_call"]["images_per_sec"],
+            "rank": rank, "n_gpus": world, "frames_this_rank": len(items), "steps": steps, "dtype": "u8",
+            "data": "synthetic (seeded sizes, torch.randint BGRA frames, device-resident)",
+            "source_GB_this_rank": round(sum(w * h * 4 for w, h in sizes) / 1e9, 2), **res,
+            "config": {"workload": "BASELINE configs[4] device-resident: %d frames, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % n}}
+
+
 def e2e(imp, n_requests, pinned):
     """PCIe-inclusive request loop on one stream: upload 1080p frame -> cubic resize -> download 224x224.
     Never the headline `value`; reported in DESIGN.md next to the device-resident number."""
@@ -296,6 +351,9 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--queue-depth", type=int, default=4096, help="--stream: requests waiting in the rank's queue")
     ap.add_argument("--inflight", type=int, default=4, help="--stream: requests a thread enqueues before it waits")
+    ap.add_argument("--mixed", type=int, default=0, metavar="N",
+                    help="BASELINE configs[4] with the N frames already in HBM: resize=224,0 over mixed sizes, one "
+                         "impgpu_batch_resize_mixed call per step (and, for comparison, one launch per frame)")
     ap.add_argument("--e2e", type=int, default=0, metavar="N",
                     help="instead of the headline, time N PCIe-inclusive requests (upload + resize + download) and exit")
     args = ap.parse_args()
@@ -360,6 +418,10 @@ def main():
         imp.env_destroy()
         if use_dist:
             dist.destroy_process_group()
+        return
+    if args.mixed:
+        print(json.dumps(mixed_resident(imp, args.mixed, args.steps, args.warmup, rank, world)), flush=True)
+        imp.env_destroy()
         return
     if args.e2e:
         res = {"metric": "PCIe-inclusive requests/sec: upload 1920x1080 BGRA + INTER_CUBIC ->224x224 + download, one stream",

@@ -226,6 +226,16 @@ int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive,
 int impgpu_batch_cv_resize(const void* src, long long src_frame_stride, int src_width, int src_height, int src_step,
                            void* dst, long long dst_frame_stride, int dst_width, int dst_height, int dst_step,
                            int channels, int count, int interpolation, void* stream);
+/* The per-frame Resize() loop of bridge.c:588-604 over frames that all DIFFER in size (BASELINE configs[4], frames already
+ * in HBM): each item is cvResize'd with the interpolation Resize() picks for it -- NN when `simple`, CUBIC when either
+ * side grows, AREA otherwise (bridge.c:188-192) -- but frames that share a kernel ride in one launch (a descriptor per
+ * frame), so a run of thumbnails costs a handful of launches instead of one per request.  Same bytes as calling
+ * impgpu_batch_cv_resize once per item.  Nothing is launched if any item is malformed (IMP_ERROR_INVALID_ARGS). */
+typedef struct impgpu_resize_item {
+    const void* src; int src_width, src_height, src_step;
+    void*       dst; int dst_width, dst_height, dst_step;
+} impgpu_resize_item;
+int impgpu_batch_resize_mixed(const impgpu_resize_item* items, int count, int channels, int simple, void* stream);
 /* cfg3 chain on a batch: resize (AREA/CUBIC by the reference's rule) -> rotate -> watermark.
  * rotate in {0, 90, 180, 270}; config->watermark may be NULL. dst geometry must match. */
 int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_stride, int src_width, int src_height, int src_step,

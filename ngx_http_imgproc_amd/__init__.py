@@ -14,5 +14,5 @@ from .ops import (  # noqa: F401
     INTER_NN, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4,
     Config, Image, env_start, env_destroy, sync,
     crop_geometry, resize_geometry, filter_check, check_destructive,
-    batch_cv_resize, batch_resize_rotate_watermark, batch_filters, run_ops, Request, gif_compose,
+    batch_cv_resize, batch_resize_mixed, ResizeItem, batch_resize_rotate_watermark, batch_filters, run_ops, Request, gif_compose,
 )

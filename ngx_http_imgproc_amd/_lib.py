@@ -123,6 +123,7 @@ SIGNATURES = {
     "impgpu_request_free": (None, [PP]),
     "impgpu_batch_cv_resize": (C.c_int, [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, C.c_longlong, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, P]),
+    "impgpu_batch_resize_mixed": (C.c_int, [P, C.c_int, C.c_int, C.c_int, P]),
     "impgpu_batch_filters": (C.c_int, [P, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
                                        C.c_int, C.c_int, P]),
     "impgpu_batch_resize_rotate_watermark": (C.c_int, [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, C.c_longlong,

@@ -3,6 +3,7 @@
 // (imp_args.cpp), then enqueues kernels on the env stream.  impgpu_run_ops is the operator
 // segment of RunJob (bridge.c:574-656) with Crop folded into the next operator's source view
 // and runs of pointwise filters fused into one launch.
+#include <cstddef>
 #include <cstring>
 #include "imp_internal.h"
 
@@ -403,6 +404,15 @@ int impgpu_batch_cv_resize(const void* src, long long src_frame_stride, int src_
     f.dst = (uint8_t*)dst; f.dst_stride = dst_frame_stride; f.dw = dst_width; f.dh = dst_height; f.dstep = dst_step;
     f.count = count;
     return launch_cv_resize(f, interpolation, stream ? (hipStream_t)stream : env_stream());
+}
+
+int impgpu_batch_resize_mixed(const impgpu_resize_item* items, int count, int channels, int simple, void* stream) {
+    if (count < 0 || (count > 0 && !items)) return IMP_ERROR_INVALID_ARGS;
+    if (int rc = need_env()) return rc;
+    static_assert(sizeof(MixFrame) == sizeof(impgpu_resize_item) && offsetof(MixFrame, dst) == offsetof(impgpu_resize_item, dst),
+                  "MixFrame mirrors impgpu_resize_item");
+    return launch_resize_mixed(reinterpret_cast<const MixFrame*>(items), count, channels, simple,
+                               stream ? (hipStream_t)stream : env_stream());
 }
 
 int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_stride, int src_width, int src_height, int src_step,

@@ -165,6 +165,7 @@ struct AreaAxis {           // general INTER_AREA: per destination index a run o
     int max_count = 0;
 };
 void build_area_axis(int ssize, int dsize, double scale, AreaAxis* out);
+int  area_max_count(int ssize, int dsize, double scale);          // AreaAxis::max_count alone
 int  gaussian_ksize(double sigma);
 void gaussian_kernel_fixed(int n, double sigma, std::vector<int>* ik);
 
@@ -176,6 +177,9 @@ struct Frames {             // `count` frames of one geometry
 };
 // imp_resize.hip
 int launch_cv_resize(const Frames& f, int interp, hipStream_t s);
+// `count` frames of different geometry, each Resize()d by the reference's rule (BASELINE configs[4], device-resident)
+struct MixFrame { const uint8_t* src; int sw, sh, sstep; uint8_t* dst; int dw, dh, dstep; };
+int launch_resize_mixed(const MixFrame* frames, int count, int channels, int simple, hipStream_t s);
 // exact-2x AREA + rotate 90/270 of BGRA in one pass; IMP_ERROR_UNSUPPORTED when the geometry does not qualify.
 // With a 4-channel overlay the Watermark step (bridge.c:629-640) rides on the store phase of the same kernel.
 struct OverlayArgs { const uint8_t* ov; int ostep, rx, ry, maxcol, maxrow; float alpha; };

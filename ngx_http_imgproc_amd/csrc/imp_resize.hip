@@ -16,9 +16,11 @@
 // of the same instruction.  blockIdx.y is the frame of the batch.  For BGRA the KS taps of a
 // row are one (4-byte aligned) 8/16/32-byte vector load per lane.  The per-geometry weight
 // tables (a few KB, built on the host in imp_tables.cpp) stay L1/L2 resident.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <mutex>
 #include <tuple>
 #include "imp_internal.h"
@@ -1578,11 +1580,10 @@ __global__ __launch_bounds__(256) void k_area2x2_c4(RArgs a, int gpr) {
 struct AreaDev {
     const int *xstart, *xcount, *xaoff; const float* xalpha;
     const int *ystart, *ycount, *yaoff; const float* yalpha;
-    // k_resize_area_v4 only (nv = 0: not built)
+    // k_resize_area_v4r / _v3r only (nv = 0: not built)
     const int* xstart_pad;      // [dw] run start clamped to sw - 4*nv
     const float* xalpha_pad;    // [dw][4*nv] weights of each run, shifted to xstart_pad and zero-padded
-    const float* ybeta_pad;     // [dh][nyp] row weights, zero-padded
-    int nv, nyp;
+    int nv;
     // k_resize_area_v4r: destination rows in groups of AREA_ROWS that share one walk over their source rows
     const float* ybeta_grp;     // [ceil(dh / AREA_ROWS)][nypg][AREA_ROWS]: weight of source row (ystart[g*R] + j) in row g*R + k, else 0
     int nypg;                   // source rows a group walks (max over groups)
@@ -1636,160 +1637,13 @@ __global__ __launch_bounds__(256) void k_resize_area(RArgs a, AreaDev t) {
     }
 }
 
-// BGRA with source runs of at most 4*NV pixels (scale_x < 4*NV - 1): every lane pulls its whole
-// run of a source row with NV 16-byte loads instead of one dword per tap.  The host tables give a
-// window start clamped so the vector loads never leave the row, the run's weights shifted to that
-// start and zero-padded to 4*NV, and the row weights zero-padded to a launch-uniform count, so the
-// kernel has no edge path and a uniform trip count.  Zero weights are exact no-ops on the
-// non-negative partial sums (x + p*0.f == x), so the float sequence is still exactly resizeArea_'s.
-typedef float float2_t __attribute__((ext_vector_type(2)));
-
-template <int NV>
-__global__ __launch_bounds__(256) void k_resize_area_v4(RArgs a, AreaDev t, int bpf, int count) {
-    int frame, blk;
-    if (!frame_block(bpf, count, &frame, &blk)) return;
-    const int idx = blk * 256 + threadIdx.x;
-    if (idx >= a.dw * a.dh) return;
-    const int dy = idx / a.dw, dx = idx - dy * a.dw;
-    const uint8_t* S = a.src + (long long)frame * a.src_stride;
-    const int xs = t.xstart_pad[dx];
-    float al[NV * 4];
-    __builtin_memcpy(al, __builtin_assume_aligned(t.xalpha_pad + (size_t)dx * (NV * 4), 16), NV * 16);
-    const int ys = t.ystart[dy];
-    const float* yb = t.ybeta_pad + (size_t)dy * t.nyp;
-    // channels (0,1) and (2,3) ride in the two halves of packed-FP32 registers: v_pk_mul_f32 and
-    // v_pk_add_f32 round each half exactly like the scalar ops (contraction is off)
-    float2_t s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
-    for (int j = 0; j < t.nyp; j++) {
-        const int sy = min(ys + j, a.sh - 1);
-        const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 4;
-        uint32_t px[NV * 4];
-        // plain (temporal) loads: neighbouring lanes' runs and the next destination row's first source
-        // row overlap this one's, and those re-reads must hit in cache (non-temporal cost -37 % here)
-        __builtin_memcpy(px, __builtin_assume_aligned(row, 4), NV * 16);
-        float2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < NV * 4; k++) {
-            const float2_t w = {al[k], al[k]};
-            const float2_t p01 = {(float)(px[k] & 0xff), (float)((px[k] >> 8) & 0xff)};
-            const float2_t p23 = {(float)((px[k] >> 16) & 0xff), (float)(px[k] >> 24)};
-            b01 = b01 + p01 * w;
-            b23 = b23 + p23 * w;
-        }
-        const float2_t be = {yb[j], yb[j]};
-        if (j == 0) { s01 = be * b01; s23 = be * b23; }
-        else { s01 = s01 + be * b01; s23 = s23 + be * b23; }
-    }
-    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)dy * a.dstep + (size_t)dx * 4;
-    *(uint32_t*)d = (uint32_t)sat_u8(__float2int_rn(s01.x)) | ((uint32_t)sat_u8(__float2int_rn(s01.y)) << 8) |
-                    ((uint32_t)sat_u8(__float2int_rn(s23.x)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s23.y)) << 24);
-}
-
-// AREA_ROWS vertically adjacent destination pixels per lane.  Consecutive destination rows share their boundary
-// source row (1080 -> 224: 5.82 rows fetched per output row for 4.82 new ones), and with a lane per output that row
-// is fetched -- and its horizontal sum computed -- twice, the second time often from HBM again (PMC: +16 %).  Here a
-// lane walks the source rows of its group once; each row's horizontal sum (the same float sequence as before, so
-// the same bits) is added to every row of the group with that row's weight, which is 0 where the source row does
-// not belong to it: s + 0 * b == s exactly, so the sums see the reference's additions in the reference's order.
-template <int NV>
-__global__ __launch_bounds__(256) void k_resize_area_v4r(RArgs a, AreaDev t, int bpf, int count) {
-    constexpr int R = AREA_ROWS;
-    int frame, blk;
-    if (!frame_block(bpf, count, &frame, &blk)) return;
-    const int ng = (a.dh + R - 1) / R;
-    const int idx = blk * 256 + threadIdx.x;
-    if (idx >= a.dw * ng) return;
-    const int g = idx / a.dw, dx = idx - g * a.dw;
-    const uint8_t* S = a.src + (long long)frame * a.src_stride;
-    const int xs = t.xstart_pad[dx];
-    float al[NV * 4];
-    __builtin_memcpy(al, __builtin_assume_aligned(t.xalpha_pad + (size_t)dx * (NV * 4), 16), NV * 16);
-    const int ys = t.ystart[g * R];
-    const float* yb = t.ybeta_grp + (size_t)g * t.nypg * R;
-    float2_t s01[R], s23[R];
-#pragma unroll
-    for (int k = 0; k < R; k++) { s01[k] = float2_t{0.f, 0.f}; s23[k] = float2_t{0.f, 0.f}; }
-    for (int j = 0; j < t.nypg; j++) {
-        const int sy = min(ys + j, a.sh - 1);
-        const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 4;
-        uint32_t px[NV * 4];
-        __builtin_memcpy(px, __builtin_assume_aligned(row, 4), NV * 16);
-        float2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < NV * 4; k++) {
-            const float2_t w = {al[k], al[k]};
-            const float2_t p01 = {(float)(px[k] & 0xff), (float)((px[k] >> 8) & 0xff)};
-            const float2_t p23 = {(float)((px[k] >> 16) & 0xff), (float)(px[k] >> 24)};
-            b01 = b01 + p01 * w;
-            b23 = b23 + p23 * w;
-        }
-        float be4[R];
-        __builtin_memcpy(be4, __builtin_assume_aligned(yb + (size_t)j * R, 16), R * 4);
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            const float2_t be = {be4[k], be4[k]};
-            s01[k] = s01[k] + be * b01;
-            s23[k] = s23[k] + be * b23;
-        }
-    }
-    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)(g * R) * a.dstep + (size_t)dx * 4;
-#pragma unroll
-    for (int k = 0; k < R; k++)
-        if (g * R + k < a.dh)
-            *(uint32_t*)(d + (size_t)k * a.dstep) =
-                (uint32_t)sat_u8(__float2int_rn(s01[k].x)) | ((uint32_t)sat_u8(__float2int_rn(s01[k].y)) << 8) |
-                ((uint32_t)sat_u8(__float2int_rn(s23[k].x)) << 16) | ((uint32_t)sat_u8(__float2int_rn(s23[k].y)) << 24);
-}
-
 // The same for 3-channel BGR frames -- what cvDecodeImage hands the reference for every JPEG, and the mode its
 // Resize() picks for every shrink.  A run of 4*NV pixels is 12*NV bytes at an arbitrary byte address; gfx950
 // takes unaligned vector loads, and every (pixel, channel) sits at a compile-time byte of the loaded dwords,
 // so each tap is v_cvt_f32_ubyteN + mul + add with no shuffling.
 template <int NV>
-__global__ __launch_bounds__(256) void k_resize_area_v3(RArgs a, AreaDev t, int bpf, int count) {
-    int frame, blk;
-    if (!frame_block(bpf, count, &frame, &blk)) return;
-    const int idx = blk * 256 + threadIdx.x;
-    if (idx >= a.dw * a.dh) return;
-    const int dy = idx / a.dw, dx = idx - dy * a.dw;
-    const uint8_t* S = a.src + (long long)frame * a.src_stride;
-    const int xs = t.xstart_pad[dx];
-    float al[NV * 4];
-    __builtin_memcpy(al, __builtin_assume_aligned(t.xalpha_pad + (size_t)dx * (NV * 4), 16), NV * 16);
-    const int ys = t.ystart[dy];
-    const float* yb = t.ybeta_pad + (size_t)dy * t.nyp;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int j = 0; j < t.nyp; j++) {
-        const int sy = min(ys + j, a.sh - 1);
-        const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 3;
-        uint32_t w[NV * 3];
-        load_bytes_aligned<NV * 3>(w, row);
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < NV * 4; k++) {
-            const int o0 = 3 * k, o1 = 3 * k + 1, o2 = 3 * k + 2;
-            b0 = __fadd_rn(b0, __fmul_rn((float)((w[o0 >> 2] >> (8 * (o0 & 3))) & 0xff), al[k]));
-            b1 = __fadd_rn(b1, __fmul_rn((float)((w[o1 >> 2] >> (8 * (o1 & 3))) & 0xff), al[k]));
-            b2 = __fadd_rn(b2, __fmul_rn((float)((w[o2 >> 2] >> (8 * (o2 & 3))) & 0xff), al[k]));
-        }
-        const float be = yb[j];
-        if (j == 0) { s0 = __fmul_rn(be, b0); s1 = __fmul_rn(be, b1); s2 = __fmul_rn(be, b2); }
-        else {
-            s0 = __fadd_rn(s0, __fmul_rn(be, b0)); s1 = __fadd_rn(s1, __fmul_rn(be, b1)); s2 = __fadd_rn(s2, __fmul_rn(be, b2));
-        }
-    }
-    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)dy * a.dstep + (size_t)dx * 3;
-    d[0] = (uint8_t)sat_u8(__float2int_rn(s0));
-    d[1] = (uint8_t)sat_u8(__float2int_rn(s1));
-    d[2] = (uint8_t)sat_u8(__float2int_rn(s2));
-}
-
-// k_resize_area_v3 with AREA_ROWS vertically adjacent outputs per lane (see k_resize_area_v4r)
-template <int NV>
-__global__ __launch_bounds__(256) void k_resize_area_v3r(RArgs a, AreaDev t, int bpf, int count) {
+__device__ __forceinline__ void area_v3r_body(const RArgs& a, const AreaDev& t, int frame, int blk) {
     constexpr int R = AREA_ROWS;
-    int frame, blk;
-    if (!frame_block(bpf, count, &frame, &blk)) return;
     const int ng = (a.dh + R - 1) / R;
     const int idx = blk * 256 + threadIdx.x;
     if (idx >= a.dw * ng) return;
@@ -1834,6 +1688,312 @@ __global__ __launch_bounds__(256) void k_resize_area_v3r(RArgs a, AreaDev t, int
             q[1] = (uint8_t)sat_u8(__float2int_rn(s1[k]));
             q[2] = (uint8_t)sat_u8(__float2int_rn(s2[k]));
         }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_resize_area_v3r(RArgs a, AreaDev t, int bpf, int count) {
+    int frame, blk;
+    if (frame_block(bpf, count, &frame, &blk)) area_v3r_body<NV>(a, t, frame, blk);
+}
+
+// ------------------------------------------------------------------ AREA, general, weights computed in the kernel
+// computeResizeAreaTab's cell arithmetic (imp_tables.cpp build_area_axis, the same doubles in the same order, IEEE
+// divide, contraction off) evaluated by each lane for its own destination column and its group of AREA_ROWS rows:
+// no per-geometry table, so nothing to build on the host, upload or cache when every request has its own size
+// (BASELINE configs[4]).  The pixel arithmetic is k_resize_area_v4r / _v3r's: the same float sequence, zero weights
+// where a source pixel does not belong to a cell.
+struct AreaCell {                                      // one destination cell along one axis
+    int s1, s2;                                        // whole source pixels [s1, s2)
+    float af, am, al;                                  // weights of pixel s1 - 1 (if hf), of the whole ones, of pixel s2 (if hl)
+    bool hf, hl;
+    __device__ __forceinline__ float weight(int sp) const {
+        float w = (sp >= s1 && sp < s2) ? am : 0.f;
+        w = (hf && sp == s1 - 1) ? af : w;
+        return (hl && sp == s2) ? al : w;
+    }
+    __device__ __forceinline__ int first() const { return hf ? s1 - 1 : ((s1 < s2 || hl) ? s1 : 0); }   // s1 == s2 when only hl
+    __device__ __forceinline__ int end() const { return hl ? s2 + 1 : s2; }
+};
+__device__ __forceinline__ AreaCell area_cell(int d, int ssize, double scale) {
+    AreaCell c;
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, ssize - f1);
+    int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+    if (s2 > ssize - 1) s2 = ssize - 1;
+    if (s1 > s2) s1 = s2;
+    c.s1 = s1; c.s2 = s2;
+    c.hf = s1 - f1 > 1e-3;
+    c.af = (float)((s1 - f1) / cell);
+    c.am = (float)(1.0 / cell);
+    c.hl = f2 - s2 > 1e-3;
+    c.al = (float)(fmin(fmin(f2 - s2, 1.), cell) / cell);
+    return c;
+}
+
+struct AreaGeom { double scale_x, scale_y; };
+
+template <int CN, int NV, int R>
+__device__ __forceinline__ void area_cells_body(const RArgs& a, const AreaGeom& gm, int frame, int blk) {
+    const int ng = (a.dh + R - 1) / R;
+    const int idx = blk * 256 + threadIdx.x;
+    if (idx >= a.dw * ng) return;
+    const int g = idx / a.dw, dx = idx - g * a.dw;
+    const uint8_t* S = a.src + (long long)frame * a.src_stride;
+    // this lane's column: a window of 4*NV pixels that holds the whole cell, clamped so it never leaves the row
+    const AreaCell cx = area_cell(dx, a.sw, gm.scale_x);
+    const int xs = min(cx.first(), a.sw - 4 * NV);
+    float al[NV * 4];
+#pragma unroll
+    for (int k = 0; k < NV * 4; k++) al[k] = cx.weight(xs + k);
+    AreaCell cy[R];
+    int jend = 0;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int dy = min(g * R + k, a.dh - 1);
+        cy[k] = area_cell(dy, a.sh, gm.scale_y);
+        if (g * R + k >= a.dh) { cy[k].s1 = cy[k].s2 = -8; cy[k].hf = cy[k].hl = false; }      // no source row has weight in it
+        else jend = max(jend, cy[k].end());
+    }
+    const int ys = cy[0].first();
+    float acc[R][CN];
+#pragma unroll
+    for (int k = 0; k < R; k++)
+#pragma unroll
+        for (int c = 0; c < CN; c++) acc[k][c] = 0.f;
+    for (int sy = ys; sy < jend; sy++) {
+        float b[CN];
+#pragma unroll
+        for (int c = 0; c < CN; c++) b[c] = 0.f;
+        if constexpr (CN == 4) {
+            const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 4;
+            uint32_t px[NV * 4];
+            __builtin_memcpy(px, __builtin_assume_aligned(row, 4), NV * 16);
+#pragma unroll
+            for (int k = 0; k < NV * 4; k++) {
+                b[0] = __fadd_rn(b[0], __fmul_rn((float)(px[k] & 0xff), al[k]));
+                b[1] = __fadd_rn(b[1], __fmul_rn((float)((px[k] >> 8) & 0xff), al[k]));
+                b[2] = __fadd_rn(b[2], __fmul_rn((float)((px[k] >> 16) & 0xff), al[k]));
+                b[3] = __fadd_rn(b[3], __fmul_rn((float)(px[k] >> 24), al[k]));
+            }
+        } else {
+            const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 3;
+            uint32_t w[NV * 3];
+            load_bytes_aligned<NV * 3>(w, row);
+#pragma unroll
+            for (int k = 0; k < NV * 4; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int o = 3 * k + c;
+                    b[c] = __fadd_rn(b[c], __fmul_rn((float)((w[o >> 2] >> (8 * (o & 3))) & 0xff), al[k]));
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const float be = cy[k].weight(sy);
+#pragma unroll
+            for (int c = 0; c < CN; c++) acc[k][c] = __fadd_rn(acc[k][c], __fmul_rn(be, b[c]));
+        }
+    }
+    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)(g * R) * a.dstep + (size_t)dx * CN;
+#pragma unroll
+    for (int k = 0; k < R; k++)
+        if (g * R + k < a.dh) {
+            uint8_t* q = d + (size_t)k * a.dstep;
+            if constexpr (CN == 4)
+                *(uint32_t*)q = (uint32_t)sat_u8(__float2int_rn(acc[k][0])) | ((uint32_t)sat_u8(__float2int_rn(acc[k][1])) << 8) |
+                                ((uint32_t)sat_u8(__float2int_rn(acc[k][2])) << 16) | ((uint32_t)sat_u8(__float2int_rn(acc[k][3])) << 24);
+            else {
+#pragma unroll
+                for (int c = 0; c < CN; c++) q[c] = (uint8_t)sat_u8(__float2int_rn(acc[k][c]));
+            }
+        }
+}
+
+template <int CN, int NV, int R>
+__global__ __launch_bounds__(256) void k_resize_area_cells(RArgs a, AreaGeom gm, int bpf, int count) {
+    int frame, blk;
+    if (frame_block(bpf, count, &frame, &blk)) area_cells_body<CN, NV, R>(a, gm, frame, blk);
+}
+
+// ------------------------------------------------------------------ AREA, general, rows streamed through LDS (BGRA)
+// resizeArea_'s own shape: walk the source rows once, reduce each horizontally into the destination columns, add the
+// result into the destination row(s) it belongs to.  A WAVE owns 64 destination columns and a band of destination rows:
+//   * it fetches its segment of a source row with CONTIGUOUS 16-byte loads (lane l takes granule l, l + 64, ...: 1 KB per
+//     instruction, like a copy) one row ahead of the arithmetic, and parks the row in a wave-private LDS line -- no
+//     barrier anywhere, a wave's LDS operations execute in order;
+//   * every lane then reads ITS cell's window (4*NV pixels, weights in registers, zero where the window is wider than the
+//     cell) from that line: the same float sequence as k_resize_area_cells, fed from LDS instead of lane-strided global
+//     loads (which fetched every 128-byte line through up to nine different instructions);
+//   * the vertical cell is the same for the whole wave, so the row walk is scalar control flow: a source row shared by
+//     two destination rows is reduced once and added to both, a finished row is stored as 256 contiguous bytes.
+// Source rows are read once per band (+ one shared row per band boundary), never re-read across lanes.
+template <int W>
+__device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& gm, int frame, int item, int nstrips, int bh,
+                                               uint32_t* __restrict__ line) {
+    constexpr int NV = (W + 3) / 4;                              // 16-byte granules a lane fetches per source row
+    const int lane = threadIdx.x & 63;
+    const int band = item / nstrips, strip = item - band * nstrips;
+    const int dy0 = band * bh;
+    if (dy0 >= a.dh) return;
+    const int dy1 = min(dy0 + bh, a.dh);
+    const bool live = strip * 64 + lane < a.dw;
+    const int dx = min(strip * 64 + lane, a.dw - 1);             // idle lanes shadow the last column
+    const AreaCell cx = area_cell(dx, a.sw, gm.scale_x);
+    const int xs = min(cx.first(), a.sw - W);
+    float al[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) al[k] = cx.weight(xs + k);
+    // the wave's segment: from lane 0's window (16-byte granule aligned) to the end of lane 63's
+    const int a0 = __builtin_amdgcn_readlane(xs, 0) & ~3;
+    const int ngran = (__builtin_amdgcn_readlane(xs, 63) + W - a0 + 3) >> 2;     // <= 64 * NV
+    const int base = xs - a0;
+    const uint8_t* S = a.src + (long long)frame * a.src_stride + (size_t)a0 * 4;
+    // Every lane fetches a granule and parks it, with no predication: lanes past the segment repeat its last granule
+    // (same address, same LDS slot, same data).  When the last granule would leave the row (sw % 4 != 0) it is moved
+    // back to end exactly at the row's end and parked dword by dword where those pixels belong (wave-uniform branch).
+    const bool ragged = a0 + 4 * ngran > a.sw;
+    int gofs[NV], lofs[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int gi = min(j * 64 + lane, ngran - 1);
+        lofs[j] = (ragged && gi == ngran - 1) ? a.sw - 4 - a0 : gi * 4;
+        gofs[j] = lofs[j] * 4;
+    }
+    uint32_t nxt[NV][4];
+    auto fetch = [&](int sy) {
+        const uint8_t* row = S + (size_t)sy * a.sstep;
+#pragma unroll
+        for (int j = 0; j < NV; j++) load_stream<4>(nxt[j], row + gofs[j]);
+    };
+    float b[4];
+    auto reduce = [&]() {                                        // park the fetched row
+        asm volatile("" ::: "memory");
+        if (!ragged) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                typedef unsigned int u32x4a_t __attribute__((ext_vector_type(4), aligned(16)));
+                const u32x4a_t q = {nxt[j][0], nxt[j][1], nxt[j][2], nxt[j][3]};
+                *(u32x4a_t*)(line + lofs[j]) = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) line[lofs[j] + t] = nxt[j][t];
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto hsum = [&]() {
+        b[0] = b[1] = b[2] = b[3] = 0.f;
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const uint32_t px = line[base + k];
+            b[0] = __fadd_rn(b[0], __fmul_rn((float)(px & 0xff), al[k]));
+            b[1] = __fadd_rn(b[1], __fmul_rn((float)((px >> 8) & 0xff), al[k]));
+            b[2] = __fadd_rn(b[2], __fmul_rn((float)((px >> 16) & 0xff), al[k]));
+            b[3] = __fadd_rn(b[3], __fmul_rn((float)(px >> 24), al[k]));
+        }
+        asm volatile("" ::: "memory");
+    };
+
+    // rows: lane k works out the vertical cell of the band's k-th destination row once (bh <= 64); the walk below reads
+    // them back with v_readlane, so everything in it is the same in all lanes -> scalar registers, scalar branches
+    const AreaCell mine = area_cell(min(dy0 + lane, dy1 - 1), a.sh, gm.scale_y);
+    const int sy_end = __builtin_amdgcn_readlane(mine.end(), dy1 - 1 - dy0);
+    uint8_t* D = a.dst + (long long)frame * a.dst_stride + (size_t)dx * 4;
+    int cur = -1;                                                // the source row `b` holds
+    for (int dy = dy0; dy < dy1; dy++) {
+        const int r = dy - dy0;
+        const int s1 = __builtin_amdgcn_readlane(mine.s1, r), s2 = __builtin_amdgcn_readlane(mine.s2, r);
+        const int hf = __builtin_amdgcn_readlane((int)mine.hf, r), hl = __builtin_amdgcn_readlane((int)mine.hl, r);
+        const float yaf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.af), r));
+        const float yam = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.am), r));
+        const float yal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.al), r));
+        const int first = hf ? s1 - 1 : s1, end = hl ? s2 + 1 : s2;      // (s1 == s2 when the cell is its last partial row alone)
+        if (cur < 0) { fetch(first); cur = first - 1; }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sy = first; sy < end; sy++) {
+            while (cur < sy) {                                   // (cells are contiguous: this runs once, or not at all for a shared row)
+                cur++;
+                reduce();
+                if (cur + 1 < sy_end) fetch(cur + 1);
+                hsum();
+            }
+            const float be = (hf && sy == s1 - 1) ? yaf : ((hl && sy == s2) ? yal : yam);
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = __fadd_rn(acc[c], __fmul_rn(be, b[c]));
+        }
+        if (live) {
+            uint32_t px = cvt_pk_u8(acc[0], 0u, 0);
+            px = cvt_pk_u8(acc[1], px, 1);
+            px = cvt_pk_u8(acc[2], px, 2);
+            px = cvt_pk_u8(acc[3], px, 3);
+            *(uint32_t*)(D + (size_t)dy * a.dstep) = px;
+        }
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_resize_area_rows(RArgs a, AreaGeom gm, int nstrips, int bh, int nitems, int bpf, int count) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * ((W + 3) / 4) * 4];
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blk * 4 + wv;
+    if (item < nitems) area_rows_body<W>(a, gm, frame, item, nstrips, bh, s_line[wv]);
+}
+
+// ------------------------------------------------------------------ AREA over frames of DIFFERENT geometry (BASELINE configs[4])
+// One launch for a run of requests whose frames all differ in size (bridge.c:588-604 calls Resize() on whatever arrives):
+// a descriptor per frame -- its views and its two scale factors -- instead of launch arguments.  Blocks are dealt to the
+// XCDs like frame_block deals them (block id mod 8 = XCD): descriptor list g holds the frames of XCD g back to back, each
+// with the number of the first block it owns inside that list, and a block finds its frame by bisection over those.
+struct MixDesc { RArgs a; AreaGeom gm; int first, nblk, nv, rows, nstrips, nitems; };   // BGRA: nv = window W, rows = band height
+struct MixIndex { int off[9]; };                       // descriptors of XCD g: [off[g], off[g + 1])
+constexpr int MIX_NV = 5;                              // windows of up to 20 source columns: shrinks up to 18x (3840 -> 224 is 17.1x)
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_resize_area_mix(const MixDesc* __restrict__ d, MixIndex ix) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_line[CN == 4 ? 4 : 1][CN == 4 ? 64 * MIX_NV * 4 : 4];
+    const int g = blockIdx.x & 7, q = blockIdx.x >> 3;
+    int lo = ix.off[g], hi = ix.off[g + 1];
+    if (lo == hi || q >= d[hi - 1].first + d[hi - 1].nblk) return;
+    while (hi - lo > 1) {                              // last descriptor whose first block is <= q
+        const int mid = (lo + hi) >> 1;
+        if (d[mid].first <= q) lo = mid; else hi = mid;
+    }
+    const MixDesc& m = d[lo];
+    const int blk = q - m.first;
+    if constexpr (CN == 4) {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int item = blk * 4 + wv;
+        if (item >= m.nitems) return;
+        switch (m.nv) {                                // block-uniform: one scalar branch
+            case 2: area_rows_body<2>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 4: area_rows_body<4>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 6: area_rows_body<6>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 8: area_rows_body<8>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 10: area_rows_body<10>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 12: area_rows_body<12>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 14: area_rows_body<14>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 16: area_rows_body<16>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 18: area_rows_body<18>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            default: area_rows_body<20>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+        }
+    } else {
+        switch (m.nv * 2 + (m.rows == 1)) {
+            case 2: area_cells_body<3, 1, AREA_ROWS>(m.a, m.gm, 0, blk); break;
+            case 3: area_cells_body<3, 1, 1>(m.a, m.gm, 0, blk); break;
+            case 4: area_cells_body<3, 2, AREA_ROWS>(m.a, m.gm, 0, blk); break;
+            case 5: area_cells_body<3, 2, 1>(m.a, m.gm, 0, blk); break;
+            case 6: area_cells_body<3, 3, AREA_ROWS>(m.a, m.gm, 0, blk); break;
+            case 7: area_cells_body<3, 3, 1>(m.a, m.gm, 0, blk); break;
+            case 8: area_cells_body<3, 4, AREA_ROWS>(m.a, m.gm, 0, blk); break;
+            case 9: area_cells_body<3, 4, 1>(m.a, m.gm, 0, blk); break;
+            case 10: area_cells_body<3, 5, AREA_ROWS>(m.a, m.gm, 0, blk); break;
+            default: area_cells_body<3, 5, 1>(m.a, m.gm, 0, blk); break;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ per-geometry table cache
@@ -1909,26 +2069,23 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
     std::vector<uint8_t> blob;
     TableSet ts;
     size_t o[12] = {0};
-    int nv = 0, nyp = 0, nypg = 0;
+    int nv = 0, nypg = 0;
     if (interp == IMP_INTER_AREA) {
         AreaAxis ax, ay;
         build_area_axis(sw, dw, scale_x, &ax);
         build_area_axis(sh, dh, scale_y, &ay);
         o[0] = put(blob, ax.start); o[1] = put(blob, ax.count); o[2] = put(blob, ax.aoff); o[3] = put(blob, ax.alpha);
         o[4] = put(blob, ay.start); o[5] = put(blob, ay.count); o[6] = put(blob, ay.aoff); o[7] = put(blob, ay.alpha);
-        if (ax.max_count <= 16 && ay.max_count <= 32 && sw >= 4 * ((ax.max_count + 3) / 4)) {   // k_resize_area_v4 tables
+        if (ax.max_count <= 16 && sw >= 4 * ((ax.max_count + 3) / 4)) {   // k_resize_area_v4r / _v3r tables
             nv = (ax.max_count + 3) / 4;
-            nyp = ay.max_count;
             std::vector<int> xsp(dw);
-            std::vector<float> pad((size_t)dw * nv * 4, 0.f), ypad((size_t)dh * nyp, 0.f);
+            std::vector<float> pad((size_t)dw * nv * 4, 0.f);
             for (int d = 0; d < dw; d++) {
                 xsp[d] = ax.start[d] < sw - nv * 4 ? ax.start[d] : sw - nv * 4;
                 const int shift = ax.start[d] - xsp[d];      // shift + count <= 4*nv because start + count <= sw
                 for (int k = 0; k < ax.count[d]; k++) pad[(size_t)d * nv * 4 + shift + k] = ax.alpha[ax.aoff[d] + k];
             }
-            for (int d = 0; d < dh; d++)
-                for (int k = 0; k < ay.count[d]; k++) ypad[(size_t)d * nyp + k] = ay.alpha[ay.aoff[d] + k];
-            o[8] = put(blob, pad); o[9] = put(blob, xsp); o[10] = put(blob, ypad);
+            o[8] = put(blob, pad); o[9] = put(blob, xsp);
             // row groups of k_resize_area_v4r
             const int ng = (dh + AREA_ROWS - 1) / AREA_ROWS;
             for (int g = 0; g < ng; g++) {
@@ -1941,7 +2098,7 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
                 for (int jj = 0; jj < ay.count[d]; jj++)
                     ygrp[((size_t)g * nypg + j0 + jj) * AREA_ROWS + k] = ay.alpha[ay.aoff[d] + jj];
             }
-            o[11] = put(blob, ygrp);
+            o[10] = put(blob, ygrp);
         }
     } else {
         TapAxis tx, ty;
@@ -1981,10 +2138,8 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         ts.area.yaoff = (const int*)(dev + o[6]);  ts.area.yalpha = (const float*)(dev + o[7]);
         ts.area.xalpha_pad = nv ? (const float*)(dev + o[8]) : nullptr;
         ts.area.xstart_pad = nv ? (const int*)(dev + o[9]) : nullptr;
-        ts.area.ybeta_pad = nv ? (const float*)(dev + o[10]) : nullptr;
         ts.area.nv = nv;
-        ts.area.nyp = nyp;
-        ts.area.ybeta_grp = nv ? (const float*)(dev + o[11]) : nullptr;
+        ts.area.ybeta_grp = nv ? (const float*)(dev + o[10]) : nullptr;
         ts.area.nypg = nypg;
     } else {
         ts.xofs = (const int*)(dev + o[0]); ts.xco = (const short*)(dev + o[1]);
@@ -2000,6 +2155,33 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
 }
 
 // ------------------------------------------------------------------ launcher
+// k_resize_area_rows for this geometry?  *w = window (the widest horizontal cell, widened until a wave's segment fits its
+// 64 * ceil(W/4) granules), *bh = destination rows per band: 16, less while that leaves fewer than ~4096 waves.
+static bool area_rows_plan(int sw, int sh, int dw, int dh, double scale_x, long long frames, bool even, int* w, int* bh) {
+    (void)sh;
+    int ww = area_max_count(sw, dw, scale_x);
+    if (even) ww += ww & 1;                                // the mixed-geometry kernel carries the even windows only
+    while (ww <= 4 * MIX_NV && 63 * scale_x + ww + 8 > 256 * ((ww + 3) / 4)) ww += even ? 2 : 1;
+    if (ww < 1 || ww > 4 * MIX_NV || sw < ww || sw < 4) return false;
+    static const int bh_env = std::getenv("IMPGPU_AREA_BH") ? std::atoi(std::getenv("IMPGPU_AREA_BH")) : 0;
+    int b = 16;
+    const long long nstrips = (dw + 63) / 64;
+    while (b > 4 && frames * nstrips * ((dh + b - 1) / b) < 4096) b /= 2;
+    if (bh_env > 0) b = std::min(64, bh_env);
+    *w = ww;
+    *bh = b;
+    return true;
+}
+
+template <int W>
+static void launch_area_rows(int w, dim3 grid, hipStream_t s, const RArgs& a, const AreaGeom& gm, int nstrips, int bh, int nitems,
+                             int bpf, int count) {
+    if constexpr (W >= 1) {
+        if (w == W) hipLaunchKernelGGL((k_resize_area_rows<W>), grid, dim3(256), 0, s, a, gm, nstrips, bh, nitems, bpf, count);
+        else launch_area_rows<W - 1>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, count);
+    }
+}
+
 template <int CN>
 static int launch_cn(const RArgs& a, int count, int interp, double scale_x, double scale_y, hipStream_t s) {
     const dim3 block(256), grid((unsigned)(((long long)a.dw * a.dh + 255) / 256), (unsigned)count);
@@ -2037,35 +2219,54 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             } else
                 hipLaunchKernelGGL((k_resize_area_int<CN>), grid, block, 0, s, a, isx, isy);
         } else {
-            TableSet ts;
-            if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, s, &ts)) return rc;
+            // BGRA with cells of at most 20 source columns (shrinks up to 18x): source rows streamed through wave-private
+            // LDS lines, weights computed in the kernel -- no per-geometry table to build, upload or cache.
+            const AreaGeom gm{scale_x, scale_y};
+            if (CN == 4) {
+                int w = 0, bh = 0;
+                if (area_rows_plan(a.sw, a.sh, a.dw, a.dh, scale_x, count, false, &w, &bh)) {
+                    const int nstrips = (a.dw + 63) / 64, nitems = nstrips * ((a.dh + bh - 1) / bh), rbpf = (nitems + 3) / 4;
+                    const dim3 rgrid((unsigned)rbpf, (unsigned)((count + 7) / 8 * 8));
+                    launch_area_rows<4 * MIX_NV>(w, rgrid, s, a, gm, nstrips, bh, nitems, rbpf, count);
+                    IMP_HIP(hipGetLastError());
+                    return IMP_OK;
+                }
+            }
+            // BGR: a batch of one geometry takes per-geometry tables and groups of AREA_ROWS destination rows sharing their
+            // source-row walk (k_resize_area_v3r); too few blocks for 256 CUs -- a lone request, a GIF of a few frames --
+            // takes one output per lane with the weights computed in the kernel (no table for a never-seen size).
+            static const bool cells = std::getenv("IMPGPU_AREA_CELLS") != nullptr;      // A/B: the table-free kernel for batches too
             const int bpf = (int)grid.x;                       // blocks per frame
             const dim3 fgrid(grid.x, (unsigned)((count + 7) / 8 * 8));   // whole groups of 8 frames (frame-per-XCD order)
-            // BGRA: row groups share their source-row walk unless a group would walk a very long run (tiny outputs)
-            static const bool no_grp = std::getenv("IMPGPU_AREA_NO_GROUPS") != nullptr;
             const int ng = (a.dh + AREA_ROWS - 1) / AREA_ROWS;
             const int gbpf = (int)(((long long)a.dw * ng + 255) / 256);
             const dim3 ggrid((unsigned)gbpf, (unsigned)((count + 7) / 8 * 8));
-            // (a lone frame keeps one output per lane: a quarter of the blocks would not fill 256 CUs)
             const bool big = (long long)gbpf * count >= 1024;
-            const bool grp = CN == 4 && !no_grp && big && ts.area.nv >= 1 && ts.area.nv <= 4 && ts.area.nypg <= 96;
-            const bool grp3 = CN == 3 && !no_grp && big && ts.area.nv >= 1 && ts.area.nv <= 4 && ts.area.nypg <= 96;
-            if (grp && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4r<1>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4r<2>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4r<3>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v4r<4>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp3 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v3r<1>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp3 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v3r<2>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp3 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v3r<3>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp3 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v3r<4>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (CN == 4 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v4<1>), fgrid, block, 0, s, a, ts.area, bpf, count);
-            else if (CN == 4 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v4<2>), fgrid, block, 0, s, a, ts.area, bpf, count);
-            else if (CN == 4 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v4<3>), fgrid, block, 0, s, a, ts.area, bpf, count);
-            else if (CN == 4 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v4<4>), fgrid, block, 0, s, a, ts.area, bpf, count);
-            else if (CN == 3 && ts.area.nv == 1) hipLaunchKernelGGL((k_resize_area_v3<1>), fgrid, block, 0, s, a, ts.area, bpf, count);
-            else if (CN == 3 && ts.area.nv == 2) hipLaunchKernelGGL((k_resize_area_v3<2>), fgrid, block, 0, s, a, ts.area, bpf, count);
-            else if (CN == 3 && ts.area.nv == 3) hipLaunchKernelGGL((k_resize_area_v3<3>), fgrid, block, 0, s, a, ts.area, bpf, count);
-            else if (CN == 3 && ts.area.nv == 4) hipLaunchKernelGGL((k_resize_area_v3<4>), fgrid, block, 0, s, a, ts.area, bpf, count);
+            const int nvx = CN == 3 ? (area_max_count(a.sw, a.dw, scale_x) + 3) / 4 : 0;
+            const bool windowed = nvx >= 1 && nvx <= MIX_NV && a.sw >= 4 * nvx;
+            TableSet ts;
+            if (!windowed || (big && !cells))
+                if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, s, &ts)) return rc;
+            const bool grp = windowed && big && !cells && ts.area.nv == nvx && ts.area.nypg <= 96;
+            if (windowed && !grp) {
+#define IMP_CELLS(NV_) \
+    do { \
+        if (big) hipLaunchKernelGGL((k_resize_area_cells<3, NV_, AREA_ROWS>), ggrid, block, 0, s, a, gm, gbpf, count); \
+        else hipLaunchKernelGGL((k_resize_area_cells<3, NV_, 1>), fgrid, block, 0, s, a, gm, bpf, count); \
+    } while (0)
+                switch (nvx) {
+                    case 1: IMP_CELLS(1); break;
+                    case 2: IMP_CELLS(2); break;
+                    case 3: IMP_CELLS(3); break;
+                    case 4: IMP_CELLS(4); break;
+                    default: IMP_CELLS(5); break;
+                }
+#undef IMP_CELLS
+            }
+            else if (grp && nvx == 1) hipLaunchKernelGGL((k_resize_area_v3r<1>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp && nvx == 2) hipLaunchKernelGGL((k_resize_area_v3r<2>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp && nvx == 3) hipLaunchKernelGGL((k_resize_area_v3r<3>), ggrid, block, 0, s, a, ts.area, gbpf, count);
+            else if (grp && nvx == 4) hipLaunchKernelGGL((k_resize_area_v3r<4>), ggrid, block, 0, s, a, ts.area, gbpf, count);
             else hipLaunchKernelGGL((k_resize_area<CN>), grid, block, 0, s, a, ts.area);
         }
     } else {
@@ -2364,6 +2565,111 @@ int launch_cv_resize(const Frames& f, int interp, hipStream_t s) {
         case 4: return launch_cn<4>(a, f.count, interp, scale_x, scale_y, s);
     }
     return IMP_ERROR_INVALID_ARGS;
+}
+
+// Resize() over `count` frames of different geometry with as few launches as the mix allows.  Per frame the
+// interpolation is the reference's (bridge.c:183-193) and the arithmetic is launch_cv_resize's: frames that take the
+// general AREA path (every non-integer shrink whose cells span at most 16 source columns) are gathered into descriptor
+// launches, one per window width class, with their weights computed in the kernel; the rest (integer factors,
+// enlargements, NN, extreme ratios) go one launch each on the same stream.
+static int launch_mix(std::vector<MixDesc>& v, int cn, hipStream_t s) {
+    if (v.empty()) return IMP_OK;
+    // blocks differ a hundredfold in work (a 4K source against a 256-pixel one, same 224-wide output): the frames go
+    // longest first to the XCD list with the least source bytes so far, so each list starts with its heavy frames and
+    // the launch's tail is made of light ones
+    std::vector<int> order(v.size());
+    for (size_t i = 0; i < v.size(); i++) order[i] = (int)i;
+    auto cost = [&](int i) { return (long long)v[i].a.sw * v[i].a.sh; };
+    static const bool no_sort = std::getenv("IMPGPU_MIX_NOSORT") != nullptr;
+    if (!no_sort) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) > cost(y); });
+    std::vector<int> list[8];
+    long long load[8] = {0};
+    for (int i : order) {
+        int g = 0;
+        for (int k = 1; k < 8; k++)
+            if (load[k] < load[g]) g = k;
+        list[g].push_back(i);
+        load[g] += cost(i) + 4096;
+    }
+    std::vector<MixDesc> sorted;
+    sorted.reserve(v.size());
+    MixIndex ix{};
+    int most = 0;
+    for (int g = 0; g < 8; g++) {
+        ix.off[g] = (int)sorted.size();
+        int first = 0;
+        for (int i : list[g]) {
+            MixDesc d = v[i];
+            d.first = first;
+            first += d.nblk;
+            sorted.push_back(d);
+        }
+        most = std::max(most, first);
+    }
+    ix.off[8] = (int)sorted.size();
+    v.clear();
+    void* dev = nullptr;
+    if (int rc = upload_small(sorted.data(), sorted.size() * sizeof(MixDesc), &dev, s)) return rc;
+    const dim3 grid((unsigned)most * 8), block(256);
+    if (cn == 4) hipLaunchKernelGGL((k_resize_area_mix<4>), grid, block, 0, s, (const MixDesc*)dev, ix);
+    else hipLaunchKernelGGL((k_resize_area_mix<3>), grid, block, 0, s, (const MixDesc*)dev, ix);
+    const hipError_t e = hipGetLastError();
+    dev_free_on(dev, s);
+    IMP_HIP(e);
+    return IMP_OK;
+}
+
+int launch_resize_mixed(const MixFrame* fr, int count, int cn, int simple, hipStream_t s) {
+    if (count <= 0) return IMP_OK;
+    if (!fr || (cn != 1 && cn != 3 && cn != 4)) return IMP_ERROR_INVALID_ARGS;
+    for (int i = 0; i < count; i++) {                      // nothing is launched unless every frame is well-formed
+        const MixFrame& f = fr[i];
+        if (!f.src || !f.dst || f.sw <= 0 || f.sh <= 0 || f.dw <= 0 || f.dh <= 0 || f.sstep < f.sw * cn || f.dstep < f.dw * cn)
+            return IMP_ERROR_INVALID_ARGS;
+        if (cn == 4 && (((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)f.sstep | (uintptr_t)f.dstep) & 3)) return IMP_ERROR_INVALID_ARGS;
+    }
+    std::vector<MixDesc> gathered_frames;
+    gathered_frames.reserve(count);
+    for (int i = 0; i < count; i++) {
+        const MixFrame& f = fr[i];
+        const int interp = simple ? IMP_INTER_NN : ((f.dw > f.sw || f.dh > f.sh) ? IMP_INTER_CUBIC : IMP_INTER_AREA);   // bridge.c:188-192
+        const double scale_x = 1. / ((double)f.dw / f.sw), scale_y = 1. / ((double)f.dh / f.sh);
+        const bool whole = std::fabs(scale_x - std::lrint(scale_x)) < 2.220446049250313e-16 &&
+                           std::fabs(scale_y - std::lrint(scale_y)) < 2.220446049250313e-16;
+        bool gathered = false;
+        if (interp == IMP_INTER_AREA && !whole && cn != 1) {
+            MixDesc d{};
+            d.a = RArgs{f.src, 0, f.sstep, f.sw, f.sh, f.dst, 0, f.dstep, f.dw, f.dh};
+            d.gm = AreaGeom{scale_x, scale_y};
+            if (cn == 4) {
+                if (area_rows_plan(f.sw, f.sh, f.dw, f.dh, scale_x, count, true, &d.nv, &d.rows)) {
+                    d.nstrips = (f.dw + 63) / 64;
+                    d.nitems = d.nstrips * ((f.dh + d.rows - 1) / d.rows);
+                    d.nblk = (d.nitems + 3) / 4;
+                    gathered = true;
+                }
+            } else {
+                // the widest cell decides the window: ceil(scale) <= widest <= floor(scale) + 2; the axis is walked only
+                // when those two ends name different windows (a wider window than needed is still exact, only slower)
+                const int nv_lo = ((int)std::ceil(scale_x) + 3) / 4, nv_hi = ((int)std::floor(scale_x) + 2 + 3) / 4;
+                const int nv = nv_lo == nv_hi ? nv_hi : (area_max_count(f.sw, f.dw, scale_x) + 3) / 4;
+                if (nv >= 1 && nv <= MIX_NV && f.sw >= 4 * nv) {
+                    d.nv = nv;
+                    d.rows = scale_y < 8 ? AREA_ROWS : 1;   // tall cells: sharing one boundary row in nine is not worth a quarter of the blocks
+                    d.nblk = (int)(((long long)f.dw * ((f.dh + d.rows - 1) / d.rows) + 255) / 256);
+                    gathered = true;
+                }
+            }
+            if (gathered) gathered_frames.push_back(d);
+        }
+        if (!gathered) {
+            Frames one{};
+            one.src = f.src; one.src_stride = 0; one.v = View{f.src, f.sw, f.sh, cn, f.sstep};
+            one.dst = f.dst; one.dst_stride = 0; one.dw = f.dw; one.dh = f.dh; one.dstep = f.dstep; one.count = 1;
+            if (int rc = launch_cv_resize(one, interp, s)) return rc;
+        }
+    }
+    return launch_mix(gathered_frames, cn, s);
 }
 
 }  // namespace imp

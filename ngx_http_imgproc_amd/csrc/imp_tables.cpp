@@ -95,6 +95,21 @@ void build_area_axis(int ssize, int dsize, double scale, AreaAxis* out) {
     }
 }
 
+// The widest cell of an axis (AreaAxis::max_count without building the axis): what picks the window class of the
+// kernels that compute their weights themselves.
+int area_max_count(int ssize, int dsize, double scale) {
+    int most = 0;
+    for (int d = 0; d < dsize; d++) {
+        const double f1 = d * scale, f2 = f1 + scale;
+        int s1 = (int)std::ceil(f1), s2 = (int)std::floor(f2);
+        if (s2 > ssize - 1) s2 = ssize - 1;
+        if (s1 > s2) s1 = s2;
+        const int n = (s1 - f1 > 1e-3) + (s2 - s1) + (f2 - s2 > 1e-3);
+        if (n > most) most = n;
+    }
+    return most;
+}
+
 int gaussian_ksize(double sigma) {
     if (!(sigma > 0)) return 0;
     return round_half_even(sigma * 3 * 2 + 1) | 1;

@@ -245,6 +245,18 @@ def batch_cv_resize(src_ptr, src_stride, sw, sh, sstep, dst_ptr, dst_stride, dw,
         raise ImpError(rc, "impgpu_batch_cv_resize")
 
 
+class ResizeItem(C.Structure):
+    """impgpu_resize_item (include/impgpu.h)."""
+    _fields_ = [("src", C.c_void_p), ("src_width", C.c_int), ("src_height", C.c_int), ("src_step", C.c_int),
+                ("dst", C.c_void_p), ("dst_width", C.c_int), ("dst_height", C.c_int), ("dst_step", C.c_int)]
+
+
+def batch_resize_mixed(items, channels, simple=False, stream=None):
+    """items: [(src_ptr, sw, sh, sstep, dst_ptr, dw, dh, dstep)] of frames resident in HBM; returns the IMP_* code."""
+    arr = (ResizeItem * len(items))(*[ResizeItem(*it) for it in items])
+    return lib.impgpu_batch_resize_mixed(arr, len(items), channels, int(simple), C.c_void_p(stream or 0))
+
+
 def batch_resize_rotate_watermark(src_ptr, src_stride, sw, sh, sstep, dst_ptr, dst_stride, dstep, rw, rh, rotate,
                                   config, channels, count, stream=None):
     rc = lib.impgpu_batch_resize_rotate_watermark(C.c_void_p(src_ptr), src_stride, sw, sh, sstep, C.c_void_p(dst_ptr),

@@ -174,3 +174,91 @@ def test_batch_calls_on_a_callers_stream_need_no_host_wait(gpu):
             rc, f = orc.filter(f, "kelvin=1", 1)
             assert np.array_equal(gotf[i], f), (gamma, i)
     cfg.release()
+
+
+def _mixed_batch(gpu, frames_np, targets, simple=False, stream=None):
+    """Upload every frame to its own tensor, run impgpu_batch_resize_mixed once, return (rc, outputs)."""
+    import torch
+
+    c = frames_np[0].shape[2]
+    srcs = [torch.from_numpy(f).cuda() for f in frames_np]
+    dsts = [torch.zeros((dh, dw, c), dtype=torch.uint8, device="cuda") for dw, dh in targets]
+    torch.cuda.synchronize()
+    items = [(s.data_ptr(), f.shape[1], f.shape[0], f.shape[1] * c, d.data_ptr(), dw, dh, dw * c)
+             for s, f, d, (dw, dh) in zip(srcs, frames_np, dsts, targets)]
+    rc = gpu.batch_resize_mixed(items, c, simple=simple, stream=stream)
+    if stream is None:
+        gpu.sync()
+    return rc, dsts
+
+
+@pytest.mark.parametrize("c", [3, 4])
+def test_mixed_geometry_batch_is_the_per_frame_resize(gpu, c):
+    """impgpu_batch_resize_mixed: BASELINE configs[4] on resident frames.  40 sizes of the stream generator plus the
+    geometries that must NOT ride the descriptor launch -- exact 2x / 4x / 3x factors (resizeAreaFast_), an enlargement
+    (CUBIC), runs longer than 16 pixels (a 3840-wide frame to 100), a 1x1 frame -- every output compared with the
+    oracle's cvResize under the interpolation Resize() picks (bridge.c:188-192)."""
+    sizes = mixed_sizes(40, seed=0x1A4D0A07)
+    sizes = [(min(w, 1400), min(h, 1400)) for w, h in sizes]                  # keep the oracle's share of the run short
+    sizes += [(448, 300), (896, 448), (672, 99), (100, 60), (3840, 64), (1, 1), (224, 224), (225, 224)]
+    cfg = gpu.Config()
+    frames, targets = [], []
+    for i, (w, h) in enumerate(sizes):
+        frames.append(noise_image(h, w, c, 5200 + i))
+        if (w, h) == (3840, 64):
+            targets.append((100, 5))
+        elif (w, h) == (448, 300):
+            targets.append((224, 150))                                         # exact 2x2
+        elif (w, h) == (896, 448):
+            targets.append((224, 112))                                         # exact 4x4
+        elif (w, h) == (672, 99):
+            targets.append((224, 33))                                          # exact 3x3
+        else:
+            rc, (dw, dh, _) = gpu.resize_geometry(w, h, "224,0,up", cfg)
+            assert rc == 0
+            targets.append((dw, dh))
+    rc, outs = _mixed_batch(gpu, frames, targets)
+    assert rc == 0
+    for f, (dw, dh), out in zip(frames, targets, outs):
+        interp = orc.INTER_CUBIC if (dw > f.shape[1] or dh > f.shape[0]) else orc.INTER_AREA
+        want = orc.cv_resize(f, dw, dh, interp)
+        assert np.array_equal(out.cpu().numpy(), want), (f.shape, dw, dh)
+
+
+def test_mixed_geometry_batch_outlives_the_table_cache(gpu):
+    """600 distinct geometries in one call: the launcher must flush its descriptor launches before the lane's
+    256-entry table cache recycles a table they point at; then the same call on a caller's stream, and with simple=1 (NN)."""
+    import torch
+
+    geoms = [(60 + (i % 41), 40 + (i // 41) % 23, 11 + i % 13) for i in range(600)]
+    assert len(set(geoms)) == 600
+    frames = [noise_image(h, w, 4, 6000 + i) for i, (w, h, _) in enumerate(geoms)]
+    targets = [(tw, max(1, round(h * tw / w))) for (w, h, tw) in geoms]
+    rc, outs = _mixed_batch(gpu, frames, targets)
+    assert rc == 0
+    for f, (dw, dh), out in zip(frames, targets, outs):
+        assert np.array_equal(out.cpu().numpy(), orc.cv_resize(f, dw, dh, orc.INTER_AREA)), (f.shape, dw, dh)
+    stream = torch.cuda.Stream()
+    rc, outs = _mixed_batch(gpu, frames[:150], targets[:150], stream=stream.cuda_stream)
+    assert rc == 0
+    stream.synchronize()
+    for f, (dw, dh), out in zip(frames[:150], targets[:150], outs):
+        assert np.array_equal(out.cpu().numpy(), orc.cv_resize(f, dw, dh, orc.INTER_AREA)), (f.shape, dw, dh)
+    rc, outs = _mixed_batch(gpu, frames[:40], targets[:40], simple=True)
+    assert rc == 0
+    for f, (dw, dh), out in zip(frames[:40], targets[:40], outs):
+        assert np.array_equal(out.cpu().numpy(), orc.cv_resize(f, dw, dh, orc.INTER_NN)), (f.shape, dw, dh)
+
+
+def test_mixed_geometry_batch_rejects_a_malformed_item_before_launching(gpu):
+    import torch
+
+    frames = [noise_image(50, 70, 4, 6900 + i) for i in range(3)]
+    srcs = [torch.from_numpy(f).cuda() for f in frames]
+    dsts = [torch.full((20, 30, 4), 7, dtype=torch.uint8, device="cuda") for _ in frames]
+    items = [(s.data_ptr(), 70, 50, 280, d.data_ptr(), 30, 20, 120) for s, d in zip(srcs, dsts)]
+    items[2] = items[2][:7] + (100,)                                           # destination pitch shorter than a row
+    assert gpu.batch_resize_mixed(items, 4) == gpu.IMP_ERROR_INVALID_ARGS
+    gpu.sync()
+    assert all(int(d.min()) == 7 and int(d.max()) == 7 for d in dsts)          # the two good items were not run either
+    assert gpu.batch_resize_mixed([], 4) == 0

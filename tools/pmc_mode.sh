@@ -5,6 +5,7 @@ mode=$1; out=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=/root/repo
+mkdir -p $R/$out
 i=0
 for set in "$@"; do
   i=$((i+1))
