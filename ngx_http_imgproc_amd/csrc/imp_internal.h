@@ -87,6 +87,7 @@ bool fault_hit(int step);
 // ---------------------------------------------------------------- AlphaBlendOver on one BGRA pixel pair (filters.c:633-659)
 // Shared by k_blend_over (imp_pixel.hip) and the fused resize + rotate + watermark kernel (imp_resize.hip): the float
 // sequence of the reference, one operation per rounding (`alpha` = 1 - opacity, filters.c:620).
+#ifdef __HIPCC__          // device code: the host-only builds of the grammar files (sanitizer tests) skip it
 __device__ __forceinline__ uint32_t blend_over_bgra(uint32_t d, uint32_t s, float alpha) {
     const int dB = d & 0xff, dG = (d >> 8) & 0xff, dR = (d >> 16) & 0xff;
     const float dA = (float)((double)(d >> 24) / 255.0);
@@ -105,6 +106,7 @@ __device__ __forceinline__ uint32_t blend_over_bgra(uint32_t d, uint32_t s, floa
     const int tAi = (a255 > -2147483904.f && a255 < 2147483648.f) ? (int)a255 : (int)0x80000000;
     return (uint32_t)(tB & 0xff) | ((uint32_t)(tG & 0xff) << 8) | ((uint32_t)(tR & 0xff) << 16) | ((uint32_t)(tAi & 0xff) << 24);
 }
+#endif
 
 // ---------------------------------------------------------------- host grammar (imp_args.cpp)
 int crop_geometry(int col, int row, const char* args, const char* gravity, int* x, int* y, int* w, int* h);

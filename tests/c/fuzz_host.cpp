@@ -101,6 +101,7 @@ int main() {
                 if (a.start[d] < 0 || a.start[d] + a.count[d] > ss) { std::printf("out-of-range run\n"); return 1; }
                 for (int k = 0; k < a.count[d]; k++) sum += a.alpha[a.aoff[d] + k];
             }
+            if (imp::area_max_count(ss, ds, 1. / ((double)ds / ss)) != a.max_count) { std::printf("area_max_count disagrees\n"); return 1; }
             std::printf("%.3f %d\n", sum, a.max_count);
         } else if (kind == "gauss") {
             double sigma;
