@@ -100,3 +100,38 @@ def test_request_line_end_to_end(gpu, uri, ext):
     if rc == 0:
         assert np.array_equal(im.numpy(), want), uri
     im.release()
+
+
+@pytest.mark.gpu
+def test_cfg1_jpeg_request_between_host_codecs(gpu):
+    """BASELINE configs[0] with real codecs either side of the path, as RunJob has them (bridge.c:383-411 decode,
+    :660-700 encode; advancedio.c stays on the host): a 640x480 JPEG is decoded on the host (Pillow's libjpeg standing
+    in for FreeImage's), the decoded BGR frame goes through the literal request on the device, and the result is
+    encoded back to JPEG with the request's quality.  The device chain is compared bit for bit with the oracle on the
+    same decoded pixels; the codec round trip only has to keep the geometry and stay close to what was encoded."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from test_gpu_chain import oracle_chain
+
+    rgb = smooth_image(480, 640, 3, seed=3)[:, :, ::-1]
+    blob = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(rgb)).save(blob, format="JPEG", quality=92)
+    decoded = np.asarray(Image.open(io.BytesIO(blob.getvalue())).convert("RGB"))
+    bgr = np.ascontiguousarray(decoded[:, :, ::-1])                       # what cvDecodeImage / FreeImage hand RunJob
+    uri, ext = "/img.jpg?crop=320px,240px,0px,0px&resize=160,0&quality=85&filter-gamma=1.3", "jpg"
+    cfg = gpu.Config(allow_experiments=True)
+    r = gpu.Request(uri, ext, cfg)
+    rc_o, q = orc.parse_request(uri, ext, 5)
+    assert r.code == rc_o == 0 and r.quality == "85" and r.need_flatten == 1
+    rc_w, _, want = oracle_chain(bgr, crop=q["crop"], gravity=q["gravity"], resize=q["resize"], simple=q["simple"],
+                                 filters=q["filters"], flatten=q["need_flatten"])
+    im = gpu.Image(bgr)
+    rc, step = r.run(im, cfg)
+    assert rc == rc_w == 0, (rc, step)
+    out = im.numpy()
+    im.release()
+    assert out.shape == (120, 160, 3) and np.array_equal(out, want)
+    enc = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(out[:, :, ::-1])).save(enc, format="JPEG", quality=int(r.quality))
+    back = np.asarray(Image.open(io.BytesIO(enc.getvalue())).convert("RGB"))[:, :, ::-1]
+    assert back.shape == out.shape and np.abs(back.astype(int) - out).mean() < 3.0
