@@ -1444,59 +1444,14 @@ __global__ __launch_bounds__(256) void k_area2x2_v3(RArgs a, int qpr) {
 
 // ------------------------------------------------------------------ AREA, other integer scales (3x3, 4x4, 4x3 ...), streaming form
 // resizeAreaFast_ for integer scales: the box sum is exact integer work and the mean is saturate(cvRound(sum * (1.f/area))).
-// Like k_area2x2_v4 a lane owns FOUR neighbouring destination pixels of a row: ISX 16-byte loads per source row, ISY rows,
-// the 4 * ISX source pixels of a row landing on their destination pixel at compile time; two channels per add in the
-// 16-bit halves of a dword (ISX * ISY * 255 fits 16 bits up to 257 source pixels per box), one 16-byte store.  The per-pixel
-// k_resize_area_int it replaces issued one dword load per source pixel: 0.45 (4x4) and 0.27 (8x8) of the roofline.
-template <int ISX>
-__global__ __launch_bounds__(256) void k_area_box4(RArgs a, int isy, int qpr, float scale) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= qpr * a.dh) return;
-    const int dy = idx / qpr, q = idx - dy * qpr;
-    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride + (size_t)(dy * isy) * a.sstep + (size_t)q * (16 * ISX);
-    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep + (size_t)q * 16;
-    const int n = min(4, a.dw - 4 * q);
-    const uint32_t M = 0x00ff00ffu;
-    uint32_t e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};        // (B,R) and (G,A) sums of the four boxes
-    if (n == 4) {
-        for (int ky = 0; ky < isy; ky++) {
-            uint32_t p[4 * ISX];
-            load_stream<4 * ISX>(p, S + (size_t)ky * a.sstep);
-#pragma unroll
-            for (int i = 0; i < 4 * ISX; i++) {
-                e[i / ISX] += p[i] & M;
-                o[i / ISX] += (p[i] >> 8) & M;
-            }
-        }
-    } else {
-        for (int ky = 0; ky < isy; ky++)
-            for (int i = 0; i < n * ISX; i++) {
-                const uint32_t p = *(const uint32_t*)(S + (size_t)ky * a.sstep + 4 * i);
-                e[i / ISX] += p & M;
-                o[i / ISX] += (p >> 8) & M;
-            }
-    }
-    uint32_t out[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {      // v_cvt_pk_u8_f32 = saturate(round-half-even(x)) = saturate_cast<uchar>(cvRound(x))
-        uint32_t px = cvt_pk_u8(__fmul_rn((float)(e[j] & 0xffff), scale), 0u, 0);
-        px = cvt_pk_u8(__fmul_rn((float)(o[j] & 0xffff), scale), px, 1);
-        px = cvt_pk_u8(__fmul_rn((float)(e[j] >> 16), scale), px, 2);
-        out[j] = cvt_pk_u8(__fmul_rn((float)(o[j] >> 16), scale), px, 3);
-    }
-    if (n == 4) {
-        const u32x4_t ov = {out[0], out[1], out[2], out[3]};
-        __builtin_nontemporal_store(ov, (u32x4_t*)D);
-    } else {
-        for (int j = 0; j < n; j++) *(uint32_t*)(D + 4 * j) = out[j];
-    }
-}
-
+// Two channels per add in the 16-bit halves of a dword (ISX * ISY * 255 fits 16 bits up to 257 source pixels per box).
+// The per-pixel k_resize_area_int these replace issued one dword load per source pixel: 0.45 (4x4) and 0.27 (8x8) of the
+// roofline; a first streaming form that gave each lane ISX adjacent 16-byte granules (64 to 128 bytes between lanes) had
+// every 128-byte line fetched by four to eight different instructions: 0.49 / 0.29 (0.57 for ISX = 3).
+//
 // Power-of-two widths (1/4 and 1/8 thumbnails): here every wave-instruction reads 1 KB CONTIGUOUS (lane l takes the l-th
 // 16-byte granule of the j-th 1 KB piece), so a 16-byte granule is one whole box column group (ISX = 4) or half of one
-// (ISX = 8, the two halves meet through one DPP exchange at the end).  k_area_box4 above gives each lane ISX adjacent
-// granules -- 64 or 128 bytes apart between lanes -- and every 128-byte line is then fetched by four to eight different
-// instructions (0.49 / 0.29 of the roofline against 0.57 for ISX = 3).
+// (ISX = 8, the two halves meet through one DPP exchange at the end).
 template <int ISX>
 __global__ __launch_bounds__(256) void k_area_boxc(RArgs a, int isy, int gpr, float scale) {
     static_assert(ISX == 4 || ISX == 8, "16-byte granules must tile a box row");
@@ -1574,6 +1529,97 @@ __global__ __launch_bounds__(256) void k_area2x2_c4(RArgs a, int gpr) {
             const u32x2_t o = {box4_swar(r0[j][0], r0[j][1], r1[j][0], r1[j][1]), box4_swar(r0[j][2], r0[j][3], r1[j][2], r1[j][3])};
             __builtin_nontemporal_store(o, (u32x2_t*)(D + (size_t)dy[j] * a.dstep + (size_t)gx[j] * 8));
         }
+}
+
+// The same for 3-channel frames (every JPEG), any ISX in 2..8 -- 2 x 2 keeps k_area2x2_v3's integer rounding -- and for
+// the BGRA widths whose box rows no 16-byte granule respects (3, 5, 6, 7).  The work is split the other way round: a wave
+// takes a run of P destination pixels of one row (P * CN * ISX <= 4096 source bytes, P a multiple of 4), reads the ISY source
+// rows of that run as contiguous 16-byte granules and adds them up BYTE COLUMN by byte column (two columns per 32-bit
+// add in 16-bit halves), parks the 16-bit column sums in a wave-private LDS line, and then every lane gathers the
+// ISX x CN columns of four destination pixels from that line: box sums are exact integers whatever the order.
+template <int CN, int ISX>
+__global__ __launch_bounds__(256) void k_area_boxl(RArgs a, int isy, int P, int cpr, float scale) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_cols[4][2048];      // 4096 byte columns x 16 bit per wave
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + wv;
+    if (gw >= cpr * a.dh) return;
+    const int dy = gw / cpr, d0 = (gw - dy * cpr) * P;
+    const int np = min(P, a.dw - d0);                            // destination pixels of this run
+    const int nbytes = np * CN * ISX;                             // source bytes per row
+    const int ndw = (nbytes + 3) >> 2;                           // ... in dwords (rows are 4-byte aligned and padded)
+    const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride + (size_t)(dy * isy) * a.sstep + (size_t)d0 * CN * ISX;
+    uint32_t* cols = s_cols[wv];
+    const uint32_t M = 0x00ff00ffu;
+    uint32_t e[4][4], o[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) e[j][t] = o[j][t] = 0;
+    for (int ky = 0; ky < isy; ky++) {
+        const uint8_t* row = S + (size_t)ky * a.sstep;
+        uint32_t p[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int w0 = (j * 64 + lane) * 4;                  // first dword of this lane's granule
+            if (w0 + 4 <= ndw) load_stream<4>(p[j], row + (size_t)w0 * 4);
+            else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) p[j][t] = w0 + t < ndw ? *(const uint32_t*)(row + (size_t)(w0 + t) * 4) : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) { e[j][t] += p[j][t] & M; o[j][t] += (p[j][t] >> 8) & M; }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                                // byte column c of the run -> 16-bit slot c of the line
+        typedef unsigned int u32x4a_t __attribute__((ext_vector_type(4), aligned(16)));
+        const int g = j * 64 + lane;
+        const u32x4a_t lo = {(e[j][0] & 0xffffu) | (o[j][0] << 16), (e[j][0] >> 16) | (o[j][0] & 0xffff0000u),
+                             (e[j][1] & 0xffffu) | (o[j][1] << 16), (e[j][1] >> 16) | (o[j][1] & 0xffff0000u)};
+        const u32x4a_t hi = {(e[j][2] & 0xffffu) | (o[j][2] << 16), (e[j][2] >> 16) | (o[j][2] & 0xffff0000u),
+                             (e[j][3] & 0xffffu) | (o[j][3] << 16), (e[j][3] >> 16) | (o[j][3] & 0xffff0000u)};
+        *(u32x4a_t*)(cols + g * 8) = lo;
+        *(u32x4a_t*)(cols + g * 8 + 4) = hi;
+    }
+    asm volatile("" ::: "memory");
+    uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep + (size_t)d0 * CN;
+    for (int q = lane; q * 4 < np; q += 64) {                    // four destination pixels = 4 * CN * ISX columns, two per dword
+        uint32_t r[2 * CN * ISX];
+        typedef unsigned int u32x2a_t __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+        for (int i = 0; i < CN * ISX; i++) {
+            const u32x2a_t v = *(const u32x2a_t*)(cols + q * 2 * CN * ISX + 2 * i);
+            r[2 * i] = v.x; r[2 * i + 1] = v.y;
+        }
+        uint32_t out[CN] = {};
+#pragma unroll
+        for (int pp = 0; pp < 4; pp++)
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int k = 0; k < ISX; k++) {
+                    const int i = (pp * ISX + k) * CN + c;           // 16-bit slot inside r
+                    sum += (i & 1) ? (r[i >> 1] >> 16) : (r[i >> 1] & 0xffffu);
+                }
+                const int ob = pp * CN + c;
+                out[ob >> 2] = cvt_pk_u8(__fmul_rn((float)sum, scale), out[ob >> 2], ob & 3);
+            }
+        uint8_t* dq = D + (size_t)q * 4 * CN;
+        if (q * 4 + 4 <= np) {
+            typedef unsigned int u32xn_t __attribute__((ext_vector_type(CN), aligned(4)));
+            u32xn_t ov;
+#pragma unroll
+            for (int i = 0; i < CN; i++) ov[i] = out[i];
+            *(u32xn_t*)dq = ov;
+        } else {
+            for (int bidx = 0; bidx < (np - q * 4) * CN; bidx++) dq[bidx] = (uint8_t)(out[bidx >> 2] >> (8 * (bidx & 3)));
+        }
+    }
 }
 
 // ------------------------------------------------------------------ AREA, general (float tables)
@@ -2202,19 +2248,35 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                 else if (CN == 4) hipLaunchKernelGGL(k_area2x2_v4, qgrid, block, 0, s, a, qpr);
                 else hipLaunchKernelGGL(k_area2x2_v3, qgrid, block, 0, s, a, qpr);
             } else if (CN == 4 && rows4 && isx >= 3 && isx <= 8 && isy >= 1 && isx * isy <= 257 && a.sw == isx * a.dw && a.sh >= isy * a.dh) {
-                const int qpr = (a.dw + 3) / 4;
-                const dim3 qgrid((unsigned)(((long long)qpr * a.dh + 255) / 256), (unsigned)count);
                 const float scale = 1.f / (float)(isx * isy);
                 const int cpr = a.sw / 4;                         // 16-byte granules per source row (k_area_boxc)
                 const dim3 cgrid((unsigned)(((long long)cpr * a.dh + 1023) / 1024), (unsigned)count);
-                switch (isx) {
-                    case 3: hipLaunchKernelGGL((k_area_box4<3>), qgrid, block, 0, s, a, isy, qpr, scale); break;
-                    case 4: hipLaunchKernelGGL((k_area_boxc<4>), cgrid, block, 0, s, a, isy, cpr, scale); break;
+                static const bool all_lds = std::getenv("IMPGPU_BOXL") != nullptr;        // A/B: 4 and 8 through their other form
+                const int P = (4096 / (4 * isx)) & ~3, lcpr = (a.dw + P - 1) / P;
+                const dim3 lgrid((unsigned)(((long long)lcpr * a.dh + 3) / 4), (unsigned)count);
+                switch (isx + (all_lds ? 100 : 0)) {
+                    case 104: hipLaunchKernelGGL((k_area_boxc<4>), cgrid, block, 0, s, a, isy, cpr, scale); break;
                     case 8: hipLaunchKernelGGL((k_area_boxc<8>), cgrid, block, 0, s, a, isy, cpr, scale); break;
-                    case 5: hipLaunchKernelGGL((k_area_box4<5>), qgrid, block, 0, s, a, isy, qpr, scale); break;
-                    case 6: hipLaunchKernelGGL((k_area_box4<6>), qgrid, block, 0, s, a, isy, qpr, scale); break;
-                    case 7: hipLaunchKernelGGL((k_area_box4<7>), qgrid, block, 0, s, a, isy, qpr, scale); break;
-                    default: hipLaunchKernelGGL((k_area_box4<8>), qgrid, block, 0, s, a, isy, qpr, scale); break;
+                    case 3: case 103: hipLaunchKernelGGL((k_area_boxl<4, 3>), lgrid, block, 0, s, a, isy, P, lcpr, scale); break;
+                    case 5: case 105: hipLaunchKernelGGL((k_area_boxl<4, 5>), lgrid, block, 0, s, a, isy, P, lcpr, scale); break;
+                    case 6: case 106: hipLaunchKernelGGL((k_area_boxl<4, 6>), lgrid, block, 0, s, a, isy, P, lcpr, scale); break;
+                    case 7: case 107: hipLaunchKernelGGL((k_area_boxl<4, 7>), lgrid, block, 0, s, a, isy, P, lcpr, scale); break;
+                    case 4: hipLaunchKernelGGL((k_area_boxl<4, 4>), lgrid, block, 0, s, a, isy, P, lcpr, scale); break;
+                    default: hipLaunchKernelGGL((k_area_boxl<4, 8>), lgrid, block, 0, s, a, isy, P, lcpr, scale); break;
+                }
+            } else if (CN == 3 && rows4 && isx >= 2 && isx <= 8 && isy >= 1 && isx * isy <= 257 && !(isx == 2 && isy == 2) &&
+                       a.sw == isx * a.dw && a.sh >= isy * a.dh) {
+                const int P = (4096 / (3 * isx)) & ~3, cpr = (a.dw + P - 1) / P;
+                const dim3 bgrid((unsigned)(((long long)cpr * a.dh + 3) / 4), (unsigned)count);
+                const float scale = 1.f / (float)(isx * isy);
+                switch (isx) {
+                    case 2: hipLaunchKernelGGL((k_area_boxl<3, 2>), bgrid, block, 0, s, a, isy, P, cpr, scale); break;
+                    case 3: hipLaunchKernelGGL((k_area_boxl<3, 3>), bgrid, block, 0, s, a, isy, P, cpr, scale); break;
+                    case 4: hipLaunchKernelGGL((k_area_boxl<3, 4>), bgrid, block, 0, s, a, isy, P, cpr, scale); break;
+                    case 5: hipLaunchKernelGGL((k_area_boxl<3, 5>), bgrid, block, 0, s, a, isy, P, cpr, scale); break;
+                    case 6: hipLaunchKernelGGL((k_area_boxl<3, 6>), bgrid, block, 0, s, a, isy, P, cpr, scale); break;
+                    case 7: hipLaunchKernelGGL((k_area_boxl<3, 7>), bgrid, block, 0, s, a, isy, P, cpr, scale); break;
+                    default: hipLaunchKernelGGL((k_area_boxl<3, 8>), bgrid, block, 0, s, a, isy, P, cpr, scale); break;
                 }
             } else
                 hipLaunchKernelGGL((k_resize_area_int<CN>), grid, block, 0, s, a, isx, isy);

@@ -252,7 +252,8 @@ def test_area_2x2_on_a_cropped_view_and_batch(gpu):
 
 @pytest.mark.parametrize("scale", [(3, 3), (4, 4), (4, 3), (3, 5), (5, 2), (6, 6), (7, 1), (8, 8), (8, 16), (2, 3), (9, 9), (16, 16)])
 @pytest.mark.parametrize("dims", [(270, 480), (33, 45), (5, 3), (1, 1), (17, 130)])
-def test_area_integer_scales_streaming_kernel_bit_exact(gpu, scale, dims):
+@pytest.mark.parametrize("c", [4, 3])
+def test_area_integer_scales_streaming_kernel_bit_exact(gpu, scale, dims, c):
     """resizeAreaFast_ at integer scales other than 2x2: k_area_boxc<4|8> (contiguous granules, rows shorter than a wave's
     run wrap inside it), k_area_box4<ISX> for 3, 5, 6, 7 (any ISY with ISX*ISY <= 257) and the per-pixel fallback beyond;
     widths that leave a partial quad; saturate(cvRound(sum * (1.f / area)))."""
@@ -260,11 +261,11 @@ def test_area_integer_scales_streaming_kernel_bit_exact(gpu, scale, dims):
     dh, dw = dims
     if dh * isy * dw * isx > 6_000_000:
         pytest.skip("frame larger than this test needs")
-    arr = noise_image(dh * isy, dw * isx, 4, 24)
+    arr = noise_image(dh * isy, dw * isx, c, 24)
     want = orc.cv_resize(arr, dw, dh, orc.INTER_AREA)
     got = gpu_resize(gpu, arr, dw, dh, orc.INTER_AREA)
     assert np.array_equal(got, want), "max diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
     if isx * isy > 1:
-        s = arr.reshape(dh, isy, dw, isx, 4).astype(np.int64).sum(axis=(1, 3))
+        s = arr.reshape(dh, isy, dw, isx, c).astype(np.int64).sum(axis=(1, 3))
         mean = np.rint((s.astype(np.float32) * np.float32(1.0 / (isx * isy))).astype(np.float64))      # float32 product, half-even
         assert np.abs(got.astype(int) - mean).max() <= 1
