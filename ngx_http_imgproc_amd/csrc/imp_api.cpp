@@ -454,6 +454,22 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
         rc = launch_area2x2_rotate(fz, rotate, fuse ? &wm : nullptr, s);
         watermark_done = fuse && rc == IMP_OK;
     }
+    if (rc == IMP_ERROR_UNSUPPORTED && interp == IMP_INTER_AREA && channels == 4) {
+        // any other BGRA shrink: the rotate and the watermark ride on the store phase of the row-streaming AREA kernel
+        Frames fz = rs;
+        fz.dst = (uint8_t*)dst; fz.dst_stride = dst_frame_stride; fz.dstep = dst_step;
+        OverlayArgs wm{};
+        const impgpu_image* ov = config->watermark;
+        const bool fuse = ov && ov->c == 4 && !(((uintptr_t)ov->d | (uintptr_t)ov->step) & 3);
+        if (fuse) {
+            rc = watermark_rect(fw, fh, ov->w, ov->h, config, &wm.rx, &wm.ry, &wm.maxcol, &wm.maxrow);
+            if (rc) return rc;
+            wm.ov = ov->d; wm.ostep = ov->step;
+            wm.alpha = 1 - (float)(config->watermark_opacity / 100.0);     // bridge.c:275, filters.c:620
+        }
+        rc = launch_area_rotate(fz, rotate, fuse ? &wm : nullptr, s);
+        watermark_done = fuse && rc == IMP_OK;
+    }
     if (rc != IMP_ERROR_UNSUPPORTED) {
         // fused path taken (or failed with a device error)
     } else if (rotate == 0) {

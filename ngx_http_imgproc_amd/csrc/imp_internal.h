@@ -186,6 +186,9 @@ int launch_resize_mixed(const MixFrame* frames, int count, int channels, int sim
 // With a 4-channel overlay the Watermark step (bridge.c:629-640) rides on the store phase of the same kernel.
 struct OverlayArgs { const uint8_t* ov; int ostep, rx, ry, maxcol, maxrow; float alpha; };
 int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s);
+// general INTER_AREA of BGRA frames + rotate 0/90/180/270 + watermark in one pass (f.dw x f.dh = the resized geometry,
+// f.dst = the final frames); IMP_ERROR_UNSUPPORTED when the geometry takes another resize kernel.
+int launch_area_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s);
 // imp_geom.hip
 int launch_copy(const Frames& f, hipStream_t s);                       // crop copy / clone (dw,dh = v.w,v.h)
 int launch_flip(const Frames& f, int mode, hipStream_t s);             // cvFlip

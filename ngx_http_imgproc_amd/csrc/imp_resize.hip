@@ -1873,9 +1873,19 @@ __global__ __launch_bounds__(256) void k_resize_area_cells(RArgs a, AreaGeom gm,
 //   * the vertical cell is the same for the whole wave, so the row walk is scalar control flow: a source row shared by
 //     two destination rows is reduced once and added to both, a finished row is stored as 256 contiguous bytes.
 // Source rows are read once per band (+ one shared row per band boundary), never re-read across lanes.
+// What happens to a finished pixel: the Filter("rotate") and Watermark steps that follow Resize in a request
+// (bridge.c:606-640) ride on the store -- the resized frame is a few hundred KB, so where its pixels land costs nothing
+// next to the source walk, and the intermediate frames never exist.  rot = 0 / 90 / 180 / 270 (filters.c:111-133).
+struct AreaTail { int rot; OverlayArgs wm; };
+__device__ __forceinline__ uint32_t overlay_px(const OverlayArgs& wm, uint32_t px, int row, int col) {
+    if (wm.ov && row >= wm.ry && row < wm.ry + wm.maxrow && col >= wm.rx && col < wm.rx + wm.maxcol)
+        px = blend_over_bgra(px, *(const uint32_t*)(wm.ov + (size_t)(row - wm.ry) * wm.ostep + (size_t)(col - wm.rx) * 4), wm.alpha);
+    return px;
+}
+
 template <int W>
 __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& gm, int frame, int item, int nstrips, int bh,
-                                               uint32_t* __restrict__ line) {
+                                               uint32_t* __restrict__ line, const AreaTail& tail, uint32_t* __restrict__ tile) {
     constexpr int NV = (W + 3) / 4;                              // 16-byte granules a lane fetches per source row
     const int lane = threadIdx.x & 63;
     const int band = item / nstrips, strip = item - band * nstrips;
@@ -1946,7 +1956,8 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
     // them back with v_readlane, so everything in it is the same in all lanes -> scalar registers, scalar branches
     const AreaCell mine = area_cell(min(dy0 + lane, dy1 - 1), a.sh, gm.scale_y);
     const int sy_end = __builtin_amdgcn_readlane(mine.end(), dy1 - 1 - dy0);
-    uint8_t* D = a.dst + (long long)frame * a.dst_stride + (size_t)dx * 4;
+    uint8_t* D = a.dst + (long long)frame * a.dst_stride;
+    const bool quarter = tail.rot == 90 || tail.rot == 270;     // (kernel argument: scalar)
     int cur = -1;                                                // the source row `b` holds
     for (int dy = dy0; dy < dy1; dy++) {
         const int r = dy - dy0;
@@ -1969,24 +1980,56 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[c] = __fadd_rn(acc[c], __fmul_rn(be, b[c]));
         }
-        if (live) {
-            uint32_t px = cvt_pk_u8(acc[0], 0u, 0);
-            px = cvt_pk_u8(acc[1], px, 1);
-            px = cvt_pk_u8(acc[2], px, 2);
-            px = cvt_pk_u8(acc[3], px, 3);
-            *(uint32_t*)(D + (size_t)dy * a.dstep) = px;
+        uint32_t px = cvt_pk_u8(acc[0], 0u, 0);
+        px = cvt_pk_u8(acc[1], px, 1);
+        px = cvt_pk_u8(acc[2], px, 2);
+        px = cvt_pk_u8(acc[3], px, 3);
+        if (quarter) tile[(dy - dy0) * 65 + lane] = px;          // leaves with the band, turned (below)
+        else if (live) {
+            // R[i][j] = H[rh-1-i][rw-1-j] (180); H = the resized frame, dw x dh
+            const int orow = tail.rot == 180 ? a.dh - 1 - dy : dy, ocol = tail.rot == 180 ? a.dw - 1 - dx : dx;
+            *(uint32_t*)(D + (size_t)orow * a.dstep + (size_t)ocol * 4) = overlay_px(tail.wm, px, orow, ocol);
+        }
+    }
+    if (quarter) {
+        // R[i][j] = H[rh-1-j][i] (90), H[j][rw-1-i] (270): a destination row takes this band's pixels of ONE column, a
+        // contiguous run of dy1 - dy0 pixels -- written 16 bytes per lane, four lanes per run of 16, once per band (a
+        // scattered store per finished row would sit in front of every later source-row wait: one vmcnt for both)
+        asm volatile("" ::: "memory");
+        const int nb = dy1 - dy0, nq = (nb + 3) >> 2;
+        const int ncol = min(64, a.dw - strip * 64);
+        const int j0 = tail.rot == 90 ? a.dh - dy1 : dy0;        // first destination column of the run
+        for (int t = lane; t < ncol * nq; t += 64) {
+            const int col = t / nq, qi = t - col * nq;
+            const int hx = strip * 64 + col;
+            const int orow = tail.rot == 90 ? hx : a.dw - 1 - hx;
+            uint32_t v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int k = 4 * qi + jj;                       // k-th pixel of the run
+                const int r = tail.rot == 90 ? nb - 1 - k : k;   // band row it comes from
+                v[jj] = overlay_px(tail.wm, tile[min(max(r, 0), nb - 1) * 65 + col], orow, j0 + k);
+            }
+            uint8_t* q = D + (size_t)orow * a.dstep + (size_t)(j0 + 4 * qi) * 4;
+            if (4 * qi + 4 <= nb) {
+                const u32x4_t o4 = {v[0], v[1], v[2], v[3]};
+                *(u32x4_t*)q = o4;
+            } else {
+                for (int jj = 0; 4 * qi + jj < nb; jj++) *(uint32_t*)(q + 4 * jj) = v[jj];
+            }
         }
     }
 }
 
 template <int W>
-__global__ __launch_bounds__(256) void k_resize_area_rows(RArgs a, AreaGeom gm, int nstrips, int bh, int nitems, int bpf, int count) {
+__global__ __launch_bounds__(256) void k_resize_area_rows(RArgs a, AreaGeom gm, int nstrips, int bh, int nitems, int bpf, int count, AreaTail tail) {
     __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * ((W + 3) / 4) * 4];
+    __shared__ uint32_t s_tile[4][16 * 65];                      // quarter turns: a band (<= 16 rows) waits here to leave turned
     int frame, blk;
     if (!frame_block(bpf, count, &frame, &blk)) return;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int item = blk * 4 + wv;
-    if (item < nitems) area_rows_body<W>(a, gm, frame, item, nstrips, bh, s_line[wv]);
+    if (item < nitems) area_rows_body<W>(a, gm, frame, item, nstrips, bh, s_line[wv], tail, s_tile[wv]);
 }
 
 // ------------------------------------------------------------------ AREA over frames of DIFFERENT geometry (BASELINE configs[4])
@@ -2015,16 +2058,16 @@ __global__ __launch_bounds__(256) void k_resize_area_mix(const MixDesc* __restri
         const int item = blk * 4 + wv;
         if (item >= m.nitems) return;
         switch (m.nv) {                                // block-uniform: one scalar branch
-            case 2: area_rows_body<2>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            case 4: area_rows_body<4>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            case 6: area_rows_body<6>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            case 8: area_rows_body<8>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            case 10: area_rows_body<10>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            case 12: area_rows_body<12>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            case 14: area_rows_body<14>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            case 16: area_rows_body<16>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            case 18: area_rows_body<18>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
-            default: area_rows_body<20>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 2: area_rows_body<2>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 4: area_rows_body<4>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 6: area_rows_body<6>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 8: area_rows_body<8>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 10: area_rows_body<10>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 12: area_rows_body<12>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 14: area_rows_body<14>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 16: area_rows_body<16>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 18: area_rows_body<18>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            default: area_rows_body<20>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
         }
     } else {
         switch (m.nv * 2 + (m.rows == 1)) {
@@ -2221,11 +2264,36 @@ static bool area_rows_plan(int sw, int sh, int dw, int dh, double scale_x, long 
 
 template <int W>
 static void launch_area_rows(int w, dim3 grid, hipStream_t s, const RArgs& a, const AreaGeom& gm, int nstrips, int bh, int nitems,
-                             int bpf, int count) {
+                             int bpf, int count, const AreaTail& tail) {
     if constexpr (W >= 1) {
-        if (w == W) hipLaunchKernelGGL((k_resize_area_rows<W>), grid, dim3(256), 0, s, a, gm, nstrips, bh, nitems, bpf, count);
-        else launch_area_rows<W - 1>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, count);
+        if (w == W) hipLaunchKernelGGL((k_resize_area_rows<W>), grid, dim3(256), 0, s, a, gm, nstrips, bh, nitems, bpf, count, tail);
+        else launch_area_rows<W - 1>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, count, tail);
     }
+}
+
+// Resize (general INTER_AREA, BGRA) + rotate + watermark in one pass; f.dw x f.dh is the RESIZED geometry, f.dst the final
+// (rotated) frames.  IMP_ERROR_UNSUPPORTED when the geometry takes another resize kernel.
+int launch_area_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s) {
+    const View& v = f.v;
+    if (v.c != 4 || f.count <= 0 || f.count > 65535 || f.dw > v.w || f.dh > v.h) return IMP_ERROR_UNSUPPORTED;
+    if (((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)v.step | (uintptr_t)f.dstep | (uintptr_t)f.src_stride | (uintptr_t)f.dst_stride) & 3)
+        return IMP_ERROR_UNSUPPORTED;
+    const double scale_x = 1. / ((double)f.dw / v.w), scale_y = 1. / ((double)f.dh / v.h);
+    if (std::fabs(scale_x - std::lrint(scale_x)) < 2.220446049250313e-16 && std::fabs(scale_y - std::lrint(scale_y)) < 2.220446049250313e-16)
+        return IMP_ERROR_UNSUPPORTED;                      // resizeAreaFast_: the box kernels' arithmetic
+    int w = 0, bh = 0;
+    if (!area_rows_plan(v.w, v.h, f.dw, f.dh, scale_x, f.count, false, &w, &bh)) return IMP_ERROR_UNSUPPORTED;
+    bh = std::min(bh, 16);                                 // (the turned band's LDS tile)
+    const RArgs a{f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
+    const AreaGeom gm{scale_x, scale_y};
+    AreaTail tail{};
+    tail.rot = amount;
+    if (overlay) tail.wm = *overlay;
+    const int nstrips = (f.dw + 63) / 64, nitems = nstrips * ((f.dh + bh - 1) / bh), bpf = (nitems + 3) / 4;
+    const dim3 grid((unsigned)bpf, (unsigned)((f.count + 7) / 8 * 8));
+    launch_area_rows<4 * MIX_NV>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, f.count, tail);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
 }
 
 template <int CN>
@@ -2289,7 +2357,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                 if (area_rows_plan(a.sw, a.sh, a.dw, a.dh, scale_x, count, false, &w, &bh)) {
                     const int nstrips = (a.dw + 63) / 64, nitems = nstrips * ((a.dh + bh - 1) / bh), rbpf = (nitems + 3) / 4;
                     const dim3 rgrid((unsigned)rbpf, (unsigned)((count + 7) / 8 * 8));
-                    launch_area_rows<4 * MIX_NV>(w, rgrid, s, a, gm, nstrips, bh, nitems, rbpf, count);
+                    launch_area_rows<4 * MIX_NV>(w, rgrid, s, a, gm, nstrips, bh, nitems, rbpf, count, AreaTail{});
                     IMP_HIP(hipGetLastError());
                     return IMP_OK;
                 }

@@ -171,9 +171,12 @@ def test_cfg3_chain_batch_224_variant(gpu):
 
 
 @pytest.mark.parametrize("rotate", [0, 90, 180, 270])
-@pytest.mark.parametrize("geom", [((96, 128), (64, 48)), ((96, 130), (64, 48)), ((70, 90), (45, 35)), ((66, 70), (35, 33))])
+@pytest.mark.parametrize("geom", [((96, 128), (64, 48)), ((96, 130), (64, 48)), ((70, 90), (45, 35)), ((66, 70), (35, 33)),
+                                  ((300, 500), (150, 77)), ((96, 128), (32, 32))])
 def test_batch_resize_rotate_watermark_all_turns(gpu, rotate, geom):
-    """Batch chain API: the fused 2x2-box + quarter-turn kernel (exact halves) and the unfused fallback agree with the oracle."""
+    """Batch chain API: the fused 2x2-box + quarter-turn kernel (exact halves), the row-streaming AREA kernel with the turn
+    and the blend on its stores (any other BGRA shrink; several column strips, a partial last one) and the unfused
+    fallback (integer factors other than 2) agree with the oracle."""
     (sh, sw), (rw, rh) = geom
     n = 3
     frames = [noise_image(sh, sw, 4, 60 + i) for i in range(n)]
@@ -190,6 +193,29 @@ def test_batch_resize_rotate_watermark_all_turns(gpu, rotate, geom):
     for i in range(n):
         rc, step, want = oracle_chain(frames[i], resize="%d,%d" % (rw, rh), filters=filters, overlay=ov, wm=("c", "b", 1, 2, 70))
         assert rc == 0 and np.array_equal(out[i], want), (rotate, geom, i)
+    src.release(); dst.release(); cfg.release()
+
+
+@pytest.mark.parametrize("rotate", [90, 270, 180])
+def test_fused_area_rotate_with_full_bands(gpu, rotate):
+    """Enough frames that the row-streaming kernel takes its 16-row bands (as in bench.py --mode chain224): the turned
+    band leaves through the LDS tile in runs of 16 pixels, the last band of 50 rows is partial."""
+    n, sh, sw, rw, rh = 1100, 120, 80, 37, 50
+    rng = np.random.Generator(np.random.PCG64(0x1A4D7700 + rotate))
+    frames = rng.integers(0, 256, size=(n, sh, sw, 4), dtype=np.uint8)
+    ov = noise_image(9, 20, 4, 62)
+    cfg = gpu.Config()
+    assert cfg.prepare_watermark(ov, "l", "t", 3, 1, 55) == 0
+    fw, fh = (rh, rw) if rotate in (90, 270) else (rw, rh)
+    src = gpu.Image(frames.reshape(n * sh, sw, 4))
+    dst = gpu.Image(np.zeros((n * fh, fw, 4), np.uint8))
+    gpu.batch_resize_rotate_watermark(src.device_ptr, sh * sw * 4, sw, sh, sw * 4, dst.device_ptr, fh * fw * 4, fw * 4,
+                                      rw, rh, rotate, cfg, 4, n)
+    out = dst.numpy().reshape(n, fh, fw, 4)
+    for i in range(0, n, 7):
+        rc, step, want = oracle_chain(frames[i], resize="%d,%d" % (rw, rh), filters=["rotate=%d" % rotate], overlay=ov,
+                                      wm=("l", "t", 3, 1, 55))
+        assert rc == 0 and np.array_equal(out[i], want), (rotate, i)
     src.release(); dst.release(); cfg.release()
 
 
