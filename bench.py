@@ -56,7 +56,7 @@ WORKLOADS = {
 }
 
 
-def mixed_resident(imp, n, steps, warmup, rank, world):
+def mixed_resident(imp, n, steps, warmup, rank, world, c=4):
     """BASELINE configs[4] without PCIe: this rank's share of n mixed-size BGRA frames (workloads.mixed_sizes) resident in
     HBM, every one resized to 224 wide (INTER_AREA, bridge.c:190).  A step = all of them once: (a) one
     impgpu_batch_resize_mixed call, (b) one impgpu_batch_cv_resize launch per frame from one thread."""
@@ -71,20 +71,21 @@ def mixed_resident(imp, n, steps, warmup, rank, world):
     for w, h in sizes:
         rc, (dw, dh, _) = imp.resize_geometry(w, h, MIXED_RESIZE.decode(), cfg)
         assert rc == 0
-        srcs.append(torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda", generator=g))
-        dsts.append(torch.zeros((dh, dw, 4), dtype=torch.uint8, device="cuda"))
-        items.append((srcs[-1].data_ptr(), w, h, w * 4, dsts[-1].data_ptr(), dw, dh, dw * 4))
-        alg += w * h * 4 + dw * dh * 4
+        sp, dp = (w * c + 3) & ~3, (dw * c + 3) & ~3                 # cvCreateImage's widthStep
+        srcs.append(torch.randint(0, 256, (h, sp), dtype=torch.uint8, device="cuda", generator=g))
+        dsts.append(torch.zeros((dh, dp), dtype=torch.uint8, device="cuda"))
+        items.append((srcs[-1].data_ptr(), w, h, sp, dsts[-1].data_ptr(), dw, dh, dp))
+        alg += w * h * c + dw * dh * c
     stream = torch.cuda.Stream()
     stream.wait_stream(torch.cuda.current_stream())
     arr = (imp.ResizeItem * len(items))(*[imp.ResizeItem(*it) for it in items])
 
     def gathered():
-        assert imp.lib.impgpu_batch_resize_mixed(arr, len(items), 4, 0, stream.cuda_stream) == 0
+        assert imp.lib.impgpu_batch_resize_mixed(arr, len(items), c, 0, stream.cuda_stream) == 0
 
     def per_frame():
         for sp, w, h, ss, dp, dw, dh, ds in items:
-            imp.batch_cv_resize(sp, 0, w, h, ss, dp, 0, dw, dh, ds, 4, 1, imp.INTER_AREA, stream=stream.cuda_stream)
+            imp.batch_cv_resize(sp, 0, w, h, ss, dp, 0, dw, dh, ds, c, 1, imp.INTER_AREA, stream=stream.cuda_stream)
 
     res = {}
     for name, fn in (("one_call", gathered), ("launch_per_frame", per_frame)):
@@ -105,9 +106,9 @@ def mixed_resident(imp, n, steps, warmup, rank, world):
                      "alg_GBps": round(alg * steps / secs / 1e9, 1), "frac_of_8TBps": round(alg * steps / secs / 1e9 / HBM_PEAK_GBPS, 4),
                      "device_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 3)}
     return {"metric": "images/sec mixed-size resident stream resize=224,0", "unit": "images/sec", "value": res["one_call"]["images_per_sec"],
-            "rank": rank, "n_gpus": world, "frames_this_rank": len(items), "steps": steps, "dtype": "u8",
-            "data": "synthetic (seeded sizes, torch.randint BGRA frames, device-resident)",
-            "source_GB_this_rank": round(sum(w * h * 4 for w, h in sizes) / 1e9, 2), **res,
+            "rank": rank, "n_gpus": world, "frames_this_rank": len(items), "channels": c, "steps": steps, "dtype": "u8",
+            "data": "synthetic (seeded sizes, torch.randint frames, device-resident)",
+            "source_GB_this_rank": round(sum(w * h * c for w, h in sizes) / 1e9, 2), **res,
             "config": {"workload": "BASELINE configs[4] device-resident: %d frames, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % n}}
 
 
@@ -354,6 +355,7 @@ def main():
     ap.add_argument("--mixed", type=int, default=0, metavar="N",
                     help="BASELINE configs[4] with the N frames already in HBM: resize=224,0 over mixed sizes, one "
                          "impgpu_batch_resize_mixed call per step (and, for comparison, one launch per frame)")
+    ap.add_argument("--channels", type=int, default=4, choices=(3, 4), help="--mixed: BGRA (4) or BGR (3, what a JPEG decodes to)")
     ap.add_argument("--e2e", type=int, default=0, metavar="N",
                     help="instead of the headline, time N PCIe-inclusive requests (upload + resize + download) and exit")
     args = ap.parse_args()
@@ -420,7 +422,7 @@ def main():
             dist.destroy_process_group()
         return
     if args.mixed:
-        print(json.dumps(mixed_resident(imp, args.mixed, args.steps, args.warmup, rank, world)), flush=True)
+        print(json.dumps(mixed_resident(imp, args.mixed, args.steps, args.warmup, rank, world, args.channels)), flush=True)
         imp.env_destroy()
         return
     if args.e2e:

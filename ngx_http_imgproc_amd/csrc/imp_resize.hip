@@ -1626,13 +1626,6 @@ __global__ __launch_bounds__(256) void k_area_boxl(RArgs a, int isy, int P, int 
 struct AreaDev {
     const int *xstart, *xcount, *xaoff; const float* xalpha;
     const int *ystart, *ycount, *yaoff; const float* yalpha;
-    // k_resize_area_v4r / _v3r only (nv = 0: not built)
-    const int* xstart_pad;      // [dw] run start clamped to sw - 4*nv
-    const float* xalpha_pad;    // [dw][4*nv] weights of each run, shifted to xstart_pad and zero-padded
-    int nv;
-    // k_resize_area_v4r: destination rows in groups of AREA_ROWS that share one walk over their source rows
-    const float* ybeta_grp;     // [ceil(dh / AREA_ROWS)][nypg][AREA_ROWS]: weight of source row (ystart[g*R] + j) in row g*R + k, else 0
-    int nypg;                   // source rows a group walks (max over groups)
 };
 #define AREA_ROWS 4
 
@@ -1683,70 +1676,11 @@ __global__ __launch_bounds__(256) void k_resize_area(RArgs a, AreaDev t) {
     }
 }
 
-// The same for 3-channel BGR frames -- what cvDecodeImage hands the reference for every JPEG, and the mode its
-// Resize() picks for every shrink.  A run of 4*NV pixels is 12*NV bytes at an arbitrary byte address; gfx950
-// takes unaligned vector loads, and every (pixel, channel) sits at a compile-time byte of the loaded dwords,
-// so each tap is v_cvt_f32_ubyteN + mul + add with no shuffling.
-template <int NV>
-__device__ __forceinline__ void area_v3r_body(const RArgs& a, const AreaDev& t, int frame, int blk) {
-    constexpr int R = AREA_ROWS;
-    const int ng = (a.dh + R - 1) / R;
-    const int idx = blk * 256 + threadIdx.x;
-    if (idx >= a.dw * ng) return;
-    const int g = idx / a.dw, dx = idx - g * a.dw;
-    const uint8_t* S = a.src + (long long)frame * a.src_stride;
-    const int xs = t.xstart_pad[dx];
-    float al[NV * 4];
-    __builtin_memcpy(al, __builtin_assume_aligned(t.xalpha_pad + (size_t)dx * (NV * 4), 16), NV * 16);
-    const int ys = t.ystart[g * R];
-    const float* yb = t.ybeta_grp + (size_t)g * t.nypg * R;
-    float s0[R], s1[R], s2[R];
-#pragma unroll
-    for (int k = 0; k < R; k++) s0[k] = s1[k] = s2[k] = 0.f;
-    for (int j = 0; j < t.nypg; j++) {
-        const int sy = min(ys + j, a.sh - 1);
-        const uint8_t* row = S + (size_t)sy * a.sstep + (size_t)xs * 3;
-        uint32_t w[NV * 3];
-        load_bytes_aligned<NV * 3>(w, row);
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < NV * 4; k++) {
-            const int o0 = 3 * k, o1 = 3 * k + 1, o2 = 3 * k + 2;
-            b0 = __fadd_rn(b0, __fmul_rn((float)((w[o0 >> 2] >> (8 * (o0 & 3))) & 0xff), al[k]));
-            b1 = __fadd_rn(b1, __fmul_rn((float)((w[o1 >> 2] >> (8 * (o1 & 3))) & 0xff), al[k]));
-            b2 = __fadd_rn(b2, __fmul_rn((float)((w[o2 >> 2] >> (8 * (o2 & 3))) & 0xff), al[k]));
-        }
-        float be[R];
-        __builtin_memcpy(be, __builtin_assume_aligned(yb + (size_t)j * R, 16), R * 4);
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            s0[k] = __fadd_rn(s0[k], __fmul_rn(be[k], b0));
-            s1[k] = __fadd_rn(s1[k], __fmul_rn(be[k], b1));
-            s2[k] = __fadd_rn(s2[k], __fmul_rn(be[k], b2));
-        }
-    }
-    uint8_t* d = a.dst + (long long)frame * a.dst_stride + (size_t)(g * R) * a.dstep + (size_t)dx * 3;
-#pragma unroll
-    for (int k = 0; k < R; k++)
-        if (g * R + k < a.dh) {
-            uint8_t* q = d + (size_t)k * a.dstep;
-            q[0] = (uint8_t)sat_u8(__float2int_rn(s0[k]));
-            q[1] = (uint8_t)sat_u8(__float2int_rn(s1[k]));
-            q[2] = (uint8_t)sat_u8(__float2int_rn(s2[k]));
-        }
-}
-
-template <int NV>
-__global__ __launch_bounds__(256) void k_resize_area_v3r(RArgs a, AreaDev t, int bpf, int count) {
-    int frame, blk;
-    if (frame_block(bpf, count, &frame, &blk)) area_v3r_body<NV>(a, t, frame, blk);
-}
-
 // ------------------------------------------------------------------ AREA, general, weights computed in the kernel
 // computeResizeAreaTab's cell arithmetic (imp_tables.cpp build_area_axis, the same doubles in the same order, IEEE
 // divide, contraction off) evaluated by each lane for its own destination column and its group of AREA_ROWS rows:
 // no per-geometry table, so nothing to build on the host, upload or cache when every request has its own size
-// (BASELINE configs[4]).  The pixel arithmetic is k_resize_area_v4r / _v3r's: the same float sequence, zero weights
+// (BASELINE configs[4]).  The float sequence is resizeArea_'s, with zero weights
 // where a source pixel does not belong to a cell.
 struct AreaCell {                                      // one destination cell along one axis
     int s1, s2;                                        // whole source pixels [s1, s2)
@@ -1876,6 +1810,7 @@ __global__ __launch_bounds__(256) void k_resize_area_cells(RArgs a, AreaGeom gm,
 // What happens to a finished pixel: the Filter("rotate") and Watermark steps that follow Resize in a request
 // (bridge.c:606-640) ride on the store -- the resized frame is a few hundred KB, so where its pixels land costs nothing
 // next to the source walk, and the intermediate frames never exist.  rot = 0 / 90 / 180 / 270 (filters.c:111-133).
+constexpr int MIX_NV = 5;                              // windows of up to 20 source columns: shrinks up to 18x (3840 -> 224 is 17.1x)
 struct AreaTail { int rot; OverlayArgs wm; };
 __device__ __forceinline__ uint32_t overlay_px(const OverlayArgs& wm, uint32_t px, int row, int col) {
     if (wm.ov && row >= wm.ry && row < wm.ry + wm.maxrow && col >= wm.rx && col < wm.rx + wm.maxcol)
@@ -1883,9 +1818,10 @@ __device__ __forceinline__ uint32_t overlay_px(const OverlayArgs& wm, uint32_t p
     return px;
 }
 
-template <int W>
+template <int CN, int W>
 __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& gm, int frame, int item, int nstrips, int bh,
                                                uint32_t* __restrict__ line, const AreaTail& tail, uint32_t* __restrict__ tile) {
+    static_assert(CN == 3 || CN == 4, "interleaved BGR / BGRA");
     constexpr int NV = (W + 3) / 4;                              // 16-byte granules a lane fetches per source row
     const int lane = threadIdx.x & 63;
     const int band = item / nstrips, strip = item - band * nstrips;
@@ -1899,21 +1835,25 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
     float al[W];
 #pragma unroll
     for (int k = 0; k < W; k++) al[k] = cx.weight(xs + k);
-    // the wave's segment: from lane 0's window (16-byte granule aligned) to the end of lane 63's
-    const int a0 = __builtin_amdgcn_readlane(xs, 0) & ~3;
-    const int ngran = (__builtin_amdgcn_readlane(xs, 63) + W - a0 + 3) >> 2;     // <= 64 * NV
-    const int base = xs - a0;
-    const uint8_t* S = a.src + (long long)frame * a.src_stride + (size_t)a0 * 4;
+    // the wave's segment, in BYTES of the source row (rows are 4-byte aligned): from lane 0's window, rounded down to a
+    // 16-byte granule, to the end of lane 63's
+    // (a segment that starts inside the row's last 16 bytes starts a granule early, so the moved-back granule below never
+    // lands in front of the line; the launcher guarantees rows of at least 16 bytes)
+    const int row_end = (a.sw * CN + 3) & ~3;
+    const int b0 = min((__builtin_amdgcn_readlane(xs, 0) * CN) & ~15, (row_end - 16) & ~15);
+    const int ngran = ((__builtin_amdgcn_readlane(xs, 63) + W) * CN - b0 + 15) >> 4;  // <= 64 * NV (area_rows_plan)
+    const int wofs = xs * CN - b0;                               // this lane's window in the parked line, in bytes
+    const uint8_t* S = a.src + (long long)frame * a.src_stride + (size_t)b0;
     // Every lane fetches a granule and parks it, with no predication: lanes past the segment repeat its last granule
-    // (same address, same LDS slot, same data).  When the last granule would leave the row (sw % 4 != 0) it is moved
-    // back to end exactly at the row's end and parked dword by dword where those pixels belong (wave-uniform branch).
-    const bool ragged = a0 + 4 * ngran > a.sw;
+    // (same address, same LDS slot, same data).  When the last granule would leave the row's padded end it is moved back
+    // to end exactly there and parked dword by dword where those bytes belong (wave-uniform branch).
+    const bool ragged = b0 + 16 * ngran > row_end;
     int gofs[NV], lofs[NV];
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const int gi = min(j * 64 + lane, ngran - 1);
-        lofs[j] = (ragged && gi == ngran - 1) ? a.sw - 4 - a0 : gi * 4;
-        gofs[j] = lofs[j] * 4;
+        gofs[j] = (ragged && gi == ngran - 1) ? row_end - 16 - b0 : gi * 16;
+        lofs[j] = gofs[j] >> 2;
     }
     uint32_t nxt[NV][4];
     auto fetch = [&](int sy) {
@@ -1921,7 +1861,7 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
 #pragma unroll
         for (int j = 0; j < NV; j++) load_stream<4>(nxt[j], row + gofs[j]);
     };
-    float b[4];
+    float b[CN];
     auto reduce = [&]() {                                        // park the fetched row
         asm volatile("" ::: "memory");
         if (!ragged) {
@@ -1940,14 +1880,35 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
         asm volatile("" ::: "memory");
     };
     auto hsum = [&]() {
-        b[0] = b[1] = b[2] = b[3] = 0.f;
 #pragma unroll
-        for (int k = 0; k < W; k++) {
-            const uint32_t px = line[base + k];
-            b[0] = __fadd_rn(b[0], __fmul_rn((float)(px & 0xff), al[k]));
-            b[1] = __fadd_rn(b[1], __fmul_rn((float)((px >> 8) & 0xff), al[k]));
-            b[2] = __fadd_rn(b[2], __fmul_rn((float)((px >> 16) & 0xff), al[k]));
-            b[3] = __fadd_rn(b[3], __fmul_rn((float)(px >> 24), al[k]));
+        for (int c = 0; c < CN; c++) b[c] = 0.f;
+        if constexpr (CN == 4) {
+            const uint32_t* win = line + (wofs >> 2);
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const uint32_t px = win[k];
+                b[0] = __fadd_rn(b[0], __fmul_rn((float)(px & 0xff), al[k]));
+                b[1] = __fadd_rn(b[1], __fmul_rn((float)((px >> 8) & 0xff), al[k]));
+                b[2] = __fadd_rn(b[2], __fmul_rn((float)((px >> 16) & 0xff), al[k]));
+                b[3] = __fadd_rn(b[3], __fmul_rn((float)(px >> 24), al[k]));
+            }
+        } else {
+            // 3 W bytes at a byte offset: aligned dwords + v_alignbyte_b32, then every (pixel, channel) is a compile-time byte
+            constexpr int ND = (3 * W + 3) / 4;
+            const uint32_t* win = line + (wofs >> 2);
+            const unsigned sh = (unsigned)wofs & 3u;
+            uint32_t t[ND + 1], w[ND];
+#pragma unroll
+            for (int i = 0; i <= ND; i++) t[i] = win[i];
+#pragma unroll
+            for (int i = 0; i < ND; i++) w[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], sh);
+#pragma unroll
+            for (int k = 0; k < W; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int o = 3 * k + c;
+                    b[c] = __fadd_rn(b[c], __fmul_rn((float)((w[o >> 2] >> (8 * (o & 3))) & 0xff), al[k]));
+                }
         }
         asm volatile("" ::: "memory");
     };
@@ -1968,7 +1929,9 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
         const float yal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.al), r));
         const int first = hf ? s1 - 1 : s1, end = hl ? s2 + 1 : s2;      // (s1 == s2 when the cell is its last partial row alone)
         if (cur < 0) { fetch(first); cur = first - 1; }
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float acc[CN];
+#pragma unroll
+        for (int c = 0; c < CN; c++) acc[c] = 0.f;
         for (int sy = first; sy < end; sy++) {
             while (cur < sy) {                                   // (cells are contiguous: this runs once, or not at all for a shared row)
                 cur++;
@@ -1978,12 +1941,17 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
             }
             const float be = (hf && sy == s1 - 1) ? yaf : ((hl && sy == s2) ? yal : yam);
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[c] = __fadd_rn(acc[c], __fmul_rn(be, b[c]));
+            for (int c = 0; c < CN; c++) acc[c] = __fadd_rn(acc[c], __fmul_rn(be, b[c]));
         }
-        uint32_t px = cvt_pk_u8(acc[0], 0u, 0);
-        px = cvt_pk_u8(acc[1], px, 1);
-        px = cvt_pk_u8(acc[2], px, 2);
-        px = cvt_pk_u8(acc[3], px, 3);
+        uint32_t px = 0;
+#pragma unroll
+        for (int c = 0; c < CN; c++) px = cvt_pk_u8(acc[c], px, c);
+        if constexpr (CN == 3) {                                 // (no turn, no overlay for BGR: the launcher never asks)
+            if (live) {
+                uint8_t* q = D + (size_t)dy * a.dstep + (size_t)dx * 3;
+                q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16);
+            }
+        } else
         if (quarter) tile[(dy - dy0) * 65 + lane] = px;          // leaves with the band, turned (below)
         else if (live) {
             // R[i][j] = H[rh-1-i][rw-1-j] (180); H = the resized frame, dw x dh
@@ -1991,7 +1959,7 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
             *(uint32_t*)(D + (size_t)orow * a.dstep + (size_t)ocol * 4) = overlay_px(tail.wm, px, orow, ocol);
         }
     }
-    if (quarter) {
+    if (CN == 4 && quarter) {
         // R[i][j] = H[rh-1-j][i] (90), H[j][rw-1-i] (270): a destination row takes this band's pixels of ONE column, a
         // contiguous run of dy1 - dy0 pixels -- written 16 bytes per lane, four lanes per run of 16, once per band (a
         // scattered store per finished row would sit in front of every later source-row wait: one vmcnt for both)
@@ -2021,15 +1989,15 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
     }
 }
 
-template <int W>
+template <int CN, int W>
 __global__ __launch_bounds__(256) void k_resize_area_rows(RArgs a, AreaGeom gm, int nstrips, int bh, int nitems, int bpf, int count, AreaTail tail) {
     __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * ((W + 3) / 4) * 4];
-    __shared__ uint32_t s_tile[4][16 * 65];                      // quarter turns: a band (<= 16 rows) waits here to leave turned
+    __shared__ uint32_t s_tile[4][CN == 4 ? 16 * 65 : 1];        // quarter turns: a band (<= 16 rows) waits here to leave turned
     int frame, blk;
     if (!frame_block(bpf, count, &frame, &blk)) return;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int item = blk * 4 + wv;
-    if (item < nitems) area_rows_body<W>(a, gm, frame, item, nstrips, bh, s_line[wv], tail, s_tile[wv]);
+    if (item < nitems) area_rows_body<CN, W>(a, gm, frame, item, nstrips, bh, s_line[wv], tail, s_tile[wv]);
 }
 
 // ------------------------------------------------------------------ AREA over frames of DIFFERENT geometry (BASELINE configs[4])
@@ -2037,13 +2005,12 @@ __global__ __launch_bounds__(256) void k_resize_area_rows(RArgs a, AreaGeom gm, 
 // a descriptor per frame -- its views and its two scale factors -- instead of launch arguments.  Blocks are dealt to the
 // XCDs like frame_block deals them (block id mod 8 = XCD): descriptor list g holds the frames of XCD g back to back, each
 // with the number of the first block it owns inside that list, and a block finds its frame by bisection over those.
-struct MixDesc { RArgs a; AreaGeom gm; int first, nblk, nv, rows, nstrips, nitems; };   // BGRA: nv = window W, rows = band height
+struct MixDesc { RArgs a; AreaGeom gm; int first, nblk, nv, rows, nstrips, nitems; };   // nitems > 0: row-streaming body, nv = window W, rows = band height
 struct MixIndex { int off[9]; };                       // descriptors of XCD g: [off[g], off[g + 1])
-constexpr int MIX_NV = 5;                              // windows of up to 20 source columns: shrinks up to 18x (3840 -> 224 is 17.1x)
 
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_area_mix(const MixDesc* __restrict__ d, MixIndex ix) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_line[CN == 4 ? 4 : 1][CN == 4 ? 64 * MIX_NV * 4 : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * MIX_NV * 4];
     const int g = blockIdx.x & 7, q = blockIdx.x >> 3;
     int lo = ix.off[g], hi = ix.off[g + 1];
     if (lo == hi || q >= d[hi - 1].first + d[hi - 1].nblk) return;
@@ -2053,23 +2020,23 @@ __global__ __launch_bounds__(256) void k_resize_area_mix(const MixDesc* __restri
     }
     const MixDesc& m = d[lo];
     const int blk = q - m.first;
-    if constexpr (CN == 4) {
+    if (m.nitems > 0) {                                // (everything here is block-uniform: scalar branches)
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int item = blk * 4 + wv;
         if (item >= m.nitems) return;
-        switch (m.nv) {                                // block-uniform: one scalar branch
-            case 2: area_rows_body<2>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            case 4: area_rows_body<4>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            case 6: area_rows_body<6>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            case 8: area_rows_body<8>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            case 10: area_rows_body<10>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            case 12: area_rows_body<12>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            case 14: area_rows_body<14>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            case 16: area_rows_body<16>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            case 18: area_rows_body<18>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
-            default: area_rows_body<20>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+        switch (m.nv) {
+            case 2: area_rows_body<CN, 2>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 4: area_rows_body<CN, 4>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 6: area_rows_body<CN, 6>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 8: area_rows_body<CN, 8>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 10: area_rows_body<CN, 10>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 12: area_rows_body<CN, 12>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 14: area_rows_body<CN, 14>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 16: area_rows_body<CN, 16>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            case 18: area_rows_body<CN, 18>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
+            default: area_rows_body<CN, 20>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv], AreaTail{}, nullptr); break;
         }
-    } else {
+    } else if constexpr (CN == 3) {                    // BGR rows that are not 4-byte aligned
         switch (m.nv * 2 + (m.rows == 1)) {
             case 2: area_cells_body<3, 1, AREA_ROWS>(m.a, m.gm, 0, blk); break;
             case 3: area_cells_body<3, 1, 1>(m.a, m.gm, 0, blk); break;
@@ -2158,37 +2125,12 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
     std::vector<uint8_t> blob;
     TableSet ts;
     size_t o[12] = {0};
-    int nv = 0, nypg = 0;
     if (interp == IMP_INTER_AREA) {
         AreaAxis ax, ay;
         build_area_axis(sw, dw, scale_x, &ax);
         build_area_axis(sh, dh, scale_y, &ay);
         o[0] = put(blob, ax.start); o[1] = put(blob, ax.count); o[2] = put(blob, ax.aoff); o[3] = put(blob, ax.alpha);
         o[4] = put(blob, ay.start); o[5] = put(blob, ay.count); o[6] = put(blob, ay.aoff); o[7] = put(blob, ay.alpha);
-        if (ax.max_count <= 16 && sw >= 4 * ((ax.max_count + 3) / 4)) {   // k_resize_area_v4r / _v3r tables
-            nv = (ax.max_count + 3) / 4;
-            std::vector<int> xsp(dw);
-            std::vector<float> pad((size_t)dw * nv * 4, 0.f);
-            for (int d = 0; d < dw; d++) {
-                xsp[d] = ax.start[d] < sw - nv * 4 ? ax.start[d] : sw - nv * 4;
-                const int shift = ax.start[d] - xsp[d];      // shift + count <= 4*nv because start + count <= sw
-                for (int k = 0; k < ax.count[d]; k++) pad[(size_t)d * nv * 4 + shift + k] = ax.alpha[ax.aoff[d] + k];
-            }
-            o[8] = put(blob, pad); o[9] = put(blob, xsp);
-            // row groups of k_resize_area_v4r
-            const int ng = (dh + AREA_ROWS - 1) / AREA_ROWS;
-            for (int g = 0; g < ng; g++) {
-                const int last = std::min(dh, (g + 1) * AREA_ROWS) - 1;
-                nypg = std::max(nypg, ay.start[last] + ay.count[last] - ay.start[g * AREA_ROWS]);
-            }
-            std::vector<float> ygrp((size_t)ng * nypg * AREA_ROWS, 0.f);
-            for (int d = 0; d < dh; d++) {
-                const int g = d / AREA_ROWS, k = d % AREA_ROWS, j0 = ay.start[d] - ay.start[g * AREA_ROWS];
-                for (int jj = 0; jj < ay.count[d]; jj++)
-                    ygrp[((size_t)g * nypg + j0 + jj) * AREA_ROWS + k] = ay.alpha[ay.aoff[d] + jj];
-            }
-            o[10] = put(blob, ygrp);
-        }
     } else {
         TapAxis tx, ty;
         build_tap_axis(sw, dw, scale_x, interp, true, &tx);
@@ -2225,11 +2167,6 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         ts.area.xaoff = (const int*)(dev + o[2]);  ts.area.xalpha = (const float*)(dev + o[3]);
         ts.area.ystart = (const int*)(dev + o[4]); ts.area.ycount = (const int*)(dev + o[5]);
         ts.area.yaoff = (const int*)(dev + o[6]);  ts.area.yalpha = (const float*)(dev + o[7]);
-        ts.area.xalpha_pad = nv ? (const float*)(dev + o[8]) : nullptr;
-        ts.area.xstart_pad = nv ? (const int*)(dev + o[9]) : nullptr;
-        ts.area.nv = nv;
-        ts.area.ybeta_grp = nv ? (const float*)(dev + o[10]) : nullptr;
-        ts.area.nypg = nypg;
     } else {
         ts.xofs = (const int*)(dev + o[0]); ts.xco = (const short*)(dev + o[1]);
         ts.yofs = (const int*)(dev + o[2]); ts.yco = (const short*)(dev + o[3]);
@@ -2262,12 +2199,12 @@ static bool area_rows_plan(int sw, int sh, int dw, int dh, double scale_x, long 
     return true;
 }
 
-template <int W>
+template <int CN, int W>
 static void launch_area_rows(int w, dim3 grid, hipStream_t s, const RArgs& a, const AreaGeom& gm, int nstrips, int bh, int nitems,
                              int bpf, int count, const AreaTail& tail) {
     if constexpr (W >= 1) {
-        if (w == W) hipLaunchKernelGGL((k_resize_area_rows<W>), grid, dim3(256), 0, s, a, gm, nstrips, bh, nitems, bpf, count, tail);
-        else launch_area_rows<W - 1>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, count, tail);
+        if (w == W) hipLaunchKernelGGL((k_resize_area_rows<CN, W>), grid, dim3(256), 0, s, a, gm, nstrips, bh, nitems, bpf, count, tail);
+        else launch_area_rows<CN, W - 1>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, count, tail);
     }
 }
 
@@ -2291,7 +2228,7 @@ int launch_area_rotate(const Frames& f, int amount, const OverlayArgs* overlay, 
     if (overlay) tail.wm = *overlay;
     const int nstrips = (f.dw + 63) / 64, nitems = nstrips * ((f.dh + bh - 1) / bh), bpf = (nitems + 3) / 4;
     const dim3 grid((unsigned)bpf, (unsigned)((f.count + 7) / 8 * 8));
-    launch_area_rows<4 * MIX_NV>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, f.count, tail);
+    launch_area_rows<4, 4 * MIX_NV>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, f.count, tail);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }
@@ -2349,23 +2286,22 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             } else
                 hipLaunchKernelGGL((k_resize_area_int<CN>), grid, block, 0, s, a, isx, isy);
         } else {
-            // BGRA with cells of at most 20 source columns (shrinks up to 18x): source rows streamed through wave-private
+            // BGRA / BGR with cells of at most 20 source columns (shrinks up to 18x): source rows streamed through wave-private
             // LDS lines, weights computed in the kernel -- no per-geometry table to build, upload or cache.
             const AreaGeom gm{scale_x, scale_y};
-            if (CN == 4) {
+            const bool rows4b = !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 3);
+            if (CN == 4 || (CN == 3 && rows4b && a.sw >= 6)) {
                 int w = 0, bh = 0;
                 if (area_rows_plan(a.sw, a.sh, a.dw, a.dh, scale_x, count, false, &w, &bh)) {
                     const int nstrips = (a.dw + 63) / 64, nitems = nstrips * ((a.dh + bh - 1) / bh), rbpf = (nitems + 3) / 4;
                     const dim3 rgrid((unsigned)rbpf, (unsigned)((count + 7) / 8 * 8));
-                    launch_area_rows<4 * MIX_NV>(w, rgrid, s, a, gm, nstrips, bh, nitems, rbpf, count, AreaTail{});
+                    launch_area_rows<(CN == 3 ? 3 : 4), 4 * MIX_NV>(w, rgrid, s, a, gm, nstrips, bh, nitems, rbpf, count, AreaTail{});
                     IMP_HIP(hipGetLastError());
                     return IMP_OK;
                 }
             }
-            // BGR: a batch of one geometry takes per-geometry tables and groups of AREA_ROWS destination rows sharing their
-            // source-row walk (k_resize_area_v3r); too few blocks for 256 CUs -- a lone request, a GIF of a few frames --
-            // takes one output per lane with the weights computed in the kernel (no table for a never-seen size).
-            static const bool cells = std::getenv("IMPGPU_AREA_CELLS") != nullptr;      // A/B: the table-free kernel for batches too
+            // BGR frames whose rows are not 4-byte aligned (never cvCreateImage's, but a caller's own buffer may be): a lane
+            // per destination column, windows straight from global memory, weights computed in the kernel too
             const int bpf = (int)grid.x;                       // blocks per frame
             const dim3 fgrid(grid.x, (unsigned)((count + 7) / 8 * 8));   // whole groups of 8 frames (frame-per-XCD order)
             const int ng = (a.dh + AREA_ROWS - 1) / AREA_ROWS;
@@ -2373,12 +2309,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             const dim3 ggrid((unsigned)gbpf, (unsigned)((count + 7) / 8 * 8));
             const bool big = (long long)gbpf * count >= 1024;
             const int nvx = CN == 3 ? (area_max_count(a.sw, a.dw, scale_x) + 3) / 4 : 0;
-            const bool windowed = nvx >= 1 && nvx <= MIX_NV && a.sw >= 4 * nvx;
-            TableSet ts;
-            if (!windowed || (big && !cells))
-                if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, s, &ts)) return rc;
-            const bool grp = windowed && big && !cells && ts.area.nv == nvx && ts.area.nypg <= 96;
-            if (windowed && !grp) {
+            if (nvx >= 1 && nvx <= MIX_NV && a.sw >= 4 * nvx) {
 #define IMP_CELLS(NV_) \
     do { \
         if (big) hipLaunchKernelGGL((k_resize_area_cells<3, NV_, AREA_ROWS>), ggrid, block, 0, s, a, gm, gbpf, count); \
@@ -2392,12 +2323,13 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                     default: IMP_CELLS(5); break;
                 }
 #undef IMP_CELLS
+                IMP_HIP(hipGetLastError());
+                return IMP_OK;
             }
-            else if (grp && nvx == 1) hipLaunchKernelGGL((k_resize_area_v3r<1>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp && nvx == 2) hipLaunchKernelGGL((k_resize_area_v3r<2>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp && nvx == 3) hipLaunchKernelGGL((k_resize_area_v3r<3>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else if (grp && nvx == 4) hipLaunchKernelGGL((k_resize_area_v3r<4>), ggrid, block, 0, s, a, ts.area, gbpf, count);
-            else hipLaunchKernelGGL((k_resize_area<CN>), grid, block, 0, s, a, ts.area);
+            // everything else (gray frames, cells wider than 20 columns): run tables, one output per lane
+            TableSet ts;
+            if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, s, &ts)) return rc;
+            hipLaunchKernelGGL((k_resize_area<CN>), grid, block, 0, s, a, ts.area);
         }
     } else {
         TableSet ts;
@@ -2771,14 +2703,13 @@ int launch_resize_mixed(const MixFrame* fr, int count, int cn, int simple, hipSt
             MixDesc d{};
             d.a = RArgs{f.src, 0, f.sstep, f.sw, f.sh, f.dst, 0, f.dstep, f.dw, f.dh};
             d.gm = AreaGeom{scale_x, scale_y};
-            if (cn == 4) {
-                if (area_rows_plan(f.sw, f.sh, f.dw, f.dh, scale_x, count, true, &d.nv, &d.rows)) {
-                    d.nstrips = (f.dw + 63) / 64;
-                    d.nitems = d.nstrips * ((f.dh + d.rows - 1) / d.rows);
-                    d.nblk = (d.nitems + 3) / 4;
-                    gathered = true;
-                }
-            } else {
+            const bool aligned = !(((uintptr_t)f.src | (uintptr_t)f.sstep) & 3);
+            if ((cn == 4 || (aligned && f.sw >= 6)) && area_rows_plan(f.sw, f.sh, f.dw, f.dh, scale_x, count, true, &d.nv, &d.rows)) {
+                d.nstrips = (f.dw + 63) / 64;
+                d.nitems = d.nstrips * ((f.dh + d.rows - 1) / d.rows);
+                d.nblk = (d.nitems + 3) / 4;
+                gathered = true;
+            } else if (cn == 3) {
                 // the widest cell decides the window: ceil(scale) <= widest <= floor(scale) + 2; the axis is walked only
                 // when those two ends name different windows (a wider window than needed is still exact, only slower)
                 const int nv_lo = ((int)std::ceil(scale_x) + 3) / 4, nv_hi = ((int)std::floor(scale_x) + 2 + 3) / 4;
@@ -2787,6 +2718,7 @@ int launch_resize_mixed(const MixFrame* fr, int count, int cn, int simple, hipSt
                     d.nv = nv;
                     d.rows = scale_y < 8 ? AREA_ROWS : 1;   // tall cells: sharing one boundary row in nine is not worth a quarter of the blocks
                     d.nblk = (int)(((long long)f.dw * ((f.dh + d.rows - 1) / d.rows) + 255) / 256);
+                    d.nitems = 0;
                     gathered = true;
                 }
             }
