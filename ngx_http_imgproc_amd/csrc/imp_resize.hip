@@ -2182,7 +2182,8 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
 
 // ------------------------------------------------------------------ launcher
 // k_resize_area_rows for this geometry?  *w = window (the widest horizontal cell, widened until a wave's segment fits its
-// 64 * ceil(W/4) granules), *bh = destination rows per band: 16, less while that leaves fewer than ~4096 waves.
+// 64 * ceil(W/4) granules), *bh = destination rows per band: 16, less while that leaves fewer than ~4096 waves (down to 4:
+// a band re-reads one source row of its neighbour) or, for a lone request, fewer than ~1024 (down to 1: latency first).
 static bool area_rows_plan(int sw, int sh, int dw, int dh, double scale_x, long long frames, bool even, int* w, int* bh) {
     (void)sh;
     int ww = area_max_count(sw, dw, scale_x);
@@ -2193,6 +2194,7 @@ static bool area_rows_plan(int sw, int sh, int dw, int dh, double scale_x, long 
     int b = 16;
     const long long nstrips = (dw + 63) / 64;
     while (b > 4 && frames * nstrips * ((dh + b - 1) / b) < 4096) b /= 2;
+    while (b > 1 && frames * nstrips * ((dh + b - 1) / b) < 1024) b /= 2;
     if (bh_env > 0) b = std::min(64, bh_env);
     *w = ww;
     *bh = b;

@@ -22,9 +22,9 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
-MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_v4r<3>": "area", "k_resize_nn<4>": "nn",
+MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_rows<4, 10>": "area", "k_resize_nn<4>": "nn",
          "k_resize_taps<2, 4, 0>": "linear", "k_resize_2x_dma<8, 2": "lanczos", "k_area2x2_rotate_bgra": "chain",
-         "k_resize_up_cubic4": "upscale", "k_area2x2_v4": "area2x"}
+         "k_resize_up_cubic4": "upscale", "k_area2x2_c4": "area2x"}
 # frames per launch in tools/pmc_probe.py, as a divisor of PROBE_BATCH
 BATCH_DIV = {"lanczos": 16, "upscale": 2, "area2x": 4}
 
