@@ -2000,6 +2000,165 @@ __global__ __launch_bounds__(256) void k_resize_area_rows(RArgs a, AreaGeom gm, 
     if (item < nitems) area_rows_body<CN, W>(a, gm, frame, item, nstrips, bh, s_line[wv], tail, s_tile[wv]);
 }
 
+// Small shrink factors (windows of at most 5 pixels: factors below ~3.9): 64 destination columns are only 64 * factor
+// source pixels -- a few hundred bytes per wave and row, and the per-row work around the arithmetic (fetch, park, loop)
+// shows (1.3x: 0.40 of the roofline).  Here a lane owns FOUR adjacent destination columns, a wave 256: the same walk, four
+// windows per lane out of a segment four times as long, one 16-byte (BGRA) / 12-byte (BGR) store per lane and finished row.
+template <int CN, int W>
+__device__ __forceinline__ void area_rows4_body(const RArgs& a, const AreaGeom& gm, int frame, int item, int nstrips, int bh,
+                                                uint32_t* __restrict__ line) {
+    static_assert((CN == 3 || CN == 4) && W <= 5, "small windows only");
+    constexpr int NV = 4;                                        // 64 * 4 granules hold 255 * 3.9 + W + 8 pixels
+    const int lane = threadIdx.x & 63;
+    const int band = item / nstrips, strip = item - band * nstrips;
+    const int dy0 = band * bh;
+    if (dy0 >= a.dh) return;
+    const int dy1 = min(dy0 + bh, a.dh);
+    const int dxf = strip * 256 + lane * 4;                      // this lane's first column
+    int xs[4], wofs[4];
+    float al[4][W];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const AreaCell cx = area_cell(min(dxf + p, a.dw - 1), a.sw, gm.scale_x);   // idle columns shadow the last one
+        xs[p] = min(cx.first(), a.sw - W);
+#pragma unroll
+        for (int k = 0; k < W; k++) al[p][k] = cx.weight(xs[p] + k);
+    }
+    const int row_end = (a.sw * CN + 3) & ~3;
+    const int b0 = min((__builtin_amdgcn_readlane(xs[0], 0) * CN) & ~15, (row_end - 16) & ~15);
+    const int ngran = ((__builtin_amdgcn_readlane(xs[3], 63) + W) * CN - b0 + 15) >> 4;   // <= 256 (area_rows_plan)
+#pragma unroll
+    for (int p = 0; p < 4; p++) wofs[p] = xs[p] * CN - b0;
+    const uint8_t* S = a.src + (long long)frame * a.src_stride + (size_t)b0;
+    const bool ragged = b0 + 16 * ngran > row_end;
+    int gofs[NV], lofs[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int gi = min(j * 64 + lane, ngran - 1);
+        gofs[j] = (ragged && gi == ngran - 1) ? row_end - 16 - b0 : gi * 16;
+        lofs[j] = gofs[j] >> 2;
+    }
+    uint32_t nxt[NV][4];
+    auto fetch = [&](int sy) {
+        const uint8_t* row = S + (size_t)sy * a.sstep;
+#pragma unroll
+        for (int j = 0; j < NV; j++) load_stream<4>(nxt[j], row + gofs[j]);
+    };
+    float b[4][CN];
+    auto reduce = [&]() {
+        asm volatile("" ::: "memory");
+        if (!ragged) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                typedef unsigned int u32x4a_t __attribute__((ext_vector_type(4), aligned(16)));
+                const u32x4a_t q = {nxt[j][0], nxt[j][1], nxt[j][2], nxt[j][3]};
+                *(u32x4a_t*)(line + lofs[j]) = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) line[lofs[j] + t] = nxt[j][t];
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto hsum = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+#pragma unroll
+            for (int c = 0; c < CN; c++) b[p][c] = 0.f;
+            const uint32_t* win = line + (wofs[p] >> 2);
+            if constexpr (CN == 4) {
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    const uint32_t px = win[k];
+                    b[p][0] = __fadd_rn(b[p][0], __fmul_rn((float)(px & 0xff), al[p][k]));
+                    b[p][1] = __fadd_rn(b[p][1], __fmul_rn((float)((px >> 8) & 0xff), al[p][k]));
+                    b[p][2] = __fadd_rn(b[p][2], __fmul_rn((float)((px >> 16) & 0xff), al[p][k]));
+                    b[p][3] = __fadd_rn(b[p][3], __fmul_rn((float)(px >> 24), al[p][k]));
+                }
+            } else {
+                constexpr int ND = (3 * W + 3) / 4;
+                const unsigned sh = (unsigned)wofs[p] & 3u;
+                uint32_t t[ND + 1], w[ND];
+#pragma unroll
+                for (int i = 0; i <= ND; i++) t[i] = win[i];
+#pragma unroll
+                for (int i = 0; i < ND; i++) w[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], sh);
+#pragma unroll
+                for (int k = 0; k < W; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int o = 3 * k + c;
+                        b[p][c] = __fadd_rn(b[p][c], __fmul_rn((float)((w[o >> 2] >> (8 * (o & 3))) & 0xff), al[p][k]));
+                    }
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    const AreaCell mine = area_cell(min(dy0 + lane, dy1 - 1), a.sh, gm.scale_y);
+    const int sy_end = __builtin_amdgcn_readlane(mine.end(), dy1 - 1 - dy0);
+    uint8_t* D = a.dst + (long long)frame * a.dst_stride + (size_t)dxf * CN;
+    const int nlive = min(4, a.dw - dxf);                        // columns of this lane inside the frame (<= 0: none)
+    int cur = -1;
+    for (int dy = dy0; dy < dy1; dy++) {
+        const int r = dy - dy0;
+        const int s1 = __builtin_amdgcn_readlane(mine.s1, r), s2 = __builtin_amdgcn_readlane(mine.s2, r);
+        const int hf = __builtin_amdgcn_readlane((int)mine.hf, r), hl = __builtin_amdgcn_readlane((int)mine.hl, r);
+        const float yaf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.af), r));
+        const float yam = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.am), r));
+        const float yal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.al), r));
+        const int first = hf ? s1 - 1 : s1, end = hl ? s2 + 1 : s2;
+        if (cur < 0) { fetch(first); cur = first - 1; }
+        float acc[4][CN];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int c = 0; c < CN; c++) acc[p][c] = 0.f;
+        for (int sy = first; sy < end; sy++) {
+            while (cur < sy) {
+                cur++;
+                reduce();
+                if (cur + 1 < sy_end) fetch(cur + 1);
+                hsum();
+            }
+            const float be = (hf && sy == s1 - 1) ? yaf : ((hl && sy == s2) ? yal : yam);
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int c = 0; c < CN; c++) acc[p][c] = __fadd_rn(acc[p][c], __fmul_rn(be, b[p][c]));
+        }
+        uint32_t out[CN] = {};
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                const int ob = p * CN + c;
+                out[ob >> 2] = cvt_pk_u8(acc[p][c], out[ob >> 2], ob & 3);
+            }
+        uint8_t* q = D + (size_t)dy * a.dstep;
+        if (nlive == 4 && !(((uintptr_t)q) & 3)) {
+            typedef unsigned int u32xn_t __attribute__((ext_vector_type(CN), aligned(4)));
+            u32xn_t ov;
+#pragma unroll
+            for (int i = 0; i < CN; i++) ov[i] = out[i];
+            *(u32xn_t*)q = ov;
+        } else {
+            for (int bidx = 0; bidx < nlive * CN; bidx++) q[bidx] = (uint8_t)(out[bidx >> 2] >> (8 * (bidx & 3)));
+        }
+    }
+}
+
+template <int CN, int W>
+__global__ __launch_bounds__(256) void k_resize_area_rows4(RArgs a, AreaGeom gm, int nstrips, int bh, int nitems, int bpf, int count) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * 4 * 4];
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blk * 4 + wv;
+    if (item < nitems) area_rows4_body<CN, W>(a, gm, frame, item, nstrips, bh, s_line[wv]);
+}
+
 // ------------------------------------------------------------------ AREA over frames of DIFFERENT geometry (BASELINE configs[4])
 // One launch for a run of requests whose frames all differ in size (bridge.c:588-604 calls Resize() on whatever arrives):
 // a descriptor per frame -- its views and its two scale factors -- instead of launch arguments.  Blocks are dealt to the
@@ -2295,6 +2454,22 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             if (CN == 4 || (CN == 3 && rows4b && a.sw >= 6)) {
                 int w = 0, bh = 0;
                 if (area_rows_plan(a.sw, a.sh, a.dw, a.dh, scale_x, count, false, &w, &bh)) {
+                    static const bool no_rows4 = std::getenv("IMPGPU_NO_ROWS4") != nullptr;
+                    // four columns per lane while the windows are small and there are enough columns and waves for it
+                    const long long waves4 = (long long)count * ((a.dw + 255) / 256) * ((a.dh + bh - 1) / bh);
+                    if (!no_rows4 && w >= 2 && w <= 5 && a.dw >= 256 && waves4 >= 2048 && 255 * scale_x + w + 8 <= (CN == 4 ? 1024 : 1340)) {
+                        constexpr int C34 = CN == 3 ? 3 : 4;
+                        const int nstrips = (a.dw + 255) / 256, nitems = nstrips * ((a.dh + bh - 1) / bh), rbpf = (nitems + 3) / 4;
+                        const dim3 rgrid((unsigned)rbpf, (unsigned)((count + 7) / 8 * 8));
+                        switch (w) {
+                            case 2: hipLaunchKernelGGL((k_resize_area_rows4<C34, 2>), rgrid, block, 0, s, a, gm, nstrips, bh, nitems, rbpf, count); break;
+                            case 3: hipLaunchKernelGGL((k_resize_area_rows4<C34, 3>), rgrid, block, 0, s, a, gm, nstrips, bh, nitems, rbpf, count); break;
+                            case 4: hipLaunchKernelGGL((k_resize_area_rows4<C34, 4>), rgrid, block, 0, s, a, gm, nstrips, bh, nitems, rbpf, count); break;
+                            default: hipLaunchKernelGGL((k_resize_area_rows4<C34, 5>), rgrid, block, 0, s, a, gm, nstrips, bh, nitems, rbpf, count); break;
+                        }
+                        IMP_HIP(hipGetLastError());
+                        return IMP_OK;
+                    }
                     const int nstrips = (a.dw + 63) / 64, nitems = nstrips * ((a.dh + bh - 1) / bh), rbpf = (nitems + 3) / 4;
                     const dim3 rgrid((unsigned)rbpf, (unsigned)((count + 7) / 8 * 8));
                     launch_area_rows<(CN == 3 ? 3 : 4), 4 * MIX_NV>(w, rgrid, s, a, gm, nstrips, bh, nitems, rbpf, count, AreaTail{});

@@ -269,3 +269,24 @@ def test_area_integer_scales_streaming_kernel_bit_exact(gpu, scale, dims, c):
         s = arr.reshape(dh, isy, dw, isx, c).astype(np.int64).sum(axis=(1, 3))
         mean = np.rint((s.astype(np.float32) * np.float32(1.0 / (isx * isy))).astype(np.float64))      # float32 product, half-even
         assert np.abs(got.astype(int) - mean).max() <= 1
+
+
+@pytest.mark.parametrize("c", [4, 3])
+@pytest.mark.parametrize("geom", [((220, 300), (260, 190)), ((300, 520), (256, 150)), ((400, 900), (257, 115)), ((231, 333), (300, 200))])
+def test_area_small_factors_four_columns_per_lane(gpu, c, geom):
+    """k_resize_area_rows4: shrink factors below ~3.9 on a batch big enough to take it (a lane owns four adjacent
+    destination columns, a wave 256): widths that leave a partial quad and a partial last strip, source widths that are
+    not a multiple of 4 (the moved-back last granule), BGR byte windows; every frame against the oracle."""
+    (sh, sw), (dw, dh) = geom
+    n = 72
+    rng = np.random.Generator(np.random.PCG64(0x1A4D8800 + sw + c))
+    sstep, dstep = (sw * c + 3) & ~3, (dw * c + 3) & ~3
+    frames = rng.integers(0, 256, size=(n, sh, sw, c), dtype=np.uint8)
+    src = gpu.Image(frames.reshape(n * sh, sw, c))
+    dst = gpu.Image(np.zeros((n * dh, dw, c), np.uint8))
+    assert src.step == sstep and dst.step == dstep
+    gpu.batch_cv_resize(src.device_ptr, sh * sstep, sw, sh, sstep, dst.device_ptr, dh * dstep, dw, dh, dstep, c, n, orc.INTER_AREA)
+    out = dst.numpy().reshape(n, dh, dw, c)
+    for i in range(0, n, 5):
+        assert np.array_equal(out[i], orc.cv_resize(frames[i], dw, dh, orc.INTER_AREA)), (geom, c, i)
+    src.release(); dst.release()
