@@ -2457,7 +2457,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                     static const bool no_rows4 = std::getenv("IMPGPU_NO_ROWS4") != nullptr;
                     // four columns per lane while the windows are small and there are enough columns and waves for it
                     const long long waves4 = (long long)count * ((a.dw + 255) / 256) * ((a.dh + bh - 1) / bh);
-                    if (!no_rows4 && w >= 2 && w <= 5 && a.dw >= 256 && waves4 >= 2048 && 255 * scale_x + w + 8 <= (CN == 4 ? 1024 : 1340)) {
+                    if (!no_rows4 && w >= 2 && w <= 5 && a.dw >= 160 && waves4 >= 2048 && 255 * scale_x + w + 8 <= (CN == 4 ? 1024 : 1340)) {
                         constexpr int C34 = CN == 3 ? 3 : 4;
                         const int nstrips = (a.dw + 255) / 256, nitems = nstrips * ((a.dh + bh - 1) / bh), rbpf = (nitems + 3) / 4;
                         const dim3 rgrid((unsigned)rbpf, (unsigned)((count + 7) / 8 * 8));
