@@ -264,11 +264,18 @@ __device__ __forceinline__ uint32_t bl_cvt_pk_u8(float x, uint32_t acc, int byte
 
 // CN = 3 (every JPEG): pixels are assembled from / scattered to three bytes, channel 3 is not computed, and the last
 // (3 w) % 4 elements of a row take SymmColumnVec's scalar tail, (sum + 2^15) >> 16 on integers, like the CPU.
-template <int RH, int CN>
+// NO = output rows per wave and step (a step = 4 * NO source rows).  With NO = 2 a wave's two outputs are neighbours, so
+// the ring rows y+k and y+1-k of one tap step are the rows y+1+(k-1) and y-(k-1) of the step before: two ring reads per
+// tap instead of four, half the barriers per row -- the column pass was LDS-read bound (PMC: VALU 40 % busy, 49 x 16-byte
+// ring reads per output pixel).  Ring rows needed: RH >= 2r + 8 * NO.  (Measured and dropped: the row pass on channel
+// planes with v_dot4_u32_u8 -- half the VALU work, but byte-wise plane writes and per-plane window reads double the LDS
+// instructions of a kernel that is LDS-bound: sigma = 8 went from 57 back to 67 us.)
+template <int RH, int CN, int NO>
 __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
                                                      uint8_t* __restrict__ dst, long long dstride, int dstep,
                                                      const int* __restrict__ kxp, const float* __restrict__ kyf,
                                                      const int* __restrict__ kyi, int r, int rows_per_block) {
+    static_assert(NO == 1 || NO == 2, "one or two output rows per wave and step");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int npair = r + 1;                                   // 2r+1 taps -> r+1 pairs, the last one (tap, 0)
     const int SEGW = (64 + 2 * r + 2 + 3) & ~3;                // +2: the padded last pair reads one dword further
@@ -308,22 +315,57 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
     };
     const int vec_end = CN == 3 ? (w * 3) & ~3 : 0;            // SymmColumnVec_32s8u covers whole groups of 4 row elements
     const bool tail = CN == 3 && (x0 + lane) * 3 + 2 >= vec_end;
-
-    uint32_t cur[4], out_px = 0;
-    int out_y = -1;                                            // output row whose pixel waits in out_px
-    int ys = y0 - r + wv;                                      // this wave's source row of the step
-    request(ys, cur);
-    __syncthreads();                                           // taps are in LDS
-    for (; ys - wv <= y1 - 1 + r; ys += 4) {
-        // (a) the segment of row ys -> LDS; last step's pixel out; next row in flight
+    auto ring = [&](int y) -> float4 { return s_ring[(y & (RH - 1)) * 64 + lane]; };
+    auto finish = [&](int yo, bl_float2 sxy, bl_float2 szw) -> uint32_t {   // round, pack; the CN = 3 row tail in integers
+        uint32_t px = bl_cvt_pk_u8(sxy.x, 0u, 0);
+        px = bl_cvt_pk_u8(sxy.y, px, 1);
+        px = bl_cvt_pk_u8(szw.x, px, 2);
+        if (CN == 4) px = bl_cvt_pk_u8(szw.y, px, 3);
+        if (tail) {
+            const float4 c = ring(yo);
+            int t[3] = {s_kyi[0] * (int)c.x, s_kyi[0] * (int)c.y, s_kyi[0] * (int)c.z};
+            for (int k = 1; k <= r; k++) {
+                const float4 pa = ring(min(yo + k, h - 1)), pb = ring(max(yo - k, 0));
+                const int fk = s_kyi[k];
+                t[0] += fk * ((int)pa.x + (int)pb.x); t[1] += fk * ((int)pa.y + (int)pb.y); t[2] += fk * ((int)pa.z + (int)pb.z);
+            }
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (q < nq && lane + 64 * q < SEGW) seg[lane + 64 * q] = cur[q];
-        if (out_y >= 0 && live) emit(out_y, out_px);
-        out_y = -1;
-        request(ys + 4, cur);
-        // (b) row pass
-        {
+            for (int ch = 0; ch < 3; ch++) {
+                int ti = (t[ch] + (1 << 15)) >> 16;
+                asm volatile("" : "+v"(ti));                    // keep shift and clamp apart (v_ashr_pk_u8_i32 hazard)
+                if ((x0 + lane) * 3 + ch >= vec_end) px = (px & ~(0xffu << (8 * ch))) | ((uint32_t)sat8(ti) << (8 * ch));
+            }
+        }
+        return px;
+    };
+
+    uint32_t cur[NO][4], out_px[NO];
+    int out_y[NO];                                             // output rows whose pixels wait in out_px (-1: none)
+#pragma unroll
+    for (int i = 0; i < NO; i++) { out_y[i] = -1; out_px[i] = 0; }
+    int base = y0 - r;                                         // first source row of the step; this wave's: base + wv * NO + i
+#pragma unroll
+    for (int i = 0; i < NO; i++) request(base + wv * NO + i, cur[i]);
+    __syncthreads();                                           // taps are in LDS
+    for (; base <= y1 - 1 + r; base += 4 * NO) {
+#pragma unroll
+        for (int i = 0; i < NO; i++) {
+            const int ys = base + wv * NO + i;
+            // (a) the segment of row ys -> LDS; last step's pixels out; the row of the next step in flight
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (q < nq && lane + 64 * q < SEGW) seg[lane + 64 * q] = cur[i][q];
+            asm volatile("" ::: "memory");
+            if (i == 0) {
+#pragma unroll
+                for (int o = 0; o < NO; o++) {
+                    if (out_y[o] >= 0 && live) emit(out_y[o], out_px[o]);
+                    out_y[o] = -1;
+                }
+            }
+            request(ys + 4 * NO, cur[i]);
+            // (b) row pass
             const uint32_t* win = seg + lane;
             int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             for (int j = 0; j < npair; j++) {
@@ -341,45 +383,47 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
             s_ring[(ys & (RH - 1)) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
         }
         __syncthreads();
-        // (c) column pass for the row centred r rows above
-        const int yo = ys - r;
-        if (yo >= y0 && yo < y1) {                             // wave-uniform
-            const float4 c = s_ring[(yo & (RH - 1)) * 64 + lane];
+        // (c) column pass for the rows centred r rows above this wave's source rows.  Rows replicate at the frame's edges
+        // exactly like the CPU's BORDER_REPLICATE: clamp the ROW index, whose sums are in the ring whenever the clamped row
+        // lies inside this block's source range.
+        const int yo = base + wv * NO - r;
+        if (yo + NO - 1 >= y0 && yo < y1) {                    // wave-uniform
             const float f0 = s_ky[0];
-            bl_float2 sxy = bl_float2{c.x, c.y} * f0 + 0.f, szw = bl_float2{c.z, c.w} * f0 + 0.f;
-            for (int k = 1; k <= r; k++) {
-                // rows replicate at the frame's edges exactly like the CPU's BORDER_REPLICATE: clamp the ROW index, whose
-                // sums are in the ring whenever the clamped row lies inside this block's source range
-                const int ya = min(yo + k, h - 1), yb = max(yo - k, 0);
-                const float4 pa = s_ring[(ya & (RH - 1)) * 64 + lane], pb = s_ring[(yb & (RH - 1)) * 64 + lane];
-                const float f = s_ky[k];
-                sxy = sxy + (bl_float2{pa.x, pa.y} + bl_float2{pb.x, pb.y}) * f;
-                szw = szw + (bl_float2{pa.z, pa.w} + bl_float2{pb.z, pb.w}) * f;
-            }
-            uint32_t px = bl_cvt_pk_u8(sxy.x, 0u, 0);
-            px = bl_cvt_pk_u8(sxy.y, px, 1);
-            px = bl_cvt_pk_u8(szw.x, px, 2);
-            if (CN == 4) px = bl_cvt_pk_u8(szw.y, px, 3);
-            if (tail) {                                        // this pixel holds elements of the row's scalar tail: integer form for those
-                int t[3] = {s_kyi[0] * (int)c.x, s_kyi[0] * (int)c.y, s_kyi[0] * (int)c.z};
+            if constexpr (NO == 1) {
+                const float4 c = ring(yo);
+                bl_float2 sxy = bl_float2{c.x, c.y} * f0 + 0.f, szw = bl_float2{c.z, c.w} * f0 + 0.f;
                 for (int k = 1; k <= r; k++) {
-                    const int ya = min(yo + k, h - 1), yb = max(yo - k, 0);
-                    const float4 pa = s_ring[(ya & (RH - 1)) * 64 + lane], pb = s_ring[(yb & (RH - 1)) * 64 + lane];
-                    const int fk = s_kyi[k];
-                    t[0] += fk * ((int)pa.x + (int)pb.x); t[1] += fk * ((int)pa.y + (int)pb.y); t[2] += fk * ((int)pa.z + (int)pb.z);
+                    const float4 pa = ring(min(yo + k, h - 1)), pb = ring(max(yo - k, 0));
+                    const float f = s_ky[k];
+                    sxy = sxy + (bl_float2{pa.x, pa.y} + bl_float2{pb.x, pb.y}) * f;
+                    szw = szw + (bl_float2{pa.z, pa.w} + bl_float2{pb.z, pb.w}) * f;
                 }
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    int ti = (t[ch] + (1 << 15)) >> 16;
-                    asm volatile("" : "+v"(ti));                // keep shift and clamp apart (v_ashr_pk_u8_i32 hazard)
-                    if ((x0 + lane) * 3 + ch >= vec_end) px = (px & ~(0xffu << (8 * ch))) | ((uint32_t)sat8(ti) << (8 * ch));
+                out_px[0] = finish(yo, sxy, szw);
+                out_y[0] = yo;
+            } else {
+                // outputs yo and yo + 1: row yo+k of this tap is row (yo+1)+(k-1) of the last one, row (yo+1)-k is row yo-(k-1)
+                const int ylo = max(yo, 0), yhi = min(yo + 1, h - 1);      // (clamped like every other ring row)
+                float4 b0 = ring(ylo), a1 = ring(yhi);                     // k = 0: the two centre rows
+                bl_float2 s0xy = bl_float2{b0.x, b0.y} * f0 + 0.f, s0zw = bl_float2{b0.z, b0.w} * f0 + 0.f;
+                bl_float2 s1xy = bl_float2{a1.x, a1.y} * f0 + 0.f, s1zw = bl_float2{a1.z, a1.w} * f0 + 0.f;
+                for (int k = 1; k <= r; k++) {
+                    const float4 a0 = a1, b1 = b0;                          // slid from the tap before
+                    a1 = ring(min(yo + 1 + k, h - 1));
+                    b0 = ring(max(yo - k, 0));
+                    const float f = s_ky[k];
+                    s0xy = s0xy + (bl_float2{a0.x, a0.y} + bl_float2{b0.x, b0.y}) * f;
+                    s0zw = s0zw + (bl_float2{a0.z, a0.w} + bl_float2{b0.z, b0.w}) * f;
+                    s1xy = s1xy + (bl_float2{a1.x, a1.y} + bl_float2{b1.x, b1.y}) * f;
+                    s1zw = s1zw + (bl_float2{a1.z, a1.w} + bl_float2{b1.z, b1.w}) * f;
                 }
+                if (yo >= y0) { out_px[0] = finish(yo, s0xy, s0zw); out_y[0] = yo; }
+                if (yo + 1 < y1) { out_px[1] = finish(yo + 1, s1xy, s1zw); out_y[1] = yo + 1; }
             }
-            out_px = px;
-            out_y = yo;
         }
     }
-    if (out_y >= 0 && live) emit(out_y, out_px);
+#pragma unroll
+    for (int o = 0; o < NO; o++)
+        if (out_y[o] >= 0 && live) emit(out_y[o], out_px[o]);
 }
 
 // src view -> dst (same size, BGRA, separate buffers).  IMP_ERROR_UNSUPPORTED when the fused form does not apply
@@ -428,6 +472,8 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
     if (r > 16) {       // column strips with an LDS ring (k_blur_strip4)
         const int RH = 2 * r + 8 <= 64 ? 64 : 128;
+        static const bool one_row = std::getenv("IMPGPU_BLUR_NO1") != nullptr;     // A/B: one output row per wave and step
+        const int NO = (!one_row && 2 * r + 16 <= RH) ? 2 : 1;
         const int SEGW = (64 + 2 * r + 2 + 3) & ~3;
         const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + 4 * SEGW) * 4 + (size_t)RH * 64 * 16;
         const int nbx = (v.w + 63) / 64;
@@ -435,18 +481,24 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
         while (rpb > 64 && (long long)nbx * ((v.h + rpb - 1) / rpb) * f.count < 1024) rpb /= 2;
         const dim3 sgrid((unsigned)nbx, (unsigned)((v.h + rpb - 1) / rpb), (unsigned)f.count);
         hipError_t e = hipSuccess;
-#define IMP_BLUR_STRIP(RH_, CN_)                                                                                                   \
+#define IMP_BLUR_STRIP(RH_, CN_, NO_)                                                                                              \
     do {                                                                                                                           \
-        e = hipFuncSetAttribute((const void*)k_blur_strip4<RH_, CN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        e = hipFuncSetAttribute((const void*)k_blur_strip4<RH_, CN_, NO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
         if (e == hipSuccess)                                                                                                       \
-            hipLaunchKernelGGL((k_blur_strip4<RH_, CN_>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst,   \
-                               f.dst_stride, f.dstep, (const int*)dev_k, (const float*)((const int*)dev_k + off_f),                 \
+            hipLaunchKernelGGL((k_blur_strip4<RH_, CN_, NO_>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h,     \
+                               f.dst, f.dst_stride, f.dstep, (const int*)dev_k, (const float*)((const int*)dev_k + off_f),          \
                                (const int*)dev_k + off_i, r, rpb);                                                                  \
     } while (0)
-        if (RH == 64 && v.c == 4) IMP_BLUR_STRIP(64, 4);
-        else if (RH == 64) IMP_BLUR_STRIP(64, 3);
-        else if (v.c == 4) IMP_BLUR_STRIP(128, 4);
-        else IMP_BLUR_STRIP(128, 3);
+        switch ((RH == 64 ? 0 : 4) + (v.c == 4 ? 0 : 2) + (NO == 2 ? 0 : 1)) {
+            case 0: IMP_BLUR_STRIP(64, 4, 2); break;
+            case 1: IMP_BLUR_STRIP(64, 4, 1); break;
+            case 2: IMP_BLUR_STRIP(64, 3, 2); break;
+            case 3: IMP_BLUR_STRIP(64, 3, 1); break;
+            case 4: IMP_BLUR_STRIP(128, 4, 2); break;
+            case 5: IMP_BLUR_STRIP(128, 4, 1); break;
+            case 6: IMP_BLUR_STRIP(128, 3, 2); break;
+            default: IMP_BLUR_STRIP(128, 3, 1); break;
+        }
 #undef IMP_BLUR_STRIP
         if (e == hipSuccess) e = hipGetLastError();
         dev_free_on(dev_k, s);
