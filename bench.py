@@ -422,8 +422,23 @@ def main():
             dist.destroy_process_group()
         return
     if args.mixed:
-        print(json.dumps(mixed_resident(imp, args.mixed, args.steps, args.warmup, rank, world, args.channels)), flush=True)
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
+        res = mixed_resident(imp, args.mixed, args.steps, args.warmup, rank, world, args.channels)
+        if use_dist:                               # frames shard round-robin: images add up, the slowest rank sets the time
+            oc = res["one_call"]
+            t = torch.tensor([oc["ms_per_step"], float(res["frames_this_rank"])], dtype=torch.float64, device="cuda")
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            res["value"] = round(float(t[1]) / (float(tmax[0]) * 1e-3), 1)
+            res["frames_all_ranks"] = int(t[1])
+            res["scaling"] = "strong"
+        if rank == 0:
+            print(json.dumps(res), flush=True)
         imp.env_destroy()
+        if use_dist:
+            dist.destroy_process_group()
         return
     if args.e2e:
         res = {"metric": "PCIe-inclusive requests/sec: upload 1920x1080 BGRA + INTER_CUBIC ->224x224 + download, one stream",
