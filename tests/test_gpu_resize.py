@@ -255,7 +255,7 @@ def test_area_2x2_on_a_cropped_view_and_batch(gpu):
 @pytest.mark.parametrize("c", [4, 3])
 def test_area_integer_scales_streaming_kernel_bit_exact(gpu, scale, dims, c):
     """resizeAreaFast_ at integer scales other than 2x2: k_area_boxc<4|8> (contiguous granules, rows shorter than a wave's
-    run wrap inside it), k_area_box4<ISX> for 3, 5, 6, 7 (any ISY with ISX*ISY <= 257) and the per-pixel fallback beyond;
+    run wrap inside it; 8 only), k_area_boxl<4,ISX> for 3..7 (any ISY with ISX*ISY <= 257) and the per-pixel fallback beyond;
     widths that leave a partial quad; saturate(cvRound(sum * (1.f / area)))."""
     isx, isy = scale
     dh, dw = dims
