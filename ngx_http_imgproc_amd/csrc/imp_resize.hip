@@ -2750,6 +2750,87 @@ __global__ __launch_bounds__(256) void k_area2x2_rotate_bgra(RArgs a, int amount
     }
 }
 
+// Streaming form of the same chain (the default for even halved widths; IMPGPU_CHAIN_STREAM=0 selects the block-tile kernel
+// above): no block-wide phases.  A WAVE owns SW = 128 columns of the halved image and a band of BH = 32 rows; it reads its
+// two source rows per halved row as one contiguous KB each, four halved rows per batch with the next batch already in
+// flight, boxes them into a wave-private LDS band tile and, once the band is full, writes it out turned: BH pixels per
+// destination row, 16 bytes per lane.  The four waves of a block take four consecutive bands of one strip, so a block
+// leaves 4 * BH contiguous pixels in each destination row and the runs of neighbouring bands meet in one L2.  Measured on
+// cfg3 (1024 frames): 64x64 block tiles 495-521 k img/s, this kernel 128x32 518-545 k (+4.5..7 %), 64x64 / 64x32 strips
+// 465 k, 128x16 460 k, 128x64 376 k (132 KB of LDS: one block per CU), non-temporal stores 428 k.
+template <int SW, int BH>      // strip width and band height in halved pixels
+__global__ __launch_bounds__(256) void k_area2x2_turn(RArgs a, int amount, int rw, int rh, int nstrips, int nbands, int bpf, int count,
+                                                      OverlayArgs wm) {
+    constexpr int LPR = SW / 2;                                 // lanes per halved row (a lane boxes two neighbouring outputs)
+    constexpr int RPI = 64 / LPR;                               // halved rows per wave-instruction
+    extern __shared__ uint32_t s_dyn[];                         // [4 waves][BH][SW + 1]
+    int frame, blk;
+    if (!frame_block(bpf, count, &frame, &blk)) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blk * 4 + wv;                              // band fastest: the waves of a block are neighbours in y
+    const int strip = item / nbands, band = item - strip * nbands;
+    if (strip >= nstrips) return;
+    uint32_t* tile = s_dyn + wv * (BH * (SW + 1));
+    const int hx0 = strip * SW, hy0 = band * BH;
+    const int nb = min(BH, rh - hy0);
+    const int ncol = min(SW, rw - hx0);                         // even (launcher)
+    const int rsub = lane / LPR, g = lane - rsub * LPR;         // this lane's row inside an instruction's group, its granule
+    const bool have = 2 * g < ncol;
+    const uint8_t* S = a.src + (long long)frame * a.src_stride + (size_t)(2 * hy0) * a.sstep + (size_t)(hx0 * 2 + (have ? g * 4 : 0)) * 4;
+    uint32_t cur[4][2][4], nxt[4][2][4];
+    auto fetch = [&](int r0, uint32_t (&v)[4][2][4]) {          // halved rows r0 .. r0 + 4 * RPI - 1 of the band (clamped: repeats are dropped later)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint8_t* p = S + (size_t)(2 * min(r0 + u * RPI + rsub, nb - 1)) * a.sstep;
+            load_stream<4>(v[u][0], p);
+            load_stream<4>(v[u][1], p + a.sstep);
+        }
+    };
+    fetch(0, cur);
+    for (int r0 = 0; r0 < nb; r0 += 4 * RPI) {
+        if (r0 + 4 * RPI < nb) fetch(r0 + 4 * RPI, nxt);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = r0 + u * RPI + rsub;
+            if (r < nb) {
+                tile[r * (SW + 1) + 2 * g] = box2x2(cur[u][0][0], cur[u][0][1], cur[u][1][0], cur[u][1][1]);
+                tile[r * (SW + 1) + 2 * g + 1] = box2x2(cur[u][0][2], cur[u][0][3], cur[u][1][2], cur[u][1][3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) cur[u][h][t] = nxt[u][h][t];
+    }
+    asm volatile("" ::: "memory");
+    // R[i][j] = H[rh-1-j][i] (90), H[j][rw-1-i] (270)
+    uint8_t* D = a.dst + (long long)frame * a.dst_stride;
+    const int nq = (nb + 3) >> 2;
+    const int j0 = amount == 90 ? rh - (hy0 + nb) : hy0;
+    for (int t = lane; t < ncol * nq; t += 64) {
+        const int col = t / nq, qi = t - col * nq;
+        const int hx = hx0 + col;
+        const int orow = amount == 90 ? hx : rw - 1 - hx;
+        uint32_t v[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int k = 4 * qi + jj;
+            const int r = amount == 90 ? nb - 1 - k : k;
+            v[jj] = overlay_px(wm, tile[min(max(r, 0), nb - 1) * (SW + 1) + col], orow, j0 + k);
+        }
+        uint8_t* q = D + (size_t)orow * a.dstep + (size_t)(j0 + 4 * qi) * 4;
+        if (4 * qi + 4 <= nb) {
+            const u32x4_t o4 = {v[0], v[1], v[2], v[3]};
+            *(u32x4_t*)q = o4;                                  // (temporal on purpose: neighbouring bands' runs meet in L2; nt measured -20 %)
+        } else {
+            for (int jj = 0; 4 * qi + jj < nb; jj++) *(uint32_t*)(q + 4 * jj) = v[jj];
+        }
+    }
+}
+
 // src: sw x sh BGRA with sw = 2*rw, sh = 2*rh; dst: rh x rw (rotated).  Returns IMP_ERROR_UNSUPPORTED when the
 // geometry is not the exact-2x BGRA case so the caller can fall back to resize + rotate.
 int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s) {
@@ -2763,6 +2844,31 @@ int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overla
     if (((uintptr_t)f.dst | (uintptr_t)f.dstep | (uintptr_t)f.dst_stride) & 3) return IMP_ERROR_UNSUPPORTED;
     RArgs a{f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
     const dim3 block(256);
+    static const int stream_cfg = std::getenv("IMPGPU_CHAIN_STREAM") ? std::atoi(std::getenv("IMPGPU_CHAIN_STREAM")) : 128032;   // SW * 1000 + BH; 0 = the block-tile kernel
+    if (stream_cfg && !(rw & 1)) {
+        OverlayArgs wm0{};
+        if (overlay) wm0 = *overlay;
+        const int sw = stream_cfg / 1000 == 64 ? 64 : 128, bh = stream_cfg % 1000 == 64 ? 64 : (stream_cfg % 1000 == 16 ? 16 : 32);
+        const int nstrips = (rw + sw - 1) / sw, nbands = (rh + bh - 1) / bh, bpf = (nstrips * nbands + 3) / 4;
+        const dim3 sgrid((unsigned)bpf, (unsigned)((f.count + 7) / 8 * 8));
+        const size_t lds = (size_t)4 * bh * (sw + 1) * 4;
+        hipError_t e = hipSuccess;
+#define IMP_TURN(SW_, BH_)                                                                                                        \
+    do {                                                                                                                          \
+        e = hipFuncSetAttribute((const void*)k_area2x2_turn<SW_, BH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        if (e == hipSuccess)                                                                                                      \
+            hipLaunchKernelGGL((k_area2x2_turn<SW_, BH_>), sgrid, block, lds, s, a, amount, rw, rh, nstrips, nbands, bpf, f.count, wm0); \
+    } while (0)
+        if (sw == 64 && bh == 64) IMP_TURN(64, 64);
+        else if (sw == 64 && bh == 32) IMP_TURN(64, 32);
+        else if (sw == 128 && bh == 64) IMP_TURN(128, 64);
+        else if (sw == 128 && bh == 16) IMP_TURN(128, 16);
+        else IMP_TURN(128, 32);
+#undef IMP_TURN
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { set_error("k_area2x2_turn", e); return IMP_ERROR_DEVICE; }
+        return IMP_OK;
+    }
     static const int shape_y = std::getenv("IMPGPU_CHAIN_TILE_Y") ? std::atoi(std::getenv("IMPGPU_CHAIN_TILE_Y")) : 0;
     const int tx = shape, ty = shape_y ? shape_y : 4096 / shape;
     const int ntx = (rw + tx - 1) / tx, nty = (rh + ty - 1) / ty;

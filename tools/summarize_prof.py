@@ -23,7 +23,7 @@ PROF = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_rows<4, 10>": "area", "k_resize_nn<4>": "nn",
-         "k_resize_taps<2, 4, 0>": "linear", "k_resize_2x_dma<8, 2": "lanczos", "k_area2x2_rotate_bgra": "chain",
+         "k_resize_taps<2, 4, 0>": "linear", "k_resize_2x_dma<8, 2": "lanczos", "k_area2x2_turn": "chain",
          "k_resize_up_cubic4": "upscale", "k_area2x2_c4": "area2x"}
 # frames per launch in tools/pmc_probe.py, as a divisor of PROBE_BATCH
 BATCH_DIV = {"lanczos": 16, "upscale": 2, "area2x": 4}
