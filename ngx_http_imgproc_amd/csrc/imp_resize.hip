@@ -443,6 +443,7 @@ __device__ __forceinline__ uint32_t cvt_pk_u8(float x, uint32_t acc, int byte) {
 // per destination row, 32 bytes: how far the footprint moves before this row, then the four weights b * 2^-22
 struct UpRow { int adv; float bf[4]; int first; int pad[2]; };      // first = first footprint row (yofs - 1); adv = first - previous row's first
 
+template <int PS>     // PS = 2, 3, 4: scale_y is exactly 1/PS (host-checked: every PS-th row advances the footprint); 0: anything
 __global__ __launch_bounds__(256) void k_resize_up_cubic4(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
                                                           const short* __restrict__ yco, const UpRow* __restrict__ rows,
                                                           int vec_end, int nbx, int rows_per_wave) {
@@ -529,6 +530,26 @@ __global__ __launch_bounds__(256) void k_resize_up_cubic4(RArgs a, const int* __
     };
     for (int k = 0; k < 4; k++) advance();                     // the first row's footprint
     int dy = row0;
+    const bool tail = dx * 4 + 3 >= vec_end;                   // this pixel holds bytes of the row's scalar tail
+    const unsigned lane_off = (unsigned)dx * 4u;
+    auto slow_row = [&](int y) {                               // any row, any strip: a dword per lane
+        const UpRow rc = rows[y];
+        while (cur < rc.first) advance();
+        uint32_t px = vpass(rc.bf);
+        if (tail) {
+            const float hc[4][4] = {{hxy[0].x, hxy[1].x, hxy[2].x, hxy[3].x}, {hxy[0].y, hxy[1].y, hxy[2].y, hxy[3].y},
+                                    {hzw[0].x, hzw[1].x, hzw[2].x, hzw[3].x}, {hzw[0].y, hzw[1].y, hzw[2].y, hzw[3].y}};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (dx * 4 + c >= vec_end) {
+                    int v = 1 << 21;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v += __mul24((int)hc[c][k], (int)yco[y * 4 + k]);
+                    px = (px & ~(0xffu << (8 * c))) | ((uint32_t)shr_sat_u8(v, 22) << (8 * c));
+                }
+        }
+        if (live) *(uint32_t*)(D + ((unsigned)y * (unsigned)a.dstep + lane_off)) = px;
+    };
 
     // Fast path (wave-uniform): a full 64-column strip, 16-byte aligned destination, whole groups of four rows.  A full
     // strip never holds the row's scalar-tail pixel (that is the last pixel of an odd-width row, and a strip is full
@@ -536,7 +557,37 @@ __global__ __launch_bounds__(256) void k_resize_up_cubic4(RArgs a, const int* __
     // (4 rows x 256 B per instruction).  Per row the scalar side does one pointer bump, one 32-byte constant row (the
     // table carries a sentinel row past the last one, so the look-ahead needs no bound) and one compare-and-branch for
     // the footprint advance (0 or 1: scale_y <= 1).
-    if (txn == 64 && !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & 15)) {
+    const bool fast = txn == 64 && !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & 15);
+    if constexpr (PS > 0) {
+        // Integer factors: the footprint advances on every PS-th row, so 4 PS rows -- four advances, after which the register
+        // ring is back where it started -- unroll into straight code whose ring shifts are renames, not the 12 register
+        // moves per advance the generic loop pays (8 % of this VALU-bound kernel's instructions at 4x, 16 % at 2x).
+        if (fast) {
+            slow_row(dy++);                                    // the chunk's first row: its footprint is in place
+            while (dy < row_end && rows[dy].adv == 0) slow_row(dy++);      // up to the next advancing row
+            const unsigned voff = (unsigned)(lane >> 4) * (unsigned)a.dstep + (unsigned)(tx0 + (lane & 15) * 4) * 4u;
+            uint32_t* park = &s_tr[wv][0][lane];
+            const u32x4_t* pick = (const u32x4_t*)&s_tr[wv][lane >> 4][(lane & 15) * 4];
+            const size_t group_bytes = (size_t)a.dstep * 4;
+            for (; dy + 4 * PS <= row_end; dy += 4 * PS) {
+                const UpRow* rq = rows + dy;
+                uint8_t* Dg = D + (size_t)dy * a.dstep;
+#pragma unroll
+                for (int r = 0; r < 4 * PS; r++) {
+                    const UpRow rc = rq[r];
+                    if (r % PS == 0) advance();                // (static)
+                    park[(r & 3) * 64] = vpass(rc.bf);
+                    if ((r & 3) == 3) {
+                        asm volatile("" ::: "memory");
+                        const u32x4_t q = *pick;
+                        asm volatile("" ::: "memory");
+                        *(u32x4_t*)(Dg + (size_t)(r >> 2) * group_bytes + voff) = q;
+                    }
+                }
+            }
+        }
+    } else
+    if (fast) {
         const unsigned voff = (unsigned)(lane >> 4) * (unsigned)a.dstep + (unsigned)(tx0 + (lane & 15) * 4) * 4u;
         uint32_t* park = &s_tr[wv][0][lane];
         const u32x4_t* pick = (const u32x4_t*)&s_tr[wv][lane >> 4][(lane & 15) * 4];
@@ -563,26 +614,7 @@ __global__ __launch_bounds__(256) void k_resize_up_cubic4(RArgs a, const int* __
     }
 
     // Generic path: partial strips, unaligned destinations, the last (rows % 4) rows of a chunk
-    const bool tail = dx * 4 + 3 >= vec_end;                   // this pixel holds bytes of the row's scalar tail
-    const unsigned lane_off = (unsigned)dx * 4u;
-    for (; dy < row_end; dy++) {
-        const UpRow rc = rows[dy];
-        while (cur < rc.first) advance();
-        uint32_t px = vpass(rc.bf);
-        if (tail) {
-            const float hc[4][4] = {{hxy[0].x, hxy[1].x, hxy[2].x, hxy[3].x}, {hxy[0].y, hxy[1].y, hxy[2].y, hxy[3].y},
-                                    {hzw[0].x, hzw[1].x, hzw[2].x, hzw[3].x}, {hzw[0].y, hzw[1].y, hzw[2].y, hzw[3].y}};
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                if (dx * 4 + c >= vec_end) {
-                    int v = 1 << 21;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v += __mul24((int)hc[c][k], (int)yco[dy * 4 + k]);
-                    px = (px & ~(0xffu << (8 * c))) | ((uint32_t)shr_sat_u8(v, 22) << (8 * c));
-                }
-        }
-        if (live) *(uint32_t*)(D + ((unsigned)dy * (unsigned)a.dstep + lane_off)) = px;
-    }
+    for (; dy < row_end; dy++) slow_row(dy);
 }
 
 // The same for 3-channel frames -- what cvDecodeImage hands Resize() for every JPEG, so every JPEG enlargement
@@ -597,6 +629,7 @@ __device__ __forceinline__ void hpass_bgr(const uint32_t* w, const short2_t* axp
 
 #define UP_CAP3_BYTES 6144   // bytes of source a wave stages in LDS
 
+template <int PS>     // see k_resize_up_cubic4
 __global__ __launch_bounds__(256) void k_resize_up_cubic3(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
                                                           const short* __restrict__ yco, const UpRow* __restrict__ rows,
                                                           int vec_end, int nbx, int rows_per_wave) {
@@ -673,8 +706,64 @@ __global__ __launch_bounds__(256) void k_resize_up_cubic3(RArgs a, const int* __
     };
     for (int k = 0; k < 4; k++) advance();
     int dy = row0;
+    const bool tail = dx * 3 + 2 >= vec_end;
+    auto slow_row = [&](int y) {                               // any row, any strip: three bytes per lane
+        const UpRow rc = rows[y];
+        while (cur < rc.first) advance();
+        uint32_t px = vpass(rc.bf);
+        if (tail) {
+            const float hc[3][4] = {{hxy[0].x, hxy[1].x, hxy[2].x, hxy[3].x}, {hxy[0].y, hxy[1].y, hxy[2].y, hxy[3].y}, {hz[0], hz[1], hz[2], hz[3]}};
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (dx * 3 + c >= vec_end) {
+                    int v = 1 << 21;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v += __mul24((int)hc[c][k], (int)yco[y * 4 + k]);
+                    px = (px & ~(0xffu << (8 * c))) | ((uint32_t)shr_sat_u8(v, 22) << (8 * c));
+                }
+        }
+        if (live) {
+            uint8_t* o = D + (size_t)y * a.dstep + (size_t)dx * 3;
+            o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16);
+        }
+    };
 
-    if (txn == 64 && !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & 3)) {
+    const bool fast = txn == 64 && !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & 3);
+    if constexpr (PS > 0) {
+        if (fast) {                                            // integer factors: the advance schedule is static (k_resize_up_cubic4)
+            slow_row(dy++);
+            while (dy < row_end && rows[dy].adv == 0) slow_row(dy++);
+            uint8_t* park = &s_tr[wv][lane * 3];
+            const size_t group_bytes = (size_t)a.dstep * 4;
+            unsigned voff[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int n = lane + 64 * j;
+                voff[j] = (unsigned)(n / 48) * (unsigned)a.dstep + (unsigned)(n % 48) * 4u;
+            }
+            for (; dy + 4 * PS <= row_end; dy += 4 * PS) {
+                const UpRow* rq = rows + dy;
+                uint8_t* Dg = D + (size_t)dy * a.dstep + (size_t)tx0 * 3;
+#pragma unroll
+                for (int r = 0; r < 4 * PS; r++) {
+                    const UpRow rc = rq[r];
+                    if (r % PS == 0) advance();
+                    const uint32_t px = vpass(rc.bf);
+                    park[(r & 3) * 192] = (uint8_t)px; park[(r & 3) * 192 + 1] = (uint8_t)(px >> 8); park[(r & 3) * 192 + 2] = (uint8_t)(px >> 16);
+                    if ((r & 3) == 3) {
+                        asm volatile("" ::: "memory");
+                        uint32_t q[3];
+#pragma unroll
+                        for (int j = 0; j < 3; j++) q[j] = ((const uint32_t*)&s_tr[wv][0])[lane + 64 * j];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < 3; j++) *(uint32_t*)(Dg + (size_t)(r >> 2) * group_bytes + voff[j]) = q[j];
+                    }
+                }
+            }
+        }
+    } else
+    if (fast) {
         uint8_t* park = &s_tr[wv][lane * 3];
         const UpRow* rq = rows + row0;
         UpRow rc = *rq;
@@ -707,27 +796,7 @@ __global__ __launch_bounds__(256) void k_resize_up_cubic3(RArgs a, const int* __
         }
     }
 
-    const bool tail = dx * 3 + 2 >= vec_end;
-    for (; dy < row_end; dy++) {
-        const UpRow rc = rows[dy];
-        while (cur < rc.first) advance();
-        uint32_t px = vpass(rc.bf);
-        if (tail) {
-            const float hc[3][4] = {{hxy[0].x, hxy[1].x, hxy[2].x, hxy[3].x}, {hxy[0].y, hxy[1].y, hxy[2].y, hxy[3].y}, {hz[0], hz[1], hz[2], hz[3]}};
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                if (dx * 3 + c >= vec_end) {
-                    int v = 1 << 21;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v += __mul24((int)hc[c][k], (int)yco[dy * 4 + k]);
-                    px = (px & ~(0xffu << (8 * c))) | ((uint32_t)shr_sat_u8(v, 22) << (8 * c));
-                }
-        }
-        if (live) {
-            uint8_t* o = D + (size_t)dy * a.dstep + (size_t)dx * 3;
-            o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16);
-        }
-    }
+    for (; dy < row_end; dy++) slow_row(dy);                   // partial strips, unaligned destinations, a chunk's last rows
 }
 
 // vertical pass over the register ring at phase U of its period; returns the packed BGRA destination pixel
@@ -2217,6 +2286,7 @@ struct TableSet {
     const int *xofs = nullptr, *yofs = nullptr;
     const short *xco = nullptr, *yco = nullptr;
     const void* yrows = nullptr;  // CUBIC: per destination row {footprint advance, yco * 2^-22 as floats, first footprint row} (UpRow)
+    int up_period = 0;        // CUBIC enlargement: P when exactly every P-th destination row advances the footprint (integer factor), else 0
     bool ysym = false;        // step2 and the one set of row weights is mirror-symmetric (vpass_px's VSYM form)
     bool step2 = false;       // xofs[d] = xofs[0] + 2d and yofs[d] = yofs[0] + 2d: k_resize_2x_roll applies
     AreaDev area{};
@@ -2306,6 +2376,14 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
             }
             yr[dh] = yr[dh - 1];
             yr[dh].adv = 0;
+            static const bool no_period = std::getenv("IMPGPU_UP_NO_PERIOD") != nullptr;
+            for (int per = 2; per <= 4 && !ts.up_period && !no_period; per++) {   // rows p, p + per, p + 2 per ... advance by one, the others not at all
+                int p0 = 1;
+                while (p0 < dh && yr[p0].adv == 0) p0++;
+                bool ok = p0 < dh;
+                for (int d = 1; d < dh && ok; d++) ok = yr[d].adv == ((d >= p0 && (d - p0) % per == 0) ? 1 : 0);
+                if (ok) ts.up_period = per;
+            }
             while (blob.size() % 32) blob.push_back(0);
             o[4] = put(blob, yr);
         }
@@ -2580,8 +2658,15 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             while (rpw > 4 && ((int)std::floor((rpw - 1) * scale_y) + 6) * wbmax > UP_CAP3_BYTES) rpw -= 4;
             while (rpw > 16 && (long long)nbx * 4 * ((a.dh + rpw - 1) / rpw) * count < 8192) rpw -= rpw > 64 ? 64 : 16;
             const int ncy = (a.dh + rpw - 1) / rpw;
-            hipLaunchKernelGGL(k_resize_up_cubic3, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
+            { const int per = ts.up_period;
+              if (per == 2) hipLaunchKernelGGL(k_resize_up_cubic3<2>, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
                                ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 3) & ~7, nbx, rpw);
+              else if (per == 3) hipLaunchKernelGGL(k_resize_up_cubic3<3>, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
+                               ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 3) & ~7, nbx, rpw);
+              else if (per == 4) hipLaunchKernelGGL(k_resize_up_cubic3<4>, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
+                               ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 3) & ~7, nbx, rpw);
+              else hipLaunchKernelGGL(k_resize_up_cubic3<0>, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
+                               ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 3) & ~7, nbx, rpw); }
         } else if (CN == 4 && interp == IMP_INTER_CUBIC && scale_y <= 1.0 && scale_x <= 2.0 && a.sw >= 4 &&
                    (long long)a.dh * a.dstep < (1LL << 32) && !std::getenv("IMPGPU_NO_UP")) {
             // enlargement (bridge.c:190's CUBIC case): wave-private strips, float H sums in a register ring
@@ -2596,8 +2681,12 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             while (rpw > 4 && ((int)std::floor((rpw - 1) * scale_y) + 6) * wmax > UP_CAP_PX) rpw -= 4;
             while (rpw > 16 && (long long)nbx * 4 * ((a.dh + rpw - 1) / rpw) * count < 8192) rpw -= rpw > 64 ? 64 : 16;
             const int ncy = (a.dh + rpw - 1) / rpw;
-            hipLaunchKernelGGL(k_resize_up_cubic4, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
-                               ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
+            const dim3 ugrid((unsigned)(nbx * ncy), (unsigned)count);
+            const int per = ts.up_period;                  // 2, 3, 4 when every per-th row (and no other) advances the footprint
+            if (per == 2) hipLaunchKernelGGL(k_resize_up_cubic4<2>, ugrid, block, 0, s, a, ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
+            else if (per == 3) hipLaunchKernelGGL(k_resize_up_cubic4<3>, ugrid, block, 0, s, a, ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
+            else if (per == 4) hipLaunchKernelGGL(k_resize_up_cubic4<4>, ugrid, block, 0, s, a, ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
+            else hipLaunchKernelGGL(k_resize_up_cubic4<0>, ugrid, block, 0, s, a, ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
         } else if (CN == 4 && scale_x <= 2.0 && scale_y <= 2.0 && a.sw >= 8) {
             static const int th = std::getenv("IMPGPU_TILE_TH") ? std::atoi(std::getenv("IMPGPU_TILE_TH")) : 8;
             const int ntx = (a.dw + TL_TW - 1) / TL_TW, nty = (a.dh + th - 1) / th;

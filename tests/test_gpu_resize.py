@@ -207,12 +207,14 @@ def test_dma_ring_results_do_not_depend_on_timing(gpu, c):
 
 @pytest.mark.parametrize("shape", [((270, 480), (1080, 1920)), ((100, 161), (333, 515)), ((64, 4), (200, 9)), ((50, 100), (200, 80)),
                                    ((37, 41), (37, 123)), ((90, 7), (91, 8)), ((33, 200), (1000, 230)), ((50, 100), (200, 128)),
-                                   ((60, 40), (61, 256)), ((30, 70), (90, 64))])
+                                   ((60, 40), (61, 256)), ((30, 70), (90, 64)), ((61, 100), (122, 200)), ((45, 64), (135, 192)),
+                                   ((33, 64), (66, 64)), ((201, 64), (804, 128)), ((150, 32), (300, 128))])
 @pytest.mark.parametrize("c", [3, 4])
 def test_cubic_enlargement_kernel_bit_exact(gpu, shape, c):
     """The reference's only CUBIC dispatch (bridge.c:190: an axis grows): k_resize_up_cubic4 / _cubic3 -- wave-private strips,
     float H sums in a register ring, scalar row weights.  Full 480x270 -> 1080p, odd widths (a scalar tail in every row),
-    4-pixel-wide sources, x shrinking while y grows, and the edge columns the 2.4.9 x rule pins to src[0] / src[w-1]."""
+    4-pixel-wide sources, x shrinking while y grows, the edge columns the 2.4.9 x rule pins to src[0] / src[w-1], and exact
+    2x / 3x / 4x heights (BGRA: the unrolled path whose footprint advances on a fixed schedule; several chunks per strip)."""
     (sh, sw), (dh, dw) = shape
     for arr in (noise_image(sh, sw, c, 21), smooth_image(sh, sw, c)):
         want = orc.cv_resize(arr, dw, dh, orc.INTER_CUBIC)
