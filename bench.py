@@ -378,6 +378,8 @@ def main():
     use_dist = world > 1 or (os.environ.get("IMPGPU_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"      # the pool exports VERSION: RCCL's banner would share stdout with the one JSON line
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     lib_path = os.path.join(ROOT, "ngx_http_imgproc_amd", "libimpgpu.so")
