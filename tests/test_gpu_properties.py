@@ -149,3 +149,74 @@ def test_tiny_and_degenerate_frames(gpu):
                     assert im.filter(f, 1) == rc == 0
                     assert np.array_equal(im.numpy(), want), (shape, c, f)
                     im.release()
+
+
+def test_mixed_geometry_batch_full_size_stream_equals_per_frame_launches(gpu):
+    """BASELINE configs[4] at its real sizes (long side 256 .. 3840, 192 frames, ~1.5 GB of BGRA): one
+    impgpu_batch_resize_mixed call must leave, frame for frame, the bytes of one impgpu_batch_cv_resize launch per frame
+    (a different band height, a different kernel entry); checked through a checksum of per-frame checksums, and against
+    the oracle on the smallest, the largest and a few frames in between."""
+    import torch
+    from ngx_http_imgproc_amd.workloads import MIXED_RESIZE, mixed_sizes
+
+    sizes = mixed_sizes(192)
+    cfg = gpu.Config()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x1A4D5151)
+    srcs, d_one, d_each, items = [], [], [], []
+    for w, h in sizes:
+        rc, (dw, dh, _) = gpu.resize_geometry(w, h, MIXED_RESIZE.decode(), cfg)
+        assert rc == 0
+        srcs.append(torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda", generator=g))
+        d_one.append(torch.zeros((dh, dw, 4), dtype=torch.uint8, device="cuda"))
+        d_each.append(torch.zeros((dh, dw, 4), dtype=torch.uint8, device="cuda"))
+        items.append((srcs[-1].data_ptr(), w, h, w * 4, d_one[-1].data_ptr(), dw, dh, dw * 4))
+    torch.cuda.synchronize()
+    assert gpu.batch_resize_mixed(items, 4) == 0
+    for (sp, w, h, ss, _, dw, dh, ds), de in zip(items, d_each):
+        gpu.batch_cv_resize(sp, 0, w, h, ss, de.data_ptr(), 0, dw, dh, ds, 4, 1, orc.INTER_AREA)
+    gpu.sync()
+    h_one = hashlib.sha256(b"".join(hashlib.sha256(t.cpu().numpy().tobytes()).digest() for t in d_one)).hexdigest()
+    h_each = hashlib.sha256(b"".join(hashlib.sha256(t.cpu().numpy().tobytes()).digest() for t in d_each)).hexdigest()
+    assert h_one == h_each
+    order = sorted(range(len(sizes)), key=lambda i: sizes[i][0] * sizes[i][1])
+    for i in (order[0], order[len(order) // 3], order[len(order) // 2], order[-1]):
+        w, h = sizes[i]
+        dh, dw = d_one[i].shape[:2]
+        assert np.array_equal(d_one[i].cpu().numpy(), orc.cv_resize(srcs[i].cpu().numpy(), dw, dh, orc.INTER_AREA)), (w, h)
+
+
+def test_mixed_geometry_batches_from_several_threads(gpu):
+    """Each calling thread has its own lane (stream, pool, staging ring): concurrent impgpu_batch_resize_mixed calls must
+    not disturb one another's descriptor uploads."""
+    import threading
+    import torch
+
+    rng = np.random.Generator(np.random.PCG64(0x1A4D6161))
+    jobs = []
+    for t in range(4):
+        frames = [rng.integers(0, 256, size=(60 + 7 * t + i, 90 + 5 * i, 4), dtype=np.uint8) for i in range(24)]
+        targets = [(31 + (i % 9), 20 + (i % 7)) for i in range(24)]
+        jobs.append((frames, targets))
+    results = [None] * 4
+
+    def work(t):
+        frames, targets = jobs[t]
+        srcs = [torch.from_numpy(f).cuda() for f in frames]
+        dsts = [torch.zeros((dh, dw, 4), dtype=torch.uint8, device="cuda") for dw, dh in targets]
+        torch.cuda.synchronize()
+        items = [(s.data_ptr(), f.shape[1], f.shape[0], f.shape[1] * 4, d.data_ptr(), dw, dh, dw * 4)
+                 for s, f, d, (dw, dh) in zip(srcs, frames, dsts, targets)]
+        ok = True
+        for _ in range(5):
+            ok = ok and gpu.batch_resize_mixed(items, 4) == 0
+        gpu.sync()
+        results[t] = ok and all(np.array_equal(d.cpu().numpy(), orc.cv_resize(f, dw, dh, orc.INTER_AREA))
+                                for d, f, (dw, dh) in zip(dsts, frames, targets))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert results == [True] * 4
