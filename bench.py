@@ -253,7 +253,7 @@ def cpu_baseline(seconds_budget=12.0):
     }
 
 
-def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, world=1):
+def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, world=1, c=4):
     """BASELINE configs[4]: mixed-size request stream (ngx_http_imgproc_amd.workloads.mixed_sizes), each request =
     upload (pinned) -> resize=224,0 (keep aspect; AREA, what the reference runs, bridge.c:588-604 on whatever size
     arrives) -> download.  Requests shard round-robin over ranks (request i -> rank i mod world, no collective); on a
@@ -271,14 +271,14 @@ def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, wo
     lib = imp.lib
     # one pinned source buffer (largest frame) filled with noise: every request reads its w*h*4 prefix
     maxpx = max(w * h for w, h in all_sizes)
-    hsrc = lib.impgpu_host_alloc(maxpx * 4)
+    hsrc = lib.impgpu_host_alloc(maxpx * c + 64)
     rng = np.random.Generator(np.random.PCG64(0x1A4D0005))
-    noise = rng.integers(0, 256, size=maxpx * 4, dtype=np.uint8)
+    noise = rng.integers(0, 256, size=maxpx * c, dtype=np.uint8)
     C.memmove(hsrc, noise.ctypes.data, noise.nbytes)
     cfg = imp.Config()
     pending = queue.Queue(maxsize=max(1, queue_depth))
     errors = []
-    out_bytes = 224 * 224 * 4 * 4          # the short side is at most 224 * 16/9
+    out_bytes = 224 * 224 * 4 * 4          # the short side is at most 224 * 16/9 (sized for 4 channels)
 
     def feeder():
         for item in mine:
@@ -297,12 +297,12 @@ def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, wo
             else:
                 w, h = item
                 img = C.c_void_p()
-                rc = lib.impgpu_image_upload_pinned(hsrc, w, h, 4, w * 4, C.byref(img))
+                rc = lib.impgpu_image_upload_pinned(hsrc, w, h, c, w * c, C.byref(img))
                 if rc == 0:
                     rc = lib.impgpu_resize(C.byref(img), MIXED_RESIZE, C.byref(cfg.c), 0)
                 if rc == 0:
                     ow = lib.impgpu_image_width(img)
-                    rc = lib.impgpu_image_download_pinned(img, hdst + out_bytes * len(live), ow * 4)
+                    rc = lib.impgpu_image_download_pinned(img, hdst + out_bytes * len(live), (ow * c + 3) & ~3)
                 live.append(img)
                 if rc:
                     errors.append((item, rc))
@@ -335,7 +335,7 @@ def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, wo
     lib.impgpu_host_free(hsrc)
     if errors:
         raise SystemExit("request_stream failed: %r" % errors[:3])
-    return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * 4 for w, h in mine)}
+    return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * c for w, h in mine)}
 
 
 def main():
@@ -355,7 +355,7 @@ def main():
     ap.add_argument("--mixed", type=int, default=0, metavar="N",
                     help="BASELINE configs[4] with the N frames already in HBM: resize=224,0 over mixed sizes, one "
                          "impgpu_batch_resize_mixed call per step (and, for comparison, one launch per frame)")
-    ap.add_argument("--channels", type=int, default=4, choices=(3, 4), help="--mixed: BGRA (4) or BGR (3, what a JPEG decodes to)")
+    ap.add_argument("--channels", type=int, default=4, choices=(3, 4), help="--mixed / --stream: BGRA (4) or BGR (3, what a JPEG decodes to)")
     ap.add_argument("--e2e", type=int, default=0, metavar="N",
                     help="instead of the headline, time N PCIe-inclusive requests (upload + resize + download) and exit")
     args = ap.parse_args()
@@ -395,11 +395,11 @@ def main():
     imp.env_start(local_rank)
     if args.stream:
         # warm this rank's lanes / pools / clocks on a short untimed prefix, then the timed stream
-        request_stream(imp, min(args.stream, 64 * args.threads), args.threads, args.queue_depth, args.inflight, rank, world)
+        request_stream(imp, min(args.stream, 64 * args.threads), args.threads, args.queue_depth, args.inflight, rank, world, args.channels)
         if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
-        r = request_stream(imp, args.stream, args.threads, args.queue_depth, args.inflight, rank, world)
+        r = request_stream(imp, args.stream, args.threads, args.queue_depth, args.inflight, rank, world, args.channels)
         torch.cuda.synchronize()
         t = torch.tensor([r["seconds"], float(r["requests"]), float(r["source_bytes"])], dtype=torch.float64, device="cuda")
         if use_dist:
@@ -414,10 +414,10 @@ def main():
                 "metric": "requests/sec, mixed-size request stream (256px-4K) resize=224,0, PCIe-inclusive",
                 "value": round(nreq / secs, 1), "unit": "requests/sec", "n_gpus": world, "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "u8",
-                "data": "synthetic (seeded sizes, noise BGRA frames in pinned host memory)",
+                "data": "synthetic (seeded sizes, noise %s frames in pinned host memory, rows tightly packed)" % ("BGRA" if args.channels == 4 else "BGR"),
                 "source_MB_per_sec": round(nbytes / secs / 1e6, 1), "seconds": round(secs, 3),
                 "config": {"workload": "BASELINE configs[4]: %d requests, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % int(nreq),
-                           "threads_per_gpu": args.threads, "queue_depth": args.queue_depth, "inflight_per_thread": args.inflight,
+                           "threads_per_gpu": args.threads, "queue_depth": args.queue_depth, "inflight_per_thread": args.inflight, "channels": args.channels,
                            "sharding": "request i -> rank i mod N, no collective"}}), flush=True)
         imp.env_destroy()
         if use_dist:

@@ -104,7 +104,10 @@ int   impgpu_image_upload(const unsigned char* data, int width, int height, int 
 int   impgpu_image_create(int width, int height, int channels, impgpu_image** out);
 /* Pinned-host variants for callers that decode into / encode from page-locked memory
  * (impgpu_host_alloc): no staging pass, fully asynchronous on the env stream.  The host
- * buffer must stay untouched until impgpu_sync() (upload) / is valid after impgpu_sync() (download). */
+ * buffer must stay untouched until impgpu_sync() (upload) / is valid after impgpu_sync() (download).
+ * `step` may be any host row pitch >= width * channels: a pitch other than the frame's own (4-byte padded rows) still
+ * crosses the link as one linear copy and is re-pitched on the device; on download the bytes between the caller's rows
+ * are then written as zeros. */
 void* impgpu_host_alloc(size_t bytes);
 void  impgpu_host_free(void* ptr);
 int   impgpu_image_upload_pinned(const unsigned char* data, int width, int height, int channels,

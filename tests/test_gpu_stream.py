@@ -262,3 +262,31 @@ def test_mixed_geometry_batch_rejects_a_malformed_item_before_launching(gpu):
     gpu.sync()
     assert all(int(d.min()) == 7 and int(d.max()) == 7 for d in dsts)          # the two good items were not run either
     assert gpu.batch_resize_mixed([], 4) == 0
+
+
+@pytest.mark.parametrize("c", [3, 4])
+def test_pinned_transfers_with_foreign_row_pitches(gpu, c):
+    """impgpu_image_upload_pinned / _download_pinned with host pitches other than the frame's own: tightly packed BGR rows
+    (what libjpeg hands out), rows padded far beyond the frame's; one linear DMA + a device re-pitch each way."""
+    lib = gpu.lib
+    w, h = 203, 57
+    frame = noise_image(h, w, c, 7300 + c)
+    for pitch in (w * c, w * c + 13, ((w * c + 3) & ~3)):
+        hsrc = lib.impgpu_host_alloc(pitch * h)
+        buf = np.ctypeslib.as_array((C.c_uint8 * (pitch * h)).from_address(hsrc)).reshape(h, pitch)
+        buf[:] = 0xEE
+        buf[:, :w * c] = frame.reshape(h, w * c)
+        img = C.c_void_p()
+        assert lib.impgpu_image_upload_pinned(hsrc, w, h, c, pitch, C.byref(img)) == 0
+        assert lib.impgpu_filter(C.byref(img), b"flip=10", 1) == 0
+        opitch = w * c + 5
+        hdst = lib.impgpu_host_alloc(opitch * h)
+        out = np.ctypeslib.as_array((C.c_uint8 * (opitch * h)).from_address(hdst)).reshape(h, opitch)
+        out[:] = 0x77
+        assert lib.impgpu_image_download_pinned(img, hdst, opitch) == 0
+        assert lib.impgpu_sync() == 0
+        assert np.array_equal(out[:, :w * c].reshape(h, w, c), frame[:, ::-1]), pitch
+        assert not out[:-1, w * c:].any()                   # the gaps between rows arrive as zeros
+        lib.impgpu_image_release(C.byref(img))
+        lib.impgpu_host_free(hsrc)
+        lib.impgpu_host_free(hdst)
