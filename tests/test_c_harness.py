@@ -143,3 +143,29 @@ print(repr(codes))
     codes = eval(p.stdout.strip().split("\n")[-1])
     assert [c[0] for c in codes] == [0, 90, 0, 0] and codes[1][1] == 4 and "injected fault" in codes[1][2]
     assert codes[0][3] == codes[2][3] == (14, 20, 3) and codes[1][3] == (50, 70, 3)      # the failed request's frame is intact
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [3, 4])
+def test_mixed_batch_from_c(tmp_path, c):
+    """tests/c/mixed_harness.c: impgpu_batch_resize_mixed called from C99 with frames of five different geometries (a
+    general shrink, an exact 2x, an exact 4x, an enlargement, a wide shrink) -- the struct layout of impgpu_resize_item as a C
+    compiler sees it, owned images' device pointers and pitches, NULL stream = the env stream; every output against the
+    oracle under the interpolation Resize() picks (bridge.c:188-192)."""
+    build()
+    exe = os.path.join(ROOT, "tests", "c", "_build", "mixed_harness")
+    geoms = [((90, 131), (57, 40)), ((64, 96), (48, 32)), ((80, 120), (30, 20)), ((33, 41), (90, 70)), ((70, 600), (123, 33))]
+    cmd = [exe, str(c), "0", str(len(geoms))]
+    frames = []
+    for i, ((sh, sw), (dw, dh)) in enumerate(geoms):
+        f = noise_image(sh, sw, c, 9100 + i)
+        frames.append(f)
+        src = tmp_path / ("f%d.raw" % i)
+        f.tofile(src)
+        cmd += [str(src), str(sw), str(sh), str(dw), str(dh), str(tmp_path / ("o%d.raw" % i))]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip() == "code=0", (p.stdout, p.stderr)
+    for i, ((sh, sw), (dw, dh)) in enumerate(geoms):
+        got = np.fromfile(tmp_path / ("o%d.raw" % i), dtype=np.uint8).reshape(dh, dw, c)
+        interp = orc.INTER_CUBIC if (dw > sw or dh > sh) else orc.INTER_AREA
+        assert np.array_equal(got, orc.cv_resize(frames[i], dw, dh, interp)), geoms[i]
