@@ -338,6 +338,8 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
     Work wk{*pointer, view_of(*pointer)};
     int rc = IMP_OK;
     PixelProgram prog;
+    int fused_filters = 0;                                             // leading filters the Resize launch already applied
+    bool watermark_done = false;
 
     *step = IMP_STEP_CROP;                                             // bridge.c:575-586
     if (job->crop) {
@@ -355,7 +357,35 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
         int w, h, interp;
         rc = resize_geometry(wk.v.w, wk.v.h, job->resize, config->max_target_w, config->max_target_h, job->simple, &w, &h, &interp);
         if (rc) goto done;
-        rc = do_resize(wk, w, h, interp);
+        // A thumbnail request whose first filter is a rotation -- and, when that is its only filter, its watermark -- in
+        // ONE launch: both ride on the stores of the row-streaming AREA kernel (a lone request is launch-bound: this is a
+        // third of its launches and two intermediate frames).  Anything the fused kernel does not take goes step by step.
+        rc = IMP_ERROR_UNSUPPORTED;
+        if (interp == IMP_INTER_AREA && wk.v.c == 4 && job->filter_count >= 1) {
+            FilterPlan first;
+            PixelProgram none;
+            if (filter_plan(job->filters[0], config->allow_experiments, 4, w, h, &first, &none) == IMP_OK && first.cls == FC_ROTATE) {
+                const bool swap = first.rotate != 180;
+                const int fw = swap ? h : w, fh = swap ? w : h;
+                const impgpu_image* ov = config->watermark;
+                OverlayArgs wm{};
+                bool with_wm = job->filter_count == 1 && ov && ov->c == 4 && !(((uintptr_t)ov->d | (uintptr_t)ov->step) & 3);
+                if (with_wm && watermark_rect(fw, fh, ov->w, ov->h, config, &wm.rx, &wm.ry, &wm.maxcol, &wm.maxrow) != IMP_OK) with_wm = false;
+                if (with_wm) {
+                    wm.ov = ov->d; wm.ostep = ov->step;
+                    wm.alpha = 1 - (float)(config->watermark_opacity / 100.0);     // bridge.c:275, filters.c:620
+                }
+                impgpu_image* out = nullptr;
+                rc = image_new(fw, fh, 4, &out);
+                if (rc) goto done;
+                Frames f = one_frame(wk.v, out);
+                f.dw = w; f.dh = h;                                    // the resized geometry; `out` is the turned frame
+                rc = launch_area_rotate(f, first.rotate, with_wm ? &wm : nullptr, env_stream());
+                if (rc == IMP_OK) { wk.adopt(out); fused_filters = 1; watermark_done = with_wm; }
+                else image_delete(out);
+            }
+        }
+        if (rc == IMP_ERROR_UNSUPPORTED) rc = do_resize(wk, w, h, interp);
         if (rc) goto done;
     }
     *step = IMP_STEP_FILTERING;                                        // bridge.c:606-627
@@ -369,7 +399,7 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
         if (rc) { image_delete(out); trace_pop(); goto done; }
         wk.adopt(out);
     }
-    for (int i = 0; i < job->filter_count && !rc; i++) rc = do_filter(wk, job->filters[i], config->allow_experiments, prog);
+    for (int i = fused_filters; i < job->filter_count && !rc; i++) rc = do_filter(wk, job->filters[i], config->allow_experiments, prog);
     if (!rc) rc = flush_program(wk, prog);
     trace_pop();
     if (rc) goto done;
@@ -377,7 +407,7 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
     if (config->watermark) {
         TraceRange tr("IMP_STEP_WATERMARK");
         if (fault_hit(IMP_STEP_WATERMARK)) { rc = IMP_ERROR_DEVICE; goto done; }
-        rc = do_watermark(wk, config);
+        if (!watermark_done) rc = do_watermark(wk, config);
         if (rc) goto done;
     }
     if (job->need_flatten && wk.v.c == 4) {                            // bridge.c:642-656

@@ -76,6 +76,11 @@ CHAINS = [
     dict(resize="300,300,up", filters=["gradmap=001122,ffeedd"]),
     dict(resize="120,90", simple=1),
     dict(crop="2,1", resize="0,40", filters=["rotate=180", "blur=0.8", "gamma=0.7"], flatten=1),
+    # Resize + a leading rotation (+ the watermark when it is the only filter) leave as ONE launch for BGRA frames
+    dict(resize="100,0", filters=["rotate=270"]),
+    dict(resize="150,100", filters=["rotate=90"]),
+    dict(crop="301px,177px,13px,9px", resize="99,0", filters=["rotate=180"]),
+    dict(resize="160,120", filters=["rotate=90"]),              # exact 2x: the box kernels' arithmetic, step by step
 ]
 
 
