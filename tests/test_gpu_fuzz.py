@@ -119,3 +119,29 @@ def test_watermark_random_placement(gpu, bw, bh, ow, oh, dc, sc, gx, gy, ox, oy,
     if rc == 0:
         assert np.array_equal(im.numpy(), want)
     im.release(); cfg.release()
+
+
+@settings(max_examples=60 * SCALE, **COMMON)
+@given(sw=st.integers(8, 420), sh=st.integers(4, 260), fx=st.floats(1.0, 9.0), fy=st.floats(1.0, 9.0), whole=st.booleans(),
+       c=st.sampled_from([3, 4]), count=st.sampled_from([1, 7, 40, 160, 700]), seed=st.integers(0, 1000))
+def test_area_batches_any_geometry(gpu, sw, sh, fx, fy, whole, c, count, seed):
+    """INTER_AREA through the batch entry point: the band height, the four-columns-per-lane kernel and the box kernels are
+    picked from the batch size as well as the geometry, so the same geometries are tried at several frame counts (frames are
+    repeats of three random ones; three are compared with the oracle)."""
+    if whole:                                              # exact integer factors: resizeAreaFast_
+        kx, ky = max(1, int(fx)), max(1, int(fy))
+        dw, dh = max(1, sw // kx), max(1, sh // ky)
+        sw, sh = dw * kx, dh * ky
+    else:
+        dw, dh = max(1, int(sw / fx)), max(1, int(sh / fy))
+    if count * sw * sh * c > 120_000_000:
+        count = max(1, 120_000_000 // (sw * sh * c))
+    base = [noise_image(sh, sw, c, seed + k) for k in range(3)]
+    sstep, dstep = (sw * c + 3) & ~3, (dw * c + 3) & ~3
+    src = gpu.Image(np.concatenate([base[i % 3] for i in range(count)], axis=0))
+    dst = gpu.Image(np.zeros((count * dh, dw, c), np.uint8))
+    gpu.batch_cv_resize(src.device_ptr, sh * sstep, sw, sh, sstep, dst.device_ptr, dh * dstep, dw, dh, dstep, c, count, orc.INTER_AREA)
+    out = dst.numpy().reshape(count, dh, dw, c)
+    for i in sorted({0, count // 2, count - 1}):
+        assert np.array_equal(out[i], orc.cv_resize(base[i % 3], dw, dh, orc.INTER_AREA)), (sw, sh, dw, dh, c, count, i)
+    src.release(); dst.release()
