@@ -253,3 +253,39 @@ def gif_compose(pages, destructive=False, page=-1):
 def fi32_to_ipl(bits, w, h):
     bits = np.ascontiguousarray(bits, dtype=np.uint8)
     return Img(handle=lib.orc_fi32_to_ipl(bits.ctypes.data, w, h, w * 4)).numpy()
+
+
+# ---- JPEG decode (oracle/orc_jpeg.c; bridge.c:545-552's cvDecodeImage, pinned against Pillow's libjpeg-turbo)
+UNSUPPORTED = 1
+DECODE_FAILED = 3
+lib.orc_jpeg_decode.argtypes = [C.c_char_p, C.c_long, C.POINTER(C.c_void_p)]
+lib.orc_jpeg_info.argtypes = [C.c_char_p, C.c_long, C.POINTER(C.c_int)]
+lib.orc_jpeg_coefficients.argtypes = [C.c_char_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+
+def jpeg_decode(blob):
+    """-> (rc, H x W x {1,3} uint8 in B,G,R order or None)"""
+    h = C.c_void_p()
+    rc = lib.orc_jpeg_decode(blob, len(blob), C.byref(h))
+    if rc:
+        return rc, None
+    return rc, Img(handle=h.value).numpy()
+
+
+def jpeg_info(blob):
+    info = (C.c_int * 8)()
+    rc = lib.orc_jpeg_info(blob, len(blob), info)
+    keys = ("width", "height", "components", "hs", "vs", "restart_interval", "mcux", "mcuy")
+    return rc, (dict(zip(keys, list(info))) if rc == 0 else None)
+
+
+def jpeg_coefficients(blob, ci):
+    rc, info = jpeg_info(blob)
+    if rc:
+        return rc, None
+    h, v = (info["hs"], info["vs"]) if ci == 0 else (1, 1)
+    n = info["mcux"] * h * info["mcuy"] * v * 64
+    out = np.zeros(n, dtype=np.int16)
+    bw, bh = C.c_int(), C.c_int()
+    rc = lib.orc_jpeg_coefficients(blob, len(blob), ci, out.ctypes.data, n, bw, bh)
+    return rc, (out.reshape(bh.value, bw.value, 8, 8) if rc == 0 else None)
