@@ -338,6 +338,98 @@ def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, wo
     return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * c for w, h in mine)}
 
 
+def jpeg_pool(n_files):
+    """The first n_files sizes of the mixed-size stream as photograph-like quality-90 4:2:0 JPEGs (Pillow encodes them;
+    ngx_http_imgproc_amd.workloads.photo_like is the content, cut out of one 4K frame).  Requests cycle through this pool:
+    the library caches nothing per file, so a repeated file costs what a new one costs."""
+    import io
+    from PIL import Image
+    from ngx_http_imgproc_amd.workloads import mixed_sizes, photo_like
+
+    sizes = mixed_sizes(n_files)
+    side = max(max(w, h) for w, h in sizes)
+    big = photo_like(side, side, seed=5)
+    files = []
+    for k, (w, h) in enumerate(sizes):
+        y0, x0 = (k * 37) % (side - h + 1), (k * 91) % (side - w + 1)
+        b = io.BytesIO()
+        Image.fromarray(big[y0:y0 + h, x0:x0 + w]).save(b, "JPEG", quality=90, subsampling="4:2:0")
+        files.append((w, h, b.getvalue()))
+    return files
+
+
+def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0, world=1):
+    """The same request stream with the requests arriving as what they are in production -- JPEG files (bridge.c:376-378,
+    :545-552): decode -> resize=224,0 -> download.  decoder = "device": impgpu_image_decode_jpeg (the compressed bytes cross
+    the link; Huffman, IDCT, upsampling, colour on the device); "hosthuff": the same with the entropy stage on the calling
+    thread (IMPGPU_JPEG_HUFF=host); "host": the reference's structure -- libjpeg-turbo on the calling thread (Pillow's,
+    which releases the GIL) and impgpu_image_upload of the decoded frame."""
+    import ctypes as C
+    import io
+    import queue
+    import threading
+    import numpy as np
+    from ngx_http_imgproc_amd.shard import round_robin
+    from ngx_http_imgproc_amd.workloads import MIXED_RESIZE
+
+    lib = imp.lib
+    mine = [files[i % len(files)] for i in round_robin(n_requests, rank, world)]
+    os.environ["IMPGPU_JPEG_HUFF"] = "host" if decoder == "hosthuff" else "device"
+    cfg = imp.Config()
+    pending = queue.Queue(maxsize=max(1, queue_depth))
+    errors = []
+    out_bytes = 224 * 224 * 4 * 4
+
+    def feeder():
+        for item in mine:
+            pending.put(item)
+        for _ in range(n_threads):
+            pending.put(None)
+
+    def worker():
+        hdst = lib.impgpu_host_alloc(out_bytes)
+        if decoder == "host":
+            from PIL import Image
+        while True:
+            item = pending.get()
+            if item is None:
+                break
+            w, h, blob = item
+            img = C.c_void_p()
+            if decoder == "host":
+                a = np.asarray(Image.open(io.BytesIO(blob)))
+                rc = lib.impgpu_image_upload(a.ctypes.data, w, h, 3, w * 3, C.byref(img))
+            else:
+                rc = lib.impgpu_image_decode_jpeg(blob, len(blob), C.byref(img))
+            if rc == 0:
+                rc = lib.impgpu_resize(C.byref(img), MIXED_RESIZE, C.byref(cfg.c), 0)
+            if rc == 0:
+                ow = lib.impgpu_image_width(img)
+                rc = lib.impgpu_image_download_pinned(img, hdst, (ow * 3 + 3) & ~3)
+            if rc == 0:
+                rc = lib.impgpu_sync()
+            if img:
+                lib.impgpu_image_release(C.byref(img))
+            if rc:
+                errors.append(((w, h), rc))
+                break
+        lib.impgpu_host_free(hdst)
+
+    threads = [threading.Thread(target=worker) for _ in range(n_threads)]
+    feed = threading.Thread(target=feeder, daemon=True)
+    t0 = time.perf_counter()
+    feed.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    if errors:
+        raise SystemExit("jpeg_stream failed: %r" % errors[:3])
+    return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * 3 for w, h, _ in mine),
+            "file_bytes": sum(len(b) for _, _, b in mine)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,6 +444,9 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--queue-depth", type=int, default=4096, help="--stream: requests waiting in the rank's queue")
     ap.add_argument("--inflight", type=int, default=4, help="--stream: requests a thread enqueues before it waits")
+    ap.add_argument("--jpeg", default="", choices=("", "device", "hosthuff", "host", "all"),
+                    help="--stream: the requests arrive as JPEG files; where they are decoded (all = the three one after the other)")
+    ap.add_argument("--jpeg-files", type=int, default=64, help="--stream --jpeg: distinct files the requests cycle through")
     ap.add_argument("--mixed", type=int, default=0, metavar="N",
                     help="BASELINE configs[4] with the N frames already in HBM: resize=224,0 over mixed sizes, one "
                          "impgpu_batch_resize_mixed call per step (and, for comparison, one launch per frame)")
@@ -393,6 +488,41 @@ def main():
     import ngx_http_imgproc_amd as imp
 
     imp.env_start(local_rank)
+    if args.stream and args.jpeg:
+        files = jpeg_pool(args.jpeg_files)
+        lines = []
+        for decoder in (("device", "hosthuff", "host") if args.jpeg == "all" else (args.jpeg,)):
+            jpeg_stream(imp, min(args.stream, 8 * args.threads), args.threads, args.queue_depth, decoder, files, rank, world)
+            if use_dist:
+                dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+            r = jpeg_stream(imp, args.stream, args.threads, args.queue_depth, decoder, files, rank, world)
+            torch.cuda.synchronize()
+            t = torch.tensor([r["seconds"], float(r["requests"]), float(r["source_bytes"]), float(r["file_bytes"])], dtype=torch.float64, device="cuda")
+            if use_dist:
+                dist.barrier(device_ids=[local_rank])
+                tmax = t.clone()
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t[0] = tmax[0]
+            secs, nreq, nbytes, fbytes = float(t[0]), float(t[1]), float(t[2]), float(t[3])
+            lines.append({
+                "metric": "requests/sec, mixed-size JPEG request stream (256px-4K) decode + resize=224,0, PCIe-inclusive",
+                "value": round(nreq / secs, 1), "unit": "requests/sec", "n_gpus": world, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "u8", "decoder": decoder,
+                "data": "synthetic (seeded sizes, photograph-like content, quality-90 4:2:0 JPEG files, %d distinct)" % len(files),
+                "compressed_MB_per_sec": round(fbytes / secs / 1e6, 1), "decoded_MB_per_sec": round(nbytes / secs / 1e6, 1),
+                "bits_per_pixel": round(fbytes * 8 / (nbytes / 3), 2), "seconds": round(secs, 3),
+                "config": {"workload": "BASELINE configs[4] as JPEG files: %d requests, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % int(nreq),
+                           "threads_per_gpu": args.threads, "host_cores": os.cpu_count(), "queue_depth": args.queue_depth,
+                           "sharding": "request i -> rank i mod N, no collective"}})
+        if rank == 0:
+            for ln in lines:
+                print(json.dumps(ln), flush=True)
+        imp.env_destroy()
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if args.stream:
         # warm this rank's lanes / pools / clocks on a short untimed prefix, then the timed stream
         request_stream(imp, min(args.stream, 64 * args.threads), args.threads, args.queue_depth, args.inflight, rank, world, args.channels)

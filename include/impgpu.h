@@ -119,6 +119,25 @@ int   impgpu_image_download_pinned(const impgpu_image* image, unsigned char* dat
  * (bpp 32) or B,G,R with alpha dropped (bpp 24), written into the encoder's bitmap; the repack runs on the device. */
 int   impgpu_image_upload_fi32(const unsigned char* bits, int width, int height, int pitch, impgpu_image** out);
 int   impgpu_image_download_fi(const impgpu_image* image, int bpp, unsigned char* bits, int pitch);   /* syncs */
+/* The decode itself moved in front of the operators: IplImage* image = cvDecodeImage(&rawencoded, -1)   bridge.c:545-552
+ * for a JPEG blob (SIG_JPG, bridge.c:376-378), i.e. libjpeg with its default parameters (ISLOW IDCT, fancy upsampling)
+ * and OpenCV's R/B swap.  The compressed bytes cross the link instead of the pixels; Huffman decoding, dequantisation,
+ * IDCT, chroma upsampling and YCbCr -> B,G,R run on the device and the frame (3 channels, or 1 for a gray file, exactly
+ * what cvDecodeImage(.., -1) returns) is bit-identical to libjpeg-turbo's.  Takes 8-bit baseline / extended-sequential
+ * Huffman files with one interleaved scan and 4:4:4, 4:2:2, 4:4:0, 4:2:0 or gray sampling, with or without restart
+ * intervals.  IMP_ERROR_UNSUPPORTED = a JPEG outside that set (progressive, CMYK, ...): decode it with cvDecodeImage as
+ * before and impgpu_image_upload the pixels.  IMP_ERROR_DECODE_FAILED = damaged data; libjpeg would warn and deliver
+ * what it could, so the same fallback applies.  Waits for the device's verdict on the entropy-coded data before it
+ * returns (the only wait on the request path besides the download). */
+int   impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_image** out);
+/* the SOF header alone (host, no device): the size checks the module makes before decoding */
+int   impgpu_jpeg_info(const unsigned char* blob, size_t size, int* width, int* height, int* channels);
+/* Diagnostics (host, no device): the quantised coefficients of the file's components, MCU-padded planes one after the
+ * other, blocks in raster order, 64 shorts each in row-major order.  how = 0: a plain sequential entropy decoder;
+ * how = 1: the device's chunk-parallel scheme executed lane by lane on the host (same code as the kernel's lanes).
+ * info[0] = shorts written, [1] = the scheme's status word, [2] = sweeps to the fixed point, [3..5] = first short of
+ * each component's plane, [6..8] / [9..11] = blocks per row / column. */
+int   impgpu_jpeg_coefficients(const unsigned char* blob, size_t size, int how, short* out, size_t capacity, int* info);
 int   impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int step,
                         impgpu_image** out);               /* borrow memory already in HBM */
 int   impgpu_image_clone(const impgpu_image* src, impgpu_image** out);

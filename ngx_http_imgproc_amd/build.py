@@ -20,12 +20,15 @@ SOURCES = [
     "imp_geom.hip",
     "imp_pixel.hip",
     "imp_blur.hip",
+    "imp_jpeg.hip",
     "imp_api.cpp",
     "imp_args.cpp",
     "imp_request.cpp",
     "imp_tables.cpp",
+    "imp_jpeg.cpp",
+    "imp_jpeg_api.cpp",
 ]
-HEADERS = ["imp_internal.h", os.path.join("..", "..", "include", "impgpu.h")]
+HEADERS = ["imp_internal.h", "imp_jpeg.h", "imp_jpeg_core.h", os.path.join("..", "..", "include", "impgpu.h")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

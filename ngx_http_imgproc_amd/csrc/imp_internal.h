@@ -39,6 +39,7 @@ inline bool frame_fits(int w, int h, int c) {
 
 // ---------------------------------------------------------------- runtime (imp_runtime.hip)
 void set_error(const char* what, hipError_t e);
+void set_error_text(const char* what);             // impgpu_last_error() text for failures that are not HIP errors
 bool env_ready();
 hipStream_t env_stream();
 int  dev_alloc(size_t bytes, void** out);          // stream-ordered pool; IMP_* code
@@ -47,6 +48,9 @@ int  image_new(int w, int h, int c, impgpu_image** out);
 void image_delete(impgpu_image* im);
 // Copy a small host blob (tables, taps) into pool memory through the pinned ring, ordered on `s`.
 int  upload_small(const void* host, size_t bytes, void** dev, hipStream_t s);
+// Larger host-built blobs: fill the pinned buffer stage_begin returns, then stage_upload copies it to `dev` on the lane stream.
+int  stage_begin(size_t bytes, void** host, void** token);
+int  stage_upload(void* token, void* dev, size_t bytes);
 // Pool memory and caller-supplied ("foreign") streams -- the batch entry points.  The pool recycles blocks in the order
 // of the lane's own stream; these keep that sound without a host wait:
 void dev_free_on(void* p, hipStream_t s);                  // free once the work enqueued on `s` so far is done

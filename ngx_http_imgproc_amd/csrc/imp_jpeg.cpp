@@ -1,0 +1,547 @@
+// imp_jpeg.cpp -- host side of the JPEG front (see imp_jpeg.h): marker parser, Huffman table builder, preparation of the
+// entropy-coded segment for the device, the host entropy decoder (A/B path) and the lane-by-lane host model of the device's
+// entropy stage.  No HIP runtime calls in this file: it also builds with g++ for the sanitizer fuzz (tests/c/).
+//
+// Stands where the reference calls cvDecodeImage(&rawencoded, -1) (bridge.c:545-552): OpenCV's JpegDecoder over libjpeg
+// with default parameters (ISLOW IDCT, fancy upsampling, JCS_RGB swapped to B,G,R).  Only the byte-serial parts stay on
+// the host -- reading the marker segments (a few hundred bytes) and removing the FF00 stuffing while the scan is copied into
+// pinned memory; Huffman decoding, dequantisation, IDCT, upsampling and colour conversion run on the device.
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include "imp_jpeg_core.h"
+
+namespace imp {
+
+namespace {
+
+// zig-zag position -> row-major position inside the 8x8 block (ITU T.81 figure A.6)
+const uint8_t kNatural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Segment {            // one marker segment's payload
+    const uint8_t* p;
+    size_t n;
+    bool has(size_t at, size_t len) const { return at <= n && len <= n - at; }
+    int u8(size_t at) const { return p[at]; }
+    int u16(size_t at) const { return (p[at] << 8) | p[at + 1]; }
+};
+
+int take_sof(const Segment& s, JpegHeader* H) {
+    if (!s.has(0, 6)) return IMP_ERROR_DECODE_FAILED;
+    if (s.u8(0) != 8) return IMP_ERROR_UNSUPPORTED;                   // 12-bit samples
+    H->height = s.u16(1);
+    H->width = s.u16(3);
+    H->ncomp = s.u8(5);
+    if (H->height == 0 || H->width == 0) return IMP_ERROR_UNSUPPORTED;   // height deferred to a DNL marker
+    if (H->ncomp != 1 && H->ncomp != 3) return IMP_ERROR_UNSUPPORTED;    // CMYK / YCCK
+    if (s.n != size_t(6 + 3 * H->ncomp)) return IMP_ERROR_DECODE_FAILED;
+    for (int i = 0; i < H->ncomp; i++) {
+        JpegComp& c = H->comp[i];
+        c.id = s.u8(6 + 3 * i);
+        c.h = s.u8(7 + 3 * i) >> 4;
+        c.v = s.u8(7 + 3 * i) & 15;
+        c.tq = s.u8(8 + 3 * i);
+        if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) return IMP_ERROR_DECODE_FAILED;
+    }
+    return IMP_OK;
+}
+
+int take_dht(const Segment& s, JpegHeader* H) {
+    size_t at = 0;
+    while (at < s.n) {
+        if (!s.has(at, 17)) return IMP_ERROR_DECODE_FAILED;
+        const int cls = s.u8(at) >> 4, slot = s.u8(at) & 15;
+        if (cls > 1 || slot > 3) return IMP_ERROR_DECODE_FAILED;
+        JpegHuffSpec t;
+        int total = 0;
+        for (int l = 1; l <= 16; l++) {
+            t.bits[l] = (uint8_t)s.u8(at + l);
+            total += t.bits[l];
+        }
+        at += 17;
+        if (total > 256 || !s.has(at, (size_t)total)) return IMP_ERROR_DECODE_FAILED;
+        std::memcpy(t.vals, s.p + at, (size_t)total);
+        t.nvals = total;
+        t.present = true;
+        at += (size_t)total;
+        (cls ? H->ac : H->dc)[slot] = t;
+    }
+    return IMP_OK;
+}
+
+int take_dqt(const Segment& s, JpegHeader* H) {
+    size_t at = 0;
+    while (at < s.n) {
+        const int wide = s.u8(at) >> 4, slot = s.u8(at) & 15;
+        if (wide > 1 || slot > 3) return IMP_ERROR_DECODE_FAILED;
+        at++;
+        if (!s.has(at, size_t(64) << wide)) return IMP_ERROR_DECODE_FAILED;
+        for (int k = 0; k < 64; k++) H->qt[slot][kNatural[k]] = (uint16_t)(wide ? s.u16(at + 2 * k) : s.u8(at + k));
+        at += size_t(64) << wide;
+        H->qt_present[slot] = true;
+    }
+    return IMP_OK;
+}
+
+}  // namespace
+
+int jpeg_parse(const uint8_t* blob, size_t size, JpegHeader* H) {
+    if (!blob || size < 4 || blob[0] != 0xFF || blob[1] != 0xD8) return IMP_ERROR_UNSUPPORTED;
+    size_t at = 2;
+    bool have_frame = false, jfif = false, adobe = false;
+    int adobe_transform = 1;
+    for (;;) {
+        if (at + 2 > size || blob[at] != 0xFF) return IMP_ERROR_DECODE_FAILED;
+        while (at < size && blob[at] == 0xFF) at++;                   // any number of fill bytes may precede a marker
+        if (at >= size) return IMP_ERROR_DECODE_FAILED;
+        const int marker = blob[at++];
+        if (marker == 0xD8 || marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7)) continue;   // no payload
+        if (marker == 0xD9) return IMP_ERROR_DECODE_FAILED;           // the file ends before a scan
+        if (at + 2 > size) return IMP_ERROR_DECODE_FAILED;
+        const size_t len = (size_t(blob[at]) << 8) | blob[at + 1];
+        if (len < 2 || len > size - at) return IMP_ERROR_DECODE_FAILED;
+        const Segment s{blob + at + 2, len - 2};
+        int rc = IMP_OK;
+        switch (marker) {
+        case 0xC0: case 0xC1:                                         // baseline / extended sequential, Huffman
+            if (have_frame) return IMP_ERROR_DECODE_FAILED;
+            rc = take_sof(s, H);
+            have_frame = true;
+            break;
+        case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            return IMP_ERROR_UNSUPPORTED;                             // progressive, lossless, hierarchical, arithmetic
+        case 0xC4: rc = take_dht(s, H); break;
+        case 0xDB: rc = take_dqt(s, H); break;
+        case 0xDD:
+            if (s.n != 2) return IMP_ERROR_DECODE_FAILED;
+            H->restart_interval = s.u16(0);
+            break;
+        case 0xE0: jfif = jfif || (s.n >= 5 && !std::memcmp(s.p, "JFIF\0", 5)); break;
+        case 0xEE:
+            if (s.n >= 12 && !std::memcmp(s.p, "Adobe", 5)) { adobe = true; adobe_transform = s.u8(11); }
+            break;
+        case 0xDA: {
+            if (!have_frame || s.n < 1) return IMP_ERROR_DECODE_FAILED;
+            const int ns = s.u8(0);
+            if (s.n != size_t(4 + 2 * ns)) return IMP_ERROR_DECODE_FAILED;
+            if (ns != H->ncomp) return IMP_ERROR_UNSUPPORTED;         // one scan per component
+            for (int i = 0; i < ns; i++) {
+                if (s.u8(1 + 2 * i) != H->comp[i].id) return IMP_ERROR_UNSUPPORTED;
+                H->comp[i].td = s.u8(2 + 2 * i) >> 4;
+                H->comp[i].ta = s.u8(2 + 2 * i) & 15;
+                if (H->comp[i].td > 3 || H->comp[i].ta > 3) return IMP_ERROR_DECODE_FAILED;
+            }
+            if (s.u8(1 + 2 * ns) != 0 || s.u8(2 + 2 * ns) != 63 || s.u8(3 + 2 * ns) != 0) return IMP_ERROR_UNSUPPORTED;
+            H->scan_begin = at + len;
+            // which colour space three components mean (libjpeg's default_decompress_parms)
+            H->ycc = true;
+            if (H->ncomp == 3 && !jfif) {
+                if (adobe) H->ycc = adobe_transform != 0;
+                else if (H->comp[0].id == 'R' && H->comp[1].id == 'G' && H->comp[2].id == 'B') H->ycc = false;
+            }
+            // geometry
+            if (H->ncomp == 1) {
+                H->comp[0].h = H->comp[0].v = 1;                      // a one-component scan is never interleaved
+            } else {
+                if (H->comp[1].h != 1 || H->comp[1].v != 1 || H->comp[2].h != 1 || H->comp[2].v != 1) return IMP_ERROR_UNSUPPORTED;
+                if (H->comp[0].h > 2 || H->comp[0].v > 2) return IMP_ERROR_UNSUPPORTED;
+            }
+            H->hs = H->comp[0].h;
+            H->vs = H->comp[0].v;
+            H->mcux = (H->width + 8 * H->hs - 1) / (8 * H->hs);
+            H->mcuy = (H->height + 8 * H->vs - 1) / (8 * H->vs);
+            H->bpm = 0;
+            for (int i = 0; i < H->ncomp; i++) {
+                JpegComp& c = H->comp[i];
+                c.bw = H->mcux * c.h;
+                c.bh = H->mcuy * c.v;
+                c.dsw = (H->width * c.h + H->hs - 1) / H->hs;
+                c.dsh = (H->height * c.v + H->vs - 1) / H->vs;
+                H->bpm += c.h * c.v;
+                if (!H->qt_present[c.tq] || !H->dc[c.td].present || !H->ac[c.ta].present) return IMP_ERROR_DECODE_FAILED;
+            }
+            return IMP_OK;
+        }
+        default: break;                                               // comments, other application segments
+        }
+        if (rc) return rc;
+        at += len;
+    }
+}
+
+// Canonical code assignment (ITU T.81 annex C); refuses over-subscribed tables and DC categories above 15 like
+// libjpeg's jpeg_make_d_derived_tbl.
+int jpeg_build_table(const JpegHuffSpec& spec, bool is_dc, JpegHuffDev* out) {
+    std::memset(out, 0, sizeof *out);
+    std::memcpy(out->vals, spec.vals, sizeof out->vals);
+    unsigned code = 0;
+    int first = 0;                                                    // index of the first symbol of this length
+    for (int l = 1; l <= 16; l++) {
+        const unsigned n = spec.bits[l];
+        if (code + n > (1u << l)) return IMP_ERROR_DECODE_FAILED;
+        out->offs[l] = first - (int)code;
+        if (l <= JPEG_LOOKBITS)
+            for (unsigned k = 0; k < n; k++) {
+                const unsigned lo = (code + k) << (JPEG_LOOKBITS - l);
+                for (unsigned f = 0; f < (1u << (JPEG_LOOKBITS - l)); f++) out->lut[lo + f] = (uint16_t)jpeg_lut_entry((uint32_t)l, spec.vals[first + (int)k], is_dc);
+            }
+        code += n;
+        first += (int)n;
+        out->limit[l] = code << (16 - l);
+        code <<= 1;
+    }
+    out->limit[0] = 0;
+    out->limit[17] = 0x10000;
+    if (is_dc)
+        for (int i = 0; i < spec.nvals; i++)
+            if (spec.vals[i] > 15) return IMP_ERROR_DECODE_FAILED;
+    return IMP_OK;
+}
+
+size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs) {
+    return scan_bytes + (nsegs + 2) * JPEG_CHUNK_BYTES;
+}
+
+// Copies the entropy-coded bytes out of the file: FF 00 becomes FF, fill FFs go, an RSTn marker closes the interval (the
+// rest of its chunk is filled with 1-bits, exactly what the encoder pads the last byte with) and the next one starts on a
+// chunk boundary.  Stops at EOI, at any other marker, or at the end of the file.
+int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uint8_t* out, size_t cap, JpegScan* scan) {
+    scan->seg_first_chunk.clear();
+    scan->seg_bits.clear();
+    const size_t total_mcus = (size_t)H.mcux * H.mcuy;
+    const size_t want_segs = H.restart_interval ? (total_mcus + H.restart_interval - 1) / H.restart_interval : 1;
+    size_t at = H.scan_begin, o = 0, seg_begin = 0;
+    int expect_rst = 0;
+    bool done = false, closed = false;
+    auto close_segment = [&]() -> bool {
+        if (o == seg_begin) return false;                             // an interval with no data
+        scan->seg_first_chunk.push_back((uint32_t)(seg_begin / JPEG_CHUNK_BYTES));
+        scan->seg_bits.push_back((uint32_t)((o - seg_begin) * 8));
+        const size_t padded = (o + JPEG_CHUNK_BYTES - 1) / JPEG_CHUNK_BYTES * JPEG_CHUNK_BYTES;
+        std::memset(out + o, 0xFF, padded - o);
+        o = seg_begin = padded;
+        return true;
+    };
+    while (!done) {
+        const uint8_t* ff = at < size ? (const uint8_t*)std::memchr(blob + at, 0xFF, size - at) : nullptr;
+        const size_t run = (ff ? (size_t)(ff - blob) : size) - at;
+        if (o + run + 2 * JPEG_CHUNK_BYTES > cap) return IMP_ERROR_DECODE_FAILED;
+        std::memcpy(out + o, blob + at, run);
+        o += run;
+        at += run;
+        if (!ff) break;                                               // no EOI: the MCU count decides whether it was complete
+        size_t m = at + 1;
+        while (m < size && blob[m] == 0xFF) m++;                      // fill bytes
+        if (m >= size) break;
+        const int code = blob[m];
+        if (code == 0x00 && m == at + 1) {
+            out[o++] = 0xFF;                                          // a stuffed data byte
+            at = m + 1;
+        } else if (code >= 0xD0 && code <= 0xD7) {
+            if (!H.restart_interval || code != 0xD0 + expect_rst) return IMP_ERROR_DECODE_FAILED;
+            if (!close_segment()) return IMP_ERROR_DECODE_FAILED;
+            if (scan->seg_first_chunk.size() >= want_segs) { closed = true; break; }   // every MCU is accounted for: like libjpeg, ignore what follows
+            expect_rst = (expect_rst + 1) & 7;
+            at = m + 1;
+        } else if (code == 0x00) {
+            return IMP_ERROR_DECODE_FAILED;                           // FF FF 00: not a sequence an encoder writes
+        } else {
+            done = true;                                              // EOI or whatever follows the scan
+        }
+    }
+    if (!closed && !close_segment()) return IMP_ERROR_DECODE_FAILED;
+    if (scan->seg_first_chunk.size() != want_segs) return IMP_ERROR_DECODE_FAILED;
+    scan->nchunks = o / JPEG_CHUNK_BYTES;
+    if (o + JPEG_CHUNK_BYTES > cap) return IMP_ERROR_DECODE_FAILED;
+    std::memset(out + o, 0xFF, JPEG_CHUNK_BYTES);                     // guard chunk: a lane may look 64 bits past its own
+    if ((uint64_t)scan->nchunks * JPEG_CHUNK_BYTES * 8 >= (1ull << 32)) return IMP_ERROR_UNSUPPORTED;   // bit positions are 32-bit
+    return IMP_OK;
+}
+
+// ---- host entropy decoder: the A/B path (IMPGPU_JPEG_HUFF=host).  Same table format as the device, same strictness.
+namespace {
+struct BitFeed {
+    const uint8_t* p;
+    size_t at, end;
+    uint64_t acc = 0;
+    int have = 0;        // valid bits in acc (left-aligned reads take the top)
+    int fed_past = 0;    // bits supplied after the data ended (1-bits, like the encoder's padding)
+    void fill() {
+        while (have <= 56) {
+            uint64_t byte = 0xFF;
+            if (at < end) byte = p[at++]; else fed_past += 8;
+            acc |= byte << (56 - have);
+            have += 8;
+        }
+    }
+    unsigned peek16() { if (have < 16) fill(); return (unsigned)(acc >> 48); }
+    void drop(int n) { acc <<= n; have -= n; }
+    int take(int n) {
+        if (n == 0) return 0;
+        if (have < n) fill();
+        const int v = (int)(acc >> (64 - n));
+        drop(n);
+        return v;
+    }
+    bool overran() const { return fed_past > have; }
+};
+
+inline int huff_symbol(BitFeed& b, const JpegHuffDev& t) {
+    const unsigned peek = b.peek16();
+    const unsigned e = t.lut[peek >> (16 - JPEG_LOOKBITS)];
+    if (e & 31) {                                                     // (length, value bits, run, end-of-block) -> the symbol byte
+        b.drop((int)(e & 31));
+        return ((e >> 13) & 1) ? 0 : (int)((((e >> 9) & 15) << 4) | ((e >> 5) & 15));
+    }
+    for (int l = JPEG_LOOKBITS + 1; l <= 16; l++)
+        if (peek < t.limit[l]) { b.drop(l); return t.vals[t.offs[l] + (int)(peek >> (16 - l))]; }
+    return -1;
+}
+inline int extend_sign(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+}  // namespace
+
+int jpeg_host_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, int16_t* coef, const JpegFrame& F) {
+    // prepared (unstuffed, interval-aligned) copy first: the bit reader then never meets a marker
+    std::vector<uint8_t> buf(jpeg_scan_capacity(size - H.scan_begin, H.restart_interval ? (size_t)H.mcux * H.mcuy / H.restart_interval + 1 : 1));
+    JpegScan scan;
+    if (int rc = jpeg_prepare_scan(blob, size, H, buf.data(), buf.size(), &scan)) return rc;
+    JpegHuffDev dct[4], act[4];
+    bool built_dc[4] = {}, built_ac[4] = {};
+    for (int i = 0; i < H.ncomp; i++) {
+        const JpegComp& c = H.comp[i];
+        if (!built_dc[c.td]) { if (int rc = jpeg_build_table(H.dc[c.td], true, &dct[c.td])) return rc; built_dc[c.td] = true; }
+        if (!built_ac[c.ta]) { if (int rc = jpeg_build_table(H.ac[c.ta], false, &act[c.ta])) return rc; built_ac[c.ta] = true; }
+    }
+    const size_t total_mcus = (size_t)H.mcux * H.mcuy;
+    const size_t per_seg = H.restart_interval ? (size_t)H.restart_interval : total_mcus;
+    for (size_t sg = 0; sg < scan.seg_first_chunk.size(); sg++) {
+        BitFeed b{buf.data(), (size_t)scan.seg_first_chunk[sg] * JPEG_CHUNK_BYTES, 0};
+        b.end = b.at + scan.seg_bits[sg] / 8;
+        int pred[3] = {0, 0, 0};
+        const size_t m0 = sg * per_seg, m1 = m0 + per_seg < total_mcus ? m0 + per_seg : total_mcus;
+        for (size_t m = m0; m < m1; m++) {
+            const int mx = (int)(m % H.mcux), my = (int)(m / H.mcux);
+            for (int ci = 0; ci < H.ncomp; ci++) {
+                const JpegComp& c = H.comp[ci];
+                for (int by = 0; by < c.v; by++)
+                    for (int bx = 0; bx < c.h; bx++) {
+                        int16_t* blk = coef + F.coef_off[ci] + ((size_t)(my * c.v + by) * c.bw + (size_t)(mx * c.h + bx)) * 64;
+                        int s = huff_symbol(b, dct[c.td]);
+                        if (s < 0) return IMP_ERROR_DECODE_FAILED;
+                        if (s) pred[ci] += extend_sign(b.take(s), s);
+                        blk[0] = (int16_t)pred[ci];
+                        int z = 1;
+                        while (z < 64) {
+                            const int rs = huff_symbol(b, act[c.ta]);
+                            if (rs < 0) return IMP_ERROR_DECODE_FAILED;
+                            const int run = rs >> 4, bits = rs & 15;
+                            if (bits == 0) {
+                                if (run != 15) break;                         // end of block
+                                if (z + 16 > 64) return IMP_ERROR_DECODE_FAILED;
+                                z += 16;
+                            } else {
+                                z += run;
+                                if (z > 63) return IMP_ERROR_DECODE_FAILED;
+                                blk[kNatural[z]] = (int16_t)extend_sign(b.take(bits), bits);
+                                z++;
+                            }
+                        }
+                        if (b.overran()) return IMP_ERROR_DECODE_FAILED;
+                    }
+            }
+        }
+        // what is left of the interval must be the encoder's padding: fewer than 8 bits
+        const long long consumed = (long long)(b.at - (size_t)scan.seg_first_chunk[sg] * JPEG_CHUNK_BYTES) * 8 + b.fed_past - b.have;
+        if ((long long)scan.seg_bits[sg] - consumed >= 8) return IMP_ERROR_DECODE_FAILED;
+    }
+    return IMP_OK;
+}
+
+// What the kernels need to know about the file; the two DC and two AC table slots the components share.
+int jpeg_frame_setup(const JpegHeader& H, JpegFrame* F, int dc_ids[2], int ac_ids[2]) {
+    std::memset(F, 0, sizeof *F);
+    F->width = H.width; F->height = H.height; F->ncomp = H.ncomp; F->hs = H.hs; F->vs = H.vs;
+    F->mcux = H.mcux; F->mcuy = H.mcuy; F->bpm = H.bpm; F->ycc = H.ycc ? 1 : 0;
+    uint64_t off = 0;
+    for (int i = 0; i < H.ncomp; i++) {
+        F->bw[i] = H.comp[i].bw; F->bh[i] = H.comp[i].bh; F->dsw[i] = H.comp[i].dsw; F->dsh[i] = H.comp[i].dsh;
+        F->coef_off[i] = (unsigned)off;
+        off += (uint64_t)H.comp[i].bw * (uint64_t)H.comp[i].bh * 64u;
+    }
+    if (off >= (1ull << 31)) return IMP_ERROR_UNSUPPORTED;           // slot numbers are 32-bit
+    F->total_slots = (unsigned)off;
+    const uint64_t total_mcus = (uint64_t)H.mcux * (uint64_t)H.mcuy;
+    const uint64_t per_seg = (H.restart_interval ? (uint64_t)H.restart_interval : total_mcus) * (uint64_t)H.bpm * 64u;
+    F->slots_per_seg = (int)std::min<uint64_t>(per_seg, off);        // (an interval longer than the scan is the whole scan)
+    dc_ids[0] = dc_ids[1] = ac_ids[0] = ac_ids[1] = -1;
+    for (int i = 0; i < H.ncomp; i++) {
+        int k;
+        for (k = 0; k < 2; k++) { if (dc_ids[k] < 0) dc_ids[k] = H.comp[i].td; if (dc_ids[k] == H.comp[i].td) break; }
+        if (k == 2) return IMP_ERROR_UNSUPPORTED;                     // three different tables: rare, left to the host decoder
+        F->dctab[i] = k;
+        for (k = 0; k < 2; k++) { if (ac_ids[k] < 0) ac_ids[k] = H.comp[i].ta; if (ac_ids[k] == H.comp[i].ta) break; }
+        if (k == 2) return IMP_ERROR_UNSUPPORTED;
+        F->actab[i] = k;
+    }
+    return IMP_OK;
+}
+
+int jpeg_build_tables(const JpegHeader& H, const int dc_ids[2], const int ac_ids[2], JpegHuffDev tabs[4]) {
+    for (int k = 0; k < 2; k++) {
+        if (dc_ids[k] >= 0) if (int rc = jpeg_build_table(H.dc[dc_ids[k]], true, &tabs[k])) return rc;
+        if (ac_ids[k] >= 0) if (int rc = jpeg_build_table(H.ac[ac_ids[k]], false, &tabs[2 + k])) return rc;
+    }
+    return IMP_OK;
+}
+
+// The per-chunk interval numbers followed by the two per-interval arrays: the kernel's small side input.
+void jpeg_scan_meta(const JpegScan& scan, std::vector<uint32_t>* meta) {
+    const size_t ns = scan.seg_first_chunk.size();
+    meta->assign(scan.nchunks + 2 * ns, 0);
+    for (size_t sg = 0; sg < ns; sg++) {
+        const size_t c0 = scan.seg_first_chunk[sg], c1 = sg + 1 < ns ? scan.seg_first_chunk[sg + 1] : scan.nchunks;
+        for (size_t c = c0; c < c1; c++) (*meta)[c] = (uint32_t)sg;
+        (*meta)[scan.nchunks + sg] = scan.seg_first_chunk[sg];
+        (*meta)[scan.nchunks + ns + sg] = scan.seg_bits[sg];
+    }
+}
+
+// ---- the device's entropy stage, lane by lane on the host (diagnostics and CPU tests only; see imp_jpeg_core.h).
+// Same chunk decoder, same rule (a chunk's entry state is its predecessor's exit state, iterate until nothing changes), same
+// totals, same verdict; the workgroup structure (rounds inside a workgroup, a chain between workgroups) is only a schedule of
+// this fixed-point iteration and is not modelled.  *rounds receives the number of sweeps the fixed point took.
+int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, const JpegFrame& F0, const int dc_ids[2],
+                         const int ac_ids[2], int16_t* coef, unsigned* status, int* rounds) {
+    JpegFrame F = F0;
+    const size_t total_mcus = (size_t)H.mcux * H.mcuy;
+    const size_t nsegs = H.restart_interval ? (total_mcus + H.restart_interval - 1) / H.restart_interval : 1;
+    std::vector<uint8_t> buf(jpeg_scan_capacity(size - H.scan_begin, nsegs));
+    JpegScan scan;
+    if (int rc = jpeg_prepare_scan(blob, size, H, buf.data(), buf.size(), &scan)) return rc;
+    std::vector<JpegHuffDev> tabs(4);
+    if (int rc = jpeg_build_tables(H, dc_ids, ac_ids, tabs.data())) return rc;
+    std::vector<JpegHuffTabs> Lv(1);
+    JpegHuffTabs& L = Lv[0];
+    for (int k = 0; k < 4; k++) {
+        std::memcpy(L.lut[k], tabs[k].lut, sizeof L.lut[k]);
+        std::memcpy(L.limit[k], tabs[k].limit, sizeof L.limit[k]);
+        std::memcpy(L.offs[k], tabs[k].offs, sizeof L.offs[k]);
+        std::memcpy(L.vals[k], tabs[k].vals, sizeof L.vals[k]);
+    }
+    std::memcpy(L.natural, kNatural, 64);
+    for (int k = 0; k < F.bpm; k++) jpeg_block_steps(F, k, &L.blk_base[k], &L.blk_dx[k], &L.blk_dy[k]);
+    F.nchunks = (unsigned)scan.nchunks;
+    F.nsegs = (unsigned)scan.seg_first_chunk.size();
+    const uint8_t* bytes = buf.data();
+    auto word = [bytes](uint32_t i) -> uint32_t {
+        const uint8_t* q = bytes + (size_t)i * 4;
+        return ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    };
+    const uint32_t CB = JPEG_CHUNK_WORDS * 32;
+    const size_t n = scan.nchunks;
+    std::vector<uint32_t> meta;
+    jpeg_scan_meta(scan, &meta);
+    std::vector<uint64_t> entry(n), exitst(n);
+    std::vector<JpegDecoded> dec(n);
+    std::vector<uint32_t> seg_end(n), limit(n);
+    std::vector<char> origin(n);
+    for (size_t g = 0; g < n; g++) {
+        const uint32_t sg = meta[g], first = scan.seg_first_chunk[sg];
+        origin[g] = first == g;
+        seg_end[g] = first * CB + scan.seg_bits[sg];
+        limit[g] = std::min<uint32_t>((uint32_t)(g + 1) * CB, seg_end[g]);
+        entry[g] = jpeg_pack_state((uint32_t)g * CB, 0, 0, 0);
+        dec[g] = jpeg_decode_chunk<false>(L, word, entry[g], limit[g], seg_end[g], F, nullptr);
+        exitst[g] = dec[g].exit;
+    }
+    int sweeps = 0;
+    for (;;) {
+        std::vector<uint64_t> prev = exitst;                          // every lane reads last round's states (as the kernel does)
+        bool changed = false;
+        for (size_t g = 1; g < n; g++) {
+            if (origin[g]) continue;
+            // a predecessor that ran into an undecodable pattern (a wrong guess, normally) has nothing to hand on: the lane
+            // falls back to its own guess, otherwise that dead state would travel one chunk per sweep to the interval's end
+            const uint64_t pred = (prev[g - 1] >> 48) ? jpeg_pack_state((uint32_t)g * CB, 0, 0, 0) : prev[g - 1];
+            if (pred == entry[g]) continue;
+            entry[g] = pred;
+            dec[g] = jpeg_decode_chunk<false>(L, word, entry[g], limit[g], seg_end[g], F, nullptr);
+            exitst[g] = dec[g].exit;
+            changed = true;
+        }
+        sweeps++;
+        if (!changed) break;
+        if ((size_t)sweeps > n + 1) return IMP_ERROR_DECODE_FAILED;   // cannot happen: sweep k settles chunk k of an interval
+    }
+    if (rounds) *rounds = sweeps;
+    *status = 0;
+    uint32_t run_n = 0;
+    int run_dc[3] = {0, 0, 0};
+    for (size_t g = 0; g < n; g++) {
+        const uint32_t sg = meta[g];
+        if (origin[g]) { run_n = 0; run_dc[0] = run_dc[1] = run_dc[2] = 0; }
+        JpegWriteCtx W;
+        W.coef = coef;
+        W.slot0 = sg * (uint32_t)F.slots_per_seg + run_n;
+        W.dc0[0] = run_dc[0]; W.dc0[1] = run_dc[1]; W.dc0[2] = run_dc[2];
+        W.status = status;
+        const uint32_t base_n = run_n;
+        run_n += dec[g].n;
+        for (int k = 0; k < 3; k++) run_dc[k] += dec[g].dc[k];
+        const size_t last = (sg + 1 < F.nsegs ? scan.seg_first_chunk[sg + 1] : n) - 1;
+        uint32_t budget = 0xffffffffu, end_n = run_n;
+        if (g == last) {                                             // (see k_jpeg_entropy step 5)
+            const uint32_t want = std::min<uint32_t>((uint32_t)F.slots_per_seg, F.total_slots - sg * (uint32_t)F.slots_per_seg);
+            budget = want >= base_n ? want - base_n : 0u;
+            const JpegDecoded e = jpeg_decode_chunk<false>(L, word, entry[g], limit[g], seg_end[g], F, nullptr, budget);
+            const uint32_t pe = (uint32_t)e.exit, fle = (uint32_t)(e.exit >> 48);
+            if ((fle & JPEG_FL_INVALID) || pe > seg_end[g] || seg_end[g] - pe >= 8) *status |= JPEG_ST_BAD_CODE;
+            if (base_n + e.n != want) *status |= JPEG_ST_BAD_COUNT;
+            end_n = base_n + e.n;
+        }
+        if (end_n > (uint32_t)F.slots_per_seg) { *status |= JPEG_ST_OVERRUN; continue; }
+        (void)jpeg_decode_chunk<true>(L, word, entry[g], limit[g], seg_end[g], F, &W, budget);
+    }
+    return IMP_OK;
+}
+
+}  // namespace imp
+
+using namespace imp;
+
+extern "C" {
+
+int impgpu_jpeg_info(const unsigned char* blob, size_t size, int* width, int* height, int* channels) {
+    JpegHeader H;
+    if (int rc = jpeg_parse(blob, size, &H)) return rc;
+    if (width) *width = H.width;
+    if (height) *height = H.height;
+    if (channels) *channels = H.ncomp;
+    return IMP_OK;
+}
+
+int impgpu_jpeg_coefficients(const unsigned char* blob, size_t size, int how, short* out, size_t capacity, int* info) {
+    if (!blob || !out) return IMP_ERROR_INVALID_ARGS;
+    JpegHeader H;
+    if (int rc = jpeg_parse(blob, size, &H)) return rc;
+    JpegFrame F;
+    int dc_ids[2], ac_ids[2];
+    if (int rc = jpeg_frame_setup(H, &F, dc_ids, ac_ids)) return rc;
+    if ((size_t)F.total_slots > capacity) return IMP_ERROR_INVALID_ARGS;
+    std::memset(out, 0, (size_t)F.total_slots * sizeof(short));
+    unsigned status = 0;
+    int rounds = 0;
+    int rc;
+    if (how == 0) rc = jpeg_host_entropy(blob, size, H, out, F);
+    else rc = jpeg_emulate_entropy(blob, size, H, F, dc_ids, ac_ids, out, &status, &rounds);
+    if (info) {
+        info[0] = (int)F.total_slots; info[1] = (int)status; info[2] = rounds;
+        for (int i = 0; i < 3; i++) { info[3 + i] = (int)F.coef_off[i]; info[6 + i] = F.bw[i]; info[9 + i] = F.bh[i]; }
+    }
+    if (!rc && status) rc = IMP_ERROR_DECODE_FAILED;
+    return rc;
+}
+
+}  // extern "C"

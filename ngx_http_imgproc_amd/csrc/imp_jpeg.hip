@@ -1,0 +1,438 @@
+// imp_jpeg.hip -- device side of the JPEG front (imp_jpeg.h): what libjpeg does under cvDecodeImage at bridge.c:545-552.
+//
+//   k_jpeg_entropy   Huffman decoding of a whole scan in ONE launch.  The unstuffed stream is cut into 1024-bit chunks, one
+//                    per lane.  Only the first chunk of a restart interval starts at a known decoder state; every other lane
+//                    starts at its chunk's first bit in a guessed state and relies on the self-synchronisation of Huffman
+//                    codes: lane t takes over the state lane t-1 leaves behind and re-decodes its chunk until nothing in the
+//                    workgroup changes (a fixed point: every chunk's entry state is its predecessor's exit state, and the
+//                    first chunk of an interval is exact, so by induction all are).  Workgroups take tickets, so a
+//                    workgroup may wait for its predecessor's exit state and running totals (coefficient slots, DC sums)
+//                    -- a chained scan.  With the totals known every lane decodes its chunk once more and scatters the
+//                    non-zero coefficients into the (zeroed) planes, DC terms already integrated.
+//   k_jpeg_pixels    dequantisation, libjpeg's ISLOW 8x8 IDCT (jidctint.c), fancy chroma upsampling (jdsample.c) and
+//                    YCbCr -> B,G,R (jdcolor.c) for a 256x64 pixel tile per workgroup; the planes live only in LDS.
+// Integer arithmetic throughout; tests/test_gpu_jpeg.py compares with the Pillow-pinned oracle bit for bit.
+#include "imp_jpeg_core.h"
+
+namespace imp {
+
+namespace {
+
+constexpr int HB = JPEG_HUFF_BLOCK;
+constexpr int CW = JPEG_CHUNK_WORDS;
+constexpr int WPITCH = CW + 1;                  // LDS pitch of a chunk: lanes at the same offset hit different banks
+constexpr unsigned CHUNK_BITS = CW * 32;
+constexpr int CTL_HEADER = 4;                   // control[0] ticket, [1] status, [2] / [3] most rounds a workgroup took before / after the hand-over
+constexpr int CTL_REC = 12;                     // per workgroup: [0..2] tentative exit state (flag, lo, hi), [3..5] final exit state, [6..10] totals (flag, n, dc0..2)
+
+__constant__ uint8_t c_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+__device__ __forceinline__ uint32_t ld_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Wait for a flag another workgroup raises.  Workgroups are numbered by ticket, so the one waited for is already running
+// (or done); the bound only keeps a bug from hanging the device.
+__device__ bool wait_flag(const uint32_t* flag) {
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        if (ld_acquire(flag)) return true;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(HB) void k_jpeg_entropy(JpegFrame F, JpegHuffArgs A) {
+    __shared__ JpegHuffTabs L;
+    __shared__ uint32_t s_words[(HB + 1) * WPITCH];
+    __shared__ uint64_t s_exit[HB];
+    __shared__ uint32_t s_n[HB];
+    __shared__ int s_dc[3][HB];
+    __shared__ uint32_t s_head[HB];             // 1 = an interval starts in or before this chunk (inside the workgroup)
+    __shared__ uint32_t s_ticket;
+    __shared__ uint64_t s_pred;
+    __shared__ uint32_t s_carry[4];
+    const int t = threadIdx.x;
+    if (t == 0) s_ticket = atomicAdd(&A.control[0], 1u);
+    // tables
+    for (int i = t; i < 4 * (1 << JPEG_LOOKBITS); i += HB) L.lut[i >> JPEG_LOOKBITS][i & ((1 << JPEG_LOOKBITS) - 1)] = A.tables[i >> JPEG_LOOKBITS].lut[i & ((1 << JPEG_LOOKBITS) - 1)];
+    for (int i = t; i < 4 * 18; i += HB) { L.limit[i / 18][i % 18] = A.tables[i / 18].limit[i % 18]; L.offs[i / 18][i % 18] = A.tables[i / 18].offs[i % 18]; }
+    for (int i = t; i < 4 * 256; i += HB) L.vals[i >> 8][i & 255] = A.tables[i >> 8].vals[i & 255];
+    if (t < 64) L.natural[t] = c_natural[t];
+    if (t < F.bpm) jpeg_block_steps(F, t, &L.blk_base[t], &L.blk_dx[t], &L.blk_dy[t]);
+    __syncthreads();
+    const uint32_t b = s_ticket;
+    const uint32_t nblocks = (F.nchunks + HB - 1) / HB;
+    if (b >= nblocks) return;                                       // (whole workgroup: the grid is exactly nblocks)
+    const uint32_t g0 = b * HB, g = g0 + (uint32_t)t;
+    // the workgroup's chunks + one more, byte-swapped so that bit 31 of a word is the first bit of the stream
+    for (uint32_t i = (uint32_t)t; i < (HB + 1) * CW; i += HB) {
+        const uint32_t ch = g0 + i / CW;
+        uint32_t w = 0xffffffffu;
+        if (ch <= F.nchunks) w = __builtin_bswap32(A.words[(size_t)ch * CW + i % CW]);   // chunk nchunks is the guard chunk
+        s_words[(i / CW) * WPITCH + i % CW] = w;
+    }
+    const bool live = g < F.nchunks;
+    uint32_t seg = 0, first = 0, seg_end = 0, limit = 0;
+    bool origin = false;
+    if (live) {
+        seg = A.chunk_seg[g];
+        first = A.seg_first_chunk[seg];
+        origin = first == g;
+        seg_end = first * CHUNK_BITS + A.seg_bits[seg];
+        limit = min((g + 1) * CHUNK_BITS, seg_end);
+    }
+    const uint32_t word0 = g0 * CW;
+    auto word = [&](uint32_t i) -> uint32_t { const uint32_t k = i - word0; return s_words[(k / CW) * WPITCH + (k % CW)]; };
+    uint32_t* rec = A.control + CTL_HEADER + (size_t)b * CTL_REC;
+    const uint32_t* prec = rec - CTL_REC;
+    __syncthreads();
+
+    // ---- 1./2. Every lane decodes its chunk from a guessed state (its first bit, start of a block) -- exact only for the
+    // first chunk of an interval -- and then pulls its predecessor's exit state, re-decoding whenever that differs from the
+    // state it started from, until nothing changes in the workgroup.  Lane 0's predecessor is the previous workgroup's last
+    // lane.  A workgroup publishes its last exit state twice: TENTATIVELY as soon as its own lanes agree (Huffman codes
+    // resynchronise within a few chunks, so that state is almost always the true one already, whatever the workgroup's own
+    // entry state turns out to be), which lets all workgroups run their fix-up at the same time instead of one after the
+    // other, and FINALLY once its own entry state is final.  The chain of final states is then a flag and a compare per
+    // workgroup; only a workgroup whose tentative input was wrong converges once more.
+    const bool chained = origin || !live;                           // (read by lane 0 only) nothing to wait for
+    const uint64_t guess = jpeg_pack_state(g * CHUNK_BITS, 0, 0, 0);
+    const uint64_t none = ~0ull;                                    // "no state": its flag bits are set
+    uint64_t entry = none;
+    JpegDecoded d{};
+    s_exit[t] = none;
+    if (t == 0) s_pred = none;
+    for (int phase = 0; phase < 3; phase++) {
+        if (phase > 0) {
+            const int at = phase == 1 ? 0 : 3;                      // tentative, then final
+            if (phase == 1 && t == HB - 1 && b + 1 < nblocks) {
+                rec[1] = (uint32_t)s_exit[t];
+                rec[2] = (uint32_t)(s_exit[t] >> 32);
+                st_release(rec + 0, 1u);
+            }
+            if (t == 0 && !chained) {
+                if (wait_flag(prec + at)) s_pred = (uint64_t)prec[at + 1] | ((uint64_t)prec[at + 2] << 32);
+                else atomicOr(&A.control[1], JPEG_ST_CHAIN_TIMEOUT);
+            }
+        }
+        for (int round = 0; round <= HB + 1; round++) {
+            __syncthreads();
+            uint64_t want = t > 0 ? s_exit[t - 1] : s_pred;
+            // a predecessor with nothing to hand on (none yet, or it ran into an undecodable pattern -- a wrong guess,
+            // normally): the lane's own guess.  Otherwise that dead state would travel a chunk per round to the interval's end.
+            if (origin || (want >> 48)) want = guess;
+            __syncthreads();
+            int changed = 0;
+            if (live && want != entry) {
+                entry = want;
+                d = jpeg_decode_chunk<false>(L, word, entry, limit, seg_end, F, nullptr);
+                s_exit[t] = d.exit;
+                changed = 1;
+            }
+            if (!__syncthreads_or(changed)) { if (t == 0) atomicMax(&A.control[phase == 0 ? 2 : 3], (uint32_t)round); break; }
+        }
+    }
+    __syncthreads();
+    if (t == HB - 1 && b + 1 < nblocks) {                           // the final exit state
+        rec[4] = (uint32_t)s_exit[t];
+        rec[5] = (uint32_t)(s_exit[t] >> 32);
+        st_release(rec + 3, 1u);
+    }
+    // ---- 4. running totals inside each interval: segmented inclusive scan over (n, dc0, dc1, dc2)
+    s_n[t] = live ? d.n : 0;
+    s_dc[0][t] = d.dc[0];
+    s_dc[1][t] = d.dc[1];
+    s_dc[2][t] = d.dc[2];
+    s_head[t] = origin ? 1u : 0u;
+    __syncthreads();
+    for (int ofs = 1; ofs < HB; ofs <<= 1) {
+        uint32_t n2 = 0, h2 = 0;
+        int a0 = 0, a1 = 0, a2 = 0;
+        const bool take = t >= ofs;
+        if (take) { n2 = s_n[t - ofs]; a0 = s_dc[0][t - ofs]; a1 = s_dc[1][t - ofs]; a2 = s_dc[2][t - ofs]; h2 = s_head[t - ofs]; }
+        const uint32_t myh = s_head[t];
+        __syncthreads();
+        if (take) {
+            if (!myh) { s_n[t] += n2; s_dc[0][t] += a0; s_dc[1][t] += a1; s_dc[2][t] += a2; }
+            s_head[t] = myh | h2;
+        }
+        __syncthreads();
+    }
+    // the previous workgroup's totals for the interval that runs into this one
+    if (t == 0) {
+        s_carry[0] = s_carry[1] = s_carry[2] = s_carry[3] = 0;
+        if (!chained) {
+            if (wait_flag(prec + 6)) { s_carry[0] = prec[7]; s_carry[1] = prec[8]; s_carry[2] = prec[9]; s_carry[3] = prec[10]; }
+            else atomicOr(&A.control[1], JPEG_ST_CHAIN_TIMEOUT);
+        }
+    }
+    __syncthreads();
+    const bool open = !s_head[t];                                   // still in the interval that began in an earlier workgroup
+    const uint32_t incl_n = s_n[t] + (open ? s_carry[0] : 0u);
+    const int incl_dc0 = s_dc[0][t] + (open ? (int)s_carry[1] : 0), incl_dc1 = s_dc[1][t] + (open ? (int)s_carry[2] : 0),
+              incl_dc2 = s_dc[2][t] + (open ? (int)s_carry[3] : 0);
+    if (t == HB - 1 && b + 1 < nblocks) {
+        rec[7] = incl_n; rec[8] = (uint32_t)incl_dc0; rec[9] = (uint32_t)incl_dc1; rec[10] = (uint32_t)incl_dc2;
+        st_release(rec + 6, 1u);
+    }
+    if (!live) return;
+    // ---- 5. decode once more, now knowing where every coefficient goes.  The last chunk of an interval walks with the
+    // interval's remaining slots as a budget -- a sequential decoder stops after the last MCU and never looks at the padding
+    // bits, which in a damaged file need not be the 1-bits an encoder writes -- and gives the verdict: it must end inside
+    // the padding with exactly the interval's slots decoded.
+    const uint32_t last_chunk_of_seg = (seg + 1 < F.nsegs ? A.seg_first_chunk[seg + 1] : F.nchunks) - 1;
+    const uint32_t base_n = incl_n - d.n;
+    const uint32_t slots_here = min((uint32_t)F.slots_per_seg, F.total_slots - seg * (uint32_t)F.slots_per_seg);
+    const bool closes = g == last_chunk_of_seg;
+    JpegWriteCtx W;
+    W.coef = A.coef;
+    W.slot0 = seg * (uint32_t)F.slots_per_seg + base_n;
+    W.dc0[0] = incl_dc0 - d.dc[0];
+    W.dc0[1] = incl_dc1 - d.dc[1];
+    W.dc0[2] = incl_dc2 - d.dc[2];
+    W.status = &A.control[1];
+    if (!closes && incl_n > slots_here) { atomicOr(&A.control[1], JPEG_ST_OVERRUN); return; }   // would write outside the interval
+    const uint32_t budget = closes ? (slots_here >= base_n ? slots_here - base_n : 0u) : 0xffffffffu;
+    const JpegDecoded e = jpeg_decode_chunk<true>(L, word, entry, limit, seg_end, F, &W, budget);
+    if (closes) {
+        const uint32_t pe = (uint32_t)e.exit, fle = (uint32_t)(e.exit >> 48);
+        if ((fle & JPEG_FL_INVALID) || pe > seg_end || seg_end - pe >= 8) atomicOr(&A.control[1], JPEG_ST_BAD_CODE);
+        if (base_n + e.n != slots_here) atomicOr(&A.control[1], JPEG_ST_BAD_COUNT);
+    }
+}
+
+// ---------------------------------------------------------------- pixels
+constexpr int TILE_W = 256, TILE_H = 64;
+constexpr int YP = TILE_W;                       // luma LDS pitch
+
+
+// jidctint.c jpeg_idct_islow, one dimension: CONST_BITS 13; the caller picks the descale shift of its pass
+__device__ __forceinline__ void idct8(const int in[8], int out[8], const int shift) {
+    constexpr int C0_298 = 2446, C0_390 = 3196, C0_541 = 4433, C0_765 = 6270, C0_899 = 7373, C1_175 = 9633, C1_501 = 12299,
+                  C1_847 = 15137, C1_961 = 16069, C2_053 = 16819, C2_562 = 20995, C3_072 = 25172;
+    int z2 = in[2], z3 = in[6];
+    int z1 = (z2 + z3) * C0_541;
+    int tmp2 = z1 + z3 * (-C1_847);
+    int tmp3 = z1 + z2 * C0_765;
+    z2 = in[0];
+    z3 = in[4];
+    int tmp0 = (int)((unsigned)(z2 + z3) << 13);
+    int tmp1 = (int)((unsigned)(z2 - z3) << 13);
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7];
+    tmp1 = in[5];
+    tmp2 = in[3];
+    tmp3 = in[1];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * C1_175;
+    tmp0 *= C0_298;
+    tmp1 *= C2_053;
+    tmp2 *= C3_072;
+    tmp3 *= C1_501;
+    z1 *= -C0_899;
+    z2 *= -C2_562;
+    z3 *= -C1_961;
+    z4 *= -C0_390;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    const int half = 1 << (shift - 1);
+    out[0] = (tmp10 + tmp3 + half) >> shift;
+    out[7] = (tmp10 - tmp3 + half) >> shift;
+    out[1] = (tmp11 + tmp2 + half) >> shift;
+    out[6] = (tmp11 - tmp2 + half) >> shift;
+    out[2] = (tmp12 + tmp1 + half) >> shift;
+    out[5] = (tmp12 - tmp1 + half) >> shift;
+    out[3] = (tmp13 + tmp0 + half) >> shift;
+    out[4] = (tmp13 - tmp0 + half) >> shift;
+}
+
+__device__ __forceinline__ uint32_t sat_u8(int v) { return (uint32_t)min(max(v, 0), 255); }
+
+// one block: 64 coefficients at `blk` (natural order) -> 8 rows of 8 samples at out[0..7][0..7] in LDS
+__device__ void idct_block_to_lds(const int16_t* blk, const uint16_t* q, uint8_t* out, int pitch) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    int ws[64];
+    v4i raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) raw[k] = *(const v4i*)(blk + 8 * k);     // a row: eight shorts
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+        int in[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int pair = raw[k][x >> 1];
+            const int cv = (x & 1) ? (pair >> 16) : (int)(short)(pair & 0xffff);
+            in[k] = cv * (int)q[8 * k + x];
+        }
+        idct8(in, o, 13 - 2);
+#pragma unroll
+        for (int k = 0; k < 8; k++) ws[8 * k + x] = o[k];
+    }
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+        int o[8];
+        idct8(ws + 8 * y, o, 13 + 2 + 3);
+        const uint32_t lo = sat_u8(o[0] + 128) | (sat_u8(o[1] + 128) << 8) | (sat_u8(o[2] + 128) << 16) | (sat_u8(o[3] + 128) << 24);
+        const uint32_t hi = sat_u8(o[4] + 128) | (sat_u8(o[5] + 128) << 8) | (sat_u8(o[6] + 128) << 16) | (sat_u8(o[7] + 128) << 24);
+        *(uint2*)(out + y * pitch) = make_uint2(lo, hi);
+    }
+}
+
+template <int HS, int VS, int NC>
+__global__ __launch_bounds__(256) void k_jpeg_pixels(JpegFrame F, const int16_t* __restrict__ coef, const uint16_t* __restrict__ qt3,
+                                                     uint8_t* __restrict__ dst, int dstep) {
+    constexpr int CBW = TILE_W / 8 / HS + (HS == 2 ? 2 : 0);        // chroma blocks per tile row, halo included
+    constexpr int CBH = TILE_H / 8 / VS + (VS == 2 ? 2 : 0);
+    constexpr int CP = CBW * 8;                                     // chroma LDS pitch
+    __shared__ __attribute__((aligned(16))) uint8_t s_y[TILE_H * YP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[NC == 3 ? 2 : 1][NC == 3 ? CP * CBH * 8 : 16];
+    __shared__ uint16_t s_q[3][64];
+    const int t = threadIdx.x;
+    if (t < 64 * NC) s_q[t >> 6][t & 63] = qt3[t];
+    __syncthreads();
+    const int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    {   // luma: one block per lane
+        const int bx = tile_x * (TILE_W / 8) + (t & 31), by = tile_y * (TILE_H / 8) + (t >> 5);
+        if (bx < F.bw[0] && by < F.bh[0])
+            idct_block_to_lds(coef + F.coef_off[0] + ((size_t)by * F.bw[0] + bx) * 64, s_q[0], s_y + (t >> 5) * 8 * YP + (t & 31) * 8, YP);
+    }
+    const int cbx0 = tile_x * (TILE_W / 8 / HS) - (HS == 2 ? 1 : 0), cby0 = tile_y * (TILE_H / 8 / VS) - (VS == 2 ? 1 : 0);
+    if constexpr (NC == 3) {
+        for (int i = t; i < 2 * CBW * CBH; i += 256) {
+            const int ci = i >= CBW * CBH ? 2 : 1, j = i - (ci - 1) * CBW * CBH;
+            const int lx = j % CBW, ly = j / CBW, bx = cbx0 + lx, by = cby0 + ly;
+            if (bx >= 0 && by >= 0 && bx < F.bw[ci] && by < F.bh[ci])
+                idct_block_to_lds(coef + F.coef_off[ci] + ((size_t)by * F.bw[ci] + bx) * 64, s_q[ci], s_c[ci - 1] + ly * 8 * CP + lx * 8, CP);
+        }
+    }
+    __syncthreads();
+    // pixels: a wave takes a tile row at a time, four pixels per lane
+    const int lane = t & 63, wv = t >> 6;
+    const int X0 = tile_x * TILE_W + lane * 4;
+    if (X0 >= F.width) return;
+    for (int r = wv; r < TILE_H; r += 4) {
+        const int Y = tile_y * TILE_H + r;
+        if (Y >= F.height) break;
+        const uint32_t y4 = *(const uint32_t*)(s_y + r * YP + lane * 4);
+        uint8_t* row = dst + (size_t)Y * dstep;
+        if constexpr (NC == 1) {
+            if (X0 + 3 < F.width) *(uint32_t*)(row + X0) = y4;
+            else for (int k = 0; X0 + k < F.width; k++) row[X0 + k] = (uint8_t)(y4 >> (8 * k));
+        } else {
+            int cbv[4], crv[4];
+            const int dsw = F.dsw[1], dsh = F.dsh[1];
+            if constexpr (HS == 1 && VS == 1) {
+                const uint32_t b4 = *(const uint32_t*)(s_c[0] + r * CP + lane * 4), r4 = *(const uint32_t*)(s_c[1] + r * CP + lane * 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { cbv[k] = (b4 >> (8 * k)) & 255; crv[k] = (r4 >> (8 * k)) & 255; }
+            } else {
+                // chroma sample coordinates (absolute), then into the tile's halo plane
+                const int cy = VS == 2 ? Y >> 1 : Y;
+                int ny = cy;
+                if constexpr (VS == 2) ny = min(max((Y & 1) ? cy + 1 : cy - 1, 0), dsh - 1);
+                const int ly = cy - cby0 * 8, lny = ny - cby0 * 8;
+                const bool fancy_h = HS == 2 && dsw > 2;                 // jinit_upsampler: the replicating forms otherwise
+#pragma unroll
+                for (int comp = 0; comp < 2; comp++) {
+                    const uint8_t* P = s_c[comp];
+                    int* outv = comp ? crv : cbv;
+                    if constexpr (HS == 2) {
+                        const int cx = X0 >> 1;
+                        if (!fancy_h) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) outv[k] = P[ly * CP + (min(cx + (k >> 1), dsw - 1) - cbx0 * 8)];
+                        } else {
+                            int col[4];                                  // columns cx-1 .. cx+2, clamped like the row loops' ends
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int lx = min(max(cx - 1 + j, 0), dsw - 1) - cbx0 * 8;
+                                if constexpr (VS == 2) col[j] = 3 * P[ly * CP + lx] + P[lny * CP + lx];
+                                else col[j] = P[ly * CP + lx];
+                            }
+                            if constexpr (VS == 2) {                     // h2v2_fancy_upsample
+                                outv[0] = (3 * col[1] + col[0] + 8) >> 4;
+                                outv[1] = (3 * col[1] + col[2] + 7) >> 4;
+                                outv[2] = (3 * col[2] + col[1] + 8) >> 4;
+                                outv[3] = (3 * col[2] + col[3] + 7) >> 4;
+                            } else {                                     // h2v1_fancy_upsample
+                                outv[0] = (3 * col[1] + col[0] + 1) >> 2;
+                                outv[1] = (3 * col[1] + col[2] + 2) >> 2;
+                                outv[2] = (3 * col[2] + col[1] + 1) >> 2;
+                                outv[3] = (3 * col[2] + col[3] + 2) >> 2;
+                            }
+                        }
+                    } else {                                             // h1v2_fancy_upsample
+                        const int bias = (Y & 1) ? 2 : 1;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int lx = min(X0 + k, dsw - 1) - cbx0 * 8;
+                            outv[k] = (3 * P[ly * CP + lx] + P[lny * CP + lx] + bias) >> 2;
+                        }
+                    }
+                }
+            }
+            uint32_t px[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int yy = (y4 >> (8 * k)) & 255;
+                int rr, gg, bb;
+                if (F.ycc) {                                             // jdcolor.c build_ycc_rgb_table, SCALEBITS 16
+                    const int cb = cbv[k] - 128, cr = crv[k] - 128;
+                    rr = yy + ((91881 * cr + 32768) >> 16);
+                    bb = yy + ((116130 * cb + 32768) >> 16);
+                    gg = yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+                } else { rr = yy; gg = cbv[k]; bb = crv[k]; }
+                px[k] = sat_u8(bb) | (sat_u8(gg) << 8) | (sat_u8(rr) << 16);
+            }
+            if (X0 + 3 < F.width) {
+                uint32_t* o = (uint32_t*)(row + (size_t)X0 * 3);
+                o[0] = px[0] | (px[1] << 24);
+                o[1] = (px[1] >> 8) | (px[2] << 16);
+                o[2] = (px[2] >> 16) | (px[3] << 8);
+            } else {
+                for (int k = 0; X0 + k < F.width; k++) {
+                    row[(X0 + k) * 3 + 0] = (uint8_t)px[k];
+                    row[(X0 + k) * 3 + 1] = (uint8_t)(px[k] >> 8);
+                    row[(X0 + k) * 3 + 2] = (uint8_t)(px[k] >> 16);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t jpeg_control_bytes(unsigned nchunks) {
+    const size_t nblocks = ((size_t)nchunks + HB - 1) / HB;
+    return (CTL_HEADER + nblocks * CTL_REC) * sizeof(uint32_t);
+}
+
+int launch_jpeg_entropy(const JpegFrame& F, const JpegHuffArgs& A, hipStream_t s) {
+    if (F.nchunks == 0 || F.nsegs == 0) return IMP_ERROR_DECODE_FAILED;
+    const unsigned nblocks = (F.nchunks + HB - 1) / HB;
+    hipLaunchKernelGGL(k_jpeg_entropy, dim3(nblocks), dim3(HB), 0, s, F, A);
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+int launch_jpeg_pixels(const JpegFrame& F, const int16_t* coef, const uint16_t* qt3, uint8_t* dst, int dstep, hipStream_t s) {
+    const dim3 grid((F.width + TILE_W - 1) / TILE_W, (F.height + TILE_H - 1) / TILE_H), block(256);
+    if (F.ncomp == 1) hipLaunchKernelGGL((k_jpeg_pixels<1, 1, 1>), grid, block, 0, s, F, coef, qt3, dst, dstep);
+    else if (F.hs == 1 && F.vs == 1) hipLaunchKernelGGL((k_jpeg_pixels<1, 1, 3>), grid, block, 0, s, F, coef, qt3, dst, dstep);
+    else if (F.hs == 2 && F.vs == 1) hipLaunchKernelGGL((k_jpeg_pixels<2, 1, 3>), grid, block, 0, s, F, coef, qt3, dst, dstep);
+    else if (F.hs == 1 && F.vs == 2) hipLaunchKernelGGL((k_jpeg_pixels<1, 2, 3>), grid, block, 0, s, F, coef, qt3, dst, dstep);
+    else if (F.hs == 2 && F.vs == 2) hipLaunchKernelGGL((k_jpeg_pixels<2, 2, 3>), grid, block, 0, s, F, coef, qt3, dst, dstep);
+    else return IMP_ERROR_UNSUPPORTED;
+    IMP_HIP(hipGetLastError());
+    return IMP_OK;
+}
+
+}  // namespace imp

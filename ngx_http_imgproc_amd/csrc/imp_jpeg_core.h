@@ -1,0 +1,196 @@
+// imp_jpeg_core.h -- the chunk decoder of the device's entropy stage, written once for both sides: k_jpeg_entropy
+// (imp_jpeg.hip) runs it per lane, and the host runs the very same function lane by lane in jpeg_emulate_entropy
+// (imp_jpeg.cpp) so that the self-synchronising scheme can be checked on a machine without a GPU
+// (tests/test_jpeg_host.py) and under AddressSanitizer.  The product path never decodes on the host.
+#pragma once
+#include "imp_jpeg.h"
+
+#if defined(__HIPCC__)
+#define IMP_HD __host__ __device__
+#else
+#define IMP_HD
+#endif
+
+namespace imp {
+
+// decoder state between two symbols: bit position, block within the MCU, next coefficient index (0 = the DC term)
+constexpr uint32_t JPEG_FL_END = 1u, JPEG_FL_INVALID = 2u;
+IMP_HD inline uint64_t jpeg_pack_state(uint32_t p, uint32_t c, uint32_t z, uint32_t fl) {
+    return (uint64_t)p | ((uint64_t)(c | (z << 8) | (fl << 16)) << 32);
+}
+
+// What a decoder lane needs to know about a symbol, packed: code length (5 bits), value bits to read (4), zero run before the
+// coefficient (4), end-of-block (1).  DC symbols (the category IS the number of value bits) and AC symbols (run << 4 | size;
+// 0x00 = end of block, 0xF0 = sixteen zeros) look the same from there on.
+IMP_HD inline uint32_t jpeg_lut_entry(uint32_t len, uint32_t sym, bool is_dc) {
+    // (an AC symbol with no value bits is the end of the block unless its run is 15 -- libjpeg's reading of the values T.81
+    // leaves undefined, 0x10 .. 0xE0, which only a damaged table holds)
+    const uint32_t size = sym & 15, run = is_dc ? 0u : sym >> 4, eob = (!is_dc && size == 0 && run != 15) ? 1u : 0u;
+    return len | (size << 5) | (run << 9) | (eob << 13);
+}
+
+struct JpegHuffTabs {                       // the four tables as a decoder lane reads them (LDS on the device)
+    uint16_t lut[4][1 << JPEG_LOOKBITS];    // JpegHuffDev::lut
+    uint32_t limit[4][18];
+    int32_t offs[4][18];
+    uint8_t vals[4][256];
+    uint8_t natural[64];                    // zig-zag position -> position in the 8x8 block
+    uint32_t blk_base[8];                   // per block of the MCU: its first coefficient in MCU (0,0), in shorts
+    uint32_t blk_dx[8], blk_dy[8];          // ... and how far the same block is in the next MCU / the next MCU row
+};
+
+// blk_base / blk_dx / blk_dy of JpegHuffTabs from the frame geometry (luma blocks first, then Cb, Cr)
+IMP_HD inline void jpeg_block_steps(const JpegFrame& F, int k, uint32_t* base, uint32_t* dx, uint32_t* dy) {
+    const int nluma = F.bpm == 1 ? 1 : F.bpm - 2;
+    int ci = 0, bx = 0, by = 0;
+    if (k < nluma) { bx = k % F.hs; by = k / F.hs; } else { ci = k - nluma + 1; }
+    const int h = ci ? 1 : F.hs, v = ci ? 1 : F.vs;
+    const unsigned off = ci == 0 ? F.coef_off[0] : ci == 1 ? F.coef_off[1] : F.coef_off[2];
+    const int bw = ci == 0 ? F.bw[0] : ci == 1 ? F.bw[1] : F.bw[2];
+    *base = off + (uint32_t)(by * bw + bx) * 64u;
+    *dx = (uint32_t)h * 64u;
+    *dy = (uint32_t)(v * bw) * 64u;
+}
+
+struct JpegDecoded {
+    uint64_t exit;
+    uint32_t n;          // coefficient slots passed
+    int dc[3];           // sum of the DC differences met, per component
+};
+
+struct JpegWriteCtx {
+    int16_t* coef;
+    uint32_t slot0;      // absolute slot (within the scan) of the chunk's first symbol
+    int dc0[3];          // DC predictors at the chunk's entry
+    uint32_t* status;
+};
+
+IMP_HD inline void jpeg_flag(uint32_t* status, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(status, bits);
+#else
+    *status |= bits;
+#endif
+}
+
+// One chunk: every symbol that STARTS before `limit`, from the packed state `entry`.  `word(i)` returns the i-th 32-bit
+// word of the unstuffed stream with its first bit in bit 31.  Reads at most two words past the one holding bit limit-1.
+// `max_slots` ends the walk once that many coefficient slots have been passed: the last chunk of an interval stops after the
+// interval's last MCU like a sequential decoder does, whatever the (up to seven) padding bits behind it look like.
+//
+// Written for a SIMT lane: one loop, one table read per symbol, selects instead of branches, no array indexed by a run-time
+// value (those live in scratch memory on the device), the next stream word always one step ahead in a register.  A
+// symbol is (code length, value bits, zero run, end-of-block) straight out of the table; DC and AC symbols, ZRL and EOB all
+// take the same few instructions: the coefficient index moves by run + 1, or to the block's end.
+template <bool WRITE, class WordFn>
+IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, uint64_t entry, uint32_t limit, uint32_t seg_end,
+                                            const JpegFrame& F, const JpegWriteCtx* W, uint32_t max_slots = 0xffffffffu) {
+    JpegDecoded r;
+    r.exit = entry;
+    r.n = 0;
+    r.dc[0] = r.dc[1] = r.dc[2] = 0;
+    uint32_t p = (uint32_t)entry;
+    uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
+    if ((uint32_t)(entry >> 48)) return r;                          // nothing can follow an invalid / ended predecessor
+    if (p >= limit) return r;
+    const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
+    // per block of the MCU: its component (two bits each) and whether it takes the second DC / AC table (a bit each)
+    uint32_t comp_of = 0, dc_sel = 0, ac_sel = 0;
+    for (uint32_t k = 0; k < 6; k++) {
+        const uint32_t ci = k < nluma ? 0u : (k - nluma + 1 < 3 ? k - nluma + 1 : 2u);
+        comp_of |= ci << (2 * k);
+        dc_sel |= (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]) << k;
+        ac_sel |= (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]) << k;
+    }
+    // bit window: `have` valid bits at the top of buf, never fewer than 32 when a symbol starts; `ahead` = the word after it
+    uint32_t widx = p >> 5;
+    uint64_t buf = (((uint64_t)word(widx) << 32) | word(widx + 1)) << (p & 31);
+    int have = 64 - (int)(p & 31);
+    widx += 2;
+    uint32_t ahead = word(widx);
+    uint32_t fl = 0, n = 0, damaged = 0;
+    int dcs0 = 0, dcs1 = 0, dcs2 = 0;
+    // where the coefficients go (WRITE): MCU coordinates are carried along, a block's address is base + mx*dx + my*dy
+    uint32_t mx = 0, my = 0, blk = 0;
+    bool blk_ok = false;
+    if (WRITE) {
+        const uint32_t gb = W->slot0 >> 6, mcu = gb / bpm;
+        my = mcu / (uint32_t)F.mcux;
+        mx = mcu - my * (uint32_t)F.mcux;
+        if (gb - mcu * bpm != c || (W->slot0 & 63) != z) { jpeg_flag(W->status, JPEG_ST_BAD_COUNT); return r; }
+        blk_ok = my < (uint32_t)F.mcuy;
+        blk = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
+    }
+    while (p < limit && n < max_slots) {
+        const uint32_t ci = (comp_of >> (2 * c)) & 3;
+        const bool isdc = z == 0;
+        const uint32_t tab = isdc ? ((dc_sel >> c) & 1) : 2 + ((ac_sel >> c) & 1);
+        const uint32_t peek = (uint32_t)(buf >> 48);
+        uint32_t e = L.lut[tab][peek >> (16 - JPEG_LOOKBITS)];
+        if ((e & 31) == 0) {                                        // a code longer than the table's index: its length from
+            uint32_t len = JPEG_LOOKBITS + 1;                       // the canonical limits, its symbol from the value list
+            for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= L.limit[tab][l] ? 1u : 0u;
+            if (peek >= L.limit[tab][16]) {                         // no code starts with these 16 bits
+                fl = (seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID;   // (the 1-bits that pad an interval are no code either)
+                break;
+            }
+            const uint32_t sym = L.vals[tab][(uint32_t)(L.offs[tab][len] + (int)(peek >> (16 - len))) & 255];
+            e = jpeg_lut_entry(len, sym, isdc);
+        }
+        const uint32_t len = e & 31, size = (e >> 5) & 15, run = (e >> 9) & 15, eob = (e >> 13) & 1;
+        const uint32_t total = len + size;
+        if (p + total > seg_end) { fl = JPEG_FL_END; break; }       // the interval's padding, not a symbol
+        // the value: `size` bits after the code, negative when its first bit is 0 (T.81 F.2.2.1)
+        const uint32_t vb = (uint32_t)(buf >> 32) << len;
+        const int v = (int)((vb >> 1) >> (31 - size)) + ((int)(~vb) >> 31 & (1 - (1 << size)));
+        buf <<= total;
+        have -= (int)total;
+        p += total;
+        if (have <= 32) {
+            buf |= (uint64_t)ahead << (32 - have);
+            have += 32;
+            widx++;
+            ahead = word(widx);
+        }
+        uint32_t adv = eob ? 64 - z : run + 1;
+        const bool over = z + adv > 64;                             // a run that leaves the block: damaged
+        adv = over ? 64 - z : adv;
+        damaged |= over ? 1u : 0u;
+        if (WRITE) {
+            if (isdc) {
+                const int dcv = (ci == 0 ? W->dc0[0] + dcs0 : ci == 1 ? W->dc0[1] + dcs1 : W->dc0[2] + dcs2) + v;
+                if (blk_ok) W->coef[blk] = (int16_t)dcv;
+            } else if (size && !over && blk_ok) {
+                W->coef[blk + L.natural[z + run]] = (int16_t)v;
+            }
+        }
+        dcs0 += (isdc && ci == 0) ? v : 0;
+        dcs1 += (isdc && ci == 1) ? v : 0;
+        dcs2 += (isdc && ci == 2) ? v : 0;
+        z += adv;
+        n += adv;
+        if (z >= 64) {                                              // next block
+            z = 0;
+            c++;
+            if (WRITE) {
+                if (c == bpm) { mx++; if (mx == (uint32_t)F.mcux) { mx = 0; my++; } }
+            }
+            c = c == bpm ? 0 : c;
+            if (WRITE) {
+                blk_ok = my < (uint32_t)F.mcuy;
+                blk = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
+            }
+        }
+    }
+    if (WRITE) {
+        if (damaged || (fl & JPEG_FL_INVALID)) jpeg_flag(W->status, JPEG_ST_BAD_CODE);
+    }
+    r.exit = jpeg_pack_state(p, c, z, fl);
+    r.n = n;
+    r.dc[0] = dcs0;
+    r.dc[1] = dcs1;
+    r.dc[2] = dcs2;
+    return r;
+}
+
+}  // namespace imp

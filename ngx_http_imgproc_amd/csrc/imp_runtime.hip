@@ -139,6 +139,7 @@ bool fault_hit(int step) {
 void set_error(const char* what, hipError_t e) {
     t_error = std::string(what) + ": " + hipGetErrorString(e);
 }
+void set_error_text(const char* what) { t_error = what; }
 bool env_ready() { return g_env != nullptr; }
 
 static int no_env() {
@@ -429,6 +430,30 @@ int upload_small(const void* host, size_t bytes, void** dev, hipStream_t s) {
         if (rc) { dev_free(p); return rc; }
     }
     *dev = p;
+    return IMP_OK;
+}
+
+// A host-built blob too large for the ring (a JPEG's entropy-coded segment, its coefficient planes): the caller fills the
+// pinned buffer stage_begin hands out, stage_upload enqueues the copy on the lane's stream and fences the buffer.
+int stage_begin(size_t bytes, void** host, void** token) {
+    Lane* L = lane();
+    if (!L) return no_env();
+    Staging* S = nullptr;
+    if (int rc = stage_reserve(L, bytes ? bytes : 1, &S)) return rc;
+    *host = S->p;
+    *token = S;
+    return IMP_OK;
+}
+
+int stage_upload(void* token, void* dev, size_t bytes) {
+    Lane* L = lane();
+    if (!L) return no_env();
+    Staging* S = (Staging*)token;
+    if (!S || !bytes) return IMP_OK;                 // nothing to send: the buffer is free again at once
+    hipError_t e = hipMemcpyAsync(dev, S->p, bytes, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess) e = hipEventRecord(S->done, L->stream);
+    if (e != hipSuccess) { set_error("hipMemcpyAsync(stage_upload)", e); (void)hipStreamSynchronize(L->stream); return IMP_ERROR_DEVICE; }
+    S->busy = true;
     return IMP_OK;
 }
 

@@ -12,6 +12,8 @@ import numpy as np
 from ._lib import lib, CConfig, CJob, ImpError
 
 IMP_OK = 0
+IMP_ERROR_UNSUPPORTED = 1
+IMP_ERROR_DECODE_FAILED = 3
 IMP_ERROR_INVALID_ARGS = 50
 IMP_ERROR_UPSCALE = 51
 IMP_ERROR_NO_SUCH_FILTER = 52
@@ -106,6 +108,13 @@ class Image:
         if rc:
             raise ImpError(rc, "impgpu_image_wrap")
         return cls(handle=h.value)
+
+    @classmethod
+    def decode_jpeg(cls, blob):
+        """cvDecodeImage(&rawencoded, -1) for a JPEG blob (bridge.c:545-552), on the device -> (code, Image or None)."""
+        h = C.c_void_p()
+        rc = lib.impgpu_image_decode_jpeg(bytes(blob), len(blob), C.byref(h))
+        return rc, (cls(handle=h.value) if rc == 0 else None)
 
     def release(self):
         if self.h:
@@ -214,6 +223,12 @@ def run_ops(image, config, crop=None, gravity=None, resize=None, simple=0, filte
     step = C.c_int()
     rc = lib.impgpu_run_ops(C.byref(image.h), C.byref(job), C.byref(config.c), C.byref(step))
     return rc, step.value
+
+
+def jpeg_info(blob):
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.impgpu_jpeg_info(bytes(blob), len(blob), w, h, c)
+    return rc, (w.value, h.value, c.value)
 
 
 def crop_geometry(width, height, args, gravity=None):

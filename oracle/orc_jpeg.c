@@ -245,6 +245,7 @@ typedef struct {
     int nbits;
     int hit_marker;      /* the marker byte that stopped the byte feed (0 = none) */
     int padded;          /* zero bits supplied after the feed stopped */
+    int malformed;
 } jbits;
 
 /* jdhuff.c jpeg_fill_bit_buffer: FF 00 -> FF, fill FFs swallowed, any other FF xx stops the feed and zero bytes
@@ -257,9 +258,10 @@ static void fill(jbits* b, int need) {
             else {
                 byte = b->p[b->pos++];
                 if (byte == 0xFF) {
-                    int next;
-                    do { next = b->pos < b->end ? b->p[b->pos++] : 0xD9; } while (next == 0xFF);
+                    int next, fills = -1;
+                    do { next = b->pos < b->end ? b->p[b->pos++] : 0xD9; fills++; } while (next == 0xFF);
                     if (next != 0) { b->hit_marker = next; byte = 0; }
+                    else if (fills) b->malformed = 1;           /* FF FF 00: libjpeg reads a data FF; refused here */
                 }
             }
         }
@@ -343,14 +345,19 @@ static int decode_scan(jdec* d) {
                             blk[zigzag_to_natural[k]] = (short)extend(v, s);
                         } else {
                             if (r != 15) break;
+                            if (k + 15 > 63) return ORC_ERROR_DECODE_FAILED;   /* sixteen zeros that leave the block */
                             k += 15;
                         }
                     }
                 }
         }
         /* the supplied zeros are the youngest bits of the accumulator: more of them than bits left = one was decoded */
-        if (b.padded > b.nbits) return ORC_ERROR_DECODE_FAILED;
+        if (b.padded > b.nbits || b.malformed) return ORC_ERROR_DECODE_FAILED;
     }
+    /* Stricter than libjpeg, which skips "extraneous bytes before marker" with a warning: what follows the last MCU must be
+     * the (at most 7) padding bits and then a marker or the end of the file -- the same rule process_restart applies above */
+    if (!b.hit_marker && b.pos < b.end && (b.p[b.pos] != 0xFF || (b.pos + 1 < b.end && b.p[b.pos + 1] == 0x00)))
+        return ORC_ERROR_DECODE_FAILED;
     return ORC_OK;
 }
 

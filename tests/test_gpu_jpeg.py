@@ -1,0 +1,209 @@
+"""impgpu_image_decode_jpeg on the device against the Pillow-pinned oracle (bridge.c:545-552's cvDecodeImage).
+
+Bit-exact: the whole decode is integer arithmetic (Huffman, dequantisation, ISLOW IDCT, fancy upsampling, YCbCr tables).
+"""
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import noise_image, smooth_image
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+EXPECTED = np.load(os.path.join(GOLD, "expected_bgr.npz"))
+MODES = ["device", "host"]      # IMPGPU_JPEG_HUFF: where the entropy decoding runs (host = the A/B path)
+
+
+def golden_blob(name):
+    with open(os.path.join(GOLD, name + ".jpg"), "rb") as f:
+        return f.read()
+
+
+def encode(arr, **kw):
+    Image = pytest.importorskip("PIL.Image")
+    b = io.BytesIO()
+    Image.fromarray(arr).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+@pytest.fixture(params=MODES)
+def huff(request, monkeypatch):
+    monkeypatch.setenv("IMPGPU_JPEG_HUFF", request.param)
+    return request.param
+
+
+def decode(gpu, blob):
+    rc, im = gpu.Image.decode_jpeg(blob)
+    if rc:
+        return rc, None
+    out = im.numpy()
+    im.release()
+    return rc, out
+
+
+@pytest.mark.parametrize("case", MANIFEST["cases"], ids=[c["name"] for c in MANIFEST["cases"]])
+def test_golden_files_decode_to_pillows_pixels(gpu, huff, case):
+    """The committed files against the pixels Pillow's libjpeg-turbo produced for them (not against our oracle)."""
+    rc, got = decode(gpu, golden_blob(case["name"]))
+    assert rc == 0
+    assert list(got.shape) == case["shape"]
+    if case["name"] in EXPECTED.files:
+        assert np.array_equal(got, EXPECTED[case["name"]])
+    assert hashlib.sha256(got.tobytes()).hexdigest() == case["sha256_bgr"]
+
+
+@pytest.mark.parametrize("sub", ["4:4:4", "4:2:2", "4:2:0"])
+def test_sizes_qualities_restart_intervals(gpu, huff, sub):
+    for h, w in [(16, 16), (17, 23), (1, 1), (2, 3), (8, 8), (33, 65), (100, 75), (3, 300), (300, 3), (5, 4), (240, 321), (64, 256), (65, 257), (128, 511)]:
+        for kind, q, rst in (("smooth", 90, 0), ("noise", 75, 5), ("noise", 100, 0), ("smooth", 30, 1)):
+            arr = smooth_image(h, w, 3) if kind == "smooth" else noise_image(h, w, 3, h + w)
+            kw = dict(quality=q, subsampling=sub)
+            if rst:
+                kw["restart_marker_blocks"] = rst
+            blob = encode(arr, **kw)
+            rc_o, want = orc.jpeg_decode(blob)
+            rc, got = decode(gpu, blob)
+            assert rc == 0 and rc_o == 0, (h, w, kind, q, rst, rc)
+            assert np.array_equal(got, want), (h, w, kind, q, rst)
+
+
+def test_gray_files(gpu, huff):
+    for h, w in [(16, 16), (17, 23), (1, 1), (100, 75), (64, 260), (300, 300)]:
+        g = smooth_image(h, w, 3)[:, :, 1]
+        for kw in (dict(quality=50), dict(quality=95, optimize=True), dict(quality=80, restart_marker_rows=1)):
+            blob = encode(g, **kw)
+            rc, got = decode(gpu, blob)
+            assert rc == 0 and got.shape == (h, w, 1)
+            assert np.array_equal(got, orc.jpeg_decode(blob)[1])
+
+
+@pytest.mark.parametrize("h,w,sub,kind,q,extra", [
+    (1080, 1920, "4:2:0", "smooth", 90, {}),                          # BASELINE configs[1]'s frame
+    (1080, 1920, "4:2:0", "noise", 90, {}),
+    (1080, 1920, "4:4:4", "smooth", 95, {}),
+    (1080, 1920, "4:2:2", "noise", 60, dict(restart_marker_rows=1)),
+    (1080, 1920, "4:2:0", "smooth", 85, dict(restart_marker_blocks=1)),   # an interval per MCU: 8160 intervals
+    (2160, 3840, "4:2:0", "smooth", 90, {}),                          # configs[3]'s frame
+    (2160, 3840, "4:2:0", "noise", 50, dict(optimize=True)),
+])
+def test_full_size_frames(gpu, huff, h, w, sub, kind, q, extra):
+    arr = smooth_image(h, w, 3) if kind == "smooth" else noise_image(h, w, 3, 5)
+    blob = encode(arr, quality=q, subsampling=sub, **extra)
+    rc, got = decode(gpu, blob)
+    assert rc == 0
+    rc_o, want = orc.jpeg_decode(blob)
+    assert rc_o == 0
+    assert np.array_equal(got, want)
+
+
+def test_cfg1_jpeg_crop_on_the_device(gpu):
+    """BASELINE configs[0]: a 640x480 JPEG, crop to 320x240 -- decoded and cropped on the device, against Pillow's pixels."""
+    blob = golden_blob("c420_q50_640x480")
+    rc, im = gpu.Image.decode_jpeg(blob)
+    assert rc == 0
+    cfg = gpu.Config()
+    rc, step = gpu.run_ops(im, cfg, crop="320px,240px,0px,0px")
+    assert rc == 0
+    got = im.numpy()
+    rc_o, full = orc.jpeg_decode(blob)
+    assert got.shape == (240, 320, 3) and np.array_equal(got, full[:240, :320])
+    im.release()
+
+
+def test_decode_feeds_the_operator_chain(gpu):
+    """decode -> resize (AREA thumbnail) -> rotate -> gamma, all on the device, equals the oracle's decode + chain."""
+    arr = smooth_image(540, 960, 3, seed=4)
+    blob = encode(arr, quality=88, subsampling="4:2:0")
+    rc, im = gpu.Image.decode_jpeg(blob)
+    assert rc == 0
+    cfg = gpu.Config(allow_experiments=True)
+    rc, step = gpu.run_ops(im, cfg, resize="224,0", filters=["rotate=90", "gamma=1.6"])
+    assert rc == 0
+    _, o = orc.jpeg_decode(blob)
+    _, o = orc.resize(o, "224,0")
+    _, o = orc.filter(o, "rotate=90")
+    _, o = orc.filter(o, "gamma=1.6")
+    assert np.array_equal(im.numpy(), o)
+    im.release()
+    # a gray file takes the gray->BGR promotion of bridge.c:613-618 inside run_ops
+    blob = encode(arr[:, :, 0], quality=80)
+    rc, im = gpu.Image.decode_jpeg(blob)
+    assert rc == 0 and im.shape[2] == 1
+    rc, step = gpu.run_ops(im, cfg, resize="100,0", filters=["contrast=1.2"])
+    assert rc == 0
+    _, o = orc.jpeg_decode(blob)
+    _, o = orc.resize(o, "100,0")
+    o = orc.gray2bgr(o)
+    _, o = orc.filter(o, "contrast=1.2")
+    assert np.array_equal(im.numpy(), o)
+    im.release()
+
+
+def test_refused_files(gpu, huff):
+    arr = smooth_image(40, 40, 3)
+    assert decode(gpu, encode(arr, quality=90, progressive=True))[0] == gpu.IMP_ERROR_UNSUPPORTED
+    assert decode(gpu, b"\x89PNG\r\n\x1a\n" + b"\0" * 64)[0] == gpu.IMP_ERROR_UNSUPPORTED
+    blob = golden_blob("c420_q90_dri4_95x51")
+    for cut in (3, 20, 200, len(blob) // 2, len(blob) - 40):
+        assert decode(gpu, blob[:cut])[0] in (gpu.IMP_ERROR_UNSUPPORTED, gpu.IMP_ERROR_DECODE_FAILED)
+    # the env keeps working after a refusal
+    rc, got = decode(gpu, blob)
+    assert rc == 0 and np.array_equal(got, EXPECTED["c420_q90_dri4_95x51"])
+
+
+def test_damaged_files_same_verdict_and_pixels_as_the_oracle(gpu):
+    """Bytes flipped anywhere: the device accepts exactly the files the oracle accepts, with the same pixels."""
+    rng = np.random.Generator(np.random.PCG64(23))
+    accepted = 0
+    for name in ("c420_q90_dri4_95x51", "c444_q90_48x40", "gray_q90_57x43", "c420_q30_noise_64x64", "c420_q92_opt_120x90"):
+        src = golden_blob(name)
+        for _ in range(120):
+            b = bytearray(src)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+            diff = [(i, src[i], b[i]) for i in range(len(src)) if src[i] != b[i]]
+            b = bytes(b)
+            rc_o, want = orc.jpeg_decode(b)
+            rc, got = decode(gpu, b)
+            if rc_o == 0:
+                assert rc == 0, (name, rc, diff, gpu.lib.impgpu_last_error())
+                assert np.array_equal(got, want), name
+                accepted += 1
+            elif rc_o == orc.DECODE_FAILED:
+                assert rc in (gpu.IMP_ERROR_DECODE_FAILED, gpu.IMP_ERROR_UNSUPPORTED), (name, rc)
+            else:
+                assert rc != 0, (name, rc_o, rc)
+    assert accepted > 40
+
+
+def test_decodes_from_several_threads(gpu):
+    """Each thread has its own lane (stream, pool, staging): concurrent decodes do not disturb one another."""
+    import threading
+
+    blobs = [encode(smooth_image(200 + 16 * i, 300 + 8 * i, 3, seed=i), quality=85, subsampling="4:2:0") for i in range(8)]
+    wants = [orc.jpeg_decode(b)[1] for b in blobs]
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(6):
+                i = (k + rep) % len(blobs)
+                rc, got = decode(gpu, blobs[i])
+                if rc or not np.array_equal(got, wants[i]):
+                    errors.append((k, i, rc))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
