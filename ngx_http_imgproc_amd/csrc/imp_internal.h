@@ -58,6 +58,8 @@ int  dev_alloc_on(size_t bytes, void** out, hipStream_t s); // dev_alloc + make 
 int  stream_join(hipStream_t s);                           // `s` waits for everything the lane stream holds now
 int  stream_join_back(hipStream_t s);                      // the lane stream waits for everything `s` holds now
 bool lane_stream_idle();
+uint32_t* lane_mailbox();                                  // 64 pinned words of the calling thread's lane
+int  lane_wait();                                          // wait for the lane's stream (sleeping, unless IMPGPU_SYNC=spin)
 bool on_lane_stream(hipStream_t s);
 // Per-lane caches (resize tables): owned by the lane, dropped with it (impgpu_env_destroy), no lock.
 struct LaneCache { virtual ~LaneCache() {} };

@@ -29,15 +29,20 @@ __constant__ uint8_t c_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32
                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                       30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-__device__ __forceinline__ uint32_t ld_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Wait for a flag another workgroup raises.  Workgroups are numbered by ticket, so the one waited for is already running
-// (or done); the bound only keeps a bug from hanging the device.
+// (or done); the bound only keeps a bug from hanging the device.  The poll is a RELAXED load: an acquire load invalidates
+// the XCD's whole L2 every time round, and hundreds of waiting waves doing that every few hundred cycles took every
+// kernel on the device down with them (a request stream got slower with every thread added).  One acquire fence after
+// the flag has been seen orders the payload reads behind it.
 __device__ bool wait_flag(const uint32_t* flag) {
-    for (int spin = 0; spin < (1 << 22); spin++) {
-        if (ld_acquire(flag)) return true;
-        __builtin_amdgcn_s_sleep(4);
+    for (int spin = 0; spin < (1 << 21); spin++) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(16);
     }
     return false;
 }

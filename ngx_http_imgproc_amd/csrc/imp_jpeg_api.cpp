@@ -63,7 +63,9 @@ int impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_imag
     if (rc) { dev_free(d_qt); return rc; }
 
     sw.mark();                                                      // [0] parse + small uploads
-    unsigned status[4] = {};
+    uint32_t* status = lane_mailbox();                              // pinned: the verdict's copy stays asynchronous
+    if (!status) { dev_free(d_coef); dev_free(d_qt); return IMP_ERROR_DEVICE; }
+    status[0] = status[1] = status[2] = status[3] = 0;
     const bool on_device = huff_mode() == HUFF_DEVICE;
     if (!on_device) {
         // A/B path: entropy decoding on this thread, dense coefficient planes over the link
@@ -124,7 +126,7 @@ int impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_imag
         }
         if (!rc) {
             // the kernel's verdict (did every interval decode to exactly its MCUs?) is read before the frame is handed on
-            const hipError_t e = hipMemcpyAsync(status, (uint32_t*)d_ctl, sizeof status, hipMemcpyDeviceToHost, s);
+            const hipError_t e = hipMemcpyAsync(status, (uint32_t*)d_ctl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
             if (e != hipSuccess) { set_error("hipMemcpyAsync(jpeg status)", e); rc = IMP_ERROR_DEVICE; }
         }
         dev_free(d_tabs);
@@ -139,9 +141,8 @@ int impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_imag
     dev_free(d_qt);
     sw.mark();                                                      // [3] enqueue
     if (!rc && on_device) {
-        const hipError_t e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { set_error("hipStreamSynchronize(jpeg)", e); rc = IMP_ERROR_DEVICE; }
-        else if (status[1]) {
+        rc = lane_wait();
+        if (!rc && status[1]) {
             char text[96];
             std::snprintf(text, sizeof text, "jpeg entropy stage refused the scan (status 0x%x)", status[1]);
             set_error_text(text);

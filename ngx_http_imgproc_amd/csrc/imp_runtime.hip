@@ -30,6 +30,7 @@ namespace imp {
 constexpr int    RING_SEGS = 8;
 constexpr size_t RING_SEG_BYTES = size_t(128) << 10;   // blobs above this take a one-off pinned buffer
 constexpr int    N_STAGE = 2;
+constexpr size_t MAILBOX_BYTES = 256;                   // pinned words a kernel's verdict is copied into (behind the ring)
 
 struct Staging {
     uint8_t* p = nullptr;
@@ -56,6 +57,7 @@ struct Lane {
     hipEvent_t seg_done[RING_SEGS] = {};        // recorded on the lane stream when a segment is left
     bool seg_busy[RING_SEGS] = {};
     hipEvent_t join_ev = nullptr;               // lane stream -> foreign stream ordering
+    hipEvent_t sync_ev = nullptr;               // blocking wait for the lane stream (lane_wait)
     std::vector<hipEvent_t> ev_pool;
     std::deque<Parked> parked;
     LaneCache* caches[LANE_CACHE_SLOTS] = {};
@@ -166,7 +168,8 @@ static Lane* lane() {
     Lane* L = new Lane();
     bool ok = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&L->join_ev, hipEventDisableTiming) == hipSuccess &&
-              hipHostMalloc((void**)&L->ring, RING_SEGS * RING_SEG_BYTES, hipHostMallocDefault) == hipSuccess;
+              hipHostMalloc((void**)&L->ring, RING_SEGS * RING_SEG_BYTES + MAILBOX_BYTES, hipHostMallocDefault) == hipSuccess &&
+              hipEventCreateWithFlags(&L->sync_ev, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
     for (int i = 0; ok && i < N_STAGE; i++) ok = hipEventCreateWithFlags(&L->stage[i].done, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < RING_SEGS; i++) ok = hipEventCreateWithFlags(&L->seg_done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -338,6 +341,26 @@ bool on_lane_stream(hipStream_t s) {
     return L && s == L->stream;
 }
 
+// A few pinned words per lane for results a kernel leaves behind (a D2H copy into pageable memory would make the runtime
+// wait inside the copy call, and hold its locks while it does).
+uint32_t* lane_mailbox() {
+    Lane* L = lane();
+    return L ? (uint32_t*)(L->ring + RING_SEGS * RING_SEG_BYTES) : nullptr;
+}
+
+// Wait for the lane's stream.  hipStreamSynchronize spins on a host core for the whole wait; with more waiting threads than
+// cores (a request stream, nginx workers sharing a box) that starves the threads that have host work to do, so the default
+// is an event created with hipEventBlockingSync: the thread sleeps until the interrupt.  IMPGPU_SYNC=spin takes the other one.
+int lane_wait() {
+    Lane* L = lane();
+    if (!L) return no_env();
+    static const bool spin = [] { const char* s = std::getenv("IMPGPU_SYNC"); return s && !std::strcmp(s, "spin"); }();
+    if (spin) { IMP_HIP(hipStreamSynchronize(L->stream)); return IMP_OK; }
+    IMP_HIP(hipEventRecord(L->sync_ev, L->stream));
+    IMP_HIP(hipEventSynchronize(L->sync_ev));
+    return IMP_OK;
+}
+
 LaneCache** lane_cache_slot(int which) {
     Lane* L = lane();
     return (L && which >= 0 && which < LANE_CACHE_SLOTS) ? &L->caches[which] : nullptr;
@@ -471,6 +494,7 @@ static void lane_destroy(Lane* L) {
     for (hipEvent_t ev : L->seg_done) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : L->ev_pool) (void)hipEventDestroy(ev);
     if (L->join_ev) (void)hipEventDestroy(L->join_ev);
+    if (L->sync_ev) (void)hipEventDestroy(L->sync_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
 }
@@ -526,12 +550,7 @@ int impgpu_env_device(void) { return g_env ? g_env->device : -1; }
 const char* impgpu_last_error(void) { return t_error.c_str(); }
 void* impgpu_env_stream(void) { return (void*)env_stream(); }
 
-int impgpu_sync(void) {
-    Lane* L = lane();
-    if (!L) return no_env();
-    IMP_HIP(hipStreamSynchronize(L->stream));
-    return IMP_OK;
-}
+int impgpu_sync(void) { return lane_wait(); }
 
 int impgpu_image_create(int width, int height, int channels, impgpu_image** out) {
     if (!out) return IMP_ERROR_INVALID_ARGS;
@@ -709,7 +728,7 @@ int impgpu_image_download(const impgpu_image* im, unsigned char* data, int step)
     int rc = stage_reserve(L, bytes, &S);
     if (rc) return rc;
     IMP_HIP(hipMemcpyAsync(S->p, im->d, bytes, hipMemcpyDeviceToHost, L->stream));
-    IMP_HIP(hipStreamSynchronize(L->stream));
+    if (int rcw = lane_wait()) return rcw;
     const size_t rowbytes = (size_t)im->w * im->c;
     for (int y = 0; y < im->h; y++)
         std::memcpy(data + (size_t)y * step, S->p + (size_t)y * im->step, rowbytes);
