@@ -358,7 +358,7 @@ def jpeg_pool(n_files):
     return files
 
 
-def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0, world=1):
+def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0, world=1, batch=1):
     """The same request stream with the requests arriving as what they are in production -- JPEG files (bridge.c:376-378,
     :545-552): decode -> resize=224,0 -> download.  decoder = "device": impgpu_image_decode_jpeg (the compressed bytes cross
     the link; Huffman, IDCT, upsampling, colour on the device); "hosthuff": the same with the entropy stage on the calling
@@ -387,31 +387,54 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
             pending.put(None)
 
     def worker():
-        hdst = lib.impgpu_host_alloc(out_bytes)
+        hdst = lib.impgpu_host_alloc(out_bytes * max(1, batch))
         if decoder == "host":
             from PIL import Image
-        while True:
-            item = pending.get()
-            if item is None:
+        done = False
+        while not done:
+            items = []
+            while len(items) < max(1, batch):
+                try:
+                    item = pending.get(block=not items)          # wait for the first, take what else is already there
+                except queue.Empty:
+                    break
+                if item is None:
+                    done = True
+                    break
+                items.append(item)
+            if not items:
                 break
-            w, h, blob = item
-            img = C.c_void_p()
+            n = len(items)
+            imgs = (C.c_void_p * n)()
+            rc = 0
             if decoder == "host":
-                a = np.asarray(Image.open(io.BytesIO(blob)))
-                rc = lib.impgpu_image_upload(a.ctypes.data, w, h, 3, w * 3, C.byref(img))
+                for k, (w, h, blob) in enumerate(items):
+                    a = np.asarray(Image.open(io.BytesIO(blob)))
+                    one = C.c_void_p()
+                    rc = rc or lib.impgpu_image_upload(a.ctypes.data, w, h, 3, w * 3, C.byref(one))
+                    imgs[k] = one
             else:
-                rc = lib.impgpu_image_decode_jpeg(blob, len(blob), C.byref(img))
-            if rc == 0:
-                rc = lib.impgpu_resize(C.byref(img), MIXED_RESIZE, C.byref(cfg.c), 0)
-            if rc == 0:
-                ow = lib.impgpu_image_width(img)
-                rc = lib.impgpu_image_download_pinned(img, hdst, (ow * 3 + 3) & ~3)
+                blobs = (C.c_char_p * n)(*[b for _, _, b in items])
+                sizes = (C.c_size_t * n)(*[len(b) for _, _, b in items])
+                codes = (C.c_int * n)()
+                rc = lib.impgpu_batch_decode_jpeg(blobs, sizes, n, imgs, codes)
+                rc = rc or max(codes)
+            for k in range(n):
+                one = C.c_void_p(imgs[k])
+                if rc == 0:
+                    rc = lib.impgpu_resize(C.byref(one), MIXED_RESIZE, C.byref(cfg.c), 0)
+                if rc == 0:
+                    ow = lib.impgpu_image_width(one)
+                    rc = lib.impgpu_image_download_pinned(one, hdst + out_bytes * k, (ow * 3 + 3) & ~3)
+                imgs[k] = one
             if rc == 0:
                 rc = lib.impgpu_sync()
-            if img:
-                lib.impgpu_image_release(C.byref(img))
+            for k in range(n):
+                one = C.c_void_p(imgs[k])
+                if one:
+                    lib.impgpu_image_release(C.byref(one))
             if rc:
-                errors.append(((w, h), rc))
+                errors.append(((items[0][0], items[0][1]), rc))
                 break
         lib.impgpu_host_free(hdst)
 
@@ -446,6 +469,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=4, help="--stream: requests a thread enqueues before it waits")
     ap.add_argument("--jpeg", default="", choices=("", "device", "hosthuff", "host", "all"),
                     help="--stream: the requests arrive as JPEG files; where they are decoded (all = the three one after the other)")
+    ap.add_argument("--jpeg-batch", type=int, default=1, help="--stream --jpeg: requests a thread takes from the queue and decodes with one impgpu_batch_decode_jpeg call")
     ap.add_argument("--jpeg-files", type=int, default=64, help="--stream --jpeg: distinct files the requests cycle through")
     ap.add_argument("--mixed", type=int, default=0, metavar="N",
                     help="BASELINE configs[4] with the N frames already in HBM: resize=224,0 over mixed sizes, one "
@@ -494,11 +518,11 @@ def main():
         for decoder in (("device", "hosthuff", "host") if args.jpeg == "all" else (args.jpeg,)):
             # untimed prefix: every lane (= thread) meets the common buffer sizes once, so that the timed part measures the
             # steady state of a server, not hipMalloc / hipHostMalloc
-            jpeg_stream(imp, min(args.stream, max(256, 24 * args.threads)), args.threads, args.queue_depth, decoder, files, rank, world)
+            jpeg_stream(imp, min(args.stream, max(256, 24 * args.threads * args.jpeg_batch)), args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch)
             if use_dist:
                 dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
-            r = jpeg_stream(imp, args.stream, args.threads, args.queue_depth, decoder, files, rank, world)
+            r = jpeg_stream(imp, args.stream, args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch)
             torch.cuda.synchronize()
             t = torch.tensor([r["seconds"], float(r["requests"]), float(r["source_bytes"]), float(r["file_bytes"])], dtype=torch.float64, device="cuda")
             if use_dist:
@@ -516,7 +540,7 @@ def main():
                 "compressed_MB_per_sec": round(fbytes / secs / 1e6, 1), "decoded_MB_per_sec": round(nbytes / secs / 1e6, 1),
                 "bits_per_pixel": round(fbytes * 8 / (nbytes / 3), 2), "seconds": round(secs, 3),
                 "config": {"workload": "BASELINE configs[4] as JPEG files: %d requests, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % int(nreq),
-                           "threads_per_gpu": args.threads, "host_cores": os.cpu_count(), "queue_depth": args.queue_depth,
+                           "threads_per_gpu": args.threads, "files_per_decode_call": args.jpeg_batch, "host_cores": os.cpu_count(), "queue_depth": args.queue_depth,
                            "sharding": "request i -> rank i mod N, no collective"}})
         if rank == 0:
             for ln in lines:

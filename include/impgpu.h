@@ -130,6 +130,13 @@ int   impgpu_image_download_fi(const impgpu_image* image, int bpp, unsigned char
  * what it could, so the same fallback applies.  Waits for the device's verdict on the entropy-coded data before it
  * returns (the only wait on the request path besides the download). */
 int   impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_image** out);
+/* The same for `count` files at once -- the frames of a request queue (BASELINE configs[4]) or whatever else arrives
+ * together: ONE entropy launch and one pixel launch per chroma sampling for all of them, one wait for all verdicts, so the
+ * device is filled by a single caller.  codes[i] / images[i] are what impgpu_image_decode_jpeg would return for file i
+ * (images[i] = NULL unless codes[i] == IMP_OK); the return value is IMP_OK unless the call itself failed (no env, a HIP
+ * error), in which case no image is returned. */
+int   impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* sizes, int count,
+                               impgpu_image** images, int* codes);
 /* the SOF header alone (host, no device): the size checks the module makes before decoding */
 int   impgpu_jpeg_info(const unsigned char* blob, size_t size, int* width, int* height, int* channels);
 /* Diagnostics (host, no device): the quantised coefficients of the file's components, MCU-padded planes one after the

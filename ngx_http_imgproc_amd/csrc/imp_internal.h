@@ -48,6 +48,7 @@ int  image_new(int w, int h, int c, impgpu_image** out);
 void image_delete(impgpu_image* im);
 // Copy a small host blob (tables, taps) into pool memory through the pinned ring, ordered on `s`.
 int  upload_small(const void* host, size_t bytes, void** dev, hipStream_t s);
+int  upload_to(void* dev, const void* host, size_t bytes, hipStream_t s);   // the same copy into memory the caller holds
 // Larger host-built blobs: fill the pinned buffer stage_begin returns, then stage_upload copies it to `dev` on the lane stream.
 int  stage_begin(size_t bytes, void** host, void** token);
 int  stage_upload(void* token, void* dev, size_t bytes);

@@ -90,19 +90,29 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
 // ---- imp_jpeg.hip
 // status word the entropy kernel leaves behind: 0 = every interval decoded to exactly its MCUs
 constexpr unsigned JPEG_ST_BAD_CODE = 1u, JPEG_ST_BAD_COUNT = 2u, JPEG_ST_CHAIN_TIMEOUT = 4u, JPEG_ST_OVERRUN = 8u;
-struct JpegHuffArgs {
+// One file of a launch.  Both kernels take a table of these plus a map from workgroup number to (job, workgroup within
+// the job), so any number of files -- a request, an album, a queue's worth of requests -- costs the same two launches.
+struct JpegJob {
+    JpegFrame F;
     const uint32_t* words;                   // the prepared scan
     const uint32_t* chunk_seg;               // per chunk: its interval
     const uint32_t* seg_first_chunk;
     const uint32_t* seg_bits;
     const JpegHuffDev* tables;               // [0..1] DC, [2..3] AC
-    int16_t* coef;
-    uint32_t* control;                       // ticket, status and the chain records (zeroed before the launch)
+    const uint16_t* qt;                      // [3][64] natural order: the components' quantisation tables
+    int16_t* coef;                           // the MCU-padded coefficient planes (zeroed before the entropy launch)
+    uint32_t* header;                        // 4 words, zeroed: [1] status, [2] / [3] most rounds a workgroup took before / after the hand-over
+    uint32_t* records;                       // JPEG_CTL_REC words per workgroup of the job, zeroed: the chain
+    uint8_t* dst;                            // the frame
+    int dstep;
 };
-size_t jpeg_control_bytes(unsigned nchunks);
-int launch_jpeg_entropy(const JpegFrame& F, const JpegHuffArgs& A, hipStream_t s);
-// dequantise + ISLOW IDCT + fancy upsampling + YCbCr->BGR, coefficient planes -> frame, one launch
-int launch_jpeg_pixels(const JpegFrame& F, const int16_t* coef, const uint16_t* qt3 /* [3][64] natural */, uint8_t* dst, int dstep,
-                       hipStream_t s);
+constexpr int JPEG_CTL_REC = 12;             // [0..2] tentative exit state (flag, lo, hi), [3..5] final exit state, [6..10] totals (flag, n, dc0..2)
+constexpr int JPEG_TILE_W = 256, JPEG_TILE_H = 64;   // pixels a workgroup of the pixel kernel produces
+struct JpegMapEntry { uint32_t job, local; };
+inline unsigned jpeg_entropy_blocks(unsigned nchunks) { return (nchunks + JPEG_HUFF_BLOCK - 1) / JPEG_HUFF_BLOCK; }
+// `ticket` = one zeroed word per launch; block_map in job-major order (a job's workgroups in increasing order)
+int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* block_map, unsigned total_blocks, uint32_t* ticket, hipStream_t s);
+// dequantise + ISLOW IDCT + fancy upsampling + YCbCr->BGR, coefficient planes -> frames; all jobs of one sampling class
+int launch_jpeg_pixels(int hs, int vs, int ncomp, const JpegJob* jobs, const JpegMapEntry* tile_map, unsigned total_tiles, hipStream_t s);
 
 }  // namespace imp

@@ -22,8 +22,7 @@ constexpr int HB = JPEG_HUFF_BLOCK;
 constexpr int CW = JPEG_CHUNK_WORDS;
 constexpr int WPITCH = CW + 1;                  // LDS pitch of a chunk: lanes at the same offset hit different banks
 constexpr unsigned CHUNK_BITS = CW * 32;
-constexpr int CTL_HEADER = 4;                   // control[0] ticket, [1] status, [2] / [3] most rounds a workgroup took before / after the hand-over
-constexpr int CTL_REC = 12;                     // per workgroup: [0..2] tentative exit state (flag, lo, hi), [3..5] final exit state, [6..10] totals (flag, n, dc0..2)
+constexpr int CTL_REC = JPEG_CTL_REC;
 
 __constant__ uint8_t c_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -47,7 +46,8 @@ __device__ bool wait_flag(const uint32_t* flag) {
     return false;
 }
 
-__global__ __launch_bounds__(HB) void k_jpeg_entropy(JpegFrame F, JpegHuffArgs A) {
+__global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map,
+                                                      uint32_t* __restrict__ launch_ticket) {
     __shared__ JpegHuffTabs L;
     __shared__ uint32_t s_words[(HB + 1) * WPITCH];
     __shared__ uint64_t s_exit[HB];
@@ -58,17 +58,23 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(JpegFrame F, JpegHuffArgs A
     __shared__ uint64_t s_pred;
     __shared__ uint32_t s_carry[4];
     const int t = threadIdx.x;
-    if (t == 0) s_ticket = atomicAdd(&A.control[0], 1u);
+    // workgroups are numbered in the order they START (a ticket), never by blockIdx: the one a workgroup waits for is then
+    // always running already
+    if (t == 0) s_ticket = atomicAdd(launch_ticket, 1u);
+    __syncthreads();
+    const JpegMapEntry me = block_map[__builtin_amdgcn_readfirstlane(s_ticket)];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    const JpegFrame F = J.F;
+    struct { const uint32_t *words, *chunk_seg, *seg_first_chunk, *seg_bits; const JpegHuffDev* tables; int16_t* coef; uint32_t *header, *records; } A =
+        {J.words, J.chunk_seg, J.seg_first_chunk, J.seg_bits, J.tables, J.coef, J.header, J.records};
     // tables
     for (int i = t; i < 4 * (1 << JPEG_LOOKBITS); i += HB) L.lut[i >> JPEG_LOOKBITS][i & ((1 << JPEG_LOOKBITS) - 1)] = A.tables[i >> JPEG_LOOKBITS].lut[i & ((1 << JPEG_LOOKBITS) - 1)];
     for (int i = t; i < 4 * 18; i += HB) { L.limit[i / 18][i % 18] = A.tables[i / 18].limit[i % 18]; L.offs[i / 18][i % 18] = A.tables[i / 18].offs[i % 18]; }
     for (int i = t; i < 4 * 256; i += HB) L.vals[i >> 8][i & 255] = A.tables[i >> 8].vals[i & 255];
     if (t < 64) L.natural[t] = c_natural[t];
     if (t < F.bpm) jpeg_block_steps(F, t, &L.blk_base[t], &L.blk_dx[t], &L.blk_dy[t]);
-    __syncthreads();
-    const uint32_t b = s_ticket;
+    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
     const uint32_t nblocks = (F.nchunks + HB - 1) / HB;
-    if (b >= nblocks) return;                                       // (whole workgroup: the grid is exactly nblocks)
     const uint32_t g0 = b * HB, g = g0 + (uint32_t)t;
     // the workgroup's chunks + one more, byte-swapped so that bit 31 of a word is the first bit of the stream
     for (uint32_t i = (uint32_t)t; i < (HB + 1) * CW; i += HB) {
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(JpegFrame F, JpegHuffArgs A
     }
     const uint32_t word0 = g0 * CW;
     auto word = [&](uint32_t i) -> uint32_t { const uint32_t k = i - word0; return s_words[(k / CW) * WPITCH + (k % CW)]; };
-    uint32_t* rec = A.control + CTL_HEADER + (size_t)b * CTL_REC;
+    uint32_t* rec = A.records + (size_t)b * CTL_REC;
     const uint32_t* prec = rec - CTL_REC;
     __syncthreads();
 
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(JpegFrame F, JpegHuffArgs A
             }
             if (t == 0 && !chained) {
                 if (wait_flag(prec + at)) s_pred = (uint64_t)prec[at + 1] | ((uint64_t)prec[at + 2] << 32);
-                else atomicOr(&A.control[1], JPEG_ST_CHAIN_TIMEOUT);
+                else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
             }
         }
         for (int round = 0; round <= HB + 1; round++) {
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(JpegFrame F, JpegHuffArgs A
                 s_exit[t] = d.exit;
                 changed = 1;
             }
-            if (!__syncthreads_or(changed)) { if (t == 0) atomicMax(&A.control[phase == 0 ? 2 : 3], (uint32_t)round); break; }
+            if (!__syncthreads_or(changed)) { if (t == 0) atomicMax(&A.header[phase == 0 ? 2 : 3], (uint32_t)round); break; }
         }
     }
     __syncthreads();
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(JpegFrame F, JpegHuffArgs A
         s_carry[0] = s_carry[1] = s_carry[2] = s_carry[3] = 0;
         if (!chained) {
             if (wait_flag(prec + 6)) { s_carry[0] = prec[7]; s_carry[1] = prec[8]; s_carry[2] = prec[9]; s_carry[3] = prec[10]; }
-            else atomicOr(&A.control[1], JPEG_ST_CHAIN_TIMEOUT);
+            else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
         }
     }
     __syncthreads();
@@ -196,19 +202,19 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(JpegFrame F, JpegHuffArgs A
     W.dc0[0] = incl_dc0 - d.dc[0];
     W.dc0[1] = incl_dc1 - d.dc[1];
     W.dc0[2] = incl_dc2 - d.dc[2];
-    W.status = &A.control[1];
-    if (!closes && incl_n > slots_here) { atomicOr(&A.control[1], JPEG_ST_OVERRUN); return; }   // would write outside the interval
+    W.status = &A.header[1];
+    if (!closes && incl_n > slots_here) { atomicOr(&A.header[1], JPEG_ST_OVERRUN); return; }   // would write outside the interval
     const uint32_t budget = closes ? (slots_here >= base_n ? slots_here - base_n : 0u) : 0xffffffffu;
     const JpegDecoded e = jpeg_decode_chunk<true>(L, word, entry, limit, seg_end, F, &W, budget);
     if (closes) {
         const uint32_t pe = (uint32_t)e.exit, fle = (uint32_t)(e.exit >> 48);
-        if ((fle & JPEG_FL_INVALID) || pe > seg_end || seg_end - pe >= 8) atomicOr(&A.control[1], JPEG_ST_BAD_CODE);
-        if (base_n + e.n != slots_here) atomicOr(&A.control[1], JPEG_ST_BAD_COUNT);
+        if ((fle & JPEG_FL_INVALID) || pe > seg_end || seg_end - pe >= 8) atomicOr(&A.header[1], JPEG_ST_BAD_CODE);
+        if (base_n + e.n != slots_here) atomicOr(&A.header[1], JPEG_ST_BAD_COUNT);
     }
 }
 
 // ---------------------------------------------------------------- pixels
-constexpr int TILE_W = 256, TILE_H = 64;
+constexpr int TILE_W = JPEG_TILE_W, TILE_H = JPEG_TILE_H;
 constexpr int YP = TILE_W;                       // luma LDS pitch
 
 
@@ -292,8 +298,7 @@ __device__ void idct_block_to_lds(const int16_t* blk, const uint16_t* q, uint8_t
 }
 
 template <int HS, int VS, int NC>
-__global__ __launch_bounds__(256) void k_jpeg_pixels(JpegFrame F, const int16_t* __restrict__ coef, const uint16_t* __restrict__ qt3,
-                                                     uint8_t* __restrict__ dst, int dstep) {
+__global__ __launch_bounds__(256) void k_jpeg_pixels(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ tile_map) {
     constexpr int CBW = TILE_W / 8 / HS + (HS == 2 ? 2 : 0);        // chroma blocks per tile row, halo included
     constexpr int CBH = TILE_H / 8 / VS + (VS == 2 ? 2 : 0);
     constexpr int CP = CBW * 8;                                     // chroma LDS pitch
@@ -301,9 +306,16 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(JpegFrame F, const int16_t*
     __shared__ __attribute__((aligned(16))) uint8_t s_c[NC == 3 ? 2 : 1][NC == 3 ? CP * CBH * 8 : 16];
     __shared__ uint16_t s_q[3][64];
     const int t = threadIdx.x;
-    if (t < 64 * NC) s_q[t >> 6][t & 63] = qt3[t];
+    const JpegMapEntry me = tile_map[blockIdx.x];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    const JpegFrame F = J.F;
+    const int16_t* __restrict__ coef = J.coef;
+    uint8_t* __restrict__ dst = J.dst;
+    const int dstep = J.dstep;
+    if (t < 64 * NC) s_q[t >> 6][t & 63] = J.qt[t];
     __syncthreads();
-    const int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    const int tiles_x = (F.width + TILE_W - 1) / TILE_W;
+    const int tile_y = (int)__builtin_amdgcn_readfirstlane(me.local) / tiles_x, tile_x = (int)__builtin_amdgcn_readfirstlane(me.local) - tile_y * tiles_x;
     {   // luma: one block per lane
         const int bx = tile_x * (TILE_W / 8) + (t & 31), by = tile_y * (TILE_H / 8) + (t >> 5);
         if (bx < F.bw[0] && by < F.bh[0])
@@ -415,26 +427,21 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(JpegFrame F, const int16_t*
 
 }  // namespace
 
-size_t jpeg_control_bytes(unsigned nchunks) {
-    const size_t nblocks = ((size_t)nchunks + HB - 1) / HB;
-    return (CTL_HEADER + nblocks * CTL_REC) * sizeof(uint32_t);
-}
-
-int launch_jpeg_entropy(const JpegFrame& F, const JpegHuffArgs& A, hipStream_t s) {
-    if (F.nchunks == 0 || F.nsegs == 0) return IMP_ERROR_DECODE_FAILED;
-    const unsigned nblocks = (F.nchunks + HB - 1) / HB;
-    hipLaunchKernelGGL(k_jpeg_entropy, dim3(nblocks), dim3(HB), 0, s, F, A);
+int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* block_map, unsigned total_blocks, uint32_t* ticket, hipStream_t s) {
+    if (total_blocks == 0) return IMP_OK;
+    hipLaunchKernelGGL(k_jpeg_entropy, dim3(total_blocks), dim3(HB), 0, s, jobs, block_map, ticket);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }
 
-int launch_jpeg_pixels(const JpegFrame& F, const int16_t* coef, const uint16_t* qt3, uint8_t* dst, int dstep, hipStream_t s) {
-    const dim3 grid((F.width + TILE_W - 1) / TILE_W, (F.height + TILE_H - 1) / TILE_H), block(256);
-    if (F.ncomp == 1) hipLaunchKernelGGL((k_jpeg_pixels<1, 1, 1>), grid, block, 0, s, F, coef, qt3, dst, dstep);
-    else if (F.hs == 1 && F.vs == 1) hipLaunchKernelGGL((k_jpeg_pixels<1, 1, 3>), grid, block, 0, s, F, coef, qt3, dst, dstep);
-    else if (F.hs == 2 && F.vs == 1) hipLaunchKernelGGL((k_jpeg_pixels<2, 1, 3>), grid, block, 0, s, F, coef, qt3, dst, dstep);
-    else if (F.hs == 1 && F.vs == 2) hipLaunchKernelGGL((k_jpeg_pixels<1, 2, 3>), grid, block, 0, s, F, coef, qt3, dst, dstep);
-    else if (F.hs == 2 && F.vs == 2) hipLaunchKernelGGL((k_jpeg_pixels<2, 2, 3>), grid, block, 0, s, F, coef, qt3, dst, dstep);
+int launch_jpeg_pixels(int hs, int vs, int ncomp, const JpegJob* jobs, const JpegMapEntry* tile_map, unsigned total_tiles, hipStream_t s) {
+    if (total_tiles == 0) return IMP_OK;
+    const dim3 grid(total_tiles), block(256);
+    if (ncomp == 1) hipLaunchKernelGGL((k_jpeg_pixels<1, 1, 1>), grid, block, 0, s, jobs, tile_map);
+    else if (hs == 1 && vs == 1) hipLaunchKernelGGL((k_jpeg_pixels<1, 1, 3>), grid, block, 0, s, jobs, tile_map);
+    else if (hs == 2 && vs == 1) hipLaunchKernelGGL((k_jpeg_pixels<2, 1, 3>), grid, block, 0, s, jobs, tile_map);
+    else if (hs == 1 && vs == 2) hipLaunchKernelGGL((k_jpeg_pixels<1, 2, 3>), grid, block, 0, s, jobs, tile_map);
+    else if (hs == 2 && vs == 2) hipLaunchKernelGGL((k_jpeg_pixels<2, 2, 3>), grid, block, 0, s, jobs, tile_map);
     else return IMP_ERROR_UNSUPPORTED;
     IMP_HIP(hipGetLastError());
     return IMP_OK;

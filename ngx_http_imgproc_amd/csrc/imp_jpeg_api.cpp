@@ -1,5 +1,7 @@
-// imp_jpeg_api.cpp -- impgpu_image_decode_jpeg: the reference's cvDecodeImage(&rawencoded, -1) for a JPEG blob
-// (bridge.c:545-552) with everything but marker parsing and FF00 unstuffing on the device (imp_jpeg.h).
+// imp_jpeg_api.cpp -- impgpu_image_decode_jpeg / impgpu_batch_decode_jpeg: the reference's cvDecodeImage(&rawencoded, -1)
+// for JPEG blobs (bridge.c:545-552) with everything but marker parsing and FF00 unstuffing on the device (imp_jpeg.h).
+// One file or many, the device sees the same thing: a table of jobs, one entropy launch, one pixel launch per sampling
+// class, one wait for all verdicts.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -10,14 +12,13 @@ using namespace imp;
 
 namespace {
 
-enum HuffMode { HUFF_DEVICE = 0, HUFF_HOST = 1 };
-HuffMode huff_mode() {
+bool host_entropy_requested() {
     // A/B switch, read per call (a getenv is nothing next to a decode): "host" = entropy decoding on the calling thread
     const char* s = std::getenv("IMPGPU_JPEG_HUFF");
-    return (s && !std::strcmp(s, "host")) ? HUFF_HOST : HUFF_DEVICE;
+    return s && !std::strcmp(s, "host");
 }
 
-// IMPGPU_JPEG_TRACE=1: one line per decode on stderr with the host's share of it, in microseconds
+// IMPGPU_JPEG_TRACE=1: one line per call on stderr with the host's share of it, in microseconds
 struct Stopwatch {
     bool on;
     std::chrono::steady_clock::time_point t0;
@@ -32,130 +33,252 @@ struct Stopwatch {
     }
 };
 
+constexpr int MAX_BATCH = 256;                      // verdicts of one launch fit the lane's pinned mailbox
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Prep {                                       // one file on its way to the device
+    int code = IMP_OK;
+    JpegHeader H;
+    JpegFrame F;
+    int dc_ids[2] = {-1, -1}, ac_ids[2] = {-1, -1};
+    JpegScan scan;
+    size_t nsegs = 0;
+    size_t words_off = 0, words_cap = 0;            // bytes, in the staging buffer and in the device copy alike
+    size_t coef_off = 0;                            // bytes in the coefficient area
+    size_t side_tables = 0, side_qt = 0, side_meta = 0;   // byte offsets in the side blob
+    size_t ctl_header = 0, ctl_records = 0;         // word offsets in the control area
+    impgpu_image* im = nullptr;
+};
+
+int decode_group(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
+    Stopwatch sw;
+    const bool on_device = !host_entropy_requested();
+    hipStream_t s = env_stream();
+    if (!s) return IMP_ERROR_DEVICE;
+    std::vector<Prep> P((size_t)count);
+    // ---- headers, geometry, the sizes of everything
+    size_t words_total = 0, coef_total = 0;
+    for (int i = 0; i < count; i++) {
+        Prep& p = P[(size_t)i];
+        images[i] = nullptr;
+        if (!blobs[i]) { p.code = IMP_ERROR_INVALID_ARGS; continue; }
+        p.code = jpeg_parse(blobs[i], sizes[i], &p.H);
+        if (!p.code && !frame_fits(p.H.width, p.H.height, p.H.ncomp)) p.code = IMP_ERROR_UNSUPPORTED;
+        if (!p.code) p.code = jpeg_frame_setup(p.H, &p.F, p.dc_ids, p.ac_ids);
+        if (p.code) continue;
+        const size_t total_mcus = (size_t)p.H.mcux * p.H.mcuy;
+        p.nsegs = p.H.restart_interval ? (total_mcus + p.H.restart_interval - 1) / p.H.restart_interval : 1;
+        p.words_cap = align_up(jpeg_scan_capacity(sizes[i] - p.H.scan_begin, p.nsegs), JPEG_CHUNK_BYTES);
+        p.words_off = words_total;
+        words_total += p.words_cap;
+        p.coef_off = coef_total;
+        coef_total += align_up((size_t)p.F.total_slots * sizeof(int16_t), 256);
+    }
+    sw.mark();                                                      // [0] headers
+    // ---- the compressed bytes: FF00 unstuffing while they are copied into pinned memory -- the only pass the host makes
+    // over them (device entropy stage), or the whole entropy decoding into pinned coefficient planes (A/B path)
+    void* host = nullptr;
+    void* token = nullptr;
+    int rc = stage_begin(on_device ? words_total : coef_total, &host, &token);
+    if (rc) return rc;
+    size_t live = 0;
+    for (int i = 0; i < count; i++) {
+        Prep& p = P[(size_t)i];
+        if (p.code) continue;
+        if (on_device) {
+            p.code = jpeg_prepare_scan(blobs[i], sizes[i], p.H, (uint8_t*)host + p.words_off, p.words_cap, &p.scan);
+            if (!p.code) {
+                p.F.nchunks = (unsigned)p.scan.nchunks;
+                p.F.nsegs = (unsigned)p.scan.seg_first_chunk.size();
+            }
+        } else {
+            int16_t* planes = (int16_t*)((uint8_t*)host + p.coef_off);
+            std::memset(planes, 0, (size_t)p.F.total_slots * sizeof(int16_t));
+            p.code = jpeg_host_entropy(blobs[i], sizes[i], p.H, planes, p.F);
+        }
+        if (!p.code) p.code = image_new(p.H.width, p.H.height, p.H.ncomp, &p.im);
+        if (!p.code) live++;
+    }
+    sw.mark();                                                      // [1] unstuffing copy / host entropy decoding
+    void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr;
+    size_t njobs = 0;
+    uint32_t* mailbox = lane_mailbox();
+    if (live == 0) { (void)stage_upload(token, nullptr, 0); goto done; }
+    if (!mailbox) { rc = IMP_ERROR_DEVICE; goto fail; }
+    {
+        // ---- the side blob: per job its tables, quantisers and interval arrays, then the job table and the workgroup maps
+        size_t side = 0, ctl_words = 4;                             // control: [0] ticket, then the jobs' headers, then their records
+        size_t total_blocks = 0;
+        size_t tiles[5] = {0, 0, 0, 0, 0};                          // per sampling class
+        auto klass = [](const JpegFrame& F) { return F.ncomp == 1 ? 0 : F.hs == 1 ? (F.vs == 1 ? 1 : 3) : (F.vs == 1 ? 2 : 4); };
+        for (Prep& p : P) {
+            if (p.code) continue;
+            p.ctl_header = ctl_words;
+            ctl_words += 4;
+        }
+        for (Prep& p : P) {
+            if (p.code) continue;
+            njobs++;
+            if (on_device) {
+                p.side_tables = side;
+                side += align_up(4 * sizeof(JpegHuffDev), 64);
+                p.side_meta = side;
+                side += align_up((p.scan.nchunks + 2 * p.scan.seg_first_chunk.size()) * sizeof(uint32_t), 64);
+                p.ctl_records = ctl_words;
+                ctl_words += (size_t)jpeg_entropy_blocks(p.F.nchunks) * JPEG_CTL_REC;
+                total_blocks += jpeg_entropy_blocks(p.F.nchunks);
+            }
+            p.side_qt = side;
+            side += align_up(3 * 64 * sizeof(uint16_t), 64);
+            tiles[klass(p.F)] += (size_t)((p.F.width + JPEG_TILE_W - 1) / JPEG_TILE_W) * ((p.F.height + JPEG_TILE_H - 1) / JPEG_TILE_H);
+        }
+        const size_t side_jobs = side;
+        side += align_up(njobs * sizeof(JpegJob), 64);
+        const size_t side_blocks = side;
+        side += align_up(total_blocks * sizeof(JpegMapEntry), 64);
+        size_t side_tiles[5];
+        for (int k = 0; k < 5; k++) { side_tiles[k] = side; side += align_up(tiles[k] * sizeof(JpegMapEntry), 64); }
+        rc = dev_alloc(side, &d_side);
+        if (!rc) rc = dev_alloc(coef_total, &d_coef);
+        if (!rc && on_device) rc = dev_alloc(words_total, &d_words);
+        if (!rc && on_device) rc = dev_alloc(ctl_words * sizeof(uint32_t), &d_ctl);
+        if (rc) goto fail;
+        std::vector<uint8_t> blob(side);
+        JpegJob* jobs = (JpegJob*)(blob.data() + side_jobs);
+        JpegMapEntry* bmap = (JpegMapEntry*)(blob.data() + side_blocks);
+        JpegMapEntry* tmap[5];
+        for (int k = 0; k < 5; k++) tmap[k] = (JpegMapEntry*)(blob.data() + side_tiles[k]);
+        size_t j = 0, nb = 0, nt[5] = {0, 0, 0, 0, 0};
+        std::vector<uint32_t> meta;
+        for (Prep& p : P) {
+            if (p.code) continue;
+            JpegJob& J = jobs[j];
+            std::memset(&J, 0, sizeof J);
+            J.F = p.F;
+            if (on_device) {
+                rc = jpeg_build_tables(p.H, p.dc_ids, p.ac_ids, (JpegHuffDev*)(blob.data() + p.side_tables));
+                if (rc) { p.code = rc; rc = IMP_OK; }               // (cannot happen after jpeg_parse; keeps the job inert)
+                jpeg_scan_meta(p.scan, &meta);
+                std::memcpy(blob.data() + p.side_meta, meta.data(), meta.size() * sizeof(uint32_t));
+                J.words = (const uint32_t*)((uint8_t*)d_words + p.words_off);
+                J.chunk_seg = (const uint32_t*)((uint8_t*)d_side + p.side_meta);
+                J.seg_first_chunk = J.chunk_seg + p.F.nchunks;
+                J.seg_bits = J.seg_first_chunk + p.F.nsegs;
+                J.tables = (const JpegHuffDev*)((uint8_t*)d_side + p.side_tables);
+                J.header = (uint32_t*)d_ctl + p.ctl_header;
+                J.records = (uint32_t*)d_ctl + p.ctl_records;
+                for (unsigned b = 0; b < jpeg_entropy_blocks(p.F.nchunks); b++) bmap[nb++] = JpegMapEntry{(uint32_t)j, b};
+            }
+            uint16_t* qt3 = (uint16_t*)(blob.data() + p.side_qt);
+            for (int c = 0; c < p.H.ncomp; c++) std::memcpy(qt3 + 64 * c, p.H.qt[p.H.comp[c].tq], 64 * sizeof(uint16_t));
+            J.qt = (const uint16_t*)((uint8_t*)d_side + p.side_qt);
+            J.coef = (int16_t*)((uint8_t*)d_coef + p.coef_off);
+            J.dst = p.im->d;
+            J.dstep = p.im->step;
+            const int k = klass(p.F);
+            const uint32_t ntiles = (uint32_t)(((p.F.width + JPEG_TILE_W - 1) / JPEG_TILE_W) * ((p.F.height + JPEG_TILE_H - 1) / JPEG_TILE_H));
+            for (uint32_t tl = 0; tl < ntiles; tl++) tmap[k][nt[k]++] = JpegMapEntry{(uint32_t)j, tl};
+            j++;
+        }
+        sw.mark();                                                  // [2] tables + job table
+        rc = upload_to(d_side, blob.data(), side, s);
+        if (!rc) rc = stage_upload(token, on_device ? d_words : d_coef, on_device ? words_total : coef_total);
+        token = nullptr;
+        if (rc) goto fail;
+        if (on_device) {
+            if (hipMemsetAsync(d_ctl, 0, ctl_words * sizeof(uint32_t), s) != hipSuccess || hipMemsetAsync(d_coef, 0, coef_total, s) != hipSuccess) {
+                set_error("hipMemsetAsync(jpeg)", hipGetLastError());
+                rc = IMP_ERROR_DEVICE;
+                goto fail;
+            }
+            rc = launch_jpeg_entropy((const JpegJob*)((uint8_t*)d_side + side_jobs), (const JpegMapEntry*)((uint8_t*)d_side + side_blocks),
+                                     (unsigned)total_blocks, (uint32_t*)d_ctl, s);
+            if (rc) goto fail;
+            // the kernel's verdicts (did every interval decode to exactly its MCUs?) are read before a frame is handed on
+            const hipError_t e = hipMemcpyAsync(mailbox, (uint32_t*)d_ctl + 4, njobs * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            if (e != hipSuccess) { set_error("hipMemcpyAsync(jpeg verdicts)", e); rc = IMP_ERROR_DEVICE; goto fail; }
+        }
+        static const int KH[5] = {1, 1, 2, 1, 2}, KV[5] = {1, 1, 1, 2, 2}, KN[5] = {1, 3, 3, 3, 3};
+        for (int k = 0; k < 5 && !rc; k++)
+            rc = launch_jpeg_pixels(KH[k], KV[k], KN[k], (const JpegJob*)((uint8_t*)d_side + side_jobs),
+                                    (const JpegMapEntry*)((uint8_t*)d_side + side_tiles[k]), (unsigned)tiles[k], s);
+        if (rc) goto fail;
+    }
+    sw.mark();                                                      // [3] enqueue
+    if (on_device) {
+        rc = lane_wait();
+        if (rc) goto fail;
+        size_t j = 0;
+        for (Prep& p : P) {
+            if (p.code) continue;
+            const uint32_t status = mailbox[4 * j + 1];
+            if (sw.on) std::fprintf(stderr, "jpeg %dx%d: rounds %u + %u, status %u\n", p.H.width, p.H.height, mailbox[4 * j + 2], mailbox[4 * j + 3], status);
+            if (status) {
+                char text[96];
+                std::snprintf(text, sizeof text, "jpeg entropy stage refused the scan (status 0x%x)", status);
+                set_error_text(text);
+                p.code = IMP_ERROR_DECODE_FAILED;
+            }
+            j++;
+        }
+    }
+    sw.mark();                                                      // [4] wait for the verdicts
+    if (sw.on)
+        std::fprintf(stderr, "jpeg x%d (%zu live): headers %.0f %s %.0f jobs %.0f enqueue %.0f wait %.0f us\n", count, live, sw.marks[0],
+                     on_device ? "unstuff" : "host-entropy", sw.marks[1], sw.marks[2], sw.marks[3], sw.marks[4]);
+done:
+    dev_free(d_words);
+    dev_free(d_coef);
+    dev_free(d_side);
+    dev_free(d_ctl);
+    for (int i = 0; i < count; i++) {
+        Prep& p = P[(size_t)i];
+        if (p.code && p.im) { image_delete(p.im); p.im = nullptr; }
+        images[i] = p.im;
+        codes[i] = p.code;
+    }
+    return IMP_OK;
+fail:
+    if (token) (void)stage_upload(token, nullptr, 0);
+    (void)lane_wait();                                              // nothing of this call may still be running when its buffers go back
+    dev_free(d_words);
+    dev_free(d_coef);
+    dev_free(d_side);
+    dev_free(d_ctl);
+    for (int i = 0; i < count; i++) {
+        if (P[(size_t)i].im) image_delete(P[(size_t)i].im);
+        images[i] = nullptr;
+        codes[i] = P[(size_t)i].code ? P[(size_t)i].code : rc;
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
 
-int impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_image** out) {
-    if (!blob || !out) return IMP_ERROR_INVALID_ARGS;
-    if (!env_ready()) { set_error("impgpu_env_start has not been called", hipErrorNotInitialized); return IMP_ERROR_DEVICE; }
+int impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
+    if (count < 0 || (count && (!blobs || !sizes || !images || !codes))) return IMP_ERROR_INVALID_ARGS;
+    if (!env_ready()) { set_error_text("impgpu_env_start has not been called"); return IMP_ERROR_DEVICE; }
     TraceRange tr("IMP_STEP_DECODE");
     IMP_FAULT_POINT(IMP_STEP_DECODE);
-    Stopwatch sw;
-    JpegHeader H;
-    if (int rc = jpeg_parse(blob, size, &H)) return rc;
-    if (!frame_fits(H.width, H.height, H.ncomp)) return IMP_ERROR_UNSUPPORTED;
-    JpegFrame F;
-    int dc_ids[2], ac_ids[2];
-    if (int rc = jpeg_frame_setup(H, &F, dc_ids, ac_ids)) return rc;
-    hipStream_t s = env_stream();
-    if (!s) return IMP_ERROR_DEVICE;
-
-    // quantisation tables of the three components, natural order
-    uint16_t qt3[3][64] = {};
-    for (int i = 0; i < H.ncomp; i++) std::memcpy(qt3[i], H.qt[H.comp[i].tq], sizeof qt3[i]);
-    void* d_qt = nullptr;
-    if (int rc = upload_small(qt3, sizeof qt3, &d_qt, s)) return rc;
-
-    void* d_coef = nullptr;
-    const size_t coef_bytes = (size_t)F.total_slots * sizeof(int16_t);
-    int rc = dev_alloc(coef_bytes, &d_coef);
-    if (rc) { dev_free(d_qt); return rc; }
-
-    sw.mark();                                                      // [0] parse + small uploads
-    uint32_t* status = lane_mailbox();                              // pinned: the verdict's copy stays asynchronous
-    if (!status) { dev_free(d_coef); dev_free(d_qt); return IMP_ERROR_DEVICE; }
-    status[0] = status[1] = status[2] = status[3] = 0;
-    const bool on_device = huff_mode() == HUFF_DEVICE;
-    if (!on_device) {
-        // A/B path: entropy decoding on this thread, dense coefficient planes over the link
-        void* host = nullptr;
-        void* token = nullptr;
-        rc = stage_begin(coef_bytes, &host, &token);
-        if (!rc) {
-            std::memset(host, 0, coef_bytes);
-            rc = jpeg_host_entropy(blob, size, H, (int16_t*)host, F);
-            const int rc2 = stage_upload(token, d_coef, rc ? 0 : coef_bytes);
-            if (!rc) rc = rc2;
-        }
-    } else {
-        void *d_tabs = nullptr, *d_words = nullptr, *d_meta = nullptr, *d_ctl = nullptr;
-        {
-            std::vector<JpegHuffDev> tabs(4);
-            rc = jpeg_build_tables(H, dc_ids, ac_ids, tabs.data());
-            if (!rc) rc = upload_small(tabs.data(), 4 * sizeof(JpegHuffDev), &d_tabs, s);
-        }
-        JpegScan scan;
-        const size_t total_mcus = (size_t)H.mcux * H.mcuy;
-        const size_t nsegs = H.restart_interval ? (total_mcus + H.restart_interval - 1) / H.restart_interval : 1;
-        const size_t cap = jpeg_scan_capacity(size - H.scan_begin, nsegs);
-        void* host = nullptr;
-        void* token = nullptr;
-        if (!rc) rc = stage_begin(cap, &host, &token);
-        if (!rc) {
-            // the only pass the host makes over the compressed bytes: FF00 unstuffing while they are copied into pinned memory
-            sw.mark();                                              // [1] tables + staging
-            rc = jpeg_prepare_scan(blob, size, H, (uint8_t*)host, cap, &scan);
-            sw.mark();                                              // [2] unstuffing copy
-            const size_t bytes = rc ? 0 : (scan.nchunks + 1) * JPEG_CHUNK_BYTES;
-            if (!rc) rc = dev_alloc(bytes, &d_words);
-            const int rc2 = stage_upload(token, d_words, rc ? 0 : bytes);
-            if (!rc) rc = rc2;
-        }
-        if (!rc) {
-            F.nchunks = (unsigned)scan.nchunks;
-            F.nsegs = (unsigned)scan.seg_first_chunk.size();
-            std::vector<uint32_t> meta;
-            jpeg_scan_meta(scan, &meta);
-            rc = upload_small(meta.data(), meta.size() * sizeof(uint32_t), &d_meta, s);
-        }
-        const size_t ctl_bytes = jpeg_control_bytes(F.nchunks);
-        if (!rc) rc = dev_alloc(ctl_bytes, &d_ctl);
-        if (!rc && hipMemsetAsync(d_ctl, 0, ctl_bytes, s) != hipSuccess) { set_error("hipMemsetAsync(jpeg control)", hipGetLastError()); rc = IMP_ERROR_DEVICE; }
-        if (!rc && hipMemsetAsync(d_coef, 0, coef_bytes, s) != hipSuccess) { set_error("hipMemsetAsync(jpeg coefficients)", hipGetLastError()); rc = IMP_ERROR_DEVICE; }
-        if (!rc) {
-            JpegHuffArgs A;
-            A.words = (const uint32_t*)d_words;
-            A.chunk_seg = (const uint32_t*)d_meta;
-            A.seg_first_chunk = A.chunk_seg + F.nchunks;
-            A.seg_bits = A.seg_first_chunk + F.nsegs;
-            A.tables = (const JpegHuffDev*)d_tabs;
-            A.coef = (int16_t*)d_coef;
-            A.control = (uint32_t*)d_ctl;
-            rc = launch_jpeg_entropy(F, A, s);
-        }
-        if (!rc) {
-            // the kernel's verdict (did every interval decode to exactly its MCUs?) is read before the frame is handed on
-            const hipError_t e = hipMemcpyAsync(status, (uint32_t*)d_ctl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-            if (e != hipSuccess) { set_error("hipMemcpyAsync(jpeg status)", e); rc = IMP_ERROR_DEVICE; }
-        }
-        dev_free(d_tabs);
-        dev_free(d_words);
-        dev_free(d_meta);
-        dev_free(d_ctl);
-    }
-    impgpu_image* im = nullptr;
-    if (!rc) rc = image_new(H.width, H.height, H.ncomp, &im);
-    if (!rc) rc = launch_jpeg_pixels(F, (const int16_t*)d_coef, (const uint16_t*)d_qt, im->d, im->step, s);
-    dev_free(d_coef);
-    dev_free(d_qt);
-    sw.mark();                                                      // [3] enqueue
-    if (!rc && on_device) {
-        rc = lane_wait();
-        if (!rc && status[1]) {
-            char text[96];
-            std::snprintf(text, sizeof text, "jpeg entropy stage refused the scan (status 0x%x)", status[1]);
-            set_error_text(text);
-            rc = IMP_ERROR_DECODE_FAILED;
+    for (int at = 0; at < count; at += MAX_BATCH) {
+        const int n = count - at < MAX_BATCH ? count - at : MAX_BATCH;
+        if (int rc = decode_group(blobs + at, sizes + at, n, images + at, codes + at)) {
+            for (int i = 0; i < at; i++) impgpu_image_release(&images[i]);
+            for (int i = at + n; i < count; i++) { images[i] = nullptr; codes[i] = rc; }
+            return rc;
         }
     }
-    sw.mark();                                                      // [4] wait for the verdict
-    if (sw.on)
-        std::fprintf(stderr, "jpeg %dx%d %zu B: parse %.0f tables %.0f unstuff %.0f enqueue %.0f wait %.0f us; rounds %u + %u, status %u\n", H.width,
-                     H.height, size, sw.marks[0], sw.marks[1], sw.marks[2], sw.marks[3], sw.marks[4], status[2], status[3], status[1]);
-    if (rc) { image_delete(im); return rc; }
-    *out = im;
     return IMP_OK;
+}
+
+int impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_image** out) {
+    if (!blob || !out) return IMP_ERROR_INVALID_ARGS;
+    *out = nullptr;
+    int code = IMP_OK;
+    const int rc = impgpu_batch_decode_jpeg(&blob, &size, 1, out, &code);
+    return rc ? rc : code;
 }
 
 }  // extern "C"

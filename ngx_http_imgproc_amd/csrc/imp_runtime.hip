@@ -30,7 +30,7 @@ namespace imp {
 constexpr int    RING_SEGS = 8;
 constexpr size_t RING_SEG_BYTES = size_t(128) << 10;   // blobs above this take a one-off pinned buffer
 constexpr int    N_STAGE = 2;
-constexpr size_t MAILBOX_BYTES = 256;                   // pinned words a kernel's verdict is copied into (behind the ring)
+constexpr size_t MAILBOX_BYTES = 4096;                  // pinned words a kernel's verdict is copied into (behind the ring)
 
 struct Staging {
     uint8_t* p = nullptr;
@@ -415,21 +415,30 @@ static int stage_reserve(Lane* L, size_t bytes, Staging** out) {
 // Small host blob -> pool memory, visible to work enqueued on `s` afterwards.  The copy itself always rides the lane's
 // stream (so ONE event per ring segment fences every copy out of it); a foreign `s` is made to wait for it.
 int upload_small(const void* host, size_t bytes, void** dev, hipStream_t s) {
-    Lane* L = lane();
-    if (!L) return no_env();
     void* p = nullptr;
     int rc = dev_alloc(bytes, &p);
     if (rc) return rc;
+    rc = upload_to(p, host, bytes, s);
+    if (rc) { dev_free(p); return rc; }
+    *dev = p;
+    return IMP_OK;
+}
+
+// The copy of upload_small into memory the caller already holds (pool memory of this lane, or a part of it).
+int upload_to(void* p, const void* host, size_t bytes, hipStream_t s) {
+    Lane* L = lane();
+    if (!L) return no_env();
+    int rc;
     const size_t need = (bytes + 63) & ~size_t(63);
     hipError_t e;
     if (need > RING_SEG_BYTES) {            // GIF albums and the like: through the frame staging buffers
         Staging* S = nullptr;
         rc = stage_reserve(L, bytes, &S);
-        if (rc) { dev_free(p); return rc; }
+        if (rc) return rc;
         std::memcpy(S->p, host, bytes);
         e = hipMemcpyAsync(p, S->p, bytes, hipMemcpyHostToDevice, L->stream);
         if (e == hipSuccess) e = hipEventRecord(S->done, L->stream);
-        if (e != hipSuccess) { set_error("hipMemcpyAsync(upload)", e); (void)hipStreamSynchronize(L->stream); dev_free(p); return IMP_ERROR_DEVICE; }
+        if (e != hipSuccess) { set_error("hipMemcpyAsync(upload)", e); (void)hipStreamSynchronize(L->stream); return IMP_ERROR_DEVICE; }
         S->busy = true;
     } else {
         if (L->seg_pos + need > RING_SEG_BYTES) {             // leave this segment: fence its copies, enter the next one
@@ -446,13 +455,12 @@ int upload_small(const void* host, size_t bytes, void** dev, hipStream_t s) {
         L->seg_pos += need;
         std::memcpy(slot, host, bytes);
         e = hipMemcpyAsync(p, slot, bytes, hipMemcpyHostToDevice, L->stream);
-        if (e != hipSuccess) { set_error("hipMemcpyAsync(small)", e); dev_free(p); return IMP_ERROR_DEVICE; }
+        if (e != hipSuccess) { set_error("hipMemcpyAsync(small)", e); return IMP_ERROR_DEVICE; }
     }
     if (s != L->stream) {
         rc = stream_join(s);
-        if (rc) { dev_free(p); return rc; }
+        if (rc) return rc;
     }
-    *dev = p;
     return IMP_OK;
 }
 

@@ -225,6 +225,20 @@ def run_ops(image, config, crop=None, gravity=None, resize=None, simple=0, filte
     return rc, step.value
 
 
+def batch_decode_jpeg(blobs):
+    """impgpu_batch_decode_jpeg -> [(code, Image or None)] in the order of `blobs`."""
+    n = len(blobs)
+    keep = [bytes(b) for b in blobs]
+    arr = (C.c_char_p * n)(*keep)
+    sizes = (C.c_size_t * n)(*[len(b) for b in keep])
+    imgs = (C.c_void_p * n)()
+    codes = (C.c_int * n)()
+    rc = lib.impgpu_batch_decode_jpeg(arr, sizes, n, imgs, codes)
+    if rc:
+        raise ImpError(rc, "impgpu_batch_decode_jpeg")
+    return [(codes[i], Image(handle=imgs[i]) if codes[i] == 0 else None) for i in range(n)]
+
+
 def jpeg_info(blob):
     w, h, c = C.c_int(), C.c_int(), C.c_int()
     rc = lib.impgpu_jpeg_info(bytes(blob), len(blob), w, h, c)

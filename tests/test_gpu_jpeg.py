@@ -207,3 +207,45 @@ def test_decodes_from_several_threads(gpu):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_batch_decode_mixed_files(gpu, huff):
+    """impgpu_batch_decode_jpeg: files of every sampling, size and restart layout in ONE call, refused files among them;
+    each gets the code and the pixels the single-file call gives."""
+    blobs, wants = [], []
+    for name in [c["name"] for c in MANIFEST["cases"]]:
+        blobs.append(golden_blob(name))
+    rng = np.random.Generator(np.random.PCG64(5))
+    for k in range(24):
+        h, w = int(rng.integers(1, 500)), int(rng.integers(1, 700))
+        arr = smooth_image(h, w, 3, seed=k) if k % 2 else noise_image(h, w, 3, k)
+        kw = dict(quality=int(rng.integers(20, 100)), subsampling=["4:4:4", "4:2:2", "4:2:0"][k % 3])
+        if k % 4 == 0:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+        blobs.append(encode(arr, **kw))
+    blobs.append(encode(smooth_image(40, 40, 3), quality=90, progressive=True))      # UNSUPPORTED
+    blobs.append(golden_blob("c420_q90_dri4_95x51")[:700])                           # truncated
+    blobs.append(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
+    blobs.append(encode(smooth_image(1080, 1920, 3), quality=90, subsampling="4:2:0"))
+    res = gpu.batch_decode_jpeg(blobs)
+    assert len(res) == len(blobs)
+    for b, (code, im) in zip(blobs, res):
+        rc_o, want = orc.jpeg_decode(b)
+        if rc_o == 0:
+            assert code == 0
+            assert np.array_equal(im.numpy(), want)
+            im.release()
+        else:
+            assert code in (gpu.IMP_ERROR_UNSUPPORTED, gpu.IMP_ERROR_DECODE_FAILED) and im is None
+    assert gpu.batch_decode_jpeg([]) == []
+
+
+def test_batch_decode_more_files_than_one_launch_takes(gpu):
+    blob = golden_blob("c420_q90_67x45")
+    want = EXPECTED["c420_q90_67x45"]
+    res = gpu.batch_decode_jpeg([blob] * 300)
+    assert all(code == 0 for code, _ in res)
+    for i in (0, 255, 256, 299):
+        assert np.array_equal(res[i][1].numpy(), want)
+    for _, im in res:
+        im.release()
