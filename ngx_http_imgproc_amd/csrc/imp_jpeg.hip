@@ -20,7 +20,7 @@ namespace {
 
 constexpr int HB = JPEG_HUFF_BLOCK;
 constexpr int CW = JPEG_CHUNK_WORDS;
-constexpr int WPITCH = CW + 1;                  // LDS pitch of a chunk: lanes at the same offset hit different banks
+
 constexpr unsigned CHUNK_BITS = CW * 32;
 constexpr int CTL_REC = JPEG_CTL_REC;
 
@@ -46,14 +46,16 @@ __device__ bool wait_flag(const uint32_t* flag) {
     return false;
 }
 
-__global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map,
+__global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_jpeg_entropy(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map,
                                                       uint32_t* __restrict__ launch_ticket) {
     __shared__ JpegHuffTabs L;
-    __shared__ uint32_t s_words[(HB + 1) * WPITCH];
-    __shared__ uint64_t s_exit[HB];
+    __shared__ uint64_t s_exit[HB], s_entry[HB];
+    __shared__ uint32_t s_segend[HB];
+    __shared__ uint8_t s_queue[HB];
+    __shared__ uint32_t s_queued;
     __shared__ uint32_t s_n[HB];
     __shared__ int s_dc[3][HB];
-    __shared__ uint32_t s_head[HB];             // 1 = an interval starts in or before this chunk (inside the workgroup)
+    __shared__ uint8_t s_head[HB];              // 1 = an interval starts in or before this chunk (inside the workgroup)
     __shared__ uint32_t s_ticket;
     __shared__ uint64_t s_pred;
     __shared__ uint32_t s_carry[4];
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__
     __syncthreads();
     const JpegMapEntry me = block_map[__builtin_amdgcn_readfirstlane(s_ticket)];
     const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
-    const JpegFrame F = J.F;
+    const JpegFrame& F = J.F;           // (a reference: scalar loads from the table; a copy of the struct would live in scratch memory)
     struct { const uint32_t *words, *chunk_seg, *seg_first_chunk, *seg_bits; const JpegHuffDev* tables; int16_t* coef; uint32_t *header, *records; } A =
         {J.words, J.chunk_seg, J.seg_first_chunk, J.seg_bits, J.tables, J.coef, J.header, J.records};
     // tables
@@ -76,13 +78,6 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__
     const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
     const uint32_t nblocks = (F.nchunks + HB - 1) / HB;
     const uint32_t g0 = b * HB, g = g0 + (uint32_t)t;
-    // the workgroup's chunks + one more, byte-swapped so that bit 31 of a word is the first bit of the stream
-    for (uint32_t i = (uint32_t)t; i < (HB + 1) * CW; i += HB) {
-        const uint32_t ch = g0 + i / CW;
-        uint32_t w = 0xffffffffu;
-        if (ch <= F.nchunks) w = __builtin_bswap32(A.words[(size_t)ch * CW + i % CW]);   // chunk nchunks is the guard chunk
-        s_words[(i / CW) * WPITCH + i % CW] = w;
-    }
     const bool live = g < F.nchunks;
     uint32_t seg = 0, first = 0, seg_end = 0, limit = 0;
     bool origin = false;
@@ -93,8 +88,11 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__
         seg_end = first * CHUNK_BITS + A.seg_bits[seg];
         limit = min((g + 1) * CHUNK_BITS, seg_end);
     }
-    const uint32_t word0 = g0 * CW;
-    auto word = [&](uint32_t i) -> uint32_t { const uint32_t k = i - word0; return s_words[(k / CW) * WPITCH + (k % CW)]; };
+    // The stream is read straight from memory: a lane walks its own 128-byte line, and the decoder keeps the next word a
+    // whole refill ahead in a register, so the latency is off the critical path; staging the workgroup's 33 KB in LDS bought
+    // nothing and cost two of every three resident workgroups.  (bit 31 of a word = the first bit of the stream: byte swap)
+    const uint32_t* __restrict__ words = A.words;
+    auto word = [&](uint32_t i) -> uint32_t { return __builtin_bswap32(__builtin_nontemporal_load(words + i)); };
     uint32_t* rec = A.records + (size_t)b * CTL_REC;
     const uint32_t* prec = rec - CTL_REC;
     __syncthreads();
@@ -111,9 +109,12 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__
     const uint64_t guess = jpeg_pack_state(g * CHUNK_BITS, 0, 0, 0);
     const uint64_t none = ~0ull;                                    // "no state": its flag bits are set
     uint64_t entry = none;
-    JpegDecoded d{};
     s_exit[t] = none;
-    if (t == 0) s_pred = none;
+    s_entry[t] = none;
+    s_segend[t] = seg_end;
+    s_n[t] = 0;
+    s_dc[0][t] = s_dc[1][t] = s_dc[2][t] = 0;
+    if (t == 0) { s_pred = none; s_queued = 0; }
     for (int phase = 0; phase < 3; phase++) {
         if (phase > 0) {
             const int at = phase == 1 ? 0 : 3;                      // tentative, then final
@@ -133,15 +134,28 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__
             // a predecessor with nothing to hand on (none yet, or it ran into an undecodable pattern -- a wrong guess,
             // normally): the lane's own guess.  Otherwise that dead state would travel a chunk per round to the interval's end.
             if (origin || (want >> 48)) want = guess;
-            __syncthreads();
-            int changed = 0;
+            // The chunks whose entry state changed are queued and the queue is worked off by the first lanes of the
+            // workgroup: after the first round or two only a few chunks per workgroup still move (the ones that take long to
+            // synchronise), and they should keep one wave busy, not four.
             if (live && want != entry) {
                 entry = want;
-                d = jpeg_decode_chunk<false>(L, word, entry, limit, seg_end, F, nullptr);
-                s_exit[t] = d.exit;
-                changed = 1;
+                s_entry[t] = want;
+                s_queue[atomicAdd(&s_queued, 1u)] = (uint8_t)t;
             }
-            if (!__syncthreads_or(changed)) { if (t == 0) atomicMax(&A.header[phase == 0 ? 2 : 3], (uint32_t)round); break; }
+            __syncthreads();
+            const uint32_t queued = s_queued;
+            if (queued == 0) { if (t == 0) atomicMax(&A.header[phase == 0 ? 2 : 3], (uint32_t)round); break; }
+            if ((uint32_t)t < queued) {
+                const uint32_t k = s_queue[t];
+                const JpegDecoded d = jpeg_decode_chunk<false>(L, word, s_entry[k], min((g0 + k + 1) * CHUNK_BITS, s_segend[k]), s_segend[k], F, nullptr);
+                s_exit[k] = d.exit;
+                s_n[k] = d.n;
+                s_dc[0][k] = d.dc[0];
+                s_dc[1][k] = d.dc[1];
+                s_dc[2][k] = d.dc[2];
+            }
+            __syncthreads();
+            if (t == 0) s_queued = 0;
         }
     }
     __syncthreads();
@@ -151,11 +165,8 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__
         st_release(rec + 3, 1u);
     }
     // ---- 4. running totals inside each interval: segmented inclusive scan over (n, dc0, dc1, dc2)
-    s_n[t] = live ? d.n : 0;
-    s_dc[0][t] = d.dc[0];
-    s_dc[1][t] = d.dc[1];
-    s_dc[2][t] = d.dc[2];
-    s_head[t] = origin ? 1u : 0u;
+    struct { uint32_t n; int dc[3]; } d = {s_n[t], {s_dc[0][t], s_dc[1][t], s_dc[2][t]}};     // this chunk's own
+    s_head[t] = origin ? 1 : 0;
     __syncthreads();
     for (int ofs = 1; ofs < HB; ofs <<= 1) {
         uint32_t n2 = 0, h2 = 0;
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_entropy(const JpegJob* __restrict__
         __syncthreads();
         if (take) {
             if (!myh) { s_n[t] += n2; s_dc[0][t] += a0; s_dc[1][t] += a1; s_dc[2][t] += a2; }
-            s_head[t] = myh | h2;
+            s_head[t] = (uint8_t)(myh | h2);
         }
         __syncthreads();
     }
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(const JpegJob* __restrict__
     const int t = threadIdx.x;
     const JpegMapEntry me = tile_map[blockIdx.x];
     const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
-    const JpegFrame F = J.F;
+    const JpegFrame& F = J.F;
     const int16_t* __restrict__ coef = J.coef;
     uint8_t* __restrict__ dst = J.dst;
     const int dstep = J.dstep;
