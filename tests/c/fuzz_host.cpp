@@ -12,6 +12,10 @@
 //   taps <ssize> <dsize> <interp> <is_x> -> checksum of the table
 //   area <ssize> <dsize>                 -> checksum of the table
 //   gauss <sigma as text>                -> ksize checksum
+//   jpeg <file bytes>                    -> rc of the sequential decoder, rc + status + sweeps of the chunk-parallel scheme
+//                                           run lane by lane, checksum of the coefficients (imp_jpeg.cpp: marker parser,
+//                                           table builder, scan preparation and both entropy decoders see the bytes of a
+//                                           file somebody uploaded)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +23,7 @@
 #include <sstream>
 #include <string>
 #include "../../ngx_http_imgproc_amd/csrc/imp_internal.h"
+#include "../../include/impgpu.h"
 
 static bool unhex(const std::string& h, std::string* out) {
     out->clear();
@@ -114,6 +119,24 @@ int main() {
                 for (int v : k) sum += v;
             }
             std::printf("%d %lld\n", n, sum);
+        } else if (kind == "jpeg") {
+            std::string h, blob;
+            in >> h;
+            unhex(h, &blob);
+            // exact-size heap copies: an over-read of the file by one byte is an AddressSanitizer report
+            std::vector<unsigned char> file(blob.begin(), blob.end());
+            int w = 0, hh = 0, c = 0;
+            const int rci = impgpu_jpeg_info(file.data(), file.size(), &w, &hh, &c);
+            unsigned long long sum0 = 0, sum1 = 0;
+            int rc0 = rci, rc1 = rci, info[12] = {0};
+            if (!rci && (long long)w * hh <= 4000000) {
+                std::vector<short> out((size_t)((w + 15) / 16 * 16) * ((hh + 15) / 16 * 16) * 3 + 4096);
+                rc0 = impgpu_jpeg_coefficients(file.data(), file.size(), 0, out.data(), out.size(), info);
+                if (!rc0) for (int i = 0; i < info[0]; i++) sum0 = sum0 * 31u + (unsigned short)out[(size_t)i];
+                rc1 = impgpu_jpeg_coefficients(file.data(), file.size(), 1, out.data(), out.size(), info);
+                if (!rc1) for (int i = 0; i < info[0]; i++) sum1 = sum1 * 31u + (unsigned short)out[(size_t)i];
+            }
+            std::printf("%d %d %d %llu %llu\n", rci, rc0, rc1, sum0, sum1);
         } else {
             std::printf("?\n");
         }
