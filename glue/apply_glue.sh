@@ -28,20 +28,22 @@ sed -i '714a\
 		ImpGpuRelease(\&gpu);' "$B"
 # encoders (bridge.c:680-710) read IplImages: bring the results back right after Step = ENCODE / Code = OK (bridge.c:681)
 sed -i '681a\
-	answer->Code = ImpGpuDownload(\&gpu, \&album);\
+	answer->Code = ImpGpuDownload(\&gpu, \&album, req->pool);\
 	if (answer->Code) {\
 		goto finalize;\
 	}' "$B"
 # text exit (bridge.c:669-670): ASCII() on the device frame
 sed -i '669,670c\
 		Memory res = ImpGpuASCII(\&gpu, quality ? quality : "", req->pool);' "$B"
-# json exit (bridge.c:661): Info() with the brightness reduction on the device
-sed -i '661c\
-		u_char* json = ImpGpuInfo(\&gpu, \&album, req->pool);' "$B"
+# json exit (bridge.c:661-662): Info() with the brightness reduction on the device; a device error is an error, not "brightness 0"
+sed -i '661,662c\
+		u_char* json = ImpGpuInfo(\&gpu, \&album, req->pool, \&answer->Code);\
+		if (answer->Code) {\
+			goto finalize;\
+		}' "$B"
 # Steps 3-7 (bridge.c:574-656): the crop / resize / filter / watermark / flatten loops
 sed -i '574,656c\
 	// Steps 3-7: main operators, on the GPU (glue/imp_gpu_bridge.c -> libimpgpu.so)\
-	ImpGpuAlbum gpu = { NULL, 0 };\
 	{\
 		int lacksAlpha = answer->MIME == IMP_MIME_JPG;\
 		#ifdef IMP_FEATURE_ADVANCED_IO\
@@ -58,11 +60,17 @@ sed -i '574,656c\
 		}\
 	}\
 ' "$B"
+# Step 2 (bridge.c:545): a JPEG is decoded on the device; whatever ImpGpuDecode does not take goes to cvDecodeImage as before
+sed -i '545c\
+	ImpGpuAlbum gpu = { NULL, 0 };\
+	if (decodeBasicIo \&\& ImpGpuDecode(blob, size, \&album, \&gpu, req->pool)) {\
+		// the frame is in HBM already\
+	} else if (decodeBasicIo) {' "$B"
 # worker lifecycle (bridge.c:10-16): the two "No op" bodies
 sed -i '15c\
 	ImpGpuEnvDestroy();' "$B"
 sed -i '11c\
-	ImpGpuEnvStart((int)ngx_worker);' "$B"
+	ImpGpuEnvStart(IMP_GPU_WORKER_INDEX);' "$B"
 sed -i '5a\
 #include "glue/imp_gpu_bridge.h"' "$B"
 

@@ -48,16 +48,45 @@ static int FillConfig(Config* config, impgpu_config* g) {
     return IMP_OK;
 }
 
+int ImpGpuDecode(u_char* blob, size_t size, Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool) {
+    impgpu_image* frame = NULL;
+    /* SIG_JPG (bridge.c:8).  Anything the device decoder does not take -- progressive, CMYK, damaged files: a non-zero
+     * code -- goes to cvDecodeImage exactly as before, so no request changes its answer */
+    if (size < 3 || blob[0] != 0xFF || blob[1] != 0xD8 || blob[2] != 0xFF) {
+        return 0;
+    }
+    if (impgpu_image_decode_jpeg(blob, size, &frame) != IMP_OK) {
+        return 0;
+    }
+    gpu->Frames   = ngx_pcalloc(pool, sizeof(impgpu_image*));
+    album->Frames = ngx_palloc(pool, sizeof(Frame));
+    if (!gpu->Frames || !album->Frames) {
+        impgpu_image_release(&frame);
+        gpu->Frames = NULL;
+        return 0;
+    }
+    gpu->Frames[0] = frame;
+    gpu->Count     = 1;
+    /* the host never sees the decoded pixels: Image stays NULL until ImpGpuDownload creates the encoder's input
+     * (cvReleaseImage at bridge.c:719 accepts a NULL image) */
+    album->Count = 1;
+    album->Frames[0].Image = NULL;
+    album->Frames[0].Time = album->Frames[0].Dispose = album->Frames[0].TransparencyKey = 0;
+    return 1;
+}
+
 int ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* crop, char* gravity, char* resize, int simple,
                     char** filters, int filterCount, int lacksAlpha, Config* config, int* step) {
     impgpu_config gcfg;
     impgpu_job job;
     int fid;
 
-    gpu->Count = 0;
-    gpu->Frames = ngx_pcalloc(pool, album->Count * sizeof(impgpu_image*));
-    if (!gpu->Frames) {
-        return IMP_ERROR_MALLOC_FAILED;
+    if (!gpu->Frames) {             /* (a frame ImpGpuDecode put on the device is already there) */
+        gpu->Count = 0;
+        gpu->Frames = ngx_pcalloc(pool, album->Count * sizeof(impgpu_image*));
+        if (!gpu->Frames) {
+            return IMP_ERROR_MALLOC_FAILED;
+        }
     }
 
     *step = IMP_STEP_WATERMARK;
@@ -76,14 +105,16 @@ int ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* crop
 
     /* every frame is enqueued before any is waited for: uploads, kernels and the next frame's upload overlap */
     for (fid = 0; fid < album->Count; fid++) {
-        IplImage* image = album->Frames[fid].Image;
-        *step = IMP_STEP_DECODE;
-        rc = impgpu_image_upload((unsigned char*)image->imageData, image->width, image->height, image->nChannels,
-                                 image->widthStep, &gpu->Frames[fid]);
-        if (rc) {
-            return rc;
+        if (fid >= gpu->Count) {
+            IplImage* image = album->Frames[fid].Image;
+            *step = IMP_STEP_DECODE;
+            rc = impgpu_image_upload((unsigned char*)image->imageData, image->width, image->height, image->nChannels,
+                                     image->widthStep, &gpu->Frames[fid]);
+            if (rc) {
+                return rc;
+            }
+            gpu->Count = fid + 1;
         }
-        gpu->Count = fid + 1;
         rc = impgpu_run_ops(&gpu->Frames[fid], &job, &gcfg, step);
         if (rc) {
             return rc;
@@ -92,10 +123,13 @@ int ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* crop
     return IMP_OK;
 }
 
-u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool) {
+u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool, int* code) {
     float brightness = 0;
     u_char* json = ngx_palloc(pool, 256 * sizeof(u_char));
-    impgpu_calc_perceived_brightness(gpu->Frames[0], &brightness);
+    *code = json ? impgpu_calc_perceived_brightness(gpu->Frames[0], &brightness) : IMP_ERROR_MALLOC_FAILED;
+    if (*code) {                    /* a lost device must not read as "brightness 0", HTTP 200 */
+        return NULL;
+    }
     sprintf(
         (char*)json,
         "{"
@@ -122,27 +156,43 @@ Memory ImpGpuASCII(ImpGpuAlbum* gpu, char* args, ngx_pool_t* pool) {
     return result;
 }
 
-int ImpGpuDownload(ImpGpuAlbum* gpu, Album* album) {
-    int fid;
+int ImpGpuDownload(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool) {
+    int fid, rc = IMP_OK;
+    IplImage** fresh = ngx_pcalloc(pool, gpu->Count * sizeof(IplImage*));
+    unsigned char** rows = ngx_pcalloc(pool, gpu->Count * sizeof(unsigned char*));
+    int* steps = ngx_pcalloc(pool, gpu->Count * sizeof(int));
+    if (!fresh || !rows || !steps) {
+        return IMP_ERROR_MALLOC_FAILED;
+    }
     for (fid = 0; fid < gpu->Count; fid++) {
         impgpu_image* frame = gpu->Frames[fid];
-        IplImage* old = album->Frames[fid].Image;
         /* same header rules as every cvCreateImage in bridge.c: 8-bit, rows padded to 4 bytes -- the layout the
          * device frame already has, so cvEncodeImage / IplToFI32 / IplToFI24 read it unchanged */
-        IplImage* fresh = cvCreateImage(cvSize(impgpu_image_width(frame), impgpu_image_height(frame)), IPL_DEPTH_8U,
-                                        impgpu_image_channels(frame));
-        if (!fresh || !fresh->imageData) {
-            return IMP_ERROR_MALLOC_FAILED;
+        fresh[fid] = cvCreateImage(cvSize(impgpu_image_width(frame), impgpu_image_height(frame)), IPL_DEPTH_8U,
+                                   impgpu_image_channels(frame));
+        if (!fresh[fid] || !fresh[fid]->imageData) {
+            rc = IMP_ERROR_MALLOC_FAILED;
+            break;
         }
-        int rc = impgpu_image_download(frame, (unsigned char*)fresh->imageData, fresh->widthStep);
-        if (rc) {
-            cvReleaseImage(&fresh);
-            return rc;
-        }
-        cvReleaseImage(&old);
-        album->Frames[fid].Image = fresh;
+        rows[fid]  = (unsigned char*)fresh[fid]->imageData;
+        steps[fid] = fresh[fid]->widthStep;
     }
-    return IMP_OK;
+    /* all frames of the album in one transfer, one wait */
+    if (!rc) {
+        rc = impgpu_batch_download((const impgpu_image* const*)gpu->Frames, gpu->Count, rows, steps);
+    }
+    for (fid = 0; fid < gpu->Count; fid++) {
+        if (rc) {
+            if (fresh[fid]) {
+                cvReleaseImage(&fresh[fid]);
+            }
+        } else {
+            IplImage* old = album->Frames[fid].Image;
+            cvReleaseImage(&old);
+            album->Frames[fid].Image = fresh[fid];
+        }
+    }
+    return rc;
 }
 
 void ImpGpuRelease(ImpGpuAlbum* gpu) {

@@ -4,14 +4,17 @@
  * Compiled INTO the reference module (it uses the reference's own types: Album, Frame, Config, Memory from required.h),
  * next to bridge.c; glue/apply_glue.sh makes the edits in the reference's files that call these functions:
  *   bridge.c:10-16    OnEnvStart / OnEnvDestroy bodies      -> ImpGpuEnvStart / ImpGpuEnvDestroy
+ *   bridge.c:545      before cvDecodeImage                  -> ImpGpuDecode     (a JPEG is decoded on the device; else as before)
  *   bridge.c:574-656  crop / resize / filter / watermark / flatten loops over the album -> ImpGpuOperators
  *   bridge.c:661      Info()                                -> ImpGpuInfo      (brightness reduced on the device)
  *   bridge.c:669-670  ASCII()                               -> ImpGpuASCII
  *   bridge.c:681      before either encoder runs            -> ImpGpuDownload  (frames back into IplImages)
  *   bridge.c:714      finalize:                             -> ImpGpuRelease
  *   required.h:117    Config gains `void* WatermarkDevice`  (per-worker handle of the uploaded overlay)
- * Needs nginx, OpenCV 2.4 and FreeImage headers exactly like the files around it, so it is not built in this repository;
- * the C ABI underneath it is exercised from C by tests/c/runjob_harness.c.
+ * Needs nginx, OpenCV 2.4 and FreeImage headers exactly like the files around it, so it is not BUILT in this repository;
+ * tests/test_glue.py compiles it (and the patched bridge.c) with -fsyntax-only against declaration-only stand-ins for
+ * those headers (tests/c/decls/, a compile check of this glue and nothing else), and the C ABI underneath it is exercised
+ * from C by tests/c/runjob_harness.c.
  */
 #ifndef IMP_GPU_BRIDGE_H
 #define IMP_GPU_BRIDGE_H
@@ -23,18 +26,29 @@ typedef struct {
     int            Count;
 } ImpGpuAlbum;
 
-/* once per worker process, after fork (module.c:100-107).  worker = ngx_worker: worker i drives GPU i mod #GPUs. */
+/* once per worker process, after fork (module.c:100-107).  worker = ngx_worker (nginx >= 1.9.1) or ngx_process_slot:
+ * worker i drives GPU i mod #GPUs. */
+#if defined(nginx_version) && nginx_version >= 1009001
+#define IMP_GPU_WORKER_INDEX ((int)ngx_worker)
+#else
+#define IMP_GPU_WORKER_INDEX ((int)ngx_process_slot)
+#endif
 void   ImpGpuEnvStart(int worker);
 void   ImpGpuEnvDestroy(void);
 
-/* Steps 3-7 of RunJob for every frame of the album: upload, then crop -> resize -> [gray->BGR] -> filters -> watermark ->
+/* bridge.c:545-552 for a JPEG blob: returns 1 when the file was decoded on the device (album gets its one frame with
+ * Image = NULL, gpu holds the device frame), 0 when the caller must decode on the host as before (not a JPEG, a JPEG the
+ * device decoder does not take, or a damaged one). */
+int    ImpGpuDecode(u_char* blob, size_t size, Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool);
+
+/* Steps 3-7 of RunJob for every frame of the album: upload (unless ImpGpuDecode put it there), then crop -> resize -> [gray->BGR] -> filters -> watermark ->
  * flatten in the reference's fixed order.  `lacksAlpha` = the chosen encoder cannot store alpha (bridge.c:643-647).
  * Returns the IMP_* code and leaves the failing IMP_STEP_* in *step (JobResult.Step). */
 int    ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* crop, char* gravity, char* resize, int simple,
                        char** filters, int filterCount, int lacksAlpha, Config* config, int* step);
-u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool);            /* bridge.c:283-300 */
+u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool, int* code); /* bridge.c:283-300; NULL + *code on a device error */
 Memory ImpGpuASCII(ImpGpuAlbum* gpu, char* args, ngx_pool_t* pool);              /* filters.c:488-522 */
-int    ImpGpuDownload(ImpGpuAlbum* gpu, Album* album);                           /* results -> fresh IplImages */
+int    ImpGpuDownload(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool);         /* results -> fresh IplImages, one wait */
 void   ImpGpuRelease(ImpGpuAlbum* gpu);
 
 #endif

@@ -149,6 +149,8 @@ int   impgpu_image_wrap(void* device_ptr, int width, int height, int channels, i
                         impgpu_image** out);               /* borrow memory already in HBM */
 int   impgpu_image_clone(const impgpu_image* src, impgpu_image** out);
 int   impgpu_image_download(const impgpu_image* image, unsigned char* data, int step); /* syncs */
+/* the same for every frame of an album (bridge.c:680-710 reads them all): all copies are enqueued, then ONE wait */
+int   impgpu_batch_download(const impgpu_image* const* images, int count, unsigned char* const* datas, const int* steps);
 int   impgpu_image_width(const impgpu_image* image);
 int   impgpu_image_height(const impgpu_image* image);
 int   impgpu_image_channels(const impgpu_image* image);

@@ -94,6 +94,7 @@ SIGNATURES = {
     "impgpu_gif_compose": (C.c_int, [C.POINTER(CGifPage), C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_clone": (C.c_int, [P, PP]),
     "impgpu_image_download": (C.c_int, [P, P, C.c_int]),
+    "impgpu_batch_download": (C.c_int, [PP, C.c_int, PP, IP]),
     "impgpu_image_width": (C.c_int, [P]),
     "impgpu_image_height": (C.c_int, [P]),
     "impgpu_image_channels": (C.c_int, [P]),

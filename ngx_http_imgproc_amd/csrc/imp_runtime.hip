@@ -743,6 +743,37 @@ int impgpu_image_download(const impgpu_image* im, unsigned char* data, int step)
     return IMP_OK;
 }
 
+int impgpu_batch_download(const impgpu_image* const* images, int count, unsigned char* const* datas, const int* steps) {
+    if (count < 0 || (count && (!images || !datas || !steps))) return IMP_ERROR_INVALID_ARGS;
+    Lane* L = lane();
+    if (!L) return no_env();
+    TraceRange tr("IMP_STEP_ENCODE");
+    IMP_FAULT_POINT(IMP_STEP_ENCODE);
+    size_t total = 0;
+    for (int i = 0; i < count; i++) {
+        if (!images[i] || !datas[i] || steps[i] < images[i]->w * images[i]->c) return IMP_ERROR_INVALID_ARGS;
+        total += ((size_t)images[i]->step * images[i]->h + 63) & ~size_t(63);
+    }
+    if (!total) return IMP_OK;
+    Staging* S = nullptr;
+    if (int rc = stage_reserve(L, total, &S)) return rc;
+    size_t at = 0;
+    for (int i = 0; i < count; i++) {                           // every frame's copy is enqueued before the one wait
+        const size_t bytes = (size_t)images[i]->step * images[i]->h;
+        IMP_HIP(hipMemcpyAsync(S->p + at, images[i]->d, bytes, hipMemcpyDeviceToHost, L->stream));
+        at += (bytes + 63) & ~size_t(63);
+    }
+    if (int rc = lane_wait()) return rc;
+    at = 0;
+    for (int i = 0; i < count; i++) {
+        const impgpu_image* im = images[i];
+        const size_t rowbytes = (size_t)im->w * im->c;
+        for (int y = 0; y < im->h; y++) std::memcpy(datas[i] + (size_t)y * steps[i], S->p + at + (size_t)y * im->step, rowbytes);
+        at += ((size_t)im->step * im->h + 63) & ~size_t(63);
+    }
+    return IMP_OK;
+}
+
 int impgpu_image_width(const impgpu_image* im) { return im ? im->w : 0; }
 int impgpu_image_height(const impgpu_image* im) { return im ? im->h : 0; }
 int impgpu_image_channels(const impgpu_image* im) { return im ? im->c : 0; }

@@ -1,6 +1,9 @@
-"""glue/ (SURVEY 8f N3): the nginx-side binding as source.  It cannot be compiled here (nginx / OpenCV / FreeImage headers
-are absent), so what is checked is that glue/apply_glue.sh applies to the reference revision it names and leaves RunJob
-calling the glue instead of the five CPU loops.  The reference only exists in the build container: skipped elsewhere."""
+"""glue/ (SURVEY 8f N3): the nginx-side binding as source.  It cannot be BUILT here (nginx / OpenCV / FreeImage headers and
+libraries are absent); what is checked is that glue/apply_glue.sh applies to the reference revision it names, leaves RunJob
+calling the glue instead of the five CPU loops, and that the result COMPILES: `gcc -fsyntax-only -std=gnu99` over the
+patched bridge.c and glue/imp_gpu_bridge.c against tests/c/decls/ -- declaration-only stand-ins for those headers, test
+scaffolding for this one compile check (no oracle, no _ref, nothing is linked or run).  The reference only exists in the
+build container: skipped elsewhere."""
 import os
 import shutil
 import subprocess
@@ -22,15 +25,27 @@ def test_apply_glue_rewrites_the_operator_segment(tmp_path):
     subprocess.check_call([os.path.join(ROOT, "glue", "apply_glue.sh"), str(work)])
     bridge = (work / "bridge.c").read_text()
     run_job = bridge[bridge.index("RunJob("):]
-    for call in ("ImpGpuOperators(&album, &gpu", "ImpGpuInfo(&gpu", "ImpGpuASCII(&gpu", "ImpGpuDownload(&gpu", "ImpGpuRelease(&gpu"):
+    for call in ("ImpGpuDecode(blob, size, &album, &gpu", "ImpGpuOperators(&album, &gpu", "ImpGpuInfo(&gpu", "ImpGpuASCII(&gpu", "ImpGpuDownload(&gpu", "ImpGpuRelease(&gpu"):
         assert run_job.count(call) == 1, call
     for gone in ("Crop(&image", "Resize(&image", "Filter(&image", "Watermark(image", "BlendWithPaper(image", "CV_GRAY2BGR"):
         assert gone not in run_job, gone
-    assert "ImpGpuEnvStart((int)ngx_worker);" in bridge and "ImpGpuEnvDestroy();" in bridge
+    assert "ImpGpuEnvStart(IMP_GPU_WORKER_INDEX);" in bridge and "ImpGpuEnvDestroy();" in bridge
+    assert run_job.index("ImpGpuAlbum gpu = { NULL, 0 };") < run_job.index("goto finalize")     # declared before every jump to the release
+    assert "cvDecodeImage(&rawencoded, -1)" in run_job                                              # the host decoder stays as the fallback
     assert run_job.count("{") == run_job.count("}")                      # the edit kept the function balanced
     assert "WatermarkDevice;" in (work / "required.h").read_text()
     assert "glue/imp_gpu_bridge.c" in (work / "config").read_text() and "-limpgpu" in (work / "config").read_text()
     assert (work / "glue" / "imp_gpu_bridge.c").exists()
+    # the patched module compiles: every call matches its prototype, nothing of impgpu.h clashes with required.h, and both
+    # spellings of the worker index exist (ngx_worker came with nginx 1.9.1)
+    decls = os.path.join(ROOT, "tests", "c", "decls")
+    for extra in ([], ["-Dnginx_version=1009005"], ["-Dnginx_version=1004006"]):
+        for src in ("bridge.c", os.path.join("glue", "imp_gpu_bridge.c")):
+            p = subprocess.run(["gcc", "-fsyntax-only", "-std=gnu99", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
+                                "-Werror=int-conversion", "-I", decls, "-I", os.path.join(ROOT, "include"), "-I", str(work)] + extra + [src],
+                               cwd=str(work), capture_output=True, text=True)
+            assert p.returncode == 0, p.stderr[-3000:]
+            assert "warning" not in p.stderr, p.stderr[-3000:]
     # a second application must refuse (the hashes no longer match) instead of editing by stale line numbers
     assert subprocess.call([os.path.join(ROOT, "glue", "apply_glue.sh"), str(work)], stderr=subprocess.DEVNULL) != 0
 

@@ -249,3 +249,24 @@ def test_batch_decode_more_files_than_one_launch_takes(gpu):
         assert np.array_equal(res[i][1].numpy(), want)
     for _, im in res:
         im.release()
+
+
+def test_batch_download_one_wait_for_an_album(gpu):
+    """impgpu_batch_download (the encoders' hand-over for every frame of an album): frames of different geometry and
+    channel count, caller rows with their own pitch."""
+    import ctypes as C
+
+    frames = [noise_image(37, 53, 4, 1), noise_image(20, 31, 3, 2), noise_image(5, 7, 1, 3), noise_image(64, 64, 4, 4)]
+    ims = [gpu.Image(f) for f in frames]
+    n = len(ims)
+    outs = [np.full((f.shape[0], f.shape[1] * f.shape[2] + 5), 0xEE, dtype=np.uint8) for f in frames]
+    handles = (C.c_void_p * n)(*[im.h for im in ims])
+    datas = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    steps = (C.c_int * n)(*[o.shape[1] for o in outs])
+    assert gpu.lib.impgpu_batch_download(handles, n, datas, steps) == 0
+    for f, o in zip(frames, outs):
+        assert np.array_equal(o[:, : f.shape[1] * f.shape[2]].reshape(f.shape), f)
+        assert np.all(o[:, f.shape[1] * f.shape[2]:] == 0xEE)          # the caller's padding is not touched
+    assert gpu.lib.impgpu_batch_download(handles, n, datas, (C.c_int * n)(1, 1, 1, 1)) == gpu.IMP_ERROR_INVALID_ARGS
+    for im in ims:
+        im.release()
