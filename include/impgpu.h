@@ -97,6 +97,12 @@ const char* impgpu_last_error(void);            /* text of the last HIP failure 
 int         impgpu_sync(void);                  /* wait for the env stream */
 void*       impgpu_env_stream(void);            /* the env's hipStream_t */
 
+/* Test hook (failure detection): the nth entry (1 = the next) into the given IMP_STEP_* behaves as if its first
+ * HIP call had failed -- IMP_ERROR_DEVICE, impgpu_last_error() says "injected fault", the failing step is reported like
+ * any other -- so the path a lost device takes can be tested without losing one.  step < 0 disarms.  Armed by this call
+ * only, never by the environment. */
+int         impgpu_fault_arm(int step, long nth);
+
 /* ---- frames: the decode -> operators hand-over (bridge.c:547-552, advancedio.c:310-318)
  *      and the operators -> encode hand-over (bridge.c:703-704, advancedio.c:65-101) ---- */
 int   impgpu_image_upload(const unsigned char* data, int width, int height, int channels,

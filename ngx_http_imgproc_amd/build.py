@@ -49,7 +49,22 @@ def _hipcc():
     return "hipcc"
 
 
-OBJ = os.path.join(HERE, "_obj")
+def _extra_flags():
+    return os.environ.get("IMPGPU_EXTRA_FLAGS", "").split()      # A/B builds: -DNAME=value
+
+
+def _variant():
+    """Objects and library of an A/B build (IMPGPU_EXTRA_FLAGS) live apart from the default ones: same-named files built
+    with other flags would otherwise look up to date to the next plain build."""
+    import hashlib
+
+    extra = _extra_flags()
+    return ("_" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10]) if extra else ""
+
+
+OBJ = os.path.join(HERE, "_obj" + _variant())
+if _variant():
+    LIB = os.environ.get("IMPGPU_LIB") or os.path.join(HERE, "libimpgpu%s.so" % _variant())
 
 
 def _stale(target, deps):
@@ -75,7 +90,7 @@ def build_library(force=False, verbose=False):
 
     os.makedirs(OBJ, exist_ok=True)
     compile_flags = [f for f in FLAGS if f != "-shared"] + ["-c", "-I", os.path.join(HERE, "..", "include")]
-    compile_flags += os.environ.get("IMPGPU_EXTRA_FLAGS", "").split()      # A/B builds: -DNAME=value (pair with IMPGPU_LIB)
+    compile_flags += _extra_flags()               # an A/B build writes libimpgpu_<hash>.so (or $IMPGPU_LIB); load it with IMPGPU_LIB
     jobs = []
     for f in SOURCES:
         src = os.path.join(CSRC, f)

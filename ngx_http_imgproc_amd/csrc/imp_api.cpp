@@ -426,7 +426,9 @@ int impgpu_batch_cv_resize(const void* src, long long src_frame_stride, int src_
                            void* dst, long long dst_frame_stride, int dst_width, int dst_height, int dst_step,
                            int channels, int count, int interpolation, void* stream) {
     if (!src || !dst || (channels != 1 && channels != 3 && channels != 4)) return IMP_ERROR_INVALID_ARGS;
-    if (src_step < src_width * channels || dst_step < dst_width * channels) return IMP_ERROR_INVALID_ARGS;
+    if (!view_fits(src_width, src_height, channels, src_step) || !view_fits(dst_width, dst_height, channels, dst_step)) return IMP_ERROR_INVALID_ARGS;
+    if (count < 0 || count > 65535 || (count > 1 && (src_frame_stride < 0 || dst_frame_stride < 0))) return IMP_ERROR_INVALID_ARGS;
+    if (interpolation < IMP_INTER_NN || interpolation > IMP_INTER_LANCZOS4) return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;
     Frames f{};
     f.src = (const uint8_t*)src; f.src_stride = src_frame_stride;
@@ -437,7 +439,11 @@ int impgpu_batch_cv_resize(const void* src, long long src_frame_stride, int src_
 }
 
 int impgpu_batch_resize_mixed(const impgpu_resize_item* items, int count, int channels, int simple, void* stream) {
-    if (count < 0 || (count > 0 && !items)) return IMP_ERROR_INVALID_ARGS;
+    if (count < 0 || (count > 0 && !items) || (channels != 1 && channels != 3 && channels != 4)) return IMP_ERROR_INVALID_ARGS;
+    for (int i = 0; i < count; i++)                                     // (again in the launcher; here so that it answers without a device)
+        if (!items[i].src || !items[i].dst || !view_fits(items[i].src_width, items[i].src_height, channels, items[i].src_step) ||
+            !view_fits(items[i].dst_width, items[i].dst_height, channels, items[i].dst_step))
+            return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;
     static_assert(sizeof(MixFrame) == sizeof(impgpu_resize_item) && offsetof(MixFrame, dst) == offsetof(impgpu_resize_item, dst),
                   "MixFrame mirrors impgpu_resize_item");
@@ -451,6 +457,10 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
                                          const impgpu_config* config, int channels, int count, void* stream) {
     if (!src || !dst || !config || (channels != 3 && channels != 4)) return IMP_ERROR_INVALID_ARGS;
     if (rotate != 0 && rotate != 90 && rotate != 180 && rotate != 270) return IMP_ERROR_INVALID_ARGS;
+    if (!view_fits(src_width, src_height, channels, src_step) || resize_width <= 0 || resize_height <= 0 ||
+        !view_fits(rotate == 90 || rotate == 270 ? resize_height : resize_width, rotate == 90 || rotate == 270 ? resize_width : resize_height, channels, dst_step))
+        return IMP_ERROR_INVALID_ARGS;
+    if (count < 0 || count > 65535 || (count > 1 && (src_frame_stride < 0 || dst_frame_stride < 0))) return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : env_stream();
     const int interp = (resize_width > src_width || resize_height > src_height) ? IMP_INTER_CUBIC : IMP_INTER_AREA;  // bridge.c:190
@@ -536,7 +546,8 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
 
 int impgpu_batch_filters(void* frames, long long frame_stride, int width, int height, int channels, int step, int count,
                          const char* const* filters, int filter_count, int allow_experiments, void* stream) {
-    if (!frames || !filters || filter_count < 0 || (channels != 3 && channels != 4) || (long long)step < (long long)width * channels) return IMP_ERROR_INVALID_ARGS;
+    if (!frames || !filters || filter_count < 0 || (channels != 3 && channels != 4) || !view_fits(width, height, channels, step)) return IMP_ERROR_INVALID_ARGS;
+    if (count < 0 || count > 65535 || (count > 1 && frame_stride < 0)) return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;
     PixelProgram prog;
     for (int i = 0; i < filter_count; i++) {

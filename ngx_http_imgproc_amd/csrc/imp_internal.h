@@ -36,6 +36,13 @@ inline bool frame_fits(int w, int h, int c) {
     const long long step = ((long long)w * c + 3) & ~3LL;
     return (long long)w * h <= (1LL << 30) && step * h <= 0xffffffffLL && step <= 0x7fffffffLL;
 }
+// A caller-described frame (batch entry points, impgpu_image_wrap): positive size, a pitch that holds a row, and everything
+// the kernels compute in 32 bits -- pixel count, row offsets, byte offsets inside a frame -- in range.  64-bit arithmetic:
+// `step < w * c` in int wraps for the sizes this is meant to refuse.
+inline bool view_fits(long long w, long long h, int c, long long step) {
+    return w > 0 && h > 0 && w <= 0x7fffffffLL && h <= 0x7fffffffLL && step >= w * c && step <= 0x7fffffffLL &&
+           w * h <= (1LL << 30) && step * h <= 0xffffffffLL;
+}
 
 // ---------------------------------------------------------------- runtime (imp_runtime.hip)
 void set_error(const char* what, hipError_t e);
@@ -77,9 +84,9 @@ struct TraceRange {
     TraceRange(const TraceRange&) = delete;
     TraceRange& operator=(const TraceRange&) = delete;
 };
-// Fault injection: IMPGPU_FAULT=<step>[:<n>] read at impgpu_env_start makes the n-th (default first) entry into
-// that IMP_STEP_* behave as if its first HIP call had failed: IMP_ERROR_DEVICE, impgpu_last_error() says so, the failing
-// step is reported like any other -- the path a lost device takes, testable without losing one.
+// Fault injection: impgpu_fault_arm(step, n) makes the n-th entry into that IMP_STEP_* behave as if its first
+// HIP call had failed: IMP_ERROR_DEVICE, impgpu_last_error() says so, the failing step is reported like any other -- the
+// path a lost device takes, testable without losing one.  Never armed from the environment.
 bool fault_hit(int step);
 #define IMP_FAULT_POINT(step)                                     \
     do {                                                          \

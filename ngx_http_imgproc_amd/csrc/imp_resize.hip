@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void k_resize_taps(RArgs a, const int* __restr
                                                      const short* __restrict__ xco,
                                                      const int* __restrict__ yofs,
                                                      const short* __restrict__ yco, int vec_end) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.dw * a.dh) return;
-    const int dy = idx / a.dw, dx = idx - dy * a.dw;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // (64-bit: a 2^30-pixel frame times a block size)
+    if (idx >= (long long)a.dw * a.dh) return;
+    const int dy = (int)(idx / a.dw), dx = (int)(idx - (long long)dy * a.dw);
     const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride;
     uint8_t* D = a.dst + (long long)blockIdx.y * a.dst_stride + (size_t)dy * a.dstep + (size_t)dx * CN;
 
@@ -1382,9 +1382,9 @@ __global__ __launch_bounds__(256, 5) void k_resize_2x_dma3(RArgs a, const int* _
 // ------------------------------------------------------------------ NN
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_nn(RArgs a, double scale_x, double scale_y) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.dw * a.dh) return;
-    const int dy = idx / a.dw, dx = idx - dy * a.dw;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.dw * a.dh) return;
+    const int dy = (int)(idx / a.dw), dx = (int)(idx - (long long)dy * a.dw);
     int sx = (int)floor(dx * scale_x), sy = (int)floor(dy * scale_y);
     sx = sx > a.sw - 1 ? a.sw - 1 : sx;
     sy = sy > a.sh - 1 ? a.sh - 1 : sy;
@@ -1700,9 +1700,9 @@ struct AreaDev {
 
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_area(RArgs a, AreaDev t) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.dw * a.dh) return;
-    const int dy = idx / a.dw, dx = idx - dy * a.dw;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // (64-bit: a 2^30-pixel frame times a block size)
+    if (idx >= (long long)a.dw * a.dh) return;
+    const int dy = (int)(idx / a.dw), dx = (int)(idx - (long long)dy * a.dw);
     const uint8_t* S = a.src + (long long)blockIdx.y * a.src_stride;
     const int xs = t.xstart[dx], nx = t.xcount[dx];
     const float* xa = t.xalpha + t.xaoff[dx];
@@ -2060,7 +2060,7 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
 
 template <int CN, int W>
 __global__ __launch_bounds__(256) void k_resize_area_rows(RArgs a, AreaGeom gm, int nstrips, int bh, int nitems, int bpf, int count, AreaTail tail) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * ((W + 3) / 4) * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * ((W + 3) / 4) * 4 + 4];      // + 4: a BGR window's look-ahead dword at the line's very end stays inside it
     __shared__ uint32_t s_tile[4][CN == 4 ? 16 * 65 : 1];        // quarter turns: a band (<= 16 rows) waits here to leave turned
     int frame, blk;
     if (!frame_block(bpf, count, &frame, &blk)) return;
@@ -2220,7 +2220,7 @@ __device__ __forceinline__ void area_rows4_body(const RArgs& a, const AreaGeom& 
 
 template <int CN, int W>
 __global__ __launch_bounds__(256) void k_resize_area_rows4(RArgs a, AreaGeom gm, int nstrips, int bh, int nitems, int bpf, int count) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * 4 * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * 4 * 4 + 4];
     int frame, blk;
     if (!frame_block(bpf, count, &frame, &blk)) return;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2238,7 +2238,7 @@ struct MixIndex { int off[9]; };                       // descriptors of XCD g: 
 
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_area_mix(const MixDesc* __restrict__ d, MixIndex ix) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * MIX_NV * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * MIX_NV * 4 + 4];
     const int g = blockIdx.x & 7, q = blockIdx.x >> 3;
     int lo = ix.off[g], hi = ix.off[g + 1];
     if (lo == hi || q >= d[hi - 1].first + d[hi - 1].nblk) return;
@@ -2984,7 +2984,10 @@ int launch_cv_resize(const Frames& f, int interp, hipStream_t s) {
     if (f.count > 65535) return IMP_ERROR_INVALID_ARGS;
     if (interp < IMP_INTER_NN || interp > IMP_INTER_LANCZOS4) return IMP_ERROR_INVALID_ARGS;
     const View& v = f.v;
-    if (v.w <= 0 || v.h <= 0 || f.dw <= 0 || f.dh <= 0) return IMP_ERROR_INVALID_ARGS;
+    if (!f.src || !f.dst || (v.c != 1 && v.c != 3 && v.c != 4)) return IMP_ERROR_INVALID_ARGS;
+    // what the kernels index in 32 bits (pixels, row bytes, bytes inside a frame) has to fit: 64-bit checks, before any launch
+    if (!view_fits(v.w, v.h, v.c, v.step) || !view_fits(f.dw, f.dh, v.c, f.dstep)) return IMP_ERROR_INVALID_ARGS;
+    if (f.count > 1 && (f.src_stride < 0 || f.dst_stride < 0)) return IMP_ERROR_INVALID_ARGS;
     // cv::resize: scale = 1 / ((double)dsize / ssize)
     const double scale_x = 1. / ((double)f.dw / v.w), scale_y = 1. / ((double)f.dh / v.h);
     // the reference requests AREA only when neither axis grows (bridge.c:190)
@@ -3058,8 +3061,7 @@ int launch_resize_mixed(const MixFrame* fr, int count, int cn, int simple, hipSt
     if (!fr || (cn != 1 && cn != 3 && cn != 4)) return IMP_ERROR_INVALID_ARGS;
     for (int i = 0; i < count; i++) {                      // nothing is launched unless every frame is well-formed
         const MixFrame& f = fr[i];
-        if (!f.src || !f.dst || f.sw <= 0 || f.sh <= 0 || f.dw <= 0 || f.dh <= 0 || f.sstep < f.sw * cn || f.dstep < f.dw * cn)
-            return IMP_ERROR_INVALID_ARGS;
+        if (!f.src || !f.dst || !view_fits(f.sw, f.sh, cn, f.sstep) || !view_fits(f.dw, f.dh, cn, f.dstep)) return IMP_ERROR_INVALID_ARGS;
         if (cn == 4 && (((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)f.sstep | (uintptr_t)f.dstep) & 3)) return IMP_ERROR_INVALID_ARGS;
     }
     std::vector<MixDesc> gathered_frames;

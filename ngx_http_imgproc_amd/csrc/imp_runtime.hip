@@ -18,6 +18,7 @@
 // the host copy of request N+1 overlaps the H2D DMA of request N.
 #include <dlfcn.h>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -48,6 +49,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     std::mutex mu;                              // guards the pool: frees may come from other threads
     std::multimap<size_t, void*> free_list;     // bucket size -> buffer
+    size_t free_bytes = 0;                      // sum of the free list (trimmed above pool_cap() when the lane is idle)
     std::map<void*, size_t> live;               // buffer -> bucket size
     Staging stage[N_STAGE];                     // pinned staging for pageable upload / download, used alternately
     int stage_next = 0;
@@ -72,7 +74,8 @@ struct Env {
 };
 
 static void lane_destroy(Lane* L);
-static Env* g_env = nullptr;
+static std::atomic<Env*> g_env{nullptr};
+static std::mutex g_env_mu;                         // env start / destroy against threads that end meanwhile (LaneReturn)
 static unsigned long long g_generation = 0;
 static thread_local Lane* t_lane = nullptr;
 static thread_local unsigned long long t_lane_gen = 0;
@@ -81,10 +84,16 @@ static thread_local unsigned long long t_lane_gen = 0;
 // threads would otherwise collect a stream and tens of MB of pinned memory per dead thread until impgpu_env_destroy.
 struct LaneReturn {
     ~LaneReturn() {
-        Env* E = g_env;
-        if (!E || !t_lane || t_lane_gen != E->generation) return;
-        std::lock_guard<std::mutex> lk(E->mu);
-        E->idle.push_back(t_lane);
+        // under the env lock: impgpu_env_destroy cannot free the env between the look and the push, and the thread forgets
+        // the lane it hands back (a later thread_local destructor calling into the library gets a fresh one)
+        std::lock_guard<std::mutex> lk(g_env_mu);
+        Env* E = g_env.load();
+        if (E && t_lane && t_lane_gen == E->generation) {
+            std::lock_guard<std::mutex> lk2(E->mu);
+            E->idle.push_back(t_lane);
+        }
+        t_lane = nullptr;
+        t_lane_gen = 0;
     }
 };
 static thread_local LaneReturn t_lane_return;
@@ -93,7 +102,7 @@ static thread_local std::string t_error;
 // ---- rocTX (optional) and fault injection
 static void (*g_roctx_push)(const char*) = nullptr;
 static int (*g_roctx_pop)() = nullptr;
-static int g_fault_step = -1;
+static std::atomic<int> g_fault_step{-1};
 static long g_fault_countdown = 0;
 static std::mutex g_fault_mu;
 
@@ -113,23 +122,20 @@ static void trace_init() {
 void trace_push(const char* name) { if (g_roctx_push) g_roctx_push(name); }
 void trace_pop() { if (g_roctx_pop) (void)g_roctx_pop(); }
 
-static void fault_init() {
+// Armed only by an explicit call (impgpu_fault_arm): a stray environment variable inherited by an nginx worker must not be
+// able to fail requests.  step < 0 disarms.
+static void fault_arm(int step, long nth) {
     std::lock_guard<std::mutex> lk(g_fault_mu);
     g_fault_step = -1;
     g_fault_countdown = 0;
-    const char* s = std::getenv("IMPGPU_FAULT");
-    if (!s || !*s) return;
-    char* end = nullptr;
-    const long step = std::strtol(s, &end, 10);
-    if (end == s || step < IMP_STEP_START || step > IMP_STEP_ENCODE) return;
-    g_fault_step = (int)step;
-    g_fault_countdown = (*end == ':') ? std::strtol(end + 1, nullptr, 10) : 1;
-    if (g_fault_countdown < 1) g_fault_countdown = 1;
+    if (step < IMP_STEP_START || step > IMP_STEP_ENCODE) return;
+    g_fault_countdown = nth < 1 ? 1 : nth;
+    g_fault_step = step;
 }
 
 void set_error(const char* what, hipError_t e);
 bool fault_hit(int step) {
-    if (g_fault_step < 0) return false;                            // the only cost when not armed
+    if (g_fault_step.load(std::memory_order_relaxed) < 0) return false;   // the only cost when not armed
     std::lock_guard<std::mutex> lk(g_fault_mu);
     if (step != g_fault_step || g_fault_countdown <= 0) return false;
     if (--g_fault_countdown > 0) return false;
@@ -240,6 +246,7 @@ int dev_alloc(size_t bytes, void** out) {
         if (it != L->free_list.end()) {
             *out = it->second;
             L->free_list.erase(it);
+            L->free_bytes -= b;
             L->live[*out] = b;
             return IMP_OK;
         }
@@ -254,6 +261,7 @@ int dev_alloc(size_t bytes, void** out) {
             (void)hipStreamSynchronize(L->stream);
             for (auto& kv : L->free_list) (void)hipFree(kv.second);
             L->free_list.clear();
+            L->free_bytes = 0;
         }
         e = hipMalloc(&p, b);
         if (e != hipSuccess) { set_error("hipMalloc", e); return IMP_ERROR_MALLOC_FAILED; }
@@ -269,8 +277,34 @@ static bool lane_take_back(Lane* L, void* p) {
     auto it = L->live.find(p);
     if (it == L->live.end()) return false;
     L->free_list.emplace(it->second, p);
+    L->free_bytes += it->second;
     L->live.erase(it);
     return true;
+}
+
+// Bytes a lane may keep on its free list.  A worker that once saw a 4K frame would otherwise hold 33 MB buckets for
+// ever, and N workers x lanes share one GPU.  IMPGPU_POOL_CAP_MB (default 256; 0 = never trim).
+static size_t pool_cap() {
+    static const size_t cap = [] {
+        const char* s = std::getenv("IMPGPU_POOL_CAP_MB");
+        return (size_t)(s ? std::atoll(s) : 256) << 20;
+    }();
+    return cap;
+}
+
+// Called when the lane's stream has just been waited for (nothing enqueued can still read a free block): give the largest
+// free blocks back to the driver until the list is under the cap.  hipFree is a device-wide wait, which is why this is not
+// done on the enqueue path and only past the cap.
+static void pool_trim(Lane* L) {
+    const size_t cap = pool_cap();
+    if (!cap || L->free_bytes <= cap) return;
+    std::lock_guard<std::mutex> lk(L->mu);
+    while (L->free_bytes > cap / 2 && !L->free_list.empty()) {
+        auto it = std::prev(L->free_list.end());
+        (void)hipFree(it->second);
+        L->free_bytes -= it->first;
+        L->free_list.erase(it);
+    }
 }
 
 void dev_free(void* p) {
@@ -285,7 +319,16 @@ void dev_free(void* p) {
         lanes = E->lanes;
     }
     for (Lane* L : lanes)
-        if (L != mine && lane_take_back(L, p)) return;
+        if (L != mine && lane_take_back(L, p)) {
+            // A frame belongs to the lane (thread) that created it: the block goes back to its owner's free list with no
+            // ordering against work this thread may still have enqueued on it.  Supported only for frames that are idle
+            // (a garbage collector's finaliser); -DIMPGPU_DEBUG builds stop here so that a misuse is found in testing.
+#ifdef IMPGPU_DEBUG
+            std::fprintf(stderr, "impgpu: frame memory %p released from a thread that does not own it\n", p);
+            std::abort();
+#endif
+            return;
+        }
 }
 
 // Free `p` once everything enqueued on `s` so far is done.  On the lane's own stream that is plain stream order (the
@@ -355,9 +398,12 @@ int lane_wait() {
     Lane* L = lane();
     if (!L) return no_env();
     static const bool spin = [] { const char* s = std::getenv("IMPGPU_SYNC"); return s && !std::strcmp(s, "spin"); }();
-    if (spin) { IMP_HIP(hipStreamSynchronize(L->stream)); return IMP_OK; }
-    IMP_HIP(hipEventRecord(L->sync_ev, L->stream));
-    IMP_HIP(hipEventSynchronize(L->sync_ev));
+    if (spin) { IMP_HIP(hipStreamSynchronize(L->stream)); }
+    else {
+        IMP_HIP(hipEventRecord(L->sync_ev, L->stream));
+        IMP_HIP(hipEventSynchronize(L->sync_ev));
+    }
+    if (L->parked.empty()) pool_trim(L);        // (blocks parked behind a foreign stream's event are not on the free list)
     return IMP_OK;
 }
 
@@ -514,7 +560,8 @@ using namespace imp;
 extern "C" {
 
 int impgpu_env_start(int device) {
-    if (g_env) return IMP_OK;
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    if (g_env.load()) return IMP_OK;
     if (device < 0) {
         const char* s = std::getenv("IMPGPU_DEVICE");
         if (!s) s = std::getenv("LOCAL_RANK");
@@ -530,7 +577,6 @@ int impgpu_env_start(int device) {
     device %= n;    // round-robin of workers over the node's GPUs
     IMP_HIP(hipSetDevice(device));
     trace_init();
-    fault_init();
     Env* E = new Env();
     E->device = device;
     E->generation = ++g_generation;
@@ -545,16 +591,25 @@ int impgpu_env_start(int device) {
 }
 
 void impgpu_env_destroy(void) {
-    Env* E = g_env;
-    if (!E) return;
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    Env* E = g_env.exchange(nullptr);   // from here on no thread finds the env (other threads' t_lane pointers are
+    if (!E) return;                     // invalidated by the generation counter); a thread that ends meanwhile waits on the lock
     (void)hipDeviceSynchronize();
     for (Lane* L : E->lanes) lane_destroy(L);
-    g_env = nullptr;        // other threads' t_lane pointers are invalidated by the generation counter
     t_lane = nullptr;
+    t_lane_gen = 0;
     delete E;
 }
 
-int impgpu_env_device(void) { return g_env ? g_env->device : -1; }
+int impgpu_fault_arm(int step, long nth) {
+    fault_arm(step, nth);
+    return IMP_OK;
+}
+
+int impgpu_env_device(void) {
+    Env* E = g_env.load();
+    return E ? E->device : -1;
+}
 const char* impgpu_last_error(void) { return t_error.c_str(); }
 void* impgpu_env_stream(void) { return (void*)env_stream(); }
 

@@ -54,6 +54,15 @@ int main(int argc, char** argv) {
         fprintf(stderr, "impgpu_env_start: %s\n", impgpu_last_error());
         return 3;
     }
+    {   /* the test's way of asking for an injected device fault: HARNESS_FAULT=<step>[:<n>] -> impgpu_fault_arm (the
+         * library itself never reads the environment for this) */
+        const char* fault = getenv("HARNESS_FAULT");
+        if (fault && *fault) {
+            char* end = NULL;
+            long step = strtol(fault, &end, 10);
+            impgpu_fault_arm((int)step, (end && *end == ':') ? strtol(end + 1, NULL, 10) : 1);
+        }
+    }
     memset(&cfg, 0, sizeof cfg);                                /* OnConfigMerge defaults, module.c:168-187 */
     cfg.max_target_w = 2000; cfg.max_target_h = 2000;
     cfg.max_filters_count = 5; cfg.allow_experiments = 1;

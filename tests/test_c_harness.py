@@ -107,9 +107,9 @@ def test_error_codes_and_steps_reach_the_c_caller(tmp_path):
                                             ("5", "/a.png?filter-gamma=2", 5), ("7", "/a.png?resize=10&format=json", 7),
                                             ("8", "/a.png?resize=10", 8)])
 def test_injected_device_fault_reaches_the_c_caller_with_its_step(tmp_path, fault, uri, step):
-    """IMPGPU_FAULT=<step>: that stage behaves as if its HIP call had failed -> IMP_ERROR_DEVICE (90) and JobResult.Step,
+    """impgpu_fault_arm(step) (asked for through the harness's HARNESS_FAULT): that stage behaves as if its HIP call had failed -> IMP_ERROR_DEVICE (90) and JobResult.Step,
     which BodyFilter turns into `Job failed at step %d with code %d` + HTTP 500 (module.c:305, :326-329)."""
-    p, f, data = run(tmp_path, noise_image(40, 60, 4, 34), uri, "png", env={"IMPGPU_FAULT": fault})
+    p, f, data = run(tmp_path, noise_image(40, 60, 4, 34), uri, "png", env={"HARNESS_FAULT": fault})
     assert p.returncode == 0 and (f["code"], f["step"]) == (90, step) and data is None
 
 
@@ -125,6 +125,7 @@ import numpy as np
 import torch  # first (see tests/conftest.py)
 import ngx_http_imgproc_amd as imp
 imp.env_start(0)
+imp.lib.impgpu_fault_arm(4, 2)          # the second entry into IMP_STEP_RESIZE
 cfg = imp.Config()
 frame = np.random.default_rng(5).integers(0, 256, (50, 70, 3), dtype=np.uint8)
 codes = []
@@ -138,7 +139,7 @@ print(repr(codes))
 '''
     import os
     p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, cwd=ROOT,
-                       env=dict(os.environ, IMPGPU_FAULT="4:2", PYTHONPATH=ROOT))
+                       env=dict(os.environ, IMPGPU_FAULT="4", PYTHONPATH=ROOT))      # (a stray variable of the old name arms nothing)
     assert p.returncode == 0, p.stderr[-2000:]
     codes = eval(p.stdout.strip().split("\n")[-1])
     assert [c[0] for c in codes] == [0, 90, 0, 0] and codes[1][1] == 4 and "injected fault" in codes[1][2]

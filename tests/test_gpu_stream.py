@@ -290,3 +290,43 @@ def test_pinned_transfers_with_foreign_row_pitches(gpu, c):
         lib.impgpu_image_release(C.byref(img))
         lib.impgpu_host_free(hsrc)
         lib.impgpu_host_free(hdst)
+
+
+@pytest.mark.gpu
+def test_pool_gives_memory_back_past_its_cap(tmp_path):
+    """A lane's free list is trimmed above IMPGPU_POOL_CAP_MB when its stream has been waited for: a worker that once saw
+    large frames does not keep their buckets for ever (N workers x lanes share one GPU)."""
+    import subprocess
+    import sys
+
+    script = r'''
+import numpy as np
+import torch  # first (see tests/conftest.py)
+import ngx_http_imgproc_amd as imp
+imp.env_start(0)
+torch.cuda.init()
+free0 = torch.cuda.mem_get_info()[0]
+ims = [imp.Image(np.zeros((2160, 3840, 4), dtype=np.uint8)) for _ in range(6)]      # 6 x 33 MB
+imp.sync()
+held = free0 - torch.cuda.mem_get_info()[0]
+for im in ims:
+    im.release()
+imp.sync()                                           # the wait after which the free list is looked at
+kept = free0 - torch.cuda.mem_get_info()[0]
+small = imp.Image(np.zeros((64, 64, 4), dtype=np.uint8))   # the pool still works afterwards
+ok = small.numpy().shape == (64, 64, 4)
+imp.env_destroy()
+print(held, kept, ok)
+'''
+    import os
+    from conftest import ROOT
+    for cap, limit in (("64", 80 << 20), ("0", None)):
+        p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                           env=dict(os.environ, IMPGPU_POOL_CAP_MB=cap, PYTHONPATH=ROOT))
+        assert p.returncode == 0, p.stderr[-2000:]
+        held, kept, ok = p.stdout.strip().split("\n")[-1].split()
+        assert ok == "True" and int(held) >= 6 * 33000000
+        if limit is not None:
+            assert int(kept) < limit, (held, kept)           # trimmed to half the cap or less
+        else:
+            assert int(kept) >= 6 * 33000000                 # cap 0: never trimmed

@@ -86,3 +86,49 @@ def test_check_destructive_table():
     assert imp.check_destructive("blur=2") == 1 and imp.check_destructive("vignette=1") == 1
     assert imp.check_destructive("gamma=2") == 0 and imp.check_destructive("blurry") == 1
     assert imp.check_destructive("nosuch") == 0
+
+
+def test_batch_entry_points_refuse_geometry_the_kernels_cannot_index():
+    """Round-3 hardening: the batch ABI takes caller geometry, and the kernels index pixels, row bytes and bytes inside
+    a frame in 32 bits.  Every refusal is decided in 64-bit arithmetic before a device is even looked for."""
+    import ctypes as C
+
+    import ngx_http_imgproc_amd as imp
+
+    lib = imp.lib
+    INV = imp.IMP_ERROR_INVALID_ARGS
+    buf = (C.c_ubyte * 64)()
+    p = C.cast(buf, C.c_void_p)
+
+    def cv(sw, sh, sstep, dw, dh, dstep, c=4, count=1, interp=imp.INTER_AREA, sstride=0, dstride=0):
+        return lib.impgpu_batch_cv_resize(p, sstride, sw, sh, sstep, p, dstride, dw, dh, dstep, c, count, interp, None)
+
+    assert cv(0, 10, 40, 4, 4, 16) == INV                                  # empty source
+    assert cv(10, 10, 39, 4, 4, 16) == INV                                 # pitch shorter than a row
+    assert cv(1 << 29, 4, 1 << 31, 4, 4, 16) == INV                        # w * c wraps an int
+    assert cv(40000, 40000, 160000, 4, 4, 16) == INV                       # 1.6e9 pixels, 6.4 GB of rows
+    assert cv(20000, 60000, 80000, 4, 4, 16) == INV                        # step * h > 4 GiB
+    assert cv(100, 100, 400, 33000, 33000, 132000) == INV                  # destination too large
+    assert cv(10, 10, 40, 4, 4, 16, count=70000) == INV
+    assert cv(10, 10, 40, 4, 4, 16, count=2, sstride=-400) == INV
+    assert cv(10, 10, 40, 4, 4, 16, interp=9) == INV
+    assert cv(10, 10, 40, 4, 4, 16, c=2) == INV
+    assert cv(10, 10, 40, 4, 4, 16) == imp.IMP_ERROR_DEVICE                # well-formed: only now is the device missed (CPU run)
+
+    item = imp.ResizeItem(p, 1 << 29, 4, 1 << 31, p, 4, 4, 16)
+    assert lib.impgpu_batch_resize_mixed(C.byref(item), 1, 4, 0, None) == INV
+    item = imp.ResizeItem(p, 10, 10, 40, p, 40000, 40000, 160000)
+    assert lib.impgpu_batch_resize_mixed(C.byref(item), 1, 4, 0, None) == INV
+    item = imp.ResizeItem(p, 10, 10, 40, p, 4, 4, 16)
+    assert lib.impgpu_batch_resize_mixed(C.byref(item), 1, 5, 0, None) == INV
+    assert lib.impgpu_batch_resize_mixed(C.byref(item), 1, 4, 0, None) == imp.IMP_ERROR_DEVICE
+
+    cfg = imp.Config()
+    rrw = lib.impgpu_batch_resize_rotate_watermark
+    assert rrw(p, 0, 1 << 29, 4, 1 << 31, p, 0, 16, 4, 4, 90, C.byref(cfg.c), 4, 1, None) == INV
+    assert rrw(p, 0, 10, 10, 40, p, 0, 8, 4, 5, 90, C.byref(cfg.c), 4, 1, None) == INV           # turned frame is 5 wide: 8-byte rows do not hold it
+    assert rrw(p, 0, 10, 10, 40, p, 0, 20, 4, 5, 90, C.byref(cfg.c), 4, 1, None) == imp.IMP_ERROR_DEVICE
+    filt = (C.c_char_p * 1)(b"gamma=2")
+    assert lib.impgpu_batch_filters(p, 0, 40000, 40000, 4, 160000, 1, filt, 1, 1, None) == INV
+    assert lib.impgpu_batch_filters(p, 0, 10, 10, 4, 39, 1, filt, 1, 1, None) == INV
+    assert lib.impgpu_batch_filters(p, 0, 10, 10, 4, 40, 1, filt, 1, 1, None) == imp.IMP_ERROR_DEVICE
