@@ -269,6 +269,7 @@ def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, wo
     all_sizes = mixed_sizes(n_requests)
     mine = [all_sizes[i] for i in round_robin(n_requests, rank, world)]
     lib = imp.lib
+    bound = NUMA_BIND and lib.impgpu_env_bind_thread() == 0        # (the pinned source below is then first touched on the device's node)
     # one pinned source buffer (largest frame) filled with noise: every request reads its w*h*4 prefix
     maxpx = max(w * h for w, h in all_sizes)
     hsrc = lib.impgpu_host_alloc(maxpx * c + 64)
@@ -287,6 +288,8 @@ def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, wo
             pending.put(None)
 
     def worker():
+        if NUMA_BIND:
+            lib.impgpu_env_bind_thread()                          # host threads on the GPU's NUMA node
         hdst = lib.impgpu_host_alloc(out_bytes * inflight)
         live = []
         done = False
@@ -335,7 +338,11 @@ def request_stream(imp, n_requests, n_threads, queue_depth, inflight, rank=0, wo
     lib.impgpu_host_free(hsrc)
     if errors:
         raise SystemExit("request_stream failed: %r" % errors[:3])
-    return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * c for w, h in mine)}
+    return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * c for w, h in mine),
+            "numa_node": lib.impgpu_env_numa_node(), "threads_bound": bool(bound)}
+
+
+NUMA_BIND = True        # --no-numa clears it: --stream worker threads (and their pinned buffers) on the device's NUMA node
 
 
 def jpeg_pool(n_files):
@@ -387,6 +394,8 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
             pending.put(None)
 
     def worker():
+        if NUMA_BIND:
+            lib.impgpu_env_bind_thread()
         hdst = lib.impgpu_host_alloc(out_bytes * max(1, batch))
         if decoder == "host":
             from PIL import Image
@@ -450,7 +459,8 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
     if errors:
         raise SystemExit("jpeg_stream failed: %r" % errors[:3])
     return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * 3 for w, h, _ in mine),
-            "file_bytes": sum(len(b) for _, _, b in mine)}
+            "file_bytes": sum(len(b) for _, _, b in mine), "numa_node": lib.impgpu_env_numa_node(),
+            "threads_bound": bool(NUMA_BIND and lib.impgpu_env_numa_node() >= 0)}
 
 
 def main():
@@ -467,6 +477,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--queue-depth", type=int, default=4096, help="--stream: requests waiting in the rank's queue")
     ap.add_argument("--inflight", type=int, default=4, help="--stream: requests a thread enqueues before it waits")
+    ap.add_argument("--no-numa", action="store_true", help="--stream: do not bind the worker threads to the device's NUMA node")
     ap.add_argument("--jpeg", default="", choices=("", "device", "hosthuff", "host", "all"),
                     help="--stream: the requests arrive as JPEG files; where they are decoded (all = the three one after the other)")
     ap.add_argument("--jpeg-batch", type=int, default=1, help="--stream --jpeg: requests a thread takes from the queue and decodes with one impgpu_batch_decode_jpeg call")
@@ -478,6 +489,8 @@ def main():
     ap.add_argument("--e2e", type=int, default=0, metavar="N",
                     help="instead of the headline, time N PCIe-inclusive requests (upload + resize + download) and exit")
     args = ap.parse_args()
+    global NUMA_BIND
+    NUMA_BIND = not args.no_numa
 
     import torch
     import torch.distributed as dist
@@ -510,6 +523,7 @@ def main():
     if use_dist:
         dist.barrier(device_ids=[local_rank])
     import ngx_http_imgproc_amd as imp
+    from ngx_http_imgproc_amd.shard import elapsed_max, job_totals
 
     imp.env_start(local_rank)
     if args.stream and args.jpeg:
@@ -524,14 +538,9 @@ def main():
             torch.cuda.synchronize()
             r = jpeg_stream(imp, args.stream, args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch)
             torch.cuda.synchronize()
-            t = torch.tensor([r["seconds"], float(r["requests"]), float(r["source_bytes"]), float(r["file_bytes"])], dtype=torch.float64, device="cuda")
             if use_dist:
                 dist.barrier(device_ids=[local_rank])
-                tmax = t.clone()
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                t[0] = tmax[0]
-            secs, nreq, nbytes, fbytes = float(t[0]), float(t[1]), float(t[2]), float(t[3])
+            secs, (nreq, nbytes, fbytes) = job_totals(r["seconds"], [r["requests"], r["source_bytes"], r["file_bytes"]], dist if use_dist else None, "cuda")
             lines.append({
                 "metric": "requests/sec, mixed-size JPEG request stream (256px-4K) decode + resize=224,0, PCIe-inclusive",
                 "value": round(nreq / secs, 1), "unit": "requests/sec", "n_gpus": world, "higher_is_better": True,
@@ -541,6 +550,7 @@ def main():
                 "bits_per_pixel": round(fbytes * 8 / (nbytes / 3), 2), "seconds": round(secs, 3),
                 "config": {"workload": "BASELINE configs[4] as JPEG files: %d requests, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % int(nreq),
                            "threads_per_gpu": args.threads, "files_per_decode_call": args.jpeg_batch, "host_cores": os.cpu_count(), "queue_depth": args.queue_depth,
+                           "numa_node": r["numa_node"], "threads_bound_to_node": r["threads_bound"],
                            "sharding": "request i -> rank i mod N, no collective"}})
         if rank == 0:
             for ln in lines:
@@ -557,14 +567,9 @@ def main():
         torch.cuda.synchronize()
         r = request_stream(imp, args.stream, args.threads, args.queue_depth, args.inflight, rank, world, args.channels)
         torch.cuda.synchronize()
-        t = torch.tensor([r["seconds"], float(r["requests"]), float(r["source_bytes"])], dtype=torch.float64, device="cuda")
         if use_dist:
             dist.barrier(device_ids=[local_rank])
-            tmax = t.clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t[0] = tmax[0]
-        secs, nreq, nbytes = float(t[0]), float(t[1]), float(t[2])
+        secs, (nreq, nbytes) = job_totals(r["seconds"], [r["requests"], r["source_bytes"]], dist if use_dist else None, "cuda")
         if rank == 0:
             print(json.dumps({
                 "metric": "requests/sec, mixed-size request stream (256px-4K) resize=224,0, PCIe-inclusive",
@@ -574,6 +579,7 @@ def main():
                 "source_MB_per_sec": round(nbytes / secs / 1e6, 1), "seconds": round(secs, 3),
                 "config": {"workload": "BASELINE configs[4]: %d requests, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % int(nreq),
                            "threads_per_gpu": args.threads, "queue_depth": args.queue_depth, "inflight_per_thread": args.inflight, "channels": args.channels,
+                           "numa_node": r["numa_node"], "threads_bound_to_node": r["threads_bound"],
                            "sharding": "request i -> rank i mod N, no collective"}}), flush=True)
         imp.env_destroy()
         if use_dist:
@@ -585,12 +591,9 @@ def main():
         res = mixed_resident(imp, args.mixed, args.steps, args.warmup, rank, world, args.channels)
         if use_dist:                               # frames shard round-robin: images add up, the slowest rank sets the time
             oc = res["one_call"]
-            t = torch.tensor([oc["ms_per_step"], float(res["frames_this_rank"])], dtype=torch.float64, device="cuda")
-            tmax = t.clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            res["value"] = round(float(t[1]) / (float(tmax[0]) * 1e-3), 1)
-            res["frames_all_ranks"] = int(t[1])
+            ms, (frames,) = job_totals(oc["ms_per_step"], [res["frames_this_rank"]], dist, "cuda")
+            res["value"] = round(frames / (ms * 1e-3), 1)
+            res["frames_all_ranks"] = int(frames)
             res["scaling"] = "strong"
         if rank == 0:
             print(json.dumps(res), flush=True)
@@ -664,10 +667,10 @@ def main():
     torch.cuda.synchronize()
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream, whole timed region
     elapsed = max(wall, dev_ms / 1e3)
-    if use_dist:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+    # whole job: the slowest rank's time, every rank's frames (ngx_http_imgproc_amd.shard.job_totals; the same function under
+    # two gloo ranks in tests/test_multirank.py)
+    elapsed, (frames_all,) = job_totals(elapsed, [batch * args.steps], dist if use_dist else None, "cuda")
+    dev_ms = elapsed_max(dev_ms, dist if use_dist else None, "cuda")
 
     if rank == 0:
         launch_ms = dev_ms / args.steps                  # one kernel launch per step (chain: its launches together)
@@ -679,7 +682,7 @@ def main():
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
             "metric": "images/sec 1920x1080->224 bicubic resize" if args.mode == "cubic" else "images/sec " + args.mode,
-            "value": round(world * batch * args.steps / elapsed, 1),
+            "value": round(frames_all / elapsed, 1),
             "unit": "images/sec",
             "n_gpus": world,
             "steps": args.steps,

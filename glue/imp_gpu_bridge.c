@@ -10,7 +10,11 @@ void ImpGpuEnvStart(int worker) {
      * every later call then answers IMP_ERROR_DEVICE, which BodyFilter maps to 500 (module.c:305). */
     if (impgpu_env_start(worker) != IMP_OK) {
         fprintf(stderr, "imp::no usable GPU for worker %d: %s\n", worker, impgpu_last_error());
+        return;
     }
+    /* the worker runs next to its GPU: staging copies and pinned buffers on the device's NUMA node (a no-op on a one-node
+     * host or when the node's CPUs are not open to this process) */
+    (void)impgpu_env_bind_thread();
 }
 
 void ImpGpuEnvDestroy(void) {

@@ -93,6 +93,13 @@ typedef struct {
 int         impgpu_env_start(int device);
 void        impgpu_env_destroy(void);
 int         impgpu_env_device(void);            /* -1 when no env */
+/* NUMA: the node the env's device hangs off (its PCI function's numa_node; -1 = unknown or a one-node
+ * host), and a call that binds the CALLING thread to that node's CPUs -- a worker's staging copies then run next to
+ * the GPU's PCIe root, and pinned memory the thread allocates afterwards is that node's (first touch).  An nginx worker
+ * calls it once after impgpu_env_start; IMPGPU_NUMA_BIND=1 does it for every thread at its first call into the library.
+ * IMP_ERROR_UNSUPPORTED when the node is unknown or none of its CPUs is open to this process. */
+int         impgpu_env_numa_node(void);
+int         impgpu_env_bind_thread(void);
 const char* impgpu_last_error(void);            /* text of the last HIP failure on this thread */
 int         impgpu_sync(void);                  /* wait for the env stream */
 void*       impgpu_env_stream(void);            /* the env's hipStream_t */

@@ -79,6 +79,8 @@ SIGNATURES = {
     "impgpu_sync": (C.c_int, []),
     "impgpu_env_stream": (P, []),
     "impgpu_fault_arm": (C.c_int, [C.c_int, C.c_long]),
+    "impgpu_env_numa_node": (C.c_int, []),
+    "impgpu_env_bind_thread": (C.c_int, []),
     "impgpu_image_upload": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_create": (C.c_int, [C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_wrap": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),

@@ -17,8 +17,10 @@
 // only for copies issued a whole ring ago; frame staging alternates between two pinned buffers, so
 // the host copy of request N+1 overlaps the H2D DMA of request N.
 #include <dlfcn.h>
+#include <sched.h>
 #include <cstdlib>
 #include <atomic>
+#include <cctype>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -67,6 +69,8 @@ struct Lane {
 
 struct Env {
     int device = -1;
+    int numa_node = -1;                         // of the device's PCI function (-1: unknown / a single-node host)
+    std::vector<int> node_cpus;                 // that node's CPUs, already cut down to what this process may run on
     unsigned long long generation = 0;
     std::mutex mu;
     std::vector<Lane*> lanes;
@@ -155,6 +159,50 @@ static int no_env() {
     return IMP_ERROR_DEVICE;
 }
 
+// ---- NUMA ("one host thread per GPU, NUMA-local"): which node the device hangs off, and that node's CPUs
+static void numa_probe(Env* E) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, E->device) != hipSuccess) return;
+    for (char* c = bus; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+    char path[160];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = std::fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+    if (node < 0) return;
+    std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = std::fopen(path, "r");
+    if (!f) return;
+    char list[4096] = {0};
+    const bool got = std::fgets(list, sizeof list, f) != nullptr;
+    std::fclose(f);
+    if (!got) return;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    for (char* tok = std::strtok(list, ",\n"); tok; tok = std::strtok(nullptr, ",\n")) {      // "0-15,32-47"
+        int lo = 0, hi = 0;
+        const int n = std::sscanf(tok, "%d-%d", &lo, &hi);
+        if (n < 1) continue;
+        if (n == 1) hi = lo;
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET(c, &allowed)) E->node_cpus.push_back(c);
+    }
+    E->numa_node = node;
+}
+
+// Bind the calling thread to the CPUs of the device's node: its staging copies then run next to the PCIe root the GPU
+// hangs off, and the pinned memory it allocates afterwards (first touch) is that node's.
+static int numa_bind_thread(Env* E) {
+    if (!E || E->numa_node < 0 || E->node_cpus.empty()) return IMP_ERROR_UNSUPPORTED;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : E->node_cpus) CPU_SET(c, &set);
+    return sched_setaffinity(0, sizeof set, &set) == 0 ? IMP_OK : IMP_ERROR_UNSUPPORTED;
+}
+
 // The calling thread's lane, created on first use (HIP's current device is per thread too).
 static Lane* lane() {
     Env* E = g_env;
@@ -171,6 +219,8 @@ static Lane* lane() {
             return t_lane;
         }
     }
+    static const bool bind = [] { const char* s = std::getenv("IMPGPU_NUMA_BIND"); return s && *s == '1'; }();
+    if (bind) (void)numa_bind_thread(E);        // before the lane's pinned buffers are allocated (first touch)
     Lane* L = new Lane();
     bool ok = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&L->join_ev, hipEventDisableTiming) == hipSuccess &&
@@ -580,6 +630,7 @@ int impgpu_env_start(int device) {
     Env* E = new Env();
     E->device = device;
     E->generation = ++g_generation;
+    numa_probe(E);
     g_env = E;
     if (!lane()) {  // the calling thread's lane: fails loudly here rather than at the first operator
         g_env = nullptr;
@@ -599,6 +650,17 @@ void impgpu_env_destroy(void) {
     t_lane = nullptr;
     t_lane_gen = 0;
     delete E;
+}
+
+int impgpu_env_numa_node(void) {
+    Env* E = g_env.load();
+    return E ? E->numa_node : -1;
+}
+
+int impgpu_env_bind_thread(void) {
+    Env* E = g_env.load();
+    if (!E) return no_env();
+    return numa_bind_thread(E);
 }
 
 int impgpu_fault_arm(int step, long nth) {

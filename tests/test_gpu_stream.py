@@ -330,3 +330,32 @@ print(held, kept, ok)
             assert int(kept) < limit, (held, kept)           # trimmed to half the cap or less
         else:
             assert int(kept) >= 6 * 33000000                 # cap 0: never trimmed
+
+
+@pytest.mark.gpu
+def test_numa_node_of_the_device_and_thread_binding(gpu):
+    """the env knows the NUMA node its device hangs off; impgpu_env_bind_thread puts the calling thread on that
+    node's CPUs (or says it cannot: one-node host, foreign cpuset).  Run in a thread so the test process keeps its mask."""
+    import os
+
+    node = gpu.lib.impgpu_env_numa_node()
+    assert node >= -1
+    result = {}
+
+    def work():
+        before = os.sched_getaffinity(0)
+        rc = gpu.lib.impgpu_env_bind_thread()
+        result["rc"], result["before"], result["after"] = rc, before, os.sched_getaffinity(0)
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    if result["rc"] == 0:
+        assert node >= 0 and result["after"] and result["after"] <= result["before"]
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        assert result["after"] <= cpus
+    else:
+        assert result["rc"] == 1 and result["after"] == result["before"]      # IMP_ERROR_UNSUPPORTED: nothing changed

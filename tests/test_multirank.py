@@ -78,3 +78,45 @@ def test_round_robin_edges():
     for world in (1, 2, 4, 8):
         allidx = sorted(i for r in range(world) for i in round_robin(1024, r, world))
         assert allidx == list(range(1024))
+
+
+def _totals_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ngx_http_imgproc_amd.shard import job_totals, round_robin
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a stubbed step: each rank "processes" its round-robin share of 1000 requests; rank 1 is the slow one
+    mine = round_robin(1000, rank, world)
+    seconds = 0.5 if rank == 0 else 0.8
+    dist.barrier()
+    secs, (requests, src_bytes) = job_totals(seconds, [len(mine), 1000 * len(mine)], dist)
+    if rank == 0:
+        q.put((secs, requests, src_bytes, requests / secs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_aggregation_two_ranks_gloo():
+    """The function bench.py builds every N > 1 line from (ngx_http_imgproc_amd.shard.job_totals), under two gloo ranks:
+    the job's time is the SLOWEST rank's, its units are ALL ranks' -- value = whole-job throughput, as the driver expects."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_totals_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    secs, requests, src_bytes, value = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert abs(secs - 0.8) < 1e-12 and requests == 1000 and src_bytes == 1000 * 1000
+    assert abs(value - 1250.0) < 1e-9
+    from ngx_http_imgproc_amd.shard import job_totals
+
+    assert job_totals(0.25, [10, 20]) == (0.25, [10.0, 20.0])           # one rank: identity
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("job_totals(") >= 4 and "all_reduce" not in src    # every reporting path of bench.py goes through it
