@@ -12,6 +12,7 @@
 // double division / sqrt on gfx950 are correctly rounded, as on the CPU.
 // All kernels are HBM-bound streams: coalesced dword (BGRA) accesses, tables in LDS.
 #include <cmath>
+#include <cstring>
 #include "imp_internal.h"
 
 namespace imp {
@@ -437,39 +438,23 @@ int launch_blend_paper(uint8_t* d, long long stride, int w, int h, int step, int
 // y-inner: sum = (float)((double)sum + term).  The running float sum rounds at every step (by up
 // to 16 once it passes 2^28 on a 1080p frame), so the result is not the true mean -- a flat
 // 1080p frame of value 100 yields 0.3815, not 0.3922 -- and a tree reduction would differ from it.
-// It is reproduced bit for bit without a serial walk:
-//   * k_brightness_terms evaluates the per-pixel terms into HBM in the reference's visiting order;
-//   * k_brightness_replay replays the accumulation regime by regime.  While the sum stays inside
-//     one binade [2^e, 2^(e+1)) it is a multiple of u = 2^(e-23), and adding t = k*u + r moves it
-//     by k*u, plus u when r is above u/2, plus "round to even" when the double sum lands exactly on
-//     the midpoint -- which, because (double)sum + t is itself rounded to 53 bits first, happens
-//     precisely when |r - u/2| <= 2^(e-53) (the midpoint is a double; rounding is monotone).  So
-//     inside a regime each term is a function of ONE bit of state, the parity of the sum's mantissa:
-//     parity -> (steps, parity').  Such functions compose associatively, so 16384 terms are folded
-//     by a block-wide scan; the scan also tells where the sum leaves the binade, and only that one
-//     term is added with the literal float/double sequence before the next regime starts.
-//   One block does ~10 us per 16384-term iteration (it is bound by one CU's double-precision rate), so a 1080p frame
-//   took 1.56 ms in that form.  The binades from 2^23 up hold almost all of the terms, and inside a binade the chunk
-//   functions do not depend on where the sum stands: k_brightness_summarize lets the whole GPU fold every remaining
-//   chunk for the accumulator's current exponent, and one block then only scans those summaries to the chunk in which
-//   the sum leaves the binade and replays that chunk exactly.  The host enqueues a (summarize, replay) pair for every
-//   exponent the frame can reach; a pair whose exponent is not the accumulator's returns at once.  0.42 ms at 1080p.
-template <int CN>
-__global__ __launch_bounds__(256) void k_brightness_terms(const uint8_t* __restrict__ src, int w, int h, int step,
-                                                          double* __restrict__ terms) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)w * h) return;
-    const int x = (int)(idx / h), y = (int)(idx - (long long)x * h);   // x outer, y inner
-    const uint8_t* p = src + (size_t)y * step + (size_t)x * CN;
-    double t;
-    if (CN == 1) t = (double)p[0];
-    else {
-        const int b = p[0], g = p[1], r = p[2];
-        t = sqrt((double)(r * r) * 0.241 + (double)(g * g) * 0.691 + (double)(b * b) * 0.068);
-    }
-    terms[idx] = t;
-}
-
+// It is reproduced bit for bit without a serial walk.  While the sum stays inside one binade
+// [2^e, 2^(e+1)) it is a multiple of u = 2^(e-23), and adding t = k*u + r moves it by k*u, plus u
+// when r is above u/2, plus "round to even" when the double sum lands exactly on the midpoint --
+// which, because (double)sum + t is itself rounded to 53 bits first, happens precisely when
+// |r - u/2| <= 2^(e-53) (the midpoint is a double; rounding is monotone).  So inside a binade each
+// term is a function of ONE bit of state, the parity of the sum's mantissa: parity -> (steps, parity').
+// Such functions compose associatively, and they do not depend on where in the binade the sum stands.
+//   k_brightness_fold (the whole GPU, ONE pass over the frame): a wave takes 1024 consecutive terms of the visiting order,
+//     16 per lane -- the pixels come through LDS, read along the rows, so the column-major visiting order costs no
+//     strided traffic, and the terms are never written out -- and folds them for every binade from 2^20 up that the
+//     frame's sum can reach (at most 255 per pixel): one ParityFn per wave and binade.
+//   k_brightness_walk (one 1024-thread block): carries the accumulator through the frame.  In a binade with summaries it
+//     scans them 1024 at a time to the 1024-term chunk in which the sum leaves the binade and replays only that chunk,
+//     a term per thread (recomputed from the pixels); below 2^20, where a few thousand terms live, it replays every
+//     chunk.  The one term that crosses into the next binade is added with the literal float/double sequence.
+// Round 2 had a 16.6 MB plane of double terms, a (summarize, replay) launch pair per binade -- fourteen launches -- and
+// 0.48 ms at 1080p; this is two launches.
 struct ParityFn {            // mantissa parity in -> (steps of u added, parity out)
     double inc0, inc1;
     int b0, b1;
@@ -484,26 +469,36 @@ __device__ __forceinline__ ParityFn pf_compose(const ParityFn& first, const Pari
     r.b1 = first.b1 ? second.b1 : second.b0;
     return r;
 }
-__device__ __forceinline__ ParityFn pf_shfl_up(const ParityFn& f, int d) {
+__device__ __forceinline__ ParityFn pf_shfl(const ParityFn& f, int src_lane) {
     ParityFn r;
-    r.inc0 = __shfl_up(f.inc0, d);
-    r.inc1 = __shfl_up(f.inc1, d);
-    const int bits = __shfl_up(f.b0 | (f.b1 << 1), d);
+    r.inc0 = __shfl(f.inc0, src_lane);
+    r.inc1 = __shfl(f.inc1, src_lane);
+    const int bits = __shfl(f.b0 | (f.b1 << 1), src_lane);
     r.b0 = bits & 1;
     r.b1 = (bits >> 1) & 1;
     return r;
 }
+// inclusive scan over the 64 lanes of a wave (lane l: f_0 .. f_l composed in order)
+__device__ __forceinline__ ParityFn pf_wave_scan(ParityFn f, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const ParityFn prev = pf_shfl(f, lane - d);             // (lanes below d read themselves: discarded)
+        if (lane >= d) f = pf_compose(prev, f);
+    }
+    return f;
+}
 
-#define BR_EPT 16
-#define BR_CHUNK (1024 * BR_EPT)      // terms folded per block iteration, and the granularity of the chunk summaries
-
-struct BrState { float sum; int pad; long long pos; };        // the accumulator and the next term to add
+#define BR_EPT 16                     // terms per lane
+#define BR_WCHUNK (64 * BR_EPT)       // terms per wave = the granularity of the summaries
+#define BR_FOLD_WAVES 8               // waves per block of k_brightness_fold
+#define BR_E0 20                      // first binade with summaries (below it: a few thousand terms, replayed)
 
 struct BrRegime {                     // everything a term's classification needs inside one binade
     double u, invu, eps, mid;
 };
+__device__ __forceinline__ double br_pow2(int k) { return __longlong_as_double((long long)(1023 + k) << 52); }   // 2^k, |k| < 1000
 __device__ __forceinline__ BrRegime br_regime(int e) {
-    return BrRegime{ldexp(1.0, e - 23), ldexp(1.0, 23 - e), ldexp(1.0, e - 53), 0.5 * ldexp(1.0, e - 23)};
+    return BrRegime{br_pow2(e - 23), br_pow2(23 - e), br_pow2(e - 53), br_pow2(e - 24)};
 }
 // one term as a function of the mantissa parity (see the block comment above)
 __device__ __forceinline__ ParityFn br_classify(double t, const BrRegime& g) {
@@ -523,197 +518,218 @@ __device__ __forceinline__ ParityFn br_classify(double t, const BrRegime& g) {
     }
     return f;
 }
-// inclusive scan of one ParityFn per thread over a 1024-thread block (s_wave: 16 entries of shared scratch)
-__device__ __forceinline__ ParityFn br_block_scan(ParityFn f, ParityFn* s_wave) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const ParityFn prev = pf_shfl_up(f, d);
-        if (lane >= d) f = pf_compose(prev, f);
+// the reference's term of one pixel (filters.c:715-722): packed B | G << 8 | R << 16, or the gray value
+template <int CN>
+__device__ __forceinline__ double br_term_of(uint32_t px) {
+    if (CN == 1) return (double)(px & 0xff);
+    const int b = px & 0xff, g = (px >> 8) & 0xff, r = (px >> 16) & 0xff;
+    return sqrt((double)(r * r) * 0.241 + (double)(g * g) * 0.691 + (double)(b * b) * 0.068);
+}
+template <int CN>
+__device__ __forceinline__ uint32_t br_load_px(const uint8_t* p) {
+    if (CN == 1) return p[0];
+    if (CN == 4) return *(const uint32_t*)p;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
+template <int CN>
+__global__ __launch_bounds__(64 * BR_FOLD_WAVES) void k_brightness_fold(const uint8_t* __restrict__ src, int w, int h, int step, long long n,
+                                                                         int ne, long long nchunks, ParityFn* __restrict__ summ) {
+    constexpr int BT = BR_WCHUNK * BR_FOLD_WAVES;                 // terms per block
+    __shared__ uint32_t s_px[BT + BT / 16];                       // term j of the block at j + j / 16: a lane's 16 terms are contiguous, lanes 17 words apart
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long long i0 = (long long)blockIdx.x * BT;
+    // the block's terms are the pixels of a few whole columns (visiting order: x outer, y inner): read them along the rows
+    const int x0 = (int)(i0 / h);
+    const long long ilast = min(n, i0 + BT) - 1;
+    const int ncols = (int)(ilast / h) - x0 + 1;
+    const int items = ncols * h;
+    for (int k = t; k < items; k += 64 * BR_FOLD_WAVES) {
+        const int y = k / ncols, xc = k - y * ncols;
+        const long long i = (long long)(x0 + xc) * h + y;
+        if (i >= i0 && i <= ilast) {
+            const int j = (int)(i - i0);
+            s_px[j + (j >> 4)] = br_load_px<CN>(src + (size_t)y * step + (size_t)(x0 + xc) * CN);
+        }
     }
-    if (lane == 63) s_wave[wv] = f;
+    __syncthreads();
+    double td[BR_EPT];
+    const long long mine = i0 + (long long)t * BR_EPT;
+#pragma unroll
+    for (int j = 0; j < BR_EPT; j++) td[j] = br_term_of<CN>(s_px[t * 17 + j]);
+    const long long chunk = (long long)blockIdx.x * BR_FOLD_WAVES + wv;
+    for (int e = 0; e < ne; e++) {
+        const BrRegime g = br_regime(BR_E0 + e);
+        ParityFn f = pf_identity();
+#pragma unroll
+        for (int j = 0; j < BR_EPT; j++)
+            if (mine + j < n) f = pf_compose(f, br_classify(td[j], g));
+        f = pf_wave_scan(f, lane);
+        if (lane == 63 && chunk < nchunks) summ[(long long)e * nchunks + chunk] = f;
+    }
+}
+
+// inclusive scan of one ParityFn per thread over a block of BR_WALK_WAVES waves; s_part: that many entries of shared scratch
+#define BR_WALK_WAVES 4
+#define BR_WALK_EPT (BR_WCHUNK / (64 * BR_WALK_WAVES))            // 4 consecutive terms (or chunk summaries) per thread
+__device__ __forceinline__ ParityFn pf_block_scan(ParityFn f, ParityFn* s_part) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    f = pf_wave_scan(f, lane);
+    __syncthreads();                                              // (s_part may still be read from the previous scan)
+    if (lane == 63) s_part[wv] = f;
     __syncthreads();
     ParityFn pre = pf_identity();
-    for (int w2 = 0; w2 < wv; w2++) pre = pf_compose(pre, s_wave[w2]);
+    for (int k = 0; k < wv; k++) pre = pf_compose(pre, s_part[k]);
     return pf_compose(pre, f);
 }
 
-// Chunk summaries for ONE binade, by the whole GPU: block c folds the terms of chunk c (aligned to BR_CHUNK) into
-// one ParityFn for the exponent the accumulator currently has.  Blocks of chunks that start before the accumulator's
-// position, or launched for an exponent the accumulator is not in, return at once.
-__global__ __launch_bounds__(1024) void k_brightness_summarize(const double* __restrict__ terms, long long n,
-                                                               const BrState* __restrict__ st, int e, ParityFn* __restrict__ summ) {
-    __shared__ ParityFn s_wave[16];
-    const float sum = st->sum;
-    const long long pos = st->pos;
-    if (pos >= n || sum == 0.f || (int)((__float_as_uint(sum) >> 23) & 0xff) - 127 != e) return;
-    const long long c0 = (long long)blockIdx.x * BR_CHUNK;
-    if (c0 < pos) return;
-    const BrRegime g = br_regime(e);
-    ParityFn f = pf_identity();
-#pragma unroll
-    for (int j = 0; j < BR_EPT; j++) {
-        const long long i = c0 + (long long)threadIdx.x * BR_EPT + j;
-        if (i < n) f = pf_compose(f, br_classify(terms[i], g));
-    }
-    f = br_block_scan(f, s_wave);
-    if (threadIdx.x == 1023) summ[blockIdx.x] = f;
-}
-
-// mode 0: from (0, 0) until the terms run out or the accumulator reaches binade stop_e.
-// mode 1: one binade, e_arg: (A) exact block iterations up to the next chunk boundary, (B) a scan over the chunk
-//         summaries of k_brightness_summarize to the chunk in which the sum leaves the binade (or to the end),
-//         (C) exact block iterations inside that chunk until it has left.  Returns at once when the accumulator is
-//         not in binade e_arg, so the host can enqueue the rounds for every possible exponent without looking.
-__global__ __launch_bounds__(1024) void k_brightness_replay(const double* __restrict__ terms, long long n, BrState* st, float* out,
-                                                            int mode, int e_arg, const ParityFn* __restrict__ summ) {
-    __shared__ ParityFn s_wave[16];
-    __shared__ int s_stop[16];
-    __shared__ double s_excl[1024];               // inclusive totals (steps) per thread for the chosen start parity
-    __shared__ float s_sum;
-    __shared__ long long s_pos;
-    __shared__ long long s_lim;                   // exact iterations read terms below this index only
-    __shared__ int s_phase;
+// One block of four waves carries the accumulator through the frame (every thread holds the same sum and position).  A step
+// handles 1024 entries, four consecutive ones per thread: the thread folds its four, the block scans 256 functions -- the scan
+// is all shuffles, and four waves of them cost a quarter of what sixteen did.
+template <int CN>
+__global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const uint8_t* __restrict__ src, int w, int h, int step, long long n, int ne,
+                                                                         long long nchunks, const ParityFn* __restrict__ summ, float* __restrict__ out) {
+    constexpr int NT = 64 * BR_WALK_WAVES, EPT = BR_WALK_EPT;
+    __shared__ ParityFn s_part[BR_WALK_WAVES];
+    __shared__ double s_tot[NT];
+    __shared__ double s_term[BR_WCHUNK];
+    __shared__ int s_first[BR_WALK_WAVES], s_par[NT], s_res_taken;
+    __shared__ double s_res_steps;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) {
-        if (mode == 0) { s_sum = 0.f; s_pos = 0; }
-        else { s_sum = st->sum; s_pos = st->pos; }
-        const long long p = mode == 0 ? 0 : st->pos;
-        const long long boundary = (p + BR_CHUNK - 1) / BR_CHUNK * BR_CHUNK;
-        s_lim = mode == 0 ? n : (boundary < n ? boundary : n);
-        s_phase = 0;                               // mode 1: 0 = A, 1 = C
-    }
-    __syncthreads();
-    const int stop_e = e_arg;
-    for (;;) {
-        const float sum = s_sum;
-        const long long pos = s_pos;
-        const long long nlim = s_lim;
-        const int phase = s_phase;
-        if (pos >= n) break;
-        const unsigned sbits = __float_as_uint(sum);
-        const bool zero = sum == 0.f;
-        const int e = (int)((sbits >> 23) & 0xff) - 127;
-        if (mode == 0 && !zero && e >= stop_e) break;
-        if (mode == 1 && (zero || e != e_arg)) break;
-        const int binit = (int)(sbits & 1u);
-        const double limit = (double)(0x800000u - (sbits & 0x7fffffu));     // steps until the binade ends
-
-        if (mode == 1 && phase == 0 && pos >= nlim) {
-            // ---- (B) whole chunks: scan their summaries, 1024 at a time
-            const long long cidx = pos / BR_CHUNK + tid;
-            ParityFn f = (cidx * BR_CHUNK < n) ? summ[cidx] : pf_identity();
-            f = br_block_scan(f, s_wave);
-            const double tot = binit ? f.inc1 : f.inc0;
-            const bool stop = tot >= limit;
-            const unsigned long long bal = __ballot(stop);
-            if (lane == 0) s_stop[wv] = bal ? (wv * 64 + (int)__builtin_ctzll(bal)) : 1 << 30;
-            s_excl[tid] = tot;
-            __syncthreads();
-            if (tid == 0) {
-                int first = 1 << 30;
-                for (int w2 = 0; w2 < 16; w2++) first = min(first, s_stop[w2]);
-                if (first >= 1024) {               // none of these chunks leaves the binade: take them all
-                    s_sum = __uint_as_float(sbits + (unsigned)(long long)s_excl[1023]);
-                    const long long np = pos + 1024LL * BR_CHUNK;
-                    s_pos = np < n ? np : n;
-                    s_lim = s_pos;                 // stay in (B)
-                } else {
-                    if (first > 0) s_sum = __uint_as_float(sbits + (unsigned)(long long)s_excl[first - 1]);
-                    s_pos = pos + (long long)first * BR_CHUNK;
-                    s_lim = n;                     // (C): exact iterations; the exponent test above ends them
-                    s_phase = 1;
+    float sum = 0.f;
+    long long pos = 0;
+    auto first_of = [&](bool mine) -> int {                       // lowest thread whose flag is set (NT = none); one barrier
+        const unsigned long long bal = __ballot(mine);
+        if (lane == 0) s_first[wv] = bal ? wv * 64 + (int)__builtin_ctzll(bal) : NT;
+        __syncthreads();
+        int first = NT;
+#pragma unroll
+        for (int k = 0; k < BR_WALK_WAVES; k++) first = min(first, s_first[k]);
+        return first;
+    };
+    while (pos < n) {
+        {
+            const unsigned sbits = __float_as_uint(sum);
+            const int e = (int)((sbits >> 23) & 0xff) - 127;
+            if (sum != 0.f && e >= BR_E0 && e < BR_E0 + ne && (pos % BR_WCHUNK) == 0) {
+                // whole chunks: scan their summaries for this binade, 1024 at a time, up to the chunk in which the sum leaves it
+                const double limit = (double)(0x800000u - (sbits & 0x7fffffu));     // steps of u until the binade ends
+                const int parity = (int)(sbits & 1u);
+                const long long c0 = pos / BR_WCHUNK + (long long)tid * EPT;
+                ParityFn fk[EPT], f = pf_identity();
+#pragma unroll
+                for (int k = 0; k < EPT; k++) {
+                    fk[k] = c0 + k < nchunks ? summ[(long long)(e - BR_E0) * nchunks + c0 + k] : pf_identity();
+                    f = pf_compose(f, fk[k]);
                 }
+                const ParityFn incl = pf_block_scan(f, s_part);
+                const double tot = parity ? incl.inc1 : incl.inc0;
+                s_tot[tid] = tot;
+                s_par[tid] = parity ? incl.b1 : incl.b0;          // the accumulator's parity behind this thread's chunks
+                const int first = first_of(tot >= limit);         // the thread whose four chunks hold the leaving one
+                if (tid == min(first, NT - 1)) {
+                    // everything before that thread's chunks is consumed; of its own chunks, those before the leaving one
+                    double steps = tid > 0 && first < NT ? s_tot[tid - 1] : (first < NT ? 0.0 : s_tot[NT - 1]);
+                    int taken = first < NT ? tid * EPT : NT * EPT;
+                    if (first < NT) {
+                        int par = tid > 0 ? s_par[tid - 1] : parity;
+#pragma unroll
+                        for (int k = 0; k < EPT; k++) {
+                            const double inc = par ? fk[k].inc1 : fk[k].inc0;
+                            if (steps + inc >= limit) break;
+                            steps += inc;
+                            par = par ? fk[k].b1 : fk[k].b0;
+                            taken++;
+                        }
+                    }
+                    s_res_steps = steps;
+                    s_res_taken = taken;
+                }
+                __syncthreads();
+                if (s_res_taken > 0) {
+                    sum = __uint_as_float(sbits + (unsigned)(long long)s_res_steps);
+                    pos = min(n, pos + (long long)s_res_taken * BR_WCHUNK);
+                }
+                __syncthreads();
+                if (first == NT || pos >= n) continue;
+                // the chunk at pos leaves the binade: replay it below (the accumulator is still in binade e)
             }
-            __syncthreads();
-            continue;
         }
-
-        // ---- exact block iteration over terms [pos, min(pos + BR_CHUNK, nlim))
-        const BrRegime g = br_regime(e);
+        // ---- term-by-term replay of [pos, next chunk boundary): four consecutive terms per thread, recomputed from the pixels
+        const unsigned sb = __float_as_uint(sum);
+        const bool zero = sum == 0.f;
+        const int e2 = (int)((sb >> 23) & 0xff) - 127;
+        const double lim2 = (double)(0x800000u - (sb & 0x7fffffu));
+        const int parity = (int)(sb & 1u);
+        const long long nlim = min(n, (pos / BR_WCHUNK + 1) * BR_WCHUNK);
+        const BrRegime g = br_regime(e2);
         ParityFn f = pf_identity();
         bool nonzero = false;
 #pragma unroll
-        for (int j = 0; j < BR_EPT; j++) {
-            const long long i = pos + (long long)tid * BR_EPT + j;
+        for (int k = 0; k < EPT; k++) {
+            const long long i = pos + (long long)tid * EPT + k;
+            double t = 0.0;
             if (i < nlim) {
-                const double t = terms[i];
-                if (zero) { nonzero |= (t != 0.0); continue; }
-                f = pf_compose(f, br_classify(t, g));
+                const int x = (int)(i / h), y = (int)(i - (long long)x * h);
+                t = br_term_of<CN>(br_load_px<CN>(src + (size_t)y * step + (size_t)x * CN));
+                if (zero) nonzero |= t != 0.0;
+                else f = pf_compose(f, br_classify(t, g));
             }
+            s_term[tid * EPT + k] = t;
         }
-        f = br_block_scan(f, s_wave);
-        const double tot = binit ? f.inc1 : f.inc0;              // steps added by everything up to and including this thread
-        const bool stop = zero ? nonzero : (tot >= limit);
-        const unsigned long long bal = __ballot(stop);
-        if (lane == 0) s_stop[wv] = bal ? (wv * 64 + (int)__builtin_ctzll(bal)) : 1 << 30;
-        s_excl[tid] = tot;
-        __syncthreads();
-        if (tid == 0) {
-            int first = 1 << 30;
-            for (int w2 = 0; w2 < 16; w2++) first = min(first, s_stop[w2]);
+        const ParityFn incl = pf_block_scan(f, s_part);
+        const double tot = parity ? incl.inc1 : incl.inc0;        // steps added by everything up to and including this thread
+        s_tot[tid] = tot;
+        const int first = first_of(zero ? nonzero : (tot >= lim2));
+        if (first == NT) {                                        // everything offered stays inside the binade
+            if (!zero) sum = __uint_as_float(sb + (unsigned)(long long)s_tot[NT - 1]);
+            pos = nlim;
+        } else {
+            // that thread's terms hold the one that leaves the binade (or the first non-zero one): the literal sequence
             float ns = sum;
-            long long np;
-            if (first >= 1024) {                                  // everything offered stays inside the binade
-                if (!zero) ns = __uint_as_float(sbits + (unsigned)(long long)s_excl[1023]);
-                np = pos + (long long)BR_CHUNK;
-                if (np > nlim) np = nlim;
-            } else {
-                if (!zero && first > 0) ns = __uint_as_float(sbits + (unsigned)(long long)s_excl[first - 1]);
-                np = pos + (long long)first * BR_EPT;
-                // the thread's own terms hold the one that leaves the binade (or the first non-zero term): literal sequence
-                for (int j = 0; j < BR_EPT && np < nlim; j++, np++) ns = (float)__dadd_rn((double)ns, terms[np]);
-            }
-            s_sum = ns;
-            s_pos = np;
+            if (!zero && first > 0) ns = __uint_as_float(sb + (unsigned)(long long)s_tot[first - 1]);
+            long long np = pos + (long long)first * EPT;
+#pragma unroll
+            for (int k = 0; k < EPT; k++)
+                if (np < nlim) { ns = (float)__dadd_rn((double)ns, s_term[first * EPT + k]); np++; }
+            sum = ns;
+            pos = np;
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        st->sum = s_sum;
-        st->pos = s_pos;
-        if (s_pos >= n) *out = s_sum;
-    }
+    if (tid == 0) *out = sum;
 }
 
 int launch_brightness(const View& v, float* host_result, hipStream_t s) {
     const long long n = (long long)v.w * v.h;
-    const long long nchunks = (n + BR_CHUNK - 1) / BR_CHUNK;
-    // big frames: the binades from 2^20 up hold almost all the terms, and their chunk summaries are work for the whole
-    // GPU; small frames (a thumbnail's Info request) are cheaper in the one-block form than the ~27 launches cost
-    const bool rounds = n >= (1LL << 19) && nchunks <= 0x7fffffff;
-    void *terms = nullptr, *out = nullptr, *st = nullptr, *summ = nullptr;
-    auto drop = [&]() { if (terms) dev_free(terms); if (out) dev_free(out); if (st) dev_free(st); if (summ) dev_free(summ); };
-    if (int rc = dev_alloc((size_t)n * sizeof(double), &terms)) return rc;
-    if (int rc = dev_alloc(sizeof(float), &out)) { drop(); return rc; }
-    if (int rc = dev_alloc(sizeof(BrState), &st)) { drop(); return rc; }
-    if (rounds) if (int rc = dev_alloc((size_t)nchunks * sizeof(ParityFn), &summ)) { drop(); return rc; }
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (v.c == 1) hipLaunchKernelGGL((k_brightness_terms<1>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
-    else if (v.c == 3) hipLaunchKernelGGL((k_brightness_terms<3>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
-    else hipLaunchKernelGGL((k_brightness_terms<4>), grid, block, 0, s, v.d, v.w, v.h, v.step, (double*)terms);
-    // a binade of T terms costs the one-block form about (T / 16384 + 1) x 10 us and a round about 37 us: rounds pay from
-    // 2^23 up (44 k terms at ~150 per term).  The sum cannot pass n * 255, nor (a term is at most 255, u / 2 = 256 there)
-    // leave binade 32.
-    const int first_round = 23;
-    int last_round = 0;
-    while (last_round < 32 && (double)n * 255.0 >= ldexp(1.0, last_round + 1)) last_round++;
-    hipLaunchKernelGGL(k_brightness_replay, dim3(1), dim3(1024), 0, s, (const double*)terms, n, (BrState*)st, (float*)out, 0,
-                       rounds ? first_round : 1000, (const ParityFn*)nullptr);
-    if (rounds) {
-        for (int e = first_round; e <= last_round; e++) {
-            hipLaunchKernelGGL(k_brightness_summarize, dim3((unsigned)nchunks), dim3(1024), 0, s, (const double*)terms, n,
-                               (const BrState*)st, e, (ParityFn*)summ);
-            hipLaunchKernelGGL(k_brightness_replay, dim3(1), dim3(1024), 0, s, (const double*)terms, n, (BrState*)st, (float*)out, 1, e,
-                               (const ParityFn*)summ);
-        }
+    const long long nchunks = (n + BR_WCHUNK - 1) / BR_WCHUNK;
+    // binades with summaries: from 2^20 up to the last one the sum can reach (a term is at most 255; u / 2 = 256 in binade
+    // 32, so it never leaves that one)
+    int last = 0;
+    while (last < 32 && (double)n * 255.0 >= ldexp(1.0, last + 1)) last++;
+    const int ne = last >= BR_E0 ? last - BR_E0 + 1 : 0;
+    void *out = nullptr, *summ = nullptr;
+    if (int rc = dev_alloc(sizeof(float), &out)) return rc;
+    if (ne) if (int rc = dev_alloc((size_t)ne * (size_t)nchunks * sizeof(ParityFn), &summ)) { dev_free(out); return rc; }
+    if (ne) {
+        const dim3 grid((unsigned)((nchunks + BR_FOLD_WAVES - 1) / BR_FOLD_WAVES)), block(64 * BR_FOLD_WAVES);
+        if (v.c == 1) hipLaunchKernelGGL((k_brightness_fold<1>), grid, block, 0, s, v.d, v.w, v.h, v.step, n, ne, nchunks, (ParityFn*)summ);
+        else if (v.c == 3) hipLaunchKernelGGL((k_brightness_fold<3>), grid, block, 0, s, v.d, v.w, v.h, v.step, n, ne, nchunks, (ParityFn*)summ);
+        else hipLaunchKernelGGL((k_brightness_fold<4>), grid, block, 0, s, v.d, v.w, v.h, v.step, n, ne, nchunks, (ParityFn*)summ);
     }
+    if (v.c == 1) hipLaunchKernelGGL((k_brightness_walk<1>), dim3(1), dim3(64 * BR_WALK_WAVES), 0, s, v.d, v.w, v.h, v.step, n, ne, nchunks, (const ParityFn*)summ, (float*)out);
+    else if (v.c == 3) hipLaunchKernelGGL((k_brightness_walk<3>), dim3(1), dim3(64 * BR_WALK_WAVES), 0, s, v.d, v.w, v.h, v.step, n, ne, nchunks, (const ParityFn*)summ, (float*)out);
+    else hipLaunchKernelGGL((k_brightness_walk<4>), dim3(1), dim3(64 * BR_WALK_WAVES), 0, s, v.d, v.w, v.h, v.step, n, ne, nchunks, (const ParityFn*)summ, (float*)out);
     hipError_t e = hipGetLastError();
-    float sum = 0.f;
-    if (e == hipSuccess) e = hipMemcpyAsync(&sum, out, sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    drop();
+    uint32_t* box = lane_mailbox();
+    if (e == hipSuccess && !box) e = hipErrorNotInitialized;
+    if (e == hipSuccess) e = hipMemcpyAsync(box, out, sizeof(float), hipMemcpyDeviceToHost, s);
+    dev_free(out);
+    dev_free(summ);
     if (e != hipSuccess) { set_error("brightness", e); return IMP_ERROR_DEVICE; }
+    if (int rc = lane_wait()) return rc;
+    float sum;
+    std::memcpy(&sum, box, sizeof sum);
     // filters.c:728: float / int -> float, then / 255.0 in double, returned as float
     const float mean = sum / (float)(v.w * v.h);
     *host_result = (float)((double)mean / 255.0);

@@ -332,12 +332,14 @@ static bool lane_take_back(Lane* L, void* p) {
     return true;
 }
 
-// Bytes a lane may keep on its free list.  A worker that once saw a 4K frame would otherwise hold 33 MB buckets for
-// ever, and N workers x lanes share one GPU.  IMPGPU_POOL_CAP_MB (default 256; 0 = never trim).
+// Bytes a lane may keep on its free list.  Without a bound a worker that once saw a burst of large frames holds their
+// buckets for ever, and N workers x lanes share one GPU.  IMPGPU_POOL_CAP_MB (default 2048 -- 288 GB of HBM and a
+// hipFree / hipMalloc pair that costs more than a 1080p request: the default only catches a pool that has run away,
+// a 256-file JPEG batch legitimately recycles 1.2 GB of coefficient planes per call; 0 = never trim).
 static size_t pool_cap() {
     static const size_t cap = [] {
         const char* s = std::getenv("IMPGPU_POOL_CAP_MB");
-        return (size_t)(s ? std::atoll(s) : 256) << 20;
+        return (size_t)(s ? std::atoll(s) : 2048) << 20;
     }();
     return cap;
 }

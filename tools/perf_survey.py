@@ -81,9 +81,12 @@ def main():
     bench("filter-blur=8 (k49)", filt("blur=8"), 2 * px)
     bench("watermark 256x64", lambda im: im.watermark(cfg), 3 * 256 * 64 * 4)
     bench("blend_with_paper", lambda im: im.blend_with_paper(), 2 * px)
+    for _ in range(3):                                 # (the first call loads the kernels)
+        base.calc_perceived_brightness()
     t0 = time.perf_counter()
-    b = base.calc_perceived_brightness()
-    dt = time.perf_counter() - t0
+    for _ in range(10):
+        b = base.calc_perceived_brightness()
+    dt = (time.perf_counter() - t0) / 10
     results.append({"op": "calc_perceived_brightness (serial replay)", "us_per_frame": round(dt * 1e6, 1), "GBps": round(px / dt / 1e9, 3)})
     print("%-34s %9.1f us/frame   (value %.4f)" % ("brightness (exact replay)", dt * 1e6, b))
     chain = dict(crop="16,9", resize="640,360", filters=["gotham=1", "rotate=90"])
