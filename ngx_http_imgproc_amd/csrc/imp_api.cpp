@@ -361,10 +361,10 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
         // ONE launch: both ride on the stores of the row-streaming AREA kernel (a lone request is launch-bound: this is a
         // third of its launches and two intermediate frames).  Anything the fused kernel does not take goes step by step.
         rc = IMP_ERROR_UNSUPPORTED;
-        if (interp == IMP_INTER_AREA && wk.v.c == 4 && job->filter_count >= 1) {
+        if (interp == IMP_INTER_AREA && (wk.v.c == 4 || wk.v.c == 3) && job->filter_count >= 1) {    // BGRA, and BGR: every JPEG
             FilterPlan first;
             PixelProgram none;
-            if (filter_plan(job->filters[0], config->allow_experiments, 4, w, h, &first, &none) == IMP_OK && first.cls == FC_ROTATE) {
+            if (filter_plan(job->filters[0], config->allow_experiments, wk.v.c, w, h, &first, &none) == IMP_OK && first.cls == FC_ROTATE) {
                 const bool swap = first.rotate != 180;
                 const int fw = swap ? h : w, fh = swap ? w : h;
                 const impgpu_image* ov = config->watermark;
@@ -376,7 +376,7 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
                     wm.alpha = 1 - (float)(config->watermark_opacity / 100.0);     // bridge.c:275, filters.c:620
                 }
                 impgpu_image* out = nullptr;
-                rc = image_new(fw, fh, 4, &out);
+                rc = image_new(fw, fh, wk.v.c, &out);
                 if (rc) goto done;
                 Frames f = one_frame(wk.v, out);
                 f.dw = w; f.dh = h;                                    // the resized geometry; `out` is the turned frame
@@ -494,8 +494,8 @@ int impgpu_batch_resize_rotate_watermark(const void* src, long long src_frame_st
         rc = launch_area2x2_rotate(fz, rotate, fuse ? &wm : nullptr, s);
         watermark_done = fuse && rc == IMP_OK;
     }
-    if (rc == IMP_ERROR_UNSUPPORTED && interp == IMP_INTER_AREA && channels == 4) {
-        // any other BGRA shrink: the rotate and the watermark ride on the store phase of the row-streaming AREA kernel
+    if (rc == IMP_ERROR_UNSUPPORTED && interp == IMP_INTER_AREA) {
+        // any other shrink, BGRA or BGR: the rotate and the watermark ride on the store phase of the row-streaming AREA kernel
         Frames fz = rs;
         fz.dst = (uint8_t*)dst; fz.dst_stride = dst_frame_stride; fz.dstep = dst_step;
         OverlayArgs wm{};

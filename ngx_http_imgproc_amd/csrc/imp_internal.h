@@ -120,6 +120,23 @@ __device__ __forceinline__ uint32_t blend_over_bgra(uint32_t d, uint32_t s, floa
     const int tAi = (a255 > -2147483904.f && a255 < 2147483648.f) ? (int)a255 : (int)0x80000000;
     return (uint32_t)(tB & 0xff) | ((uint32_t)(tG & 0xff) << 8) | ((uint32_t)(tR & 0xff) << 16) | ((uint32_t)(tAi & 0xff) << 24);
 }
+// The same on a 3-channel destination pixel (packed B | G << 8 | R << 16): its alpha is 1 (filters.c:636) and none is written.
+__device__ __forceinline__ uint32_t blend_over_bgr(uint32_t d, uint32_t s, float alpha) {
+    const int dB = d & 0xff, dG = (d >> 8) & 0xff, dR = (d >> 16) & 0xff;
+    const float dA = 1.f;
+    const int sB = s & 0xff, sG = (s >> 8) & 0xff, sR = (s >> 16) & 0xff;
+    float sA = (float)((double)(s >> 24) / 255.0);
+    sA = (float)fmax((double)__fsub_rn(sA, alpha), 0.0);
+    const float inv = __fsub_rn(1.f, sA);
+    const float tA = __fadd_rn(sA, __fmul_rn(dA, inv));
+    int tB = 0, tG = 0, tR = 0;
+    if (tA != 0.f) {
+        tB = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sB, sA), __fmul_rn(__fmul_rn((float)dB, dA), inv)), tA);
+        tG = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sG, sA), __fmul_rn(__fmul_rn((float)dG, dA), inv)), tA);
+        tR = (int)__fdiv_rn(__fadd_rn(__fmul_rn((float)sR, sA), __fmul_rn(__fmul_rn((float)dR, dA), inv)), tA);
+    }
+    return (uint32_t)(tB & 0xff) | ((uint32_t)(tG & 0xff) << 8) | ((uint32_t)(tR & 0xff) << 16);
+}
 #endif
 
 // ---------------------------------------------------------------- host grammar (imp_args.cpp)

@@ -1881,11 +1881,15 @@ __global__ __launch_bounds__(256) void k_resize_area_cells(RArgs a, AreaGeom gm,
 // next to the source walk, and the intermediate frames never exist.  rot = 0 / 90 / 180 / 270 (filters.c:111-133).
 constexpr int MIX_NV = 5;                              // windows of up to 20 source columns: shrinks up to 18x (3840 -> 224 is 17.1x)
 struct AreaTail { int rot; OverlayArgs wm; };
+template <int CN = 4>      // channels of the frame the overlay lands on; the overlay itself is BGRA
 __device__ __forceinline__ uint32_t overlay_px(const OverlayArgs& wm, uint32_t px, int row, int col) {
-    if (wm.ov && row >= wm.ry && row < wm.ry + wm.maxrow && col >= wm.rx && col < wm.rx + wm.maxcol)
-        px = blend_over_bgra(px, *(const uint32_t*)(wm.ov + (size_t)(row - wm.ry) * wm.ostep + (size_t)(col - wm.rx) * 4), wm.alpha);
+    if (wm.ov && row >= wm.ry && row < wm.ry + wm.maxrow && col >= wm.rx && col < wm.rx + wm.maxcol) {
+        const uint32_t o = *(const uint32_t*)(wm.ov + (size_t)(row - wm.ry) * wm.ostep + (size_t)(col - wm.rx) * 4);
+        px = CN == 4 ? blend_over_bgra(px, o, wm.alpha) : blend_over_bgr(px, o, wm.alpha);
+    }
     return px;
 }
+__device__ __forceinline__ void store_bgr(uint8_t* q, uint32_t px) { q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16); }
 
 template <int CN, int W>
 __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& gm, int frame, int item, int nstrips, int bh,
@@ -2015,20 +2019,16 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
         uint32_t px = 0;
 #pragma unroll
         for (int c = 0; c < CN; c++) px = cvt_pk_u8(acc[c], px, c);
-        if constexpr (CN == 3) {                                 // (no turn, no overlay for BGR: the launcher never asks)
-            if (live) {
-                uint8_t* q = D + (size_t)dy * a.dstep + (size_t)dx * 3;
-                q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16);
-            }
-        } else
         if (quarter) tile[(dy - dy0) * 65 + lane] = px;          // leaves with the band, turned (below)
         else if (live) {
             // R[i][j] = H[rh-1-i][rw-1-j] (180); H = the resized frame, dw x dh
             const int orow = tail.rot == 180 ? a.dh - 1 - dy : dy, ocol = tail.rot == 180 ? a.dw - 1 - dx : dx;
-            *(uint32_t*)(D + (size_t)orow * a.dstep + (size_t)ocol * 4) = overlay_px(tail.wm, px, orow, ocol);
+            const uint32_t o = overlay_px<CN>(tail.wm, px, orow, ocol);
+            if constexpr (CN == 4) *(uint32_t*)(D + (size_t)orow * a.dstep + (size_t)ocol * 4) = o;
+            else store_bgr(D + (size_t)orow * a.dstep + (size_t)ocol * 3, o);
         }
     }
-    if (CN == 4 && quarter) {
+    if (quarter) {
         // R[i][j] = H[rh-1-j][i] (90), H[j][rw-1-i] (270): a destination row takes this band's pixels of ONE column, a
         // contiguous run of dy1 - dy0 pixels -- written 16 bytes per lane, four lanes per run of 16, once per band (a
         // scattered store per finished row would sit in front of every later source-row wait: one vmcnt for both)
@@ -2045,10 +2045,12 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
             for (int jj = 0; jj < 4; jj++) {
                 const int k = 4 * qi + jj;                       // k-th pixel of the run
                 const int r = tail.rot == 90 ? nb - 1 - k : k;   // band row it comes from
-                v[jj] = overlay_px(tail.wm, tile[min(max(r, 0), nb - 1) * 65 + col], orow, j0 + k);
+                v[jj] = overlay_px<CN>(tail.wm, tile[min(max(r, 0), nb - 1) * 65 + col], orow, j0 + k);
             }
-            uint8_t* q = D + (size_t)orow * a.dstep + (size_t)(j0 + 4 * qi) * 4;
-            if (4 * qi + 4 <= nb) {
+            uint8_t* q = D + (size_t)orow * a.dstep + (size_t)(j0 + 4 * qi) * CN;
+            if constexpr (CN == 3) {                              // (a run of BGR pixels starts at any byte: byte stores)
+                for (int jj = 0; jj < 4 && 4 * qi + jj < nb; jj++) store_bgr(q + 3 * jj, v[jj]);
+            } else if (4 * qi + 4 <= nb) {
                 const u32x4_t o4 = {v[0], v[1], v[2], v[3]};
                 *(u32x4_t*)q = o4;
             } else {
@@ -2061,7 +2063,7 @@ __device__ __forceinline__ void area_rows_body(const RArgs& a, const AreaGeom& g
 template <int CN, int W>
 __global__ __launch_bounds__(256) void k_resize_area_rows(RArgs a, AreaGeom gm, int nstrips, int bh, int nitems, int bpf, int count, AreaTail tail) {
     __shared__ __attribute__((aligned(16))) uint32_t s_line[4][64 * ((W + 3) / 4) * 4 + 4];      // + 4: a BGR window's look-ahead dword at the line's very end stays inside it
-    __shared__ uint32_t s_tile[4][CN == 4 ? 16 * 65 : 1];        // quarter turns: a band (<= 16 rows) waits here to leave turned
+    __shared__ uint32_t s_tile[4][16 * 65];                      // quarter turns: a band (<= 16 rows) waits here to leave turned
     int frame, blk;
     if (!frame_block(bpf, count, &frame, &blk)) return;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2447,11 +2449,12 @@ static void launch_area_rows(int w, dim3 grid, hipStream_t s, const RArgs& a, co
     }
 }
 
-// Resize (general INTER_AREA, BGRA) + rotate + watermark in one pass; f.dw x f.dh is the RESIZED geometry, f.dst the final
+// Resize (general INTER_AREA, BGRA or BGR) + rotate + watermark (a BGRA overlay) in one pass; f.dw x f.dh is the RESIZED geometry, f.dst the final
 // (rotated) frames.  IMP_ERROR_UNSUPPORTED when the geometry takes another resize kernel.
 int launch_area_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s) {
     const View& v = f.v;
-    if (v.c != 4 || f.count <= 0 || f.count > 65535 || f.dw > v.w || f.dh > v.h) return IMP_ERROR_UNSUPPORTED;
+    if ((v.c != 4 && v.c != 3) || f.count <= 0 || f.count > 65535 || f.dw > v.w || f.dh > v.h) return IMP_ERROR_UNSUPPORTED;
+    if (v.c == 3 && v.w < 6) return IMP_ERROR_UNSUPPORTED;   // (the BGR windows' aligned-dword reads need a few pixels of row)
     if (((uintptr_t)f.src | (uintptr_t)f.dst | (uintptr_t)v.step | (uintptr_t)f.dstep | (uintptr_t)f.src_stride | (uintptr_t)f.dst_stride) & 3)
         return IMP_ERROR_UNSUPPORTED;
     const double scale_x = 1. / ((double)f.dw / v.w), scale_y = 1. / ((double)f.dh / v.h);
@@ -2467,7 +2470,8 @@ int launch_area_rotate(const Frames& f, int amount, const OverlayArgs* overlay, 
     if (overlay) tail.wm = *overlay;
     const int nstrips = (f.dw + 63) / 64, nitems = nstrips * ((f.dh + bh - 1) / bh), bpf = (nitems + 3) / 4;
     const dim3 grid((unsigned)bpf, (unsigned)((f.count + 7) / 8 * 8));
-    launch_area_rows<4, 4 * MIX_NV>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, f.count, tail);
+    if (v.c == 4) launch_area_rows<4, 4 * MIX_NV>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, f.count, tail);
+    else launch_area_rows<3, 4 * MIX_NV>(w, grid, s, a, gm, nstrips, bh, nitems, bpf, f.count, tail);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }

@@ -178,22 +178,26 @@ def test_cfg3_chain_batch_224_variant(gpu):
 @pytest.mark.parametrize("rotate", [0, 90, 180, 270])
 @pytest.mark.parametrize("geom", [((96, 128), (64, 48)), ((96, 130), (64, 48)), ((70, 90), (45, 35)), ((66, 70), (35, 33)),
                                   ((300, 500), (150, 77)), ((96, 128), (32, 32))])
-def test_batch_resize_rotate_watermark_all_turns(gpu, rotate, geom):
+@pytest.mark.parametrize("c", [4, 3])
+def test_batch_resize_rotate_watermark_all_turns(gpu, rotate, geom, c):
     """Batch chain API: the fused 2x2-box + quarter-turn kernel (exact halves), the row-streaming AREA kernel with the turn
-    and the blend on its stores (any other BGRA shrink; several column strips, a partial last one) and the unfused
-    fallback (integer factors other than 2) agree with the oracle."""
+    and the blend on its stores (any other shrink, BGRA and -- round 3 -- BGR, what every JPEG decodes to; several column
+    strips, a partial last one) and the unfused fallback (integer factors other than 2) agree with the oracle."""
     (sh, sw), (rw, rh) = geom
+    if c == 3 and (sw * 3) % 4:
+        sw += 4 - sw % 4                                  # batch frames sit back to back: keep the BGR rows 4-byte aligned
     n = 3
-    frames = [noise_image(sh, sw, 4, 60 + i) for i in range(n)]
+    frames = [noise_image(sh, sw, c, 60 + i) for i in range(n)]
     ov = noise_image(10, 14, 4, 61)
     cfg = gpu.Config()
     assert cfg.prepare_watermark(ov, "c", "b", 1, 2, 70) == 0
     fw, fh = (rh, rw) if rotate in (90, 270) else (rw, rh)
     src = gpu.Image(np.concatenate(frames, axis=0))
-    dst = gpu.Image(np.zeros((n * fh, fw, 4), np.uint8))
-    gpu.batch_resize_rotate_watermark(src.device_ptr, sh * sw * 4, sw, sh, sw * 4, dst.device_ptr, fh * fw * 4, fw * 4,
-                                      rw, rh, rotate, cfg, 4, n)
-    out = dst.numpy().reshape(n, fh, fw, 4)
+    dst = gpu.Image(np.zeros((n * fh, fw, c), np.uint8))
+    dstep = dst.step                                      # rows padded to 4 bytes like every frame
+    gpu.batch_resize_rotate_watermark(src.device_ptr, sh * src.step, sw, sh, src.step, dst.device_ptr, fh * dstep, dstep,
+                                      rw, rh, rotate, cfg, c, n)
+    out = dst.numpy().reshape(n, fh, fw, c)
     filters = ["rotate=%d" % rotate] if rotate else []
     for i in range(n):
         rc, step, want = oracle_chain(frames[i], resize="%d,%d" % (rw, rh), filters=filters, overlay=ov, wm=("c", "b", 1, 2, 70))
@@ -202,21 +206,22 @@ def test_batch_resize_rotate_watermark_all_turns(gpu, rotate, geom):
 
 
 @pytest.mark.parametrize("rotate", [90, 270, 180])
-def test_fused_area_rotate_with_full_bands(gpu, rotate):
+@pytest.mark.parametrize("c", [4, 3])
+def test_fused_area_rotate_with_full_bands(gpu, rotate, c):
     """Enough frames that the row-streaming kernel takes its 16-row bands (as in bench.py --mode chain224): the turned
-    band leaves through the LDS tile in runs of 16 pixels, the last band of 50 rows is partial."""
+    band leaves through the LDS tile in runs of 16 pixels, the last band of 50 rows is partial.  BGRA and BGR."""
     n, sh, sw, rw, rh = 1100, 120, 80, 37, 50
     rng = np.random.Generator(np.random.PCG64(0x1A4D7700 + rotate))
-    frames = rng.integers(0, 256, size=(n, sh, sw, 4), dtype=np.uint8)
+    frames = rng.integers(0, 256, size=(n, sh, sw, c), dtype=np.uint8)
     ov = noise_image(9, 20, 4, 62)
     cfg = gpu.Config()
     assert cfg.prepare_watermark(ov, "l", "t", 3, 1, 55) == 0
     fw, fh = (rh, rw) if rotate in (90, 270) else (rw, rh)
-    src = gpu.Image(frames.reshape(n * sh, sw, 4))
-    dst = gpu.Image(np.zeros((n * fh, fw, 4), np.uint8))
-    gpu.batch_resize_rotate_watermark(src.device_ptr, sh * sw * 4, sw, sh, sw * 4, dst.device_ptr, fh * fw * 4, fw * 4,
-                                      rw, rh, rotate, cfg, 4, n)
-    out = dst.numpy().reshape(n, fh, fw, 4)
+    src = gpu.Image(frames.reshape(n * sh, sw, c))
+    dst = gpu.Image(np.zeros((n * fh, fw, c), np.uint8))
+    gpu.batch_resize_rotate_watermark(src.device_ptr, sh * src.step, sw, sh, src.step, dst.device_ptr, fh * dst.step, dst.step,
+                                      rw, rh, rotate, cfg, c, n)
+    out = dst.numpy().reshape(n, fh, fw, c)
     for i in range(0, n, 7):
         rc, step, want = oracle_chain(frames[i], resize="%d,%d" % (rw, rh), filters=["rotate=%d" % rotate], overlay=ov,
                                       wm=("l", "t", 3, 1, 55))
