@@ -39,6 +39,17 @@ WORKLOADS = {
     # the reference's only CUBIC dispatch is an enlargement (bridge.c:190): 480x270 -> 1920x1080 `up`; output-dominated
     "upscale": (480, 270, 1920, 1080, 512, 2, 480 * 270 * 4 + 1920 * 1080 * 4,
                 "batch 512 of 480x270 BGRA resize->1920x1080 INTER_CUBIC (enlargement: what Resize() sends to CUBIC)"),
+    # round 3: the rolling-strip kernel that replaced k_resize_tiled.  CUBIC with one axis growing and the other shrinking
+    # (Resize() asks for CUBIC as soon as ONE axis grows, bridge.c:190: a portrait frame made landscape), and the two
+    # modes the reference never dispatches but north_star names, enlarging and at a scale between 1 and 2
+    "upscale_x": (1080, 1920, 1920, 1080, 256, 2, 1080 * 1920 * 4 + 1920 * 1080 * 4,
+                  "batch 256 of 1080x1920 BGRA resize->1920x1080 INTER_CUBIC (x grows 1.78x, y shrinks 1.78x)"),
+    "lanczos_up": (960, 540, 1920, 1080, 256, 4, 960 * 540 * 4 + 1920 * 1080 * 4,
+                   "batch 256 of 960x540 BGRA resize->1920x1080 INTER_LANCZOS4 (2x enlargement)"),
+    "linear_up": (960, 540, 1920, 1080, 256, 1, 960 * 540 * 4 + 1920 * 1080 * 4,
+                  "batch 256 of 960x540 BGRA resize->1920x1080 INTER_LINEAR (2x enlargement)"),
+    "lanczos_15": (2880, 1620, 1920, 1080, 64, 4, 2880 * 1620 * 4 + 1920 * 1080 * 4,
+                   "batch 64 of 2880x1620 BGRA resize->1920x1080 INTER_LANCZOS4 (scale 1.5)"),
     # the simplest shrink: exact 2x2 box (cfg3's resize=960,540 on its own)
     "area2x": (1920, 1080, 960, 540, 256, 3, 1920 * 1080 * 4 + 960 * 540 * 4,
                "batch 256 of 1920x1080 BGRA resize->960x540 INTER_AREA (exact 2x2 box)"),

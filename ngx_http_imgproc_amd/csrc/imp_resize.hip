@@ -203,140 +203,6 @@ __global__ __launch_bounds__(256) void k_resize_taps(RArgs a, const int* __restr
     }
 }
 
-// ------------------------------------------------------------------ LDS-tiled separable variant
-// For scale factors <= 2 per axis (4K -> 1080p Lanczos, every enlargement) neighbouring
-// destination pixels share most of their taps: the gather kernel above would redo the horizontal
-// pass of each source row KS/scale times.  Here a 256-thread block owns a 64 x TH destination tile:
-// (1) the horizontal pass runs once per (source row of the footprint, destination column): each
-// lane pulls its KS-pixel window straight from global memory (neighbouring lanes' windows overlap,
-// so a wave's request is a few contiguous lines served by L1) and leaves int32x4 in an LDS plane;
-// (2) the vertical pass reads that plane 16 bytes per lane, bank-conflict free, and writes
-// coalesced dwords.  LDS holds only the plane (TH=16: 40 KB -> 4 tiles per CU).
-#define TL_TW 64
-
-// Tiles are numbered so that the 8 XCDs (blocks are dealt to them round-robin, so linear block id
-// mod 8 labels the XCD group) each own a contiguous band of tile rows: vertically adjacent tiles,
-// which share KS-1 halo rows, then meet in the same XCD's L2 instead of each pulling the halo
-// from HBM.  Speed only; any placement gives the same bytes.
-__device__ __forceinline__ void tile_of_block(int lin, int ntx, int nty, int* bx, int* by) {
-    const int n = ntx * nty;
-    const int per = (n + 7) >> 3;
-    int t = (lin & 7) * per + (lin >> 3);
-    if (t >= n) { *bx = -1; *by = -1; return; }      // padding blocks of the last band
-    *by = t / ntx;
-    *bx = t - *by * ntx;
-}
-
-template <int KS, int MODE, int TL_TH>
-__global__ __launch_bounds__(256) void k_resize_tiled(RArgs a, const int* __restrict__ xofs,
-                                                      const short* __restrict__ xco,
-                                                      const int* __restrict__ yofs,
-                                                      const short* __restrict__ yco, int vec_end, int ntx, int nty) {
-    constexpr int TL_SYH = (TL_TH - 1) * 2 + 10;
-    __shared__ __attribute__((aligned(16))) int4 s_hs[TL_SYH * TL_TW];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int bx, by;
-    tile_of_block(blockIdx.x, ntx, nty, &bx, &by);
-    if (bx < 0) return;
-    const int tx0 = bx * TL_TW, ty0 = by * TL_TH;
-    const int txn = min(TL_TW, a.dw - tx0), tyn = min(TL_TH, a.dh - ty0);
-    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
-    const int ylo = yofs[ty0] - (KS / 2 - 1);
-    const int syh = yofs[ty0 + tyn - 1] + KS / 2 - ylo + 1;
-    if (syh > TL_SYH) return;   // cannot happen for scales <= 2 (launcher's condition); keeps LDS indexing safe
-
-    // (1) horizontal pass: lane = destination column of the tile, waves stride over source rows.
-    // Two taps per instruction: v_perm_b32 gathers channel c of pixels 2j and 2j+1 into the two
-    // 16-bit halves of a dword, v_dot2_i32_i16 multiplies them with the packed weight pair and
-    // accumulates in int32 -- exact, and half the VALU work of byte-extract + mad.
-    if (lane < txn) {
-        short2_t axp[KS / 2];
-#pragma unroll
-        for (int j = 0; j < KS / 2; j++) {
-            axp[j].x = xco[(tx0 + lane) * KS + 2 * j];
-            axp[j].y = xco[(tx0 + lane) * KS + 2 * j + 1];
-        }
-        const int sx0 = xofs[tx0 + lane] - (KS / 2 - 1);
-        const bool interior = sx0 >= 0 && sx0 + KS <= a.sw;
-        const int sxv = clampi(sx0, 0, a.sw - KS) * 4;      // launcher guarantees sw >= KS
-        int sxk[KS];
-#pragma unroll
-        for (int k = 0; k < KS; k++) sxk[k] = clampi(sx0 + k, 0, a.sw - 1) * 4;
-        for (int r = wv; r < syh; r += 4) {
-            const uint8_t* row = S + (size_t)clampi(ylo + r, 0, a.sh - 1) * a.sstep;
-            uint32_t p[KS];
-            // every lane issues the vector load (window start clamped into the row); only lanes whose
-            // taps are replicated at the image border re-read tap by tap.  Keeping the vector load
-            // unconditional stops the compiler from folding both forms into 8 dword loads.
-            __builtin_memcpy(p, __builtin_assume_aligned(row + sxv, 4), KS * 4);
-#pragma unroll
-            for (int k = 0; k < KS; k++) asm volatile("" : "+v"(p[k]));   // opaque: or the compiler proves tap k == window[k] and drops the wide load
-            if (!interior) {
-#pragma unroll
-                for (int k = 0; k < KS; k++) p[k] = *(const uint32_t*)(row + sxk[k]);
-            }
-            int h[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                int acc = 0;
-#pragma unroll
-                for (int j = 0; j < KS / 2; j++) {
-                    const uint32_t pr = __builtin_amdgcn_perm(p[2 * j + 1], p[2 * j], 0x0c040c00u + (c << 16) + c);
-                    acc = __builtin_amdgcn_sdot2(as_short2(pr), axp[j], acc, false);
-                }
-                h[c] = acc;
-            }
-            s_hs[r * TL_TW + lane] = make_int4(h[0], h[1], h[2], h[3]);
-        }
-    }
-    __syncthreads();
-
-
-    // (2) vertical pass
-    if (lane < txn) {
-        const int dx = tx0 + lane;
-        for (int yl = wv; yl < tyn; yl += 4) {
-            const int dy = ty0 + yl;
-            const int syl = yofs[dy] - (KS / 2 - 1) - ylo;
-            int by[KS];
-#pragma unroll
-            for (int k = 0; k < KS; k++) by[k] = yco[dy * KS + k];
-            int4 h[KS];
-#pragma unroll
-            for (int k = 0; k < KS; k++) h[k] = s_hs[(syl + k) * TL_TW + lane];
-            int out[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                int hc[KS];
-#pragma unroll
-                for (int k = 0; k < KS; k++) hc[k] = c == 0 ? h[k].x : (c == 1 ? h[k].y : (c == 2 ? h[k].z : h[k].w));
-                if constexpr (MODE == M_LINEAR) {
-                    out[c] = (uint8_t)((((by[0] * (hc[0] >> 4)) >> 16) + ((by[1] * (hc[1] >> 4)) >> 16) + 2) >> 2);
-                } else if constexpr (MODE == M_CUBIC) {
-                    if (dx * 4 + c < vec_end) {
-                        const float sc = 1.f / (2048.f * 2048.f);
-                        float s = __fmul_rn(__int2float_rn(hc[0]), __fmul_rn((float)by[0], sc));
-                        s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[1]), __fmul_rn((float)by[1], sc)));
-                        s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[2]), __fmul_rn((float)by[2], sc)));
-                        s = __fadd_rn(s, __fmul_rn(__int2float_rn(hc[3]), __fmul_rn((float)by[3], sc)));
-                        out[c] = sat_u8(__float2int_rn(s));
-                    } else {
-                        int v = __mul24(hc[0], by[0]) + __mul24(hc[1], by[1]) + __mul24(hc[2], by[2]) + __mul24(hc[3], by[3]);
-                        out[c] = shr_sat_u8(v + (1 << 21), 22);
-                    }
-                } else {
-                    int v = 1 << 21;      // |hs| < 2^23: v_mad_i32_i24 is exact mod 2^32 (int32 wrap like the CPU build)
-#pragma unroll
-                    for (int k = 0; k < KS; k++) v = __mul24(hc[k], by[k]) + v;
-                    out[c] = shr_sat_u8(v, 22);
-                }
-            }
-            *(uint32_t*)(a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dy * a.dstep + (size_t)dx * 4) =
-                (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
-        }
-    }
-}
-
 // Frame-per-XCD block order for kernels whose neighbouring blocks re-read the same source rows
 // (AREA: consecutive destination rows share their boundary source row).  Blocks are dealt to the
 // 8 XCDs round-robin, so linear id mod 8 labels an XCD group; here a group works through whole
@@ -377,7 +243,7 @@ __device__ __forceinline__ void hpass_row(const uint8_t* row, int sxv, const int
     // share these lines, so they must stay cached (with the non-temporal hint PMC showed every line fetched 1.5x)
     __builtin_memcpy(p, __builtin_assume_aligned(row + sxv, 4), KS * 4);
 #pragma unroll
-    for (int k = 0; k < KS; k++) asm volatile("" : "+v"(p[k]));     // opaque: keeps the wide load (see k_resize_tiled)
+    for (int k = 0; k < KS; k++) asm volatile("" : "+v"(p[k]));     // opaque: keeps the wide load (a guarded wide load next to a per-tap fallback is otherwise folded into dword loads)
     if (!interior) {
 #pragma unroll
         for (int k = 0; k < KS; k++) p[k] = *(const uint32_t*)(row + sxk[k]);
@@ -855,7 +721,7 @@ __device__ __forceinline__ uint32_t vpass_px(const int (*ring)[4], const int* b,
 #pragma unroll
         for (int k = 0; k < KS; k++) hc[k] = ring[(k + 2 * U) % KS][c];
         if constexpr (MODE == M_LINEAR) {
-            out[c] = (uint8_t)((((b[0] * (hc[0] >> 4)) >> 16) + ((b[1] * (hc[1] >> 4)) >> 16) + 2) >> 2);
+            out[c] = (uint8_t)(((__mul24(b[0], hc[0] >> 4) >> 16) + (__mul24(b[1], hc[1] >> 4) >> 16) + 2) >> 2);   // (|hc >> 4| < 2^15, b <= 2^11: the 24-bit multiplier is exact)
         } else if constexpr (MODE == M_CUBIC) {
             if (dx * 4 + c < vec_end) {
                 const float sc = 1.f / (2048.f * 2048.f);
@@ -953,7 +819,7 @@ __global__ __launch_bounds__(256) void k_resize_2x_roll(RArgs a, const int* __re
 // KS x KS footprint for every output: 18.8 k img/s for 4K lanczos; this form shares each row sum between KS/2 outputs.)
 template <int KS>
 __device__ __forceinline__ void hpass_bgr(const uint32_t* w, const short2_t* axp, int* h) {
-    constexpr int NDW = KS * 3 / 4;
+    constexpr int NDW = (KS * 3 + 3) / 4;                       // (KS = 2: six bytes in two dwords)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         int acc = 0;
@@ -1071,6 +937,163 @@ __global__ __launch_bounds__(256) void k_resize_2x_roll3(RArgs a, const int* __r
                 }
             }
         });
+    }
+}
+
+// ------------------------------------------------------------------ any scale up to 2, any enlargement: rolling strips
+// LINEAR and LANCZOS4 at every scale that is not exactly 2 (those have the static schedules above), CUBIC when y shrinks
+// while x grows (Resize() asks for CUBIC as soon as ONE axis grows, bridge.c:190), BGRA and BGR.  Replaces the LDS-tiled
+// kernel of rounds 1-2 (0.13 of the roofline: ~250 VALU operations per output, a block-wide barrier pair per tile) and
+// the per-pixel gather that 3-channel frames used to fall to.
+// The exact-2x strips generalised: a lane owns one destination column, a wave walks a strip of rows down and keeps the
+// horizontal sums of the CURRENT footprint -- rows first .. first + KS - 1, in order -- in registers.  The footprint moves
+// by yofs[dy] - yofs[dy - 1] rows per destination row (0 or 1 when enlarging, 1 or 2 when shrinking by up to 2): every
+// step shifts the ring by one row and reduces one new source row (the windows come straight from memory: neighbouring
+// lanes overlap, so a wave's request is a few contiguous lines).  The row's weights are wave-uniform (scalar loads).
+// Nothing is shared between waves: no LDS, no barrier.
+template <int KS, int MODE>
+__device__ __forceinline__ uint32_t vpass_bgr(const int (*ring)[3], const int* by, int dx, int vec_end) {
+    int out[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int hc[KS];
+#pragma unroll
+        for (int k = 0; k < KS; k++) hc[k] = ring[k][c];
+        if constexpr (MODE == M_LINEAR) {
+            out[c] = (uint8_t)(((__mul24(by[0], hc[0] >> 4) >> 16) + (__mul24(by[1], hc[1] >> 4) >> 16) + 2) >> 2);
+        } else if constexpr (MODE == M_CUBIC) {
+            if (dx * 3 + c < vec_end) {
+                const float sc = 1.f / (2048.f * 2048.f);
+                float v = __fmul_rn(__int2float_rn(hc[0]), __fmul_rn((float)by[0], sc));
+                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[1]), __fmul_rn((float)by[1], sc)));
+                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[2]), __fmul_rn((float)by[2], sc)));
+                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[3]), __fmul_rn((float)by[3], sc)));
+                out[c] = sat_u8(__float2int_rn(v));
+            } else {
+                const int v = __mul24(hc[0], by[0]) + __mul24(hc[1], by[1]) + __mul24(hc[2], by[2]) + __mul24(hc[3], by[3]);
+                out[c] = shr_sat_u8(v + (1 << 21), 22);
+            }
+        } else {
+            int v = 1 << 21;                                   // |hc| < 2^23: the 24-bit multiplier is exact
+#pragma unroll
+            for (int k = 0; k < KS; k++) v = mad24s(hc[k], by[k], v);
+            out[c] = shr_sat_u8(v, 22);
+        }
+    }
+    return (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16);
+}
+
+constexpr int strip_row_ints(int ks) { return ks <= 2 ? 4 : ks <= 4 ? 8 : 16; }   // per destination row: {first footprint row, KS weights, padding}
+
+template <int KS, int MODE, int CN>
+__global__ __launch_bounds__(256) void k_resize_strip(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                      const int* __restrict__ srows, int vec_end, int rows_per_strip) {
+    static_assert(CN == 3 || CN == 4, "interleaved BGR / BGRA");
+    constexpr int NDW = (KS * 3 + 3) / 4;                       // dwords holding a BGR window
+    constexpr int NW = CN == 4 ? KS : NDW + 1;                  // registers of one window in flight (BGR: before the byte alignment)
+    constexpr int SR = strip_row_ints(KS);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x * 4 + wv;                      // the four waves of a block: neighbouring strips of the same rows
+    if (strip * 64 >= a.dw) return;
+    const int dx = strip * 64 + lane;
+    const int dy0 = blockIdx.y * rows_per_strip, dy1 = min(a.dh, dy0 + rows_per_strip);
+    const bool live = dx < a.dw;
+    const int dxc = live ? dx : a.dw - 1;                       // idle lanes shadow the last column (no stores)
+    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
+    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dx * CN;
+
+    short2_t axp[KS / 2];
+#pragma unroll
+    for (int j = 0; j < KS / 2; j++) { axp[j].x = xco[dxc * KS + 2 * j]; axp[j].y = xco[dxc * KS + 2 * j + 1]; }
+    const int sx0 = xofs[dxc] - (KS / 2 - 1);
+    const bool interior = sx0 >= 0 && sx0 + KS <= a.sw;
+    const int sxv = clampi(sx0, 0, a.sw - KS) * CN;
+    const unsigned bsh = (unsigned)(uintptr_t)(S + sxv) & 3u;   // BGR: where the window starts inside its first aligned dword
+    int sxk[KS];
+#pragma unroll
+    for (int k = 0; k < KS; k++) sxk[k] = clampi(sx0 + k, 0, a.sw - 1) * CN;
+
+    // A source row's window is REQUESTED two footprint steps before it is reduced (no wait at the request: loads and stores
+    // share vmcnt, and a wave that waited for every window where it asks for it spent its time in that wait) ...
+    auto request = [&](int sy, uint32_t* w) {
+        const uint8_t* row = S + (size_t)clampi(sy, 0, a.sh - 1) * a.sstep;
+        if constexpr (CN == 4) __builtin_memcpy(w, __builtin_assume_aligned(row + sxv, 4), KS * 4);
+        else {
+            const uint32_t* q = (const uint32_t*)(row + sxv - bsh);
+            __builtin_memcpy(w, __builtin_assume_aligned(q, 4), NDW * 4);
+            w[NDW] = q[(bsh + 3 * KS - 1) >> 2];                // the word the window's last byte lives in: never past it
+        }
+    };
+    // ... and reduced here: horizontal sums of that row for this column.  Border columns (the strips at the frame's edges)
+    // re-read their taps one by one at clamped positions.
+    auto reduce = [&](int sy, uint32_t* w, int* h) {
+#pragma unroll
+        for (int i = 0; i < NW; i++) asm volatile("" : "+v"(w[i]));   // opaque: keeps the wide load apart from the fallback below
+        if constexpr (CN == 4) {
+            if (!interior) {
+                const uint8_t* row = S + (size_t)clampi(sy, 0, a.sh - 1) * a.sstep;
+#pragma unroll
+                for (int k = 0; k < KS; k++) w[k] = *(const uint32_t*)(row + sxk[k]);
+            }
+            hpass_px<KS>(w, axp, h);
+        } else {
+            uint32_t v[NDW];
+#pragma unroll
+            for (int i = 0; i < NDW; i++) v[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], bsh);
+            if (!interior) {
+                const uint8_t* row = S + (size_t)clampi(sy, 0, a.sh - 1) * a.sstep;
+#pragma unroll
+                for (int i = 0; i < NDW; i++) v[i] = 0;
+#pragma unroll
+                for (int k = 0; k < KS; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int o = 3 * k + c;
+                        v[o >> 2] |= (uint32_t)row[sxk[k] + c] << (8 * (o & 3));
+                    }
+            }
+            hpass_bgr<KS>(v, axp, h);
+        }
+    };
+
+    int ring[KS][CN];
+    int first = srows[(size_t)dy0 * SR];
+    {
+        uint32_t w[NW];
+#pragma unroll
+        for (int k = 0; k < KS; k++) { request(first + k, w); reduce(first + k, w, ring[k]); }
+    }
+    uint32_t p0[NW], p1[NW];                                    // windows of rows first + KS and first + KS + 1, in flight
+    request(first + KS, p0);
+    request(first + KS + 1, p1);
+    for (int dy = dy0; dy < dy1; dy++) {
+        const int* __restrict__ rw = srows + (size_t)dy * SR;   // (wave-uniform: scalar loads)
+        const int want = rw[0];
+        while (first < want) {                                  // one source row further: shift, reduce the row that enters
+#pragma unroll
+            for (int k = 0; k + 1 < KS; k++)
+#pragma unroll
+                for (int c = 0; c < CN; c++) ring[k][c] = ring[k + 1][c];
+            reduce(first + KS, p0, ring[KS - 1]);
+            first++;
+#pragma unroll
+            for (int i = 0; i < NW; i++) p0[i] = p1[i];
+            request(first + KS + 1, p1);
+        }
+        int by[KS];
+#pragma unroll
+        for (int k = 0; k < KS; k++) by[k] = rw[1 + k];
+        if constexpr (CN == 4) {
+            const uint32_t px = vpass_px<KS, MODE, 0>(ring, by, dx, vec_end);
+            if (live) *(uint32_t*)(D + (size_t)dy * a.dstep) = px;
+        } else {
+            const uint32_t px = vpass_bgr<KS, MODE>(ring, by, dx, vec_end);
+            if (live) {
+                uint8_t* q = D + (size_t)dy * a.dstep;
+                q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16);
+            }
+        }
     }
 }
 
@@ -2235,7 +2258,7 @@ __global__ __launch_bounds__(256) void k_resize_area_rows4(RArgs a, AreaGeom gm,
 // a descriptor per frame -- its views and its two scale factors -- instead of launch arguments.  Blocks are dealt to the
 // XCDs like frame_block deals them (block id mod 8 = XCD): descriptor list g holds the frames of XCD g back to back, each
 // with the number of the first block it owns inside that list, and a block finds its frame by bisection over those.
-struct MixDesc { RArgs a; AreaGeom gm; int first, nblk, nv, rows, nstrips, nitems; };   // nitems > 0: row-streaming body, nv = window W, rows = band height
+struct MixDesc { RArgs a; AreaGeom gm; int first, nblk, nv, rows, nstrips, nitems; };   // nitems > 0: row-streaming body, nv = window W (negative: four columns per lane, window -nv), rows = band height
 struct MixIndex { int off[9]; };                       // descriptors of XCD g: [off[g], off[g + 1])
 
 template <int CN>
@@ -2250,7 +2273,17 @@ __global__ __launch_bounds__(256) void k_resize_area_mix(const MixDesc* __restri
     }
     const MixDesc& m = d[lo];
     const int blk = q - m.first;
-    if (m.nitems > 0) {                                // (everything here is block-uniform: scalar branches)
+    if (m.nitems > 0 && m.nv < 0) {                    // small factors: four destination columns per lane (k_resize_area_rows4's body)
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int item = blk * 4 + wv;
+        if (item >= m.nitems) return;
+        switch (-m.nv) {
+            case 2: area_rows4_body<CN, 2>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 3: area_rows4_body<CN, 3>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            case 4: area_rows4_body<CN, 4>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+            default: area_rows4_body<CN, 5>(m.a, m.gm, 0, item, m.nstrips, m.rows, s_line[wv]); break;
+        }
+    } else if (m.nitems > 0) {                         // (everything here is block-uniform: scalar branches)
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int item = blk * 4 + wv;
         if (item >= m.nitems) return;
@@ -2287,6 +2320,7 @@ struct TableSet {
     void* blob = nullptr;     // one device allocation
     const int *xofs = nullptr, *yofs = nullptr;
     const short *xco = nullptr, *yco = nullptr;
+    const int* srows = nullptr;   // per destination row {first footprint row, ksize weights, padding}: strip_row_ints(ksize) ints (k_resize_strip)
     const void* yrows = nullptr;  // CUBIC: per destination row {footprint advance, yco * 2^-22 as floats, first footprint row} (UpRow)
     int up_period = 0;        // CUBIC enlargement: P when exactly every P-th destination row advances the footprint (integer factor), else 0
     bool ysym = false;        // step2 and the one set of row weights is mirror-symmetric (vpass_px's VSYM form)
@@ -2389,6 +2423,17 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
             while (blob.size() % 32) blob.push_back(0);
             o[4] = put(blob, yr);
         }
+        {
+            const int sr = strip_row_ints(ty.ksize);
+            std::vector<int> rows((size_t)(dh + 1) * sr, 0);     // + a sentinel row
+            for (int d = 0; d <= dh; d++) {
+                const int dd = d < dh ? d : dh - 1;
+                rows[(size_t)d * sr] = ty.ofs[dd] - (ty.ksize / 2 - 1);
+                for (int k = 0; k < ty.ksize; k++) rows[(size_t)d * sr + 1 + k] = ty.coef[(size_t)dd * ty.ksize + k];
+            }
+            while (blob.size() % 64) blob.push_back(0);
+            o[5] = put(blob, rows);
+        }
         ts.step2 = true;
         for (int d = 1; d < dw && ts.step2; d++) ts.step2 = tx.ofs[d] == tx.ofs[0] + 2 * d;
         for (int d = 1; d < dh && ts.step2; d++) ts.step2 = ty.ofs[d] == ty.ofs[0] + 2 * d;
@@ -2410,6 +2455,7 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
         ts.xofs = (const int*)(dev + o[0]); ts.xco = (const short*)(dev + o[1]);
         ts.yofs = (const int*)(dev + o[2]); ts.yco = (const short*)(dev + o[3]);
         ts.yrows = interp == IMP_INTER_CUBIC ? (const void*)(dev + o[4]) : nullptr;
+        ts.srows = (const int*)(dev + o[5]);
     }
     TableEntry& e = C.m[key];
     e.ts = ts;
@@ -2691,21 +2737,21 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             else if (per == 3) hipLaunchKernelGGL(k_resize_up_cubic4<3>, ugrid, block, 0, s, a, ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
             else if (per == 4) hipLaunchKernelGGL(k_resize_up_cubic4<4>, ugrid, block, 0, s, a, ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
             else hipLaunchKernelGGL(k_resize_up_cubic4<0>, ugrid, block, 0, s, a, ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 4) & ~7, nbx, rpw);
-        } else if (CN == 4 && scale_x <= 2.0 && scale_y <= 2.0 && a.sw >= 8) {
-            static const int th = std::getenv("IMPGPU_TILE_TH") ? std::atoi(std::getenv("IMPGPU_TILE_TH")) : 8;
-            const int ntx = (a.dw + TL_TW - 1) / TL_TW, nty = (a.dh + th - 1) / th;
-            const int per = (ntx * nty + 7) / 8;
-            const dim3 tgrid((unsigned)(per * 8), 1, (unsigned)count);
-#define IMP_TILED(KS_, MODE_, VEC_)                                                                                      \
-    do {                                                                                                                 \
-        if (th == 16) hipLaunchKernelGGL((k_resize_tiled<KS_, MODE_, 16>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, ntx, nty); \
-        else if (th == 4) hipLaunchKernelGGL((k_resize_tiled<KS_, MODE_, 4>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, ntx, nty); \
-        else hipLaunchKernelGGL((k_resize_tiled<KS_, MODE_, 8>), tgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, VEC_, ntx, nty); \
-    } while (0)
-            if (interp == IMP_INTER_LINEAR) IMP_TILED(2, M_LINEAR, 0);
-            else if (interp == IMP_INTER_CUBIC) IMP_TILED(4, M_CUBIC, (a.dw * 4) & ~7);
-            else IMP_TILED(8, M_LANCZOS, 0);
-#undef IMP_TILED
+        } else if ((CN == 4 || CN == 3) && scale_x <= 2.0 && scale_y <= 2.0 && a.sw >= 8 &&
+                   (CN == 4 || !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 3))) {
+            // every other scale up to 2 and every other enlargement: rolling strips with a dynamic footprint advance
+            // (BGR windows are fetched as aligned dwords: rows 4-byte aligned, which every frame of the library has)
+            constexpr int C34 = CN == 3 ? 3 : 4;
+            const int nsx = (a.dw + 255) / 256;
+            int rps = 64;
+            while (rps > 8 && (long long)count * nsx * 4 * ((a.dh + rps - 1) / rps) < 8192) rps /= 2;
+            const dim3 sgrid((unsigned)nsx, (unsigned)((a.dh + rps - 1) / rps), (unsigned)count);
+            if (interp == IMP_INTER_LINEAR)
+                hipLaunchKernelGGL((k_resize_strip<2, M_LINEAR, C34>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, 0, rps);
+            else if (interp == IMP_INTER_CUBIC)
+                hipLaunchKernelGGL((k_resize_strip<4, M_CUBIC, C34>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, (a.dw * CN) & ~7, rps);
+            else
+                hipLaunchKernelGGL((k_resize_strip<8, M_LANCZOS, C34>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, 0, rps);
         } else if (interp == IMP_INTER_LINEAR)
             hipLaunchKernelGGL((k_resize_taps<2, CN, M_LINEAR>), grid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
         else if (interp == IMP_INTER_CUBIC)
@@ -3082,7 +3128,18 @@ int launch_resize_mixed(const MixFrame* fr, int count, int cn, int simple, hipSt
             d.a = RArgs{f.src, 0, f.sstep, f.sw, f.sh, f.dst, 0, f.dstep, f.dw, f.dh};
             d.gm = AreaGeom{scale_x, scale_y};
             const bool aligned = !(((uintptr_t)f.src | (uintptr_t)f.sstep) & 3);
-            if ((cn == 4 || (aligned && f.sw >= 6)) && area_rows_plan(f.sw, f.sh, f.dw, f.dh, scale_x, count, true, &d.nv, &d.rows)) {
+            int w4 = 0, bh4 = 0;
+            static const bool no_rows4 = std::getenv("IMPGPU_NO_ROWS4") != nullptr;
+            if (!no_rows4 && (cn == 4 || (aligned && f.sw >= 6)) && f.dw >= 160 && area_rows_plan(f.sw, f.sh, f.dw, f.dh, scale_x, count, false, &w4, &bh4) &&
+                w4 >= 2 && w4 <= 5 && 255 * scale_x + w4 + 8 <= (cn == 4 ? 1024 : 1340)) {
+                // windows of at most five pixels (factors below ~3.9): four destination columns per lane, like the uniform batches
+                d.nv = -w4;
+                d.rows = bh4;
+                d.nstrips = (f.dw + 255) / 256;
+                d.nitems = d.nstrips * ((f.dh + d.rows - 1) / d.rows);
+                d.nblk = (d.nitems + 3) / 4;
+                gathered = true;
+            } else if ((cn == 4 || (aligned && f.sw >= 6)) && area_rows_plan(f.sw, f.sh, f.dw, f.dh, scale_x, count, true, &d.nv, &d.rows)) {
                 d.nstrips = (f.dw + 63) / 64;
                 d.nitems = d.nstrips * ((f.dh + d.rows - 1) / d.rows);
                 d.nblk = (d.nitems + 3) / 4;

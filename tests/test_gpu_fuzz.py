@@ -6,7 +6,7 @@ import pytest
 from hypothesis import given, settings, strategies as st, HealthCheck
 
 import oracle_lib as orc
-from conftest import noise_image
+from conftest import noise_image, smooth_image
 
 pytestmark = pytest.mark.gpu
 import os
@@ -145,3 +145,33 @@ def test_area_batches_any_geometry(gpu, sw, sh, fx, fy, whole, c, count, seed):
     for i in sorted({0, count // 2, count - 1}):
         assert np.array_equal(out[i], orc.cv_resize(base[i % 3], dw, dh, orc.INTER_AREA)), (sw, sh, dw, dh, c, count, i)
     src.release(); dst.release()
+
+
+@settings(max_examples=120 * SCALE, **COMMON)
+@given(sw=st.integers(8, 700), sh=st.integers(2, 300), fx=st.floats(0.26, 2.0), fy=st.floats(0.26, 2.0), c=st.sampled_from([3, 4]),
+       interp=st.sampled_from([1, 2, 4]), seed=st.integers(0, 100))
+def test_resize_rolling_strips(gpu, sw, sh, fx, fy, c, interp, seed):
+    """Round 3's k_resize_strip (it replaced the LDS-tiled kernel and the per-pixel gather BGR frames fell to): LINEAR,
+    CUBIC and LANCZOS4 at scales up to 2 per axis in either direction, frames wider than one 256-column block and taller
+    than one strip of rows, BGRA and BGR.  (Exact halves and CUBIC enlargements in y have their own kernels and tests.)"""
+    dw, dh = max(1, int(round(sw / fx))), max(1, int(round(sh / fy)))
+    arr = noise_image(sh, sw, c, seed)
+    want = orc.cv_resize(arr, dw, dh, interp)
+    im = gpu.Image(arr)
+    assert im.cv_resize(dw, dh, interp) == 0
+    got = im.numpy()
+    im.release()
+    assert np.array_equal(got, want), (sw, sh, dw, dh, c, interp)
+
+
+def test_resize_one_axis_grows_the_other_shrinks(gpu):
+    """What Resize() sends to CUBIC besides plain enlargements (bridge.c:190: width > col || height > row): a portrait
+    frame made landscape and the reverse, through the request grammar, BGR (a JPEG) and BGRA."""
+    for c in (3, 4):
+        for (sh, sw), args in (((320, 180), "320,180,up"), ((180, 320), "180,320,up"), ((300, 100), "150,200,up")):
+            arr = smooth_image(sh, sw, c, seed=c)
+            rc_o, want = orc.resize(arr, args)
+            im = gpu.Image(arr)
+            assert im.resize(args) == rc_o == 0
+            assert np.array_equal(im.numpy(), want), (c, sh, sw, args)
+            im.release()
