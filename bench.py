@@ -389,6 +389,7 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
     import queue
     import threading
     import numpy as np
+    from ngx_http_imgproc_amd import ResizeItem
     from ngx_http_imgproc_amd.shard import round_robin
     from ngx_http_imgproc_amd.workloads import MIXED_RESIZE
 
@@ -441,16 +442,45 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
                 codes = (C.c_int * n)()
                 rc = lib.impgpu_batch_decode_jpeg(blobs, sizes, n, imgs, codes)
                 rc = rc or max(codes)
-            for k in range(n):
-                one = C.c_void_p(imgs[k])
+            if n > 1 and rc == 0:
+                # the decoded frames of the batch are resized together too: impgpu_batch_resize_mixed, one descriptor launch
+                # (the per-frame Resize() loop of bridge.c:588-604 over whatever sizes arrived), then one download each
+                outs = (C.c_void_p * n)()
+                its = (ResizeItem * n)()
+                ow_, oh_, ip_ = C.c_int(), C.c_int(), C.c_int()
+                for k in range(n):
+                    one = C.c_void_p(imgs[k])
+                    sw_, sh_ = lib.impgpu_image_width(one), lib.impgpu_image_height(one)
+                    rc = rc or lib.impgpu_resize_geometry(sw_, sh_, MIXED_RESIZE, C.byref(cfg.c), 0, ow_, oh_, ip_)
+                    o = C.c_void_p()
+                    rc = rc or lib.impgpu_image_create(ow_.value, oh_.value, 3, C.byref(o))
+                    outs[k] = o
+                    if rc == 0:
+                        its[k] = ResizeItem(lib.impgpu_image_device_ptr(one), sw_, sh_, lib.impgpu_image_step(one),
+                                            lib.impgpu_image_device_ptr(o), ow_.value, oh_.value, lib.impgpu_image_step(o))
                 if rc == 0:
-                    rc = lib.impgpu_resize(C.byref(one), MIXED_RESIZE, C.byref(cfg.c), 0)
+                    rc = lib.impgpu_batch_resize_mixed(its, n, 3, 0, None)
+                for k in range(n):
+                    o = C.c_void_p(outs[k])
+                    if rc == 0:
+                        rc = lib.impgpu_image_download_pinned(o, hdst + out_bytes * k, lib.impgpu_image_step(o))
                 if rc == 0:
-                    ow = lib.impgpu_image_width(one)
-                    rc = lib.impgpu_image_download_pinned(one, hdst + out_bytes * k, (ow * 3 + 3) & ~3)
-                imgs[k] = one
-            if rc == 0:
-                rc = lib.impgpu_sync()
+                    rc = lib.impgpu_sync()
+                for k in range(n):
+                    o = C.c_void_p(outs[k])
+                    if o:
+                        lib.impgpu_image_release(C.byref(o))
+            else:
+                for k in range(n):
+                    one = C.c_void_p(imgs[k])
+                    if rc == 0:
+                        rc = lib.impgpu_resize(C.byref(one), MIXED_RESIZE, C.byref(cfg.c), 0)
+                    if rc == 0:
+                        ow = lib.impgpu_image_width(one)
+                        rc = lib.impgpu_image_download_pinned(one, hdst + out_bytes * k, (ow * 3 + 3) & ~3)
+                    imgs[k] = one
+                if rc == 0:
+                    rc = lib.impgpu_sync()
             for k in range(n):
                 one = C.c_void_p(imgs[k])
                 if one:

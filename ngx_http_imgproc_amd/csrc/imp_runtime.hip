@@ -339,7 +339,7 @@ static bool lane_take_back(Lane* L, void* p) {
 static size_t pool_cap() {
     static const size_t cap = [] {
         const char* s = std::getenv("IMPGPU_POOL_CAP_MB");
-        return (size_t)(s ? std::atoll(s) : 2048) << 20;
+        return (size_t)(s ? std::atoll(s) : 8192) << 20;
     }();
     return cap;
 }

@@ -270,3 +270,35 @@ def test_batch_download_one_wait_for_an_album(gpu):
     assert gpu.lib.impgpu_batch_download(handles, n, datas, (C.c_int * n)(1, 1, 1, 1)) == gpu.IMP_ERROR_INVALID_ARGS
     for im in ims:
         im.release()
+
+
+def test_jpeg_request_batch_end_to_end(gpu):
+    """What bench.py --stream --jpeg device --jpeg-batch N does per batch: decode all files with one call, resize all
+    decoded frames with one descriptor launch (resize=224,0 -> the reference's per-frame Resize(), bridge.c:588-604),
+    download -- every thumbnail equals the oracle's decode + Resize()."""
+    import ctypes as C
+
+    rng = np.random.Generator(np.random.PCG64(77))
+    blobs = []
+    for k in range(12):
+        h, w = int(rng.integers(230, 900)), int(rng.integers(230, 1200))
+        arr = smooth_image(h, w, 3, seed=k) if k % 3 else noise_image(h, w, 3, k)
+        blobs.append(encode(arr, quality=int(rng.integers(60, 96)), subsampling=["4:2:0", "4:2:2", "4:4:4"][k % 3]))
+    res = gpu.batch_decode_jpeg(blobs)
+    cfg = gpu.Config()
+    items, outs = [], []
+    for code, im in res:
+        assert code == 0
+        h, w, c = im.shape
+        rc, (ow, oh, interp) = gpu.resize_geometry(w, h, "224,0", cfg)
+        assert rc == 0
+        o = gpu.Image(np.zeros((oh, ow, 3), np.uint8))
+        outs.append(o)
+        items.append((im.device_ptr, w, h, im.step, o.device_ptr, ow, oh, o.step))
+    assert gpu.batch_resize_mixed(items, 3) == 0
+    for b, (code, im), o in zip(blobs, res, outs):
+        _, full = orc.jpeg_decode(b)
+        _, want = orc.resize(full, "224,0")
+        assert np.array_equal(o.numpy(), want)
+        im.release(); o.release()
+    cfg.release()
