@@ -10,6 +10,7 @@
 // loads); BGRA pixels move as dwords / 16-byte int4 rows so both passes are coalesced.
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include "imp_internal.h"
 
 namespace imp {
@@ -270,7 +271,11 @@ __device__ __forceinline__ uint32_t bl_cvt_pk_u8(float x, uint32_t acc, int byte
 // ring reads per output pixel).  Ring rows needed: RH >= 2r + 8 * NO.  (Measured and dropped: the row pass on channel
 // planes with v_dot4_u32_u8 -- half the VALU work, but byte-wise plane writes and per-plane window reads double the LDS
 // instructions of a kernel that is LDS-bound: sigma = 8 went from 57 back to 67 us.)
-template <int RH, int CN, int NO>
+// R16: the ring holds the row sums as u16 (8 bytes per column and row) instead of floats (16): a 128-row ring is then 64 KB
+// and two workgroups fit a CU where one did (sigma = 16: 154 -> 116 us); at 64 rows the four conversions per read cost
+// more than the second pair of workgroups brings (sigma = 8: 58 -> 64 us), so that ring stays float.  u16 needs
+// 255 * sum(kx) <= 65535 (host-checked); the float ring takes any kernel.
+template <int RH, int CN, int NO, bool R16>
 __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
                                                      uint8_t* __restrict__ dst, long long dstride, int dstep,
                                                      const int* __restrict__ kxp, const float* __restrict__ kyf,
@@ -283,7 +288,8 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
     float* s_ky = (float*)(s_kx + ((npair + 3) & ~3));
     int* s_kyi = (int*)(s_ky + ((r + 1 + 3) & ~3));
     uint32_t* s_seg = (uint32_t*)(s_kyi + ((r + 1 + 3) & ~3));  // [4][SEGW]
-    float4* s_ring = (float4*)(s_seg + 4 * SEGW);              // [RH][64]
+    typedef typename std::conditional<R16, uint2, float4>::type ring_t;
+    ring_t* s_ring = (ring_t*)(s_seg + 4 * SEGW);              // [RH][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * 64;
@@ -315,7 +321,14 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
     };
     const int vec_end = CN == 3 ? (w * 3) & ~3 : 0;            // SymmColumnVec_32s8u covers whole groups of 4 row elements
     const bool tail = CN == 3 && (x0 + lane) * 3 + 2 >= vec_end;
-    auto ring = [&](int y) -> float4 { return s_ring[(y & (RH - 1)) * 64 + lane]; };
+    auto ring = [&](int y) -> float4 {
+        if constexpr (R16) {
+            const uint2 q = s_ring[(y & (RH - 1)) * 64 + lane];
+            return make_float4((float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16));
+        } else {
+            return s_ring[(y & (RH - 1)) * 64 + lane];
+        }
+    };
     auto finish = [&](int yo, bl_float2 sxy, bl_float2 szw) -> uint32_t {   // round, pack; the CN = 3 row tail in integers
         uint32_t px = bl_cvt_pk_u8(sxy.x, 0u, 0);
         px = bl_cvt_pk_u8(sxy.y, px, 1);
@@ -380,7 +393,8 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
                 pr = __builtin_amdgcn_perm(p1, p0, 0x0c060c02u); __builtin_memcpy(&c, &pr, 4); a2 = __builtin_amdgcn_sdot2(c, kk, a2, false);
                 if (CN == 4) { pr = __builtin_amdgcn_perm(p1, p0, 0x0c070c03u); __builtin_memcpy(&c, &pr, 4); a3 = __builtin_amdgcn_sdot2(c, kk, a3, false); }
             }
-            s_ring[(ys & (RH - 1)) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+            if constexpr (R16) s_ring[(ys & (RH - 1)) * 64 + lane] = make_uint2((uint32_t)a0 | ((uint32_t)a1 << 16), (uint32_t)a2 | ((uint32_t)a3 << 16));
+            else s_ring[(ys & (RH - 1)) * 64 + lane] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
         }
         __syncthreads();
         // (c) column pass for the rows centred r rows above this wave's source rows.  Rows replicate at the frame's edges
@@ -441,7 +455,8 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     gaussian_kernel_fixed(ks0, sigma, &ik);
     long long sum = 0;
     for (int k : ik) sum += k;
-    if (sum > 257) return IMP_ERROR_UNSUPPORTED;              // row sums must fit 16 bits
+    const bool fits16 = sum <= 257;                           // row sums fit 16 bits (the fused kernel's plane, the u16 ring)
+    if (sum > 65536) return IMP_ERROR_UNSUPPORTED;            // (float ring: 255 * sum < 2^24 stays exact)
     // The 8-bit fixed-point taps of a wide Gaussian are ZERO towards both ends (sigma = 8: 49 taps, the outer 4 + 4 round
     // to 0/256).  A zero tap adds 0 to the integer row sum and +0.0f to the non-negative float column sum -- both exact
     // no-ops -- and a replicated border pixel under a zero tap is irrelevant, so the kernels run on the non-zero core only.
@@ -470,34 +485,39 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     for (int k = 0; k <= r; k++) blob.push_back(ik[r + k]);
     void* dev_k = nullptr;
     if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
-    if (r > 16) {       // column strips with an LDS ring (k_blur_strip4)
-        const int RH = 2 * r + 8 <= 64 ? 64 : 128;
+    if (r > 16 || !fits16) {   // column strips with an LDS ring (k_blur_strip4); also any radius whose rounded taps sum above 257
+        const int RH = 2 * r + 8 <= 64 ? 64 : 128;           // (sigma = 4: 258 -- those kernels used to take the two-pass fallback: 89 us)
+        const bool r16 = RH == 128 && fits16;
         static const bool one_row = std::getenv("IMPGPU_BLUR_NO1") != nullptr;     // A/B: one output row per wave and step
         const int NO = (!one_row && 2 * r + 16 <= RH) ? 2 : 1;
         const int SEGW = (64 + 2 * r + 2 + 3) & ~3;
-        const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + 4 * SEGW) * 4 + (size_t)RH * 64 * 16;
+        const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + 4 * SEGW) * 4 + (size_t)RH * 64 * (r16 ? 8 : 16);
         const int nbx = (v.w + 63) / 64;
         int rpb = 256;                                         // taller strips recompute fewer halo rows; shorter ones fill the chip
         while (rpb > 64 && (long long)nbx * ((v.h + rpb - 1) / rpb) * f.count < 1024) rpb /= 2;
         const dim3 sgrid((unsigned)nbx, (unsigned)((v.h + rpb - 1) / rpb), (unsigned)f.count);
         hipError_t e = hipSuccess;
-#define IMP_BLUR_STRIP(RH_, CN_, NO_)                                                                                              \
+#define IMP_BLUR_STRIP(RH_, CN_, NO_, R16_)                                                                                        \
     do {                                                                                                                           \
-        e = hipFuncSetAttribute((const void*)k_blur_strip4<RH_, CN_, NO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        e = hipFuncSetAttribute((const void*)k_blur_strip4<RH_, CN_, NO_, R16_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
         if (e == hipSuccess)                                                                                                       \
-            hipLaunchKernelGGL((k_blur_strip4<RH_, CN_, NO_>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h,     \
+            hipLaunchKernelGGL((k_blur_strip4<RH_, CN_, NO_, R16_>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h,     \
                                f.dst, f.dst_stride, f.dstep, (const int*)dev_k, (const float*)((const int*)dev_k + off_f),          \
                                (const int*)dev_k + off_i, r, rpb);                                                                  \
     } while (0)
-        switch ((RH == 64 ? 0 : 4) + (v.c == 4 ? 0 : 2) + (NO == 2 ? 0 : 1)) {
-            case 0: IMP_BLUR_STRIP(64, 4, 2); break;
-            case 1: IMP_BLUR_STRIP(64, 4, 1); break;
-            case 2: IMP_BLUR_STRIP(64, 3, 2); break;
-            case 3: IMP_BLUR_STRIP(64, 3, 1); break;
-            case 4: IMP_BLUR_STRIP(128, 4, 2); break;
-            case 5: IMP_BLUR_STRIP(128, 4, 1); break;
-            case 6: IMP_BLUR_STRIP(128, 3, 2); break;
-            default: IMP_BLUR_STRIP(128, 3, 1); break;
+        switch ((RH == 64 ? 0 : 4) + (v.c == 4 ? 0 : 2) + (NO == 2 ? 0 : 1) + (r16 ? 8 : 0)) {
+            case 0: IMP_BLUR_STRIP(64, 4, 2, false); break;
+            case 1: IMP_BLUR_STRIP(64, 4, 1, false); break;
+            case 2: IMP_BLUR_STRIP(64, 3, 2, false); break;
+            case 3: IMP_BLUR_STRIP(64, 3, 1, false); break;
+            case 4: IMP_BLUR_STRIP(128, 4, 2, false); break;
+            case 5: IMP_BLUR_STRIP(128, 4, 1, false); break;
+            case 6: IMP_BLUR_STRIP(128, 3, 2, false); break;
+            case 7: IMP_BLUR_STRIP(128, 3, 1, false); break;
+            case 12: IMP_BLUR_STRIP(128, 4, 2, true); break;
+            case 13: IMP_BLUR_STRIP(128, 4, 1, true); break;
+            case 14: IMP_BLUR_STRIP(128, 3, 2, true); break;
+            default: IMP_BLUR_STRIP(128, 3, 1, true); break;
         }
 #undef IMP_BLUR_STRIP
         if (e == hipSuccess) e = hipGetLastError();

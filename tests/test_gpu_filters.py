@@ -91,6 +91,19 @@ def test_blur_large_radius_strip_kernel_bit_exact(gpu, sigma, c):
         assert np.array_equal(got, want), "sigma %s %r: max diff %d" % (sigma, shape, np.abs(got.astype(int) - want.astype(int)).max())
 
 
+def test_blur_every_dispatch_across_sigmas(gpu):
+    """A sweep fine enough to meet every kernel choice: fused (radius <= 16, taps summing to at most 257), strips with the
+    float ring (64 rows; and any radius whose rounded taps sum ABOVE 257 -- sigma = 4 is one -- which took the two-pass
+    fallback until round 3), strips with the u16 ring (128 rows), two-pass (radius > 60)."""
+    arr3, arr4 = noise_image(150, 203, 3, 77), noise_image(150, 203, 4, 78)
+    for i in range(1, 60):
+        sigma = "%.2f" % (0.3 + 0.47 * i)
+        for arr in (arr3, arr4):
+            want = orc.gaussian(arr, float(np.float32(sigma)))
+            rc, got = run_filter(gpu, arr, "blur=" + sigma)
+            assert rc == 0 and np.array_equal(got, want), (sigma, arr.shape[2])
+
+
 def test_blur_sigma8_full_hd_and_after_crop(gpu):
     arr = noise_image(1080, 1920, 4, 15)
     rc, got = run_filter(gpu, arr, "blur=8")
