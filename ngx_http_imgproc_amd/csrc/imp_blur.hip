@@ -280,13 +280,13 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
                                                      uint8_t* __restrict__ dst, long long dstride, int dstep,
                                                      const int* __restrict__ kxp, const float* __restrict__ kyf,
                                                      const int* __restrict__ kyi, int r, int rows_per_block) {
-    static_assert(NO == 1 || NO == 2, "one or two output rows per wave and step");
+    static_assert(NO == 1 || NO == 2 || (NO == 4 && R16), "one, two or -- u16 ring only -- four output rows per wave and step");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int npair = r + 1;                                   // 2r+1 taps -> r+1 pairs, the last one (tap, 0)
     const int SEGW = (64 + 2 * r + 2 + 3) & ~3;                // +2: the padded last pair reads one dword further
     uint32_t* s_kx = (uint32_t*)smem;                          // packed (k[2j], k[2j+1]) as 2 x i16
-    float* s_ky = (float*)(s_kx + ((npair + 3) & ~3));
-    int* s_kyi = (int*)(s_ky + ((r + 1 + 3) & ~3));
+    float* s_ky = (float*)(s_kx + ((npair + 3) & ~3));          // r + 1 taps, then zeros up to the next multiple of four (+ 4)
+    int* s_kyi = (int*)(s_ky + ((r + 1 + 3) & ~3) + 4);
     uint32_t* s_seg = (uint32_t*)(s_kyi + ((r + 1 + 3) & ~3));  // [4][SEGW]
     typedef typename std::conditional<R16, uint2, float4>::type ring_t;
     ring_t* s_ring = (ring_t*)(s_seg + 4 * SEGW);              // [RH][64]
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
     const bool live = x0 + lane < w;
     for (int i = tid; i < npair; i += 256) s_kx[i] = (uint32_t)kxp[i];
     for (int i = tid; i <= r; i += 256) { s_ky[i] = kyf[i]; s_kyi[i] = kyi[i]; }
+    for (int i = r + 1 + tid; i < ((r + 1 + 3) & ~3) + 4; i += 256) s_ky[i] = 0.f;
 
     // this lane's (up to four) columns of a segment, clamped into the row
     int sxc[4];
@@ -414,6 +415,39 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
                 }
                 out_px[0] = finish(yo, sxy, szw);
                 out_y[0] = yo;
+            } else if constexpr (NO == 4) {
+                // outputs yo .. yo + 3.  Tap k of output j pairs rows yo+j+k and yo+j-k: from one tap to the next the four upper
+                // rows move up by one and the four lower rows down by one, so TWO ring reads per tap serve four outputs (a quarter
+                // of the LDS bytes per pixel of the one-row form).  The windows are circular in registers -- row yo+q sits in
+                // up[q & 3], row yo-q in lo[(-q) & 3] -- and the taps run in groups of four so that every index is static; the
+                // kernel's taps are padded with zeros to a multiple of four (a zero tap adds +0.0f to a non-negative sum: exact;
+                // the rows it reads are u16 -> finite).
+                float4 up[4], lo[4];
+                bl_float2 sxy[4], szw[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    up[j] = lo[j] = ring(min(max(yo + j, 0), h - 1));
+                    sxy[j] = bl_float2{up[j].x, up[j].y} * f0 + 0.f;
+                    szw[j] = bl_float2{up[j].z, up[j].w} * f0 + 0.f;
+                }
+                for (int k = 1; k <= r; k += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int kk = k + u;                               // kk = 1 + u (mod 4)
+                        up[u & 3] = ring(min(yo + 3 + kk, h - 1));          // row yo + (kk + 3): slot (kk + 3) & 3 = u
+                        lo[(3 - u) & 3] = ring(max(yo - kk, 0));            // row yo - kk: slot (-kk) & 3 = (3 - u) & 3
+                        const float f = s_ky[kk];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float4 a = up[(j + 1 + u) & 3], b = lo[(j + 3 - u) & 3];   // rows yo+j+kk and yo+j-kk
+                            sxy[j] = sxy[j] + (bl_float2{a.x, a.y} + bl_float2{b.x, b.y}) * f;
+                            szw[j] = szw[j] + (bl_float2{a.z, a.w} + bl_float2{b.z, b.w}) * f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (yo + j >= y0 && yo + j < y1) { out_px[j] = finish(yo + j, sxy[j], szw[j]); out_y[j] = yo + j; }
             } else {
                 // outputs yo and yo + 1: row yo+k of this tap is row (yo+1)+(k-1) of the last one, row (yo+1)-k is row yo-(k-1)
                 const int ylo = max(yo, 0), yhi = min(yo + 1, h - 1);      // (clamped like every other ring row)
@@ -486,12 +520,19 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     void* dev_k = nullptr;
     if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
     if (r > 16 || !fits16) {   // column strips with an LDS ring (k_blur_strip4); also any radius whose rounded taps sum above 257
-        const int RH = 2 * r + 8 <= 64 ? 64 : 128;           // (sigma = 4: 258 -- those kernels used to take the two-pass fallback: 89 us)
-        const bool r16 = RH == 128 && fits16;
+        const int RH0 = 2 * r + 8 <= 64 ? 64 : 128;          // (sigma = 4: 258 -- those kernels used to take the two-pass fallback: 89 us)
         static const bool one_row = std::getenv("IMPGPU_BLUR_NO1") != nullptr;     // A/B: one output row per wave and step
-        const int NO = (!one_row && 2 * r + 16 <= RH) ? 2 : 1;
+        // Four output rows per wave and step (a 128-row ring of u16 sums: radius <= 48, taps summing to at most 257) is built,
+        // bit-exact and OFF: two ring reads per tap then serve four outputs -- a quarter of the one-row form's LDS bytes -- but
+        // the eight u16 -> float conversions per tap and 162 VGPRs cost more than the reads saved (sigma = 8: 70 us against 57,
+        // sigma = 16: 124 against 114).  The column pass is bound by its packed-FP32 issue, not by LDS.  IMPGPU_BLUR_FOUR=1 to A/B.
+        static const bool want_four = std::getenv("IMPGPU_BLUR_FOUR") != nullptr;
+        const bool four = want_four && !one_row && fits16 && 2 * r + 32 <= 128;
+        const int RH = four ? 128 : RH0;
+        const bool r16 = RH == 128 && fits16;
+        const int NO = four ? 4 : ((!one_row && 2 * r + 16 <= RH) ? 2 : 1);
         const int SEGW = (64 + 2 * r + 2 + 3) & ~3;
-        const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + 4 * SEGW) * 4 + (size_t)RH * 64 * (r16 ? 8 : 16);
+        const size_t lds = (size_t)(((r + 1 + 3) & ~3) * 3 + 4 + 4 * SEGW) * 4 + (size_t)RH * 64 * (r16 ? 8 : 16);
         const int nbx = (v.w + 63) / 64;
         int rpb = 256;                                         // taller strips recompute fewer halo rows; shorter ones fill the chip
         while (rpb > 64 && (long long)nbx * ((v.h + rpb - 1) / rpb) * f.count < 1024) rpb /= 2;
@@ -505,6 +546,9 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
                                f.dst, f.dst_stride, f.dstep, (const int*)dev_k, (const float*)((const int*)dev_k + off_f),          \
                                (const int*)dev_k + off_i, r, rpb);                                                                  \
     } while (0)
+        if (NO == 4) {
+            if (v.c == 4) IMP_BLUR_STRIP(128, 4, 4, true); else IMP_BLUR_STRIP(128, 3, 4, true);
+        } else
         switch ((RH == 64 ? 0 : 4) + (v.c == 4 ? 0 : 2) + (NO == 2 ? 0 : 1) + (r16 ? 8 : 0)) {
             case 0: IMP_BLUR_STRIP(64, 4, 2, false); break;
             case 1: IMP_BLUR_STRIP(64, 4, 1, false); break;
