@@ -62,7 +62,7 @@ sed -i '574,656c\
 ' "$B"
 # Step 2 (bridge.c:545): a JPEG is decoded on the device; whatever ImpGpuDecode does not take goes to cvDecodeImage as before
 sed -i '545c\
-	ImpGpuAlbum gpu = { NULL, 0 };\
+	ImpGpuAlbum gpu = { NULL };\
 	if (decodeBasicIo \&\& ImpGpuDecode(blob, size, \&album, \&gpu, req->pool)) {\
 		// the frame is in HBM already\
 	} else if (decodeBasicIo) {' "$B"

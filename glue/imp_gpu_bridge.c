@@ -62,15 +62,12 @@ int ImpGpuDecode(u_char* blob, size_t size, Album* album, ImpGpuAlbum* gpu, ngx_
     if (impgpu_image_decode_jpeg(blob, size, &frame) != IMP_OK) {
         return 0;
     }
-    gpu->Frames   = ngx_pcalloc(pool, sizeof(impgpu_image*));
     album->Frames = ngx_palloc(pool, sizeof(Frame));
-    if (!gpu->Frames || !album->Frames) {
+    if (!album->Frames) {
         impgpu_image_release(&frame);
-        gpu->Frames = NULL;
         return 0;
     }
-    gpu->Frames[0] = frame;
-    gpu->Count     = 1;
+    gpu->Handle = frame;
     /* the host never sees the decoded pixels: Image stays NULL until ImpGpuDownload creates the encoder's input
      * (cvReleaseImage at bridge.c:719 accepts a NULL image) */
     album->Count = 1;
@@ -84,14 +81,6 @@ int ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* crop
     impgpu_config gcfg;
     impgpu_job job;
     int fid;
-
-    if (!gpu->Frames) {             /* (a frame ImpGpuDecode put on the device is already there) */
-        gpu->Count = 0;
-        gpu->Frames = ngx_pcalloc(pool, album->Count * sizeof(impgpu_image*));
-        if (!gpu->Frames) {
-            return IMP_ERROR_MALLOC_FAILED;
-        }
-    }
 
     *step = IMP_STEP_WATERMARK;
     int rc = FillConfig(config, &gcfg);
@@ -107,30 +96,36 @@ int ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* crop
     job.filter_count = filterCount;
     job.need_flatten = lacksAlpha;      /* applied only to 4-channel frames, like bridge.c:642-656 */
 
-    /* every frame is enqueued before any is waited for: uploads, kernels and the next frame's upload overlap */
-    for (fid = 0; fid < album->Count; fid++) {
-        if (fid >= gpu->Count) {
-            IplImage* image = album->Frames[fid].Image;
-            *step = IMP_STEP_DECODE;
-            rc = impgpu_image_upload((unsigned char*)image->imageData, image->width, image->height, image->nChannels,
-                                     image->widthStep, &gpu->Frames[fid]);
-            if (rc) {
-                return rc;
-            }
-            gpu->Count = fid + 1;
+    if (!gpu->Handle) {             /* (a frame ImpGpuDecode put on the device is already there) */
+        const unsigned char** rows = ngx_palloc(pool, album->Count * sizeof(unsigned char*));
+        int* steps = ngx_palloc(pool, album->Count * sizeof(int));
+        IplImage* first = album->Frames[0].Image;
+        *step = IMP_STEP_DECODE;
+        if (!rows || !steps) {
+            return IMP_ERROR_MALLOC_FAILED;
         }
-        rc = impgpu_run_ops(&gpu->Frames[fid], &job, &gcfg, step);
+        for (fid = 0; fid < album->Count; fid++) {
+            IplImage* image = album->Frames[fid].Image;
+            if (image->width != first->width || image->height != first->height || image->nChannels != first->nChannels) {
+                return IMP_ERROR_INVALID_ARGS;      /* not an Album LoadGIF / the decoders can produce */
+            }
+            rows[fid]  = (const unsigned char*)image->imageData;
+            steps[fid] = image->widthStep;
+        }
+        rc = impgpu_album_upload(rows, album->Count, first->width, first->height, first->nChannels, steps, &gpu->Handle);
         if (rc) {
             return rc;
         }
     }
-    return IMP_OK;
+    /* nothing is waited for here: the upload, every operator (one launch each for the whole album) and the next request's
+     * upload overlap on the worker's stream */
+    return impgpu_run_ops(&gpu->Handle, &job, &gcfg, step);
 }
 
 u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool, int* code) {
     float brightness = 0;
     u_char* json = ngx_palloc(pool, 256 * sizeof(u_char));
-    *code = json ? impgpu_calc_perceived_brightness(gpu->Frames[0], &brightness) : IMP_ERROR_MALLOC_FAILED;
+    *code = json ? impgpu_calc_perceived_brightness(gpu->Handle, &brightness) : IMP_ERROR_MALLOC_FAILED;
     if (*code) {                    /* a lost device must not read as "brightness 0", HTTP 200 */
         return NULL;
     }
@@ -142,8 +137,8 @@ u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool, int* code) 
             "\"brightness\":%d,"
             "\"count\":%d"
         "}",
-        impgpu_image_width(gpu->Frames[0]),
-        impgpu_image_height(gpu->Frames[0]),
+        impgpu_image_width(gpu->Handle),
+        impgpu_image_height(gpu->Handle),
         (int)round(brightness * 100),
         album->Count
     );
@@ -152,7 +147,7 @@ u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool, int* code) 
 
 Memory ImpGpuASCII(ImpGpuAlbum* gpu, char* args, ngx_pool_t* pool) {
     Memory result;
-    impgpu_image* image = gpu->Frames[0];
+    impgpu_image* image = gpu->Handle;      /* frame 0 of an album, like bridge.c:669 */
     long buflen = (long)(impgpu_image_width(image) + 1) * impgpu_image_height(image) - 1;
     result.Buffer = ngx_palloc(pool, buflen > 0 ? buflen : 1);
     result.Length = 0;
@@ -162,18 +157,18 @@ Memory ImpGpuASCII(ImpGpuAlbum* gpu, char* args, ngx_pool_t* pool) {
 
 int ImpGpuDownload(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool) {
     int fid, rc = IMP_OK;
-    IplImage** fresh = ngx_pcalloc(pool, gpu->Count * sizeof(IplImage*));
-    unsigned char** rows = ngx_pcalloc(pool, gpu->Count * sizeof(unsigned char*));
-    int* steps = ngx_pcalloc(pool, gpu->Count * sizeof(int));
-    if (!fresh || !rows || !steps) {
+    int count = impgpu_album_count(gpu->Handle);
+    IplImage** fresh = ngx_pcalloc(pool, count * sizeof(IplImage*));
+    unsigned char** rows = ngx_pcalloc(pool, count * sizeof(unsigned char*));
+    int* steps = ngx_pcalloc(pool, count * sizeof(int));
+    if (!fresh || !rows || !steps || count != album->Count) {
         return IMP_ERROR_MALLOC_FAILED;
     }
-    for (fid = 0; fid < gpu->Count; fid++) {
-        impgpu_image* frame = gpu->Frames[fid];
+    for (fid = 0; fid < count; fid++) {
         /* same header rules as every cvCreateImage in bridge.c: 8-bit, rows padded to 4 bytes -- the layout the
-         * device frame already has, so cvEncodeImage / IplToFI32 / IplToFI24 read it unchanged */
-        fresh[fid] = cvCreateImage(cvSize(impgpu_image_width(frame), impgpu_image_height(frame)), IPL_DEPTH_8U,
-                                   impgpu_image_channels(frame));
+         * device frames already have, so cvEncodeImage / IplToFI32 / IplToFI24 read them unchanged */
+        fresh[fid] = cvCreateImage(cvSize(impgpu_image_width(gpu->Handle), impgpu_image_height(gpu->Handle)), IPL_DEPTH_8U,
+                                   impgpu_image_channels(gpu->Handle));
         if (!fresh[fid] || !fresh[fid]->imageData) {
             rc = IMP_ERROR_MALLOC_FAILED;
             break;
@@ -183,9 +178,9 @@ int ImpGpuDownload(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool) {
     }
     /* all frames of the album in one transfer, one wait */
     if (!rc) {
-        rc = impgpu_batch_download((const impgpu_image* const*)gpu->Frames, gpu->Count, rows, steps);
+        rc = impgpu_album_download(gpu->Handle, rows, steps);
     }
-    for (fid = 0; fid < gpu->Count; fid++) {
+    for (fid = 0; fid < count; fid++) {
         if (rc) {
             if (fresh[fid]) {
                 cvReleaseImage(&fresh[fid]);
@@ -200,9 +195,5 @@ int ImpGpuDownload(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool) {
 }
 
 void ImpGpuRelease(ImpGpuAlbum* gpu) {
-    int fid;
-    for (fid = 0; fid < gpu->Count; fid++) {
-        impgpu_image_release(&gpu->Frames[fid]);
-    }
-    gpu->Count = 0;
+    impgpu_image_release(&gpu->Handle);
 }

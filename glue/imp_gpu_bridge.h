@@ -21,9 +21,11 @@
 
 #include <impgpu.h>
 
+/* The device-resident counterpart of the request's Album: ONE handle for all of its frames (every frame of an album has
+ * the canvas' geometry, advancedio.c:187, so they share a block and each operator is one launch for the whole animation;
+ * impgpu_album_upload in impgpu.h). */
 typedef struct {
-    impgpu_image** Frames;   /* device-resident counterparts of Album.Frames[i].Image, ngx_palloc'ed in req->pool */
-    int            Count;
+    impgpu_image* Handle;
 } ImpGpuAlbum;
 
 /* once per worker process, after fork (module.c:100-107).  worker = ngx_worker (nginx >= 1.9.1) or ngx_process_slot:
@@ -41,8 +43,8 @@ void   ImpGpuEnvDestroy(void);
  * device decoder does not take, or a damaged one). */
 int    ImpGpuDecode(u_char* blob, size_t size, Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool);
 
-/* Steps 3-7 of RunJob for every frame of the album: upload (unless ImpGpuDecode put it there), then crop -> resize -> [gray->BGR] -> filters -> watermark ->
- * flatten in the reference's fixed order.  `lacksAlpha` = the chosen encoder cannot store alpha (bridge.c:643-647).
+/* Steps 3-7 of RunJob for all frames of the album at once: upload (unless ImpGpuDecode put the frame there), then crop ->
+ * resize -> [gray->BGR] -> filters -> watermark -> flatten in the reference's fixed order, each ONE launch over the album.  `lacksAlpha` = the chosen encoder cannot store alpha (bridge.c:643-647).
  * Returns the IMP_* code and leaves the failing IMP_STEP_* in *step (JobResult.Step). */
 int    ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* crop, char* gravity, char* resize, int simple,
                        char** filters, int filterCount, int lacksAlpha, Config* config, int* step);

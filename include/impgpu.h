@@ -164,6 +164,16 @@ int   impgpu_image_clone(const impgpu_image* src, impgpu_image** out);
 int   impgpu_image_download(const impgpu_image* image, unsigned char* data, int step); /* syncs */
 /* the same for every frame of an album (bridge.c:680-710 reads them all): all copies are enqueued, then ONE wait */
 int   impgpu_batch_download(const impgpu_image* const* images, int count, unsigned char* const* datas, const int* steps);
+/* An ALBUM: the frames of one animation (Album, required.h:56-66; filled by LoadGIF, advancedio.c:184-289, or by the
+ * one-frame decoders at bridge.c:554-572).  All frames have the canvas' geometry, so they live in ONE device block and
+ * the handle stands for all of them: impgpu_run_ops on an album handle runs every operator of the request as ONE launch
+ * over all frames (the reference loops `for fid < album.Count` around each operator, bridge.c:577-655), and so does
+ * every single operator below.  Info() and ASCII() read frame 0, as bridge.c:283-300 / 669 do; impgpu_image_download*
+ * and the batch entry points take single images.  steps may be NULL (= width * channels, tightly packed rows). */
+int   impgpu_album_upload(const unsigned char* const* datas, int count, int width, int height, int channels,
+                          const int* steps, impgpu_image** out);
+int   impgpu_album_download(const impgpu_image* album, unsigned char* const* datas, const int* steps);   /* one wait */
+int   impgpu_album_count(const impgpu_image* image);        /* 1 for a single image */
 int   impgpu_image_width(const impgpu_image* image);
 int   impgpu_image_height(const impgpu_image* image);
 int   impgpu_image_channels(const impgpu_image* image);

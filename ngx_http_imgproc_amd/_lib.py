@@ -98,6 +98,9 @@ SIGNATURES = {
     "impgpu_image_clone": (C.c_int, [P, PP]),
     "impgpu_image_download": (C.c_int, [P, P, C.c_int]),
     "impgpu_batch_download": (C.c_int, [PP, C.c_int, PP, IP]),
+    "impgpu_album_upload": (C.c_int, [PP, C.c_int, C.c_int, C.c_int, C.c_int, IP, PP]),
+    "impgpu_album_download": (C.c_int, [P, PP, IP]),
+    "impgpu_album_count": (C.c_int, [P]),
     "impgpu_image_width": (C.c_int, [P]),
     "impgpu_image_height": (C.c_int, [P]),
     "impgpu_image_channels": (C.c_int, [P]),

@@ -24,39 +24,49 @@ Frames one_frame(const View& v, impgpu_image* dst) {
     return f;
 }
 
-// The image being worked on: `owner` holds the memory, `v` is the window of it that is the
-// current frame (smaller than owner after a folded Crop).
+// The image -- or album -- being worked on: `owner` holds the memory, `v` is the window of its frame 0 that is the
+// current frame (smaller than owner after a folded Crop); frame i of an album is the same window `stride()` bytes on.
 struct Work {
     impgpu_image* owner;
     View v;
+    int count() const { return owner->frames; }
+    long long stride() const { return (long long)owner->fstride; }
     bool is_view() const { return v.d != owner->d || v.w != owner->w || v.h != owner->h; }
     void adopt(impgpu_image* im) {
         image_delete(owner);
         owner = im;
         v = view_of(im);
     }
+    // a fresh destination with this work's frame count
+    int fresh(int w, int h, int c, impgpu_image** out) const { return image_new_album(w, h, c, owner->frames, out); }
+    Frames to(impgpu_image* dst) const {
+        Frames f = one_frame(v, dst);
+        f.src_stride = stride(); f.dst_stride = (long long)dst->fstride; f.count = owner->frames;
+        return f;
+    }
+    uint8_t* px() const { return const_cast<uint8_t*>(v.d); }
 };
 
 int materialize(Work& wk) {
     if (!wk.is_view()) return IMP_OK;
     impgpu_image* out = nullptr;
-    if (int rc = image_new(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
-    if (int rc = launch_copy(one_frame(wk.v, out), env_stream())) { image_delete(out); return rc; }
+    if (int rc = wk.fresh(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
+    if (int rc = launch_copy(wk.to(out), env_stream())) { image_delete(out); return rc; }
     wk.adopt(out);
     return IMP_OK;
 }
 
 int do_resize(Work& wk, int w, int h, int interp) {
     impgpu_image* out = nullptr;
-    if (int rc = image_new(w, h, wk.v.c, &out)) return rc;
-    if (int rc = launch_cv_resize(one_frame(wk.v, out), interp, env_stream())) { image_delete(out); return rc; }
+    if (int rc = wk.fresh(w, h, wk.v.c, &out)) return rc;
+    if (int rc = launch_cv_resize(wk.to(out), interp, env_stream())) { image_delete(out); return rc; }
     wk.adopt(out);
     return IMP_OK;
 }
 
 int flush_program(Work& wk, PixelProgram& prog) {
     if (prog.empty()) return IMP_OK;
-    int rc = launch_pixel_program(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.c, wk.v.step, 1, prog, env_stream());
+    int rc = launch_pixel_program(wk.px(), wk.stride(), wk.v.w, wk.v.h, wk.v.c, wk.v.step, wk.count(), prog, env_stream());
     prog.clear();
     return rc;
 }
@@ -65,29 +75,29 @@ int apply_plan(Work& wk, const FilterPlan& plan) {
     switch (plan.cls) {
         case FC_FLIP: {
             impgpu_image* out = nullptr;
-            if (int rc = image_new(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
-            if (int rc = launch_flip(one_frame(wk.v, out), plan.flip_mode, env_stream())) { image_delete(out); return rc; }
+            if (int rc = wk.fresh(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
+            if (int rc = launch_flip(wk.to(out), plan.flip_mode, env_stream())) { image_delete(out); return rc; }
             wk.adopt(out);
             return IMP_OK;
         }
         case FC_ROTATE: {
             impgpu_image* out = nullptr;
             const bool swap = plan.rotate != 180;
-            if (int rc = image_new(swap ? wk.v.h : wk.v.w, swap ? wk.v.w : wk.v.h, wk.v.c, &out)) return rc;
-            if (int rc = launch_rotate(one_frame(wk.v, out), plan.rotate, env_stream())) { image_delete(out); return rc; }
+            if (int rc = wk.fresh(swap ? wk.v.h : wk.v.w, swap ? wk.v.w : wk.v.h, wk.v.c, &out)) return rc;
+            if (int rc = launch_rotate(wk.to(out), plan.rotate, env_stream())) { image_delete(out); return rc; }
             wk.adopt(out);
             return IMP_OK;
         }
         case FC_BLUR: {
             if (wk.v.c == 4 || wk.v.c == 3) {      // one-pass fused kernel into a fresh frame; falls through when it does not apply
                 impgpu_image* out = nullptr;
-                if (int rc = image_new(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
-                int rc = launch_gaussian_fused(one_frame(wk.v, out), plan.sigma, env_stream());
+                if (int rc = wk.fresh(wk.v.w, wk.v.h, wk.v.c, &out)) return rc;
+                int rc = launch_gaussian_fused(wk.to(out), plan.sigma, env_stream());
                 if (rc == IMP_OK) { wk.adopt(out); return IMP_OK; }
                 image_delete(out);
                 if (rc != IMP_ERROR_UNSUPPORTED) return rc;
             }
-            return launch_gaussian(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.c, wk.v.step, 1, plan.sigma, env_stream());
+            return launch_gaussian(wk.px(), wk.stride(), wk.v.w, wk.v.h, wk.v.c, wk.v.step, wk.count(), plan.sigma, env_stream());
         }
         default:
             return IMP_OK;
@@ -109,7 +119,7 @@ int do_watermark(Work& wk, const impgpu_config* cfg) {
     if (int rc = watermark_rect(wk.v.w, wk.v.h, ov->w, ov->h, cfg, &rx, &ry, &maxcol, &maxrow)) return rc;
     const float opacity = (float)(cfg->watermark_opacity / 100.0);   // bridge.c:275
     const float alpha = 1 - opacity;                                  // filters.c:620
-    return launch_blend_over(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.c, wk.v.step, 1, ov,
+    return launch_blend_over(wk.px(), wk.stride(), wk.v.w, wk.v.h, wk.v.c, wk.v.step, wk.count(), ov,
                              rx, ry, maxcol, maxrow, alpha, env_stream());
 }
 
@@ -142,8 +152,9 @@ int impgpu_image_clone(const impgpu_image* src, impgpu_image** out) {
     if (!src || !out) return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;
     impgpu_image* im = nullptr;
-    if (int rc = image_new(src->w, src->h, src->c, &im)) return rc;
-    if (int rc = launch_copy(one_frame(view_of(src), im), env_stream())) { image_delete(im); return rc; }
+    Work wk{const_cast<impgpu_image*>(src), view_of(src)};
+    if (int rc = wk.fresh(src->w, src->h, src->c, &im)) return rc;
+    if (int rc = launch_copy(wk.to(im), env_stream())) { image_delete(im); return rc; }
     *out = im;
     return IMP_OK;
 }
@@ -217,7 +228,7 @@ int impgpu_blend_with_paper(impgpu_image* image) {
     if (!image) return IMP_ERROR_INVALID_ARGS;
     if (int rc = need_env()) return rc;
     if (image->c != 4) return IMP_ERROR_INVALID_ARGS;   // reference reads channel 3 unconditionally; RunJob only calls it for 4 channels
-    return launch_blend_paper(image->d, 0, image->w, image->h, image->step, 1, env_stream());
+    return launch_blend_paper(image->d, (long long)image->fstride, image->w, image->h, image->step, image->frames, env_stream());
 }
 
 int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** frames) {
@@ -307,10 +318,11 @@ int impgpu_gray2bgr(impgpu_image** pointer) {
     if (int rc = need_env()) return rc;
     if ((*pointer)->c != 1) return IMP_OK;
     impgpu_image* out = nullptr;
-    if (int rc = image_new((*pointer)->w, (*pointer)->h, 3, &out)) return rc;
-    if (int rc = launch_gray2bgr(one_frame(view_of(*pointer), out), env_stream())) { image_delete(out); return rc; }
-    image_delete(*pointer);
-    *pointer = out;
+    Work wk{*pointer, view_of(*pointer)};
+    if (int rc = wk.fresh(wk.v.w, wk.v.h, 3, &out)) return rc;
+    if (int rc = launch_gray2bgr(wk.to(out), env_stream())) { image_delete(out); return rc; }
+    wk.adopt(out);
+    *pointer = wk.owner;
     return IMP_OK;
 }
 
@@ -322,7 +334,7 @@ static int single_stage(impgpu_image* image, int kind) {
     Stage s{};
     s.kind = kind;
     prog.stages.push_back(s);
-    return launch_pixel_program(image->d, 0, image->w, image->h, image->c, image->step, 1, prog, env_stream());
+    return launch_pixel_program(image->d, (long long)image->fstride, image->w, image->h, image->c, image->step, image->frames, prog, env_stream());
 }
 int impgpu_rgb2hsv(impgpu_image* image) { return single_stage(image, ST_RGB2HSV); }
 int impgpu_hsv2rgb(impgpu_image* image) { return single_stage(image, ST_HSV2RGB); }
@@ -376,9 +388,9 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
                     wm.alpha = 1 - (float)(config->watermark_opacity / 100.0);     // bridge.c:275, filters.c:620
                 }
                 impgpu_image* out = nullptr;
-                rc = image_new(fw, fh, wk.v.c, &out);
+                rc = wk.fresh(fw, fh, wk.v.c, &out);
                 if (rc) goto done;
-                Frames f = one_frame(wk.v, out);
+                Frames f = wk.to(out);
                 f.dw = w; f.dh = h;                                    // the resized geometry; `out` is the turned frame
                 rc = launch_area_rotate(f, first.rotate, with_wm ? &wm : nullptr, env_stream());
                 if (rc == IMP_OK) { wk.adopt(out); fused_filters = 1; watermark_done = with_wm; }
@@ -393,9 +405,9 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
     if ((wk.v.c == 1 || job->filter_count > 0) && fault_hit(IMP_STEP_FILTERING)) { rc = IMP_ERROR_DEVICE; trace_pop(); goto done; }
     if (wk.v.c == 1) {
         impgpu_image* out = nullptr;
-        rc = image_new(wk.v.w, wk.v.h, 3, &out);
+        rc = wk.fresh(wk.v.w, wk.v.h, 3, &out);
         if (rc) { trace_pop(); goto done; }
-        rc = launch_gray2bgr(one_frame(wk.v, out), env_stream());
+        rc = launch_gray2bgr(wk.to(out), env_stream());
         if (rc) { image_delete(out); trace_pop(); goto done; }
         wk.adopt(out);
     }
@@ -411,7 +423,7 @@ int impgpu_run_ops(impgpu_image** pointer, const impgpu_job* job, const impgpu_c
         if (rc) goto done;
     }
     if (job->need_flatten && wk.v.c == 4) {                            // bridge.c:642-656
-        rc = launch_blend_paper(const_cast<uint8_t*>(wk.v.d), 0, wk.v.w, wk.v.h, wk.v.step, 1, env_stream());
+        rc = launch_blend_paper(wk.px(), wk.stride(), wk.v.w, wk.v.h, wk.v.step, wk.count(), env_stream());
         if (rc) goto done;
     }
     rc = materialize(wk);

@@ -17,6 +17,10 @@ struct impgpu_image {
     int w = 0, h = 0, c = 0, step = 0;
     size_t cap = 0;         // bytes owned (0 for borrowed views)
     bool owned = false;
+    // an album (the frames of one animation, bridge.c:554-572): `frames` frames of this geometry in ONE block, frame i at
+    // d + i * fstride, so that every operator of the request is one launch for the whole album.  1 / 0 for a single image.
+    int frames = 1;
+    size_t fstride = 0;
 };
 
 namespace imp {
@@ -52,6 +56,7 @@ hipStream_t env_stream();
 int  dev_alloc(size_t bytes, void** out);          // stream-ordered pool; IMP_* code
 void dev_free(void* p);
 int  image_new(int w, int h, int c, impgpu_image** out);
+int  image_new_album(int w, int h, int c, int frames, impgpu_image** out);
 void image_delete(impgpu_image* im);
 // Copy a small host blob (tables, taps) into pool memory through the pinned ring, ordered on `s`.
 int  upload_small(const void* host, size_t bytes, void** dev, hipStream_t s);

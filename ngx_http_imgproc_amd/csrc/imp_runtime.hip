@@ -464,8 +464,10 @@ LaneCache** lane_cache_slot(int which) {
     return (L && which >= 0 && which < LANE_CACHE_SLOTS) ? &L->caches[which] : nullptr;
 }
 
-int image_new(int w, int h, int c, impgpu_image** out) {
-    if (w <= 0 || h <= 0 || (c != 1 && c != 3 && c != 4)) return IMP_ERROR_INVALID_ARGS;
+int image_new(int w, int h, int c, impgpu_image** out) { return image_new_album(w, h, c, 1, out); }
+
+int image_new_album(int w, int h, int c, int frames, impgpu_image** out) {
+    if (w <= 0 || h <= 0 || frames <= 0 || frames > 65535 || (c != 1 && c != 3 && c != 4)) return IMP_ERROR_INVALID_ARGS;
     // the kernels index pixels and row bytes in 32 bits: a frame is at most 2^30 pixels and 4 GiB - 1 of rows.  Larger
     // requests (resize=2000000000,1,up with the size watchdog off) end like a failed cvCreateImage, not in a wrapped pitch.
     if (!frame_fits(w, h, c)) { t_error = "frame too large"; return IMP_ERROR_MALLOC_FAILED; }
@@ -473,6 +475,11 @@ int image_new(int w, int h, int c, impgpu_image** out) {
     im->w = w; im->h = h; im->c = c;
     im->step = aligned_step(w, c);
     im->cap = (size_t)im->step * h;
+    if (frames > 1) {                                       // frames start on 256-byte boundaries of one block
+        im->frames = frames;
+        im->fstride = (im->cap + 255) & ~size_t(255);
+        im->cap = im->fstride * frames;
+    }
     void* p = nullptr;
     int rc = dev_alloc(im->cap + 16, &p);
     if (rc) { delete im; return rc; }
@@ -893,6 +900,70 @@ int impgpu_batch_download(const impgpu_image* const* images, int count, unsigned
     return IMP_OK;
 }
 
+int impgpu_album_upload(const unsigned char* const* datas, int count, int width, int height, int channels,
+                        const int* steps, impgpu_image** out) {
+    if (!datas || !out || count <= 0) return IMP_ERROR_INVALID_ARGS;
+    for (int i = 0; i < count; i++)
+        if (!datas[i] || (steps && (long long)steps[i] < (long long)width * channels)) return IMP_ERROR_INVALID_ARGS;
+    Lane* L = lane();
+    if (!L) return no_env();
+    TraceRange tr("IMP_STEP_DECODE");
+    IMP_FAULT_POINT(IMP_STEP_DECODE);
+    impgpu_image* im = nullptr;
+    if (int rc = image_new_album(width, height, channels, count, &im)) return rc;
+    const size_t fstride = count > 1 ? im->fstride : (size_t)im->step * height;
+    const size_t rowbytes = (size_t)width * channels;
+    // the whole album goes through one staging buffer and one copy when it fits the ring, else frame by frame
+    const size_t total = fstride * count;
+    const int per = total <= (size_t(64) << 20) ? count : 1;
+    for (int at = 0; at < count; at += per) {
+        Staging* S = nullptr;
+        int rc = stage_reserve(L, fstride * per, &S);
+        if (rc) { (void)hipStreamSynchronize(L->stream); image_delete(im); return rc; }
+        for (int k = 0; k < per; k++) {
+            const unsigned char* src = datas[at + k];
+            const size_t sstep = steps ? (size_t)steps[at + k] : rowbytes;
+            for (int y = 0; y < height; y++) std::memcpy(S->p + k * fstride + (size_t)y * im->step, src + (size_t)y * sstep, rowbytes);
+        }
+        const size_t bytes = fstride * (per - 1) + (size_t)im->step * height;
+        hipError_t e = hipMemcpyAsync(im->d + (size_t)at * fstride, S->p, bytes, hipMemcpyHostToDevice, L->stream);
+        if (e == hipSuccess) e = hipEventRecord(S->done, L->stream);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync(album upload)", e); (void)hipStreamSynchronize(L->stream); image_delete(im); return IMP_ERROR_DEVICE; }
+        S->busy = true;
+    }
+    *out = im;
+    return IMP_OK;
+}
+
+int impgpu_album_download(const impgpu_image* im, unsigned char* const* datas, const int* steps) {
+    if (!im || !datas) return IMP_ERROR_INVALID_ARGS;
+    const size_t rowbytes = (size_t)im->w * im->c;
+    for (int i = 0; i < im->frames; i++)
+        if (!datas[i] || (steps && (size_t)steps[i] < rowbytes)) return IMP_ERROR_INVALID_ARGS;
+    Lane* L = lane();
+    if (!L) return no_env();
+    TraceRange tr("IMP_STEP_ENCODE");
+    IMP_FAULT_POINT(IMP_STEP_ENCODE);
+    const size_t frame = (size_t)im->step * im->h;
+    const size_t fstride = im->frames > 1 ? im->fstride : frame;
+    // one copy and ONE wait for the whole album when it fits the staging ring, else frame by frame
+    const int per = fstride * im->frames <= (size_t(64) << 20) ? im->frames : 1;
+    for (int at = 0; at < im->frames; at += per) {
+        const size_t bytes = fstride * (per - 1) + frame;
+        Staging* S = nullptr;
+        if (int rc = stage_reserve(L, bytes, &S)) return rc;
+        IMP_HIP(hipMemcpyAsync(S->p, im->d + (size_t)at * fstride, bytes, hipMemcpyDeviceToHost, L->stream));
+        if (int rc = lane_wait()) return rc;
+        for (int k = 0; k < per; k++) {
+            const size_t dstep = steps ? (size_t)steps[at + k] : rowbytes;
+            for (int y = 0; y < im->h; y++)
+                std::memcpy(datas[at + k] + (size_t)y * dstep, S->p + k * fstride + (size_t)y * im->step, rowbytes);
+        }
+    }
+    return IMP_OK;
+}
+
+int impgpu_album_count(const impgpu_image* im) { return im ? im->frames : 0; }
 int impgpu_image_width(const impgpu_image* im) { return im ? im->w : 0; }
 int impgpu_image_height(const impgpu_image* im) { return im ? im->h : 0; }
 int impgpu_image_channels(const impgpu_image* im) { return im ? im->c : 0; }

@@ -116,6 +116,36 @@ class Image:
         rc = lib.impgpu_image_decode_jpeg(bytes(blob), len(blob), C.byref(h))
         return rc, (cls(handle=h.value) if rc == 0 else None)
 
+    @classmethod
+    def album(cls, frames):
+        """The frames of one animation (same geometry) as ONE handle: every operator then runs once for all of them
+        (impgpu_album_upload; Album, required.h:56-66)."""
+        arrs = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        arrs = [a[:, :, None] if a.ndim == 2 else a for a in arrs]
+        hh, ww, cc = arrs[0].shape
+        if any(a.shape != (hh, ww, cc) for a in arrs):
+            raise ValueError("album frames differ in geometry")
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        h = C.c_void_p()
+        rc = lib.impgpu_album_upload(ptrs, len(arrs), ww, hh, cc, None, C.byref(h))
+        if rc:
+            raise ImpError(rc, "impgpu_album_upload")
+        return cls(handle=h.value)
+
+    @property
+    def count(self):
+        return lib.impgpu_album_count(self.h)
+
+    def frames(self):
+        """Every frame of the album -> list of HxWxC arrays (impgpu_album_download: one copy, one wait)."""
+        hh, ww, cc = self.shape
+        outs = [np.empty((hh, ww, cc), dtype=np.uint8) for _ in range(self.count)]
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        rc = lib.impgpu_album_download(self.h, ptrs, None)
+        if rc:
+            raise ImpError(rc, "impgpu_album_download")
+        return outs
+
     def release(self):
         if self.h:
             lib.impgpu_image_release(C.byref(self.h))

@@ -30,7 +30,7 @@ def test_apply_glue_rewrites_the_operator_segment(tmp_path):
     for gone in ("Crop(&image", "Resize(&image", "Filter(&image", "Watermark(image", "BlendWithPaper(image", "CV_GRAY2BGR"):
         assert gone not in run_job, gone
     assert "ImpGpuEnvStart(IMP_GPU_WORKER_INDEX);" in bridge and "ImpGpuEnvDestroy();" in bridge
-    assert run_job.index("ImpGpuAlbum gpu = { NULL, 0 };") < run_job.index("goto finalize")     # declared before every jump to the release
+    assert run_job.index("ImpGpuAlbum gpu = { NULL };") < run_job.index("goto finalize")     # declared before every jump to the release
     assert "cvDecodeImage(&rawencoded, -1)" in run_job                                              # the host decoder stays as the fallback
     assert run_job.count("{") == run_job.count("}")                      # the edit kept the function balanced
     assert "WatermarkDevice;" in (work / "required.h").read_text()

@@ -308,3 +308,69 @@ def test_freeimage_side_repacks(gpu, c, bpp):
         assert np.array_equal(up.numpy(), orc.fi32_to_ipl(bits, 53, 37))
         assert np.array_equal(up.numpy(), bits[::-1])
         up.release()
+
+
+# ---------------------------------------------------------------- albums: the frames of one animation behind one handle
+@pytest.mark.parametrize("chain", CHAINS, ids=lambda d: "-".join(k for k in d))
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_album_run_ops_is_every_frame_of_the_loop(gpu, chain, c):
+    """bridge.c:577-655 loops `for fid < album.Count` around each operator; an album handle runs each operator once for
+    all frames.  Every frame must come out as the oracle chain makes it."""
+    n = 5
+    frames = [noise_image(240, 321, c, 900 + i) if i % 2 else smooth_image(240, 321, c) for i in range(n)]
+    if c == 1:
+        frames = [noise_image(240, 321, 1, 910 + i) for i in range(n)]
+    ov = noise_image(20, 48, 4, 43)
+    wm = ("r", "b", 4, 4, 60)
+    has_vig = any(f.startswith("vignette") for f in chain.get("filters", ()))
+    cfg = gpu.Config(allow_experiments=True, max_filters=5)
+    assert cfg.prepare_watermark(ov, *wm) == 0
+    al = gpu.Image.album(frames)
+    assert al.count == n
+    kw = dict(chain)
+    kw["need_flatten"] = kw.pop("flatten", 0)
+    rc, step = gpu.run_ops(al, cfg, **kw)
+    assert rc == 0, (rc, step)
+    assert al.count == n
+    outs = al.frames()
+    for i in range(n):
+        rc_o, _, want = oracle_chain(frames[i], overlay=ov, wm=wm, **chain)
+        assert rc_o == 0
+        if has_vig:
+            assert np.abs(outs[i].astype(int) - want.astype(int)).max() <= 1
+        else:
+            assert np.array_equal(outs[i], want), i
+    al.release(); cfg.release()
+
+
+def test_album_single_operators_and_round_trip(gpu):
+    n = 7
+    frames = [noise_image(33, 47, 4, 950 + i) for i in range(n)]
+    al = gpu.Image.album(frames)
+    assert al.count == n and al.shape == (33, 47, 4)
+    back = al.frames()
+    assert all(np.array_equal(a, b) for a, b in zip(back, frames))
+    assert al.crop("20px,10px,3px,5px") == 0
+    assert al.filter("gamma=1.4") == 0
+    assert al.filter("rotate=90") == 0
+    assert al.blend_with_paper() == 0
+    outs = al.frames()
+    for i in range(n):
+        rc, cur = orc.crop(frames[i], "20px,10px,3px,5px")
+        rc, cur = orc.filter(cur, "gamma=1.4", 1)
+        rc, cur = orc.filter(cur, "rotate=90", 1)
+        cur = orc.blend_with_paper(cur)
+        assert np.array_equal(outs[i], cur), i
+    # Info() reads frame 0 (bridge.c:283-300)
+    assert al.calc_perceived_brightness() == np.float32(orc.brightness(outs[0]))
+    al.release()
+
+
+def test_album_of_one_is_an_image(gpu):
+    arr = noise_image(40, 50, 3, 960)
+    al = gpu.Image.album([arr])
+    assert al.count == 1
+    assert al.resize("25,0") == 0
+    rc, want = orc.resize(arr, "25,0", 2000, 2000, 0)
+    assert np.array_equal(al.frames()[0], want) and np.array_equal(al.numpy(), want)
+    al.release()

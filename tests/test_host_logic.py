@@ -132,3 +132,26 @@ def test_batch_entry_points_refuse_geometry_the_kernels_cannot_index():
     assert lib.impgpu_batch_filters(p, 0, 40000, 40000, 4, 160000, 1, filt, 1, 1, None) == INV
     assert lib.impgpu_batch_filters(p, 0, 10, 10, 4, 39, 1, filt, 1, 1, None) == INV
     assert lib.impgpu_batch_filters(p, 0, 10, 10, 4, 40, 1, filt, 1, 1, None) == imp.IMP_ERROR_DEVICE
+
+
+def test_album_entry_points_check_their_arguments_before_the_device():
+    import ctypes as C
+
+    import ngx_http_imgproc_amd as imp
+
+    lib = imp.lib
+    INV = imp.IMP_ERROR_INVALID_ARGS
+    buf = (C.c_ubyte * 4096)()
+    ptrs = (C.c_void_p * 3)(*[C.addressof(buf)] * 3)
+    h = C.c_void_p()
+    assert lib.impgpu_album_upload(ptrs, 0, 8, 8, 4, None, C.byref(h)) == INV              # an album has frames
+    assert lib.impgpu_album_upload(None, 3, 8, 8, 4, None, C.byref(h)) == INV
+    assert lib.impgpu_album_upload(ptrs, 3, 8, 8, 4, None, None) == INV
+    holes = (C.c_void_p * 3)(C.addressof(buf), None, C.addressof(buf))
+    assert lib.impgpu_album_upload(holes, 3, 8, 8, 4, None, C.byref(h)) == INV             # a missing frame
+    steps = (C.c_int * 3)(32, 31, 32)
+    assert lib.impgpu_album_upload(ptrs, 3, 8, 8, 4, steps, C.byref(h)) == INV             # a pitch shorter than a row
+    assert lib.impgpu_album_upload(ptrs, 3, 8, 8, 4, None, C.byref(h)) == imp.IMP_ERROR_DEVICE   # well-formed: no device here
+    assert not h.value
+    assert lib.impgpu_album_download(None, ptrs, None) == INV
+    assert lib.impgpu_album_count(None) == 0
