@@ -272,6 +272,8 @@ typedef struct impgpu_gif_page {
     const unsigned char* palette;   /* FreeImage_GetPalette: 256 RGBQUAD = B,G,R,reserved bytes (advancedio.c:178) */
 } impgpu_gif_page;
 int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** frames);
+/* the same frames as ONE album handle (see impgpu_album_upload): what RunJob's operator segment then runs on */
+int impgpu_gif_compose_album(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** album);
 
 /* ---- batch entry points (benchmark / multi-frame albums: bridge.c:578,591,608,632).
  *      `count` frames of identical geometry, frame i at base + i*frame_stride bytes,

@@ -95,6 +95,7 @@ SIGNATURES = {
     "impgpu_image_upload_fi32": (C.c_int, [P, C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_download_fi": (C.c_int, [P, C.c_int, P, C.c_int]),
     "impgpu_gif_compose": (C.c_int, [C.POINTER(CGifPage), C.c_int, C.c_int, C.c_int, PP]),
+    "impgpu_gif_compose_album": (C.c_int, [C.POINTER(CGifPage), C.c_int, C.c_int, C.c_int, PP]),
     "impgpu_image_clone": (C.c_int, [P, PP]),
     "impgpu_image_download": (C.c_int, [P, P, C.c_int]),
     "impgpu_batch_download": (C.c_int, [PP, C.c_int, PP, IP]),

@@ -231,7 +231,7 @@ int impgpu_blend_with_paper(impgpu_image* image) {
     return launch_blend_paper(image->d, (long long)image->fstride, image->w, image->h, image->step, image->frames, env_stream());
 }
 
-int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** frames) {
+static int gif_compose(const impgpu_gif_page* pages, int count, int destructive, int page, bool as_album, impgpu_image** frames) {
     if (!pages || !frames || count <= 0 || page < -1) return IMP_ERROR_INVALID_ARGS;   // page < -1: the reference reads Frames[page] below the array
     if (page != -1) {                                              // advancedio.c:111-116: a page request is always a
         destructive = 1;                                           // destructive walk, and a page past the end is page 0
@@ -256,12 +256,17 @@ int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive,
     }
     std::vector<impgpu_image*> imgs((size_t)nout, nullptr);
     auto drop = [&]() { for (impgpu_image* im : imgs) if (im) image_delete(im); };
-    for (int i = 0; i < nout; i++)
-        if (int rc = image_new(cw, ch, 4, &imgs[i])) { drop(); return rc; }
+    if (as_album) {                                                // every output frame in one block behind one handle
+        imgs.resize(1);
+        if (int rc = image_new_album(cw, ch, 4, nout, &imgs[0])) return rc;
+    } else {
+        for (int i = 0; i < nout; i++)
+            if (int rc = image_new(cw, ch, 4, &imgs[i])) { drop(); return rc; }
+    }
     std::vector<uint8_t> blob(off, 0);
     std::memcpy(blob.data(), meta.data(), (size_t)npages * sizeof(GifPageDev));
     uint8_t** optr = (uint8_t**)(blob.data() + (size_t)npages * sizeof(GifPageDev));
-    for (int i = 0; i < nout; i++) optr[i] = imgs[i]->d;
+    for (int i = 0; i < nout; i++) optr[i] = as_album ? imgs[0]->d + (size_t)i * imgs[0]->fstride : imgs[i]->d;
     for (int f = 0; f < npages; f++) {
         std::memcpy(blob.data() + meta[f].pal_off, pages[f].palette, 1024);
         std::memcpy(blob.data() + meta[f].idx_off, pages[f].indices, (size_t)pages[f].pitch * pages[f].height);
@@ -274,8 +279,16 @@ int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive,
                                 cw, ch, imgs[0]->step, destructive ? 1 : 0, page, s);
     dev_free(dev);                                                 // stream-ordered: after the kernel
     if (rc) { drop(); return rc; }
-    for (int i = 0; i < nout; i++) frames[i] = imgs[i];
+    for (size_t i = 0; i < imgs.size(); i++) frames[i] = imgs[i];
     return IMP_OK;
+}
+
+int impgpu_gif_compose(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** frames) {
+    return gif_compose(pages, count, destructive, page, false, frames);
+}
+
+int impgpu_gif_compose_album(const impgpu_gif_page* pages, int count, int destructive, int page, impgpu_image** album) {
+    return gif_compose(pages, count, destructive, page, true, album);
 }
 
 int impgpu_calc_perceived_brightness(const impgpu_image* image, float* brightness) {

@@ -325,10 +325,10 @@ def batch_resize_rotate_watermark(src_ptr, src_stride, sw, sh, sstep, dst_ptr, d
         raise ImpError(rc, "impgpu_batch_resize_rotate_watermark")
 
 
-def gif_compose(pages, destructive=False, page=-1):
+def gif_compose(pages, destructive=False, page=-1, album=False):
     """LoadGIF's compositing loop (advancedio.c:204-247) on the device.  pages: dicts with `indices` (h x pitch uint8,
     FreeImage scanline order), `width`, `left`, `top`, `dispose`, `key`, `palette` (256 x 4 uint8, B,G,R,reserved).
-    Returns (code, [Image ...]): every page, or just the requested one."""
+    Returns (code, [Image ...]): every page, or just the requested one; album=True -> (code, one album Image)."""
     from ._lib import CGifPage
     keep = []
     arr = (CGifPage * max(1, len(pages)))()
@@ -343,6 +343,9 @@ def gif_compose(pages, destructive=False, page=-1):
         arr[i].palette = pal.ctypes.data
     nout = 1 if page >= 0 else len(pages)
     outs = (C.c_void_p * max(1, nout))()
+    if album:
+        rc = lib.impgpu_gif_compose_album(arr, len(pages), int(bool(destructive)), int(page), outs)
+        return rc, (Image(handle=outs[0]) if rc == 0 else None)
     rc = lib.impgpu_gif_compose(arr, len(pages), int(bool(destructive)), int(page), outs)
     if rc:
         return rc, []

@@ -174,3 +174,29 @@ def test_gif_frames_feed_the_operator_chain(gpu):
     for im, w in zip(got, want):
         assert im.cv_resize(48, 32, orc.INTER_AREA) == 0
         assert np.array_equal(im.numpy(), orc.cv_resize(w, 48, 32, orc.INTER_AREA))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("destructive", [False, True])
+def test_gif_compose_album_is_one_handle_for_the_operator_segment(gpu, destructive):
+    """LoadGIF -> RunJob for an animation: the composed frames as ONE album handle, then crop / resize / filter for all
+    frames at once (bridge.c:577-655 loops over album.Count for each)."""
+    pages = random_album(12, 9, 120, 90)
+    rc_o, want = orc.gif_compose(pages, destructive)
+    rc, al = gpu.gif_compose(pages, destructive, album=True)
+    assert rc == rc_o == 0 and al.count == 9 and al.shape == (90, 120, 4)
+    for got, w in zip(al.frames(), want):
+        assert np.array_equal(got, w)
+    cfg = gpu.Config()
+    rc, step = gpu.run_ops(al, cfg, crop="4,3", resize="60,0", simple=1, filters=["flip=10", "gamma=0.8"], need_flatten=1)
+    assert rc == 0 and al.count == 9
+    for got, w in zip(al.frames(), want):
+        rc, cur = orc.crop(w, "4,3")
+        rc, cur = orc.resize(cur, "60,0", 2000, 2000, 1)
+        rc, cur = orc.filter(cur, "flip=10", 1)
+        rc, cur = orc.filter(cur, "gamma=0.8", 1)
+        assert np.array_equal(got, orc.blend_with_paper(cur))
+    rc, one = gpu.gif_compose(pages, destructive, page=4, album=True)
+    rc_o, want1 = orc.gif_compose(pages, destructive, page=4)
+    assert rc == rc_o == 0 and one.count == 1 and np.array_equal(one.numpy(), want1[0])
+    al.release(); one.release(); cfg.release()
