@@ -25,6 +25,33 @@ if not os.path.exists(LIB_PATH):
         "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
     )
 
+
+
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  libimpgpu.so needs `libamdhip64.so.7`; PyTorch-ROCm bundles its own copy under
+    torch/lib, which its libraries ask for by another file name (`libamdhip64.so`), so the loader only recognises the two as
+    the same library when torch's copy is the one already loaded.  With the system copy loaded first, `import torch`
+    brings in a second runtime and finds no device.  So, when torch is installed and not imported yet, its copy is loaded
+    here, before libimpgpu.so binds to it by soname -- whichever of the two a program imports first, both end up on the
+    same runtime.  (A C caller -- nginx -- has no torch and links /opt/rocm's.)  IMPGPU_SYSTEM_HIP=1 skips this."""
+    import sys
+
+    if os.environ.get("IMPGPU_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
+_share_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 

@@ -359,3 +359,28 @@ def test_numa_node_of_the_device_and_thread_binding(gpu):
         assert result["after"] <= cpus
     else:
         assert result["rc"] == 1 and result["after"] == result["before"]      # IMP_ERROR_UNSUPPORTED: nothing changed
+
+
+def test_import_order_with_torch_does_not_matter():
+    """libimpgpu.so before torch used to leave torch without a device (two HIP runtimes in one process); _lib.py now puts
+    both on torch's copy.  Checked in a child process, because this one imported torch first (conftest)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import ngx_http_imgproc_amd as gpu\n"
+        "assert 'torch' not in sys.modules\n"
+        "gpu.env_start(0)\n"
+        "a = np.arange(64 * 64 * 4, dtype=np.uint8).reshape(64, 64, 4)\n"
+        "im = gpu.Image(a); assert im.cv_resize(32, 32, gpu.INTER_AREA) == 0; out = im.numpy()\n"
+        "import torch\n"
+        "assert torch.cuda.is_available(), 'torch lost the device'\n"
+        "t = torch.arange(1024, device='cuda').sum().item(); assert t == 1023 * 512\n"
+        "im2 = gpu.Image(a); assert im2.cv_resize(32, 32, gpu.INTER_AREA) == 0\n"
+        "assert np.array_equal(im2.numpy(), out)\n"
+        "print('ok')\n"
+    ) % str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
