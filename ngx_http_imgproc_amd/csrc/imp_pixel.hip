@@ -449,42 +449,48 @@ int launch_blend_paper(uint8_t* d, long long stride, int w, int h, int step, int
 //     16 per lane -- the pixels come through LDS, read along the rows, so the column-major visiting order costs no
 //     strided traffic, and the terms are never written out -- and folds them for every binade from 2^20 up that the
 //     frame's sum can reach (at most 255 per pixel): one ParityFn per wave and binade.
-//   k_brightness_walk (one 1024-thread block): carries the accumulator through the frame.  In a binade with summaries it
+//   k_brightness_walk (one block of four waves): carries the accumulator through the frame.  In a binade with summaries it
 //     scans them 1024 at a time to the 1024-term chunk in which the sum leaves the binade and replays only that chunk,
 //     a term per thread (recomputed from the pixels); below 2^20, where a few thousand terms live, it replays every
 //     chunk.  The one term that crosses into the next binade is added with the literal float/double sequence.
 // Round 2 had a 16.6 MB plane of double terms, a (summarize, replay) launch pair per binade -- fourteen launches -- and
 // 0.48 ms at 1080p; this is two launches.
-struct ParityFn {            // mantissa parity in -> (steps of u added, parity out)
-    double inc0, inc1;
-    int b0, b1;
+// A ParityFn is two words: for each parity of the incoming mantissa, (steps of u added) << 1 | parity out.  Steps saturate
+// at 2^30 - 1 -- a binade has at most 2^23 of them, so a saturated count always means "left the binade", which is all that is
+// ever asked of a count that large (its parity bit is then meaningless and never used).
+struct ParityFn {
+    uint32_t a0, a1;
 };
-__device__ __forceinline__ ParityFn pf_identity() { return ParityFn{0.0, 0.0, 0, 1}; }
+#define PF_SAT 0x7fffffffu
+__device__ __forceinline__ ParityFn pf_identity() { return ParityFn{0u, 1u}; }
+__device__ __forceinline__ ParityFn pf_make(uint32_t inc0, int b0, uint32_t inc1, int b1) {
+    return ParityFn{(min(inc0, PF_SAT >> 1) << 1) | (uint32_t)b0, (min(inc1, PF_SAT >> 1) << 1) | (uint32_t)b1};
+}
+__device__ __forceinline__ uint32_t pf_steps(const ParityFn& f, int parity) { return (parity ? f.a1 : f.a0) >> 1; }
+__device__ __forceinline__ int pf_parity(const ParityFn& f, int parity) { return (int)((parity ? f.a1 : f.a0) & 1u); }
 // `first` applied before `second`
 __device__ __forceinline__ ParityFn pf_compose(const ParityFn& first, const ParityFn& second) {
     ParityFn r;
-    r.inc0 = first.inc0 + (first.b0 ? second.inc1 : second.inc0);
-    r.b0 = first.b0 ? second.b1 : second.b0;
-    r.inc1 = first.inc1 + (first.b1 ? second.inc1 : second.inc0);
-    r.b1 = first.b1 ? second.b1 : second.b0;
+    r.a0 = min((first.a0 & ~1u) + ((first.a0 & 1u) ? second.a1 : second.a0), PF_SAT);      // both operands <= PF_SAT: no wrap
+    r.a1 = min((first.a1 & ~1u) + ((first.a1 & 1u) ? second.a1 : second.a0), PF_SAT);
     return r;
 }
-__device__ __forceinline__ ParityFn pf_shfl(const ParityFn& f, int src_lane) {
+// inclusive scan over the 64 lanes of a wave (lane l: f_0 .. f_l composed in order), all on the DPP network: shifts inside the
+// rows of 16, then lane 15 / lane 31 broadcast into the rows above.  A lane without a source gets the identity.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ ParityFn pf_dpp(const ParityFn& f) {
     ParityFn r;
-    r.inc0 = __shfl(f.inc0, src_lane);
-    r.inc1 = __shfl(f.inc1, src_lane);
-    const int bits = __shfl(f.b0 | (f.b1 << 1), src_lane);
-    r.b0 = bits & 1;
-    r.b1 = (bits >> 1) & 1;
+    r.a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.a0, CTRL, ROWS, 0xf, false);
+    r.a1 = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)f.a1, CTRL, ROWS, 0xf, false);
     return r;
 }
-// inclusive scan over the 64 lanes of a wave (lane l: f_0 .. f_l composed in order)
-__device__ __forceinline__ ParityFn pf_wave_scan(ParityFn f, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const ParityFn prev = pf_shfl(f, lane - d);             // (lanes below d read themselves: discarded)
-        if (lane >= d) f = pf_compose(prev, f);
-    }
+__device__ __forceinline__ ParityFn pf_wave_scan(ParityFn f) {
+    f = pf_compose(pf_dpp<0x111, 0xf>(f), f);                   // row_shr:1
+    f = pf_compose(pf_dpp<0x112, 0xf>(f), f);                   // row_shr:2
+    f = pf_compose(pf_dpp<0x114, 0xf>(f), f);                   // row_shr:4
+    f = pf_compose(pf_dpp<0x118, 0xf>(f), f);                   // row_shr:8
+    f = pf_compose(pf_dpp<0x142, 0xa>(f), f);                   // row_bcast:15 into rows 1 and 3
+    f = pf_compose(pf_dpp<0x143, 0xc>(f), f);                   // row_bcast:31 into rows 2 and 3
     return f;
 }
 
@@ -502,21 +508,15 @@ __device__ __forceinline__ BrRegime br_regime(int e) {
 }
 // one term as a function of the mantissa parity (see the block comment above)
 __device__ __forceinline__ ParityFn br_classify(double t, const BrRegime& g) {
-    const double k = floor(t * g.invu);
-    const double diff = (t - k * g.u) - g.mid;                    // exact: both products are exact, the differences are small
-    ParityFn f;
+    const double kd = fmin(floor(t * g.invu), 1073741823.0);      // (a term far above the binade: saturated steps)
+    const uint32_t k = (uint32_t)kd;
+    const double diff = (t - kd * g.u) - g.mid;                   // exact: both products are exact, the differences are small
     if (fabs(diff) <= g.eps) {                                    // the double sum lands on the midpoint: ties-to-even
-        const int kp = (int)((long long)k & 1);
-        f.inc0 = k + (kp ? 1.0 : 0.0);
-        f.inc1 = k + (kp ? 0.0 : 1.0);
-        f.b0 = 0; f.b1 = 0;
-    } else {
-        const double r = k + (diff > 0.0 ? 1.0 : 0.0);
-        const int rp = (int)((long long)r & 1);
-        f.inc0 = r; f.inc1 = r;
-        f.b0 = rp; f.b1 = rp ^ 1;
+        const uint32_t kp = k & 1u;
+        return pf_make(k + kp, 0, k + (kp ^ 1u), 0);
     }
-    return f;
+    const uint32_t r = k + (diff > 0.0 ? 1u : 0u);
+    return pf_make(r, (int)(r & 1u), r, (int)((r & 1u) ^ 1u));
 }
 // the reference's term of one pixel (filters.c:715-722): packed B | G << 8 | R << 16, or the gray value
 template <int CN>
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64 * BR_FOLD_WAVES) void k_brightness_fold(const ui
 #pragma unroll
         for (int j = 0; j < BR_EPT; j++)
             if (mine + j < n) f = pf_compose(f, br_classify(td[j], g));
-        f = pf_wave_scan(f, lane);
+        f = pf_wave_scan(f);
         if (lane == 63 && chunk < nchunks) summ[(long long)e * nchunks + chunk] = f;
     }
 }
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64 * BR_FOLD_WAVES) void k_brightness_fold(const ui
 #define BR_WALK_EPT (BR_WCHUNK / (64 * BR_WALK_WAVES))            // 4 consecutive terms (or chunk summaries) per thread
 __device__ __forceinline__ ParityFn pf_block_scan(ParityFn f, ParityFn* s_part) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    f = pf_wave_scan(f, lane);
+    f = pf_wave_scan(f);
     __syncthreads();                                              // (s_part may still be read from the previous scan)
     if (lane == 63) s_part[wv] = f;
     __syncthreads();
@@ -591,10 +591,10 @@ __global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const ui
                                                                          long long nchunks, const ParityFn* __restrict__ summ, float* __restrict__ out) {
     constexpr int NT = 64 * BR_WALK_WAVES, EPT = BR_WALK_EPT;
     __shared__ ParityFn s_part[BR_WALK_WAVES];
-    __shared__ double s_tot[NT];
+    __shared__ uint32_t s_tot[NT];
     __shared__ double s_term[BR_WCHUNK];
     __shared__ int s_first[BR_WALK_WAVES], s_par[NT], s_res_taken;
-    __shared__ double s_res_steps;
+    __shared__ uint32_t s_res_steps;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float sum = 0.f;
     long long pos = 0;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const ui
             const int e = (int)((sbits >> 23) & 0xff) - 127;
             if (sum != 0.f && e >= BR_E0 && e < BR_E0 + ne && (pos % BR_WCHUNK) == 0) {
                 // whole chunks: scan their summaries for this binade, 1024 at a time, up to the chunk in which the sum leaves it
-                const double limit = (double)(0x800000u - (sbits & 0x7fffffu));     // steps of u until the binade ends
+                const uint32_t limit = 0x800000u - (sbits & 0x7fffffu);             // steps of u until the binade ends
                 const int parity = (int)(sbits & 1u);
                 const long long c0 = pos / BR_WCHUNK + (long long)tid * EPT;
                 ParityFn fk[EPT], f = pf_identity();
@@ -623,22 +623,22 @@ __global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const ui
                     f = pf_compose(f, fk[k]);
                 }
                 const ParityFn incl = pf_block_scan(f, s_part);
-                const double tot = parity ? incl.inc1 : incl.inc0;
+                const uint32_t tot = pf_steps(incl, parity);
                 s_tot[tid] = tot;
-                s_par[tid] = parity ? incl.b1 : incl.b0;          // the accumulator's parity behind this thread's chunks
+                s_par[tid] = pf_parity(incl, parity);             // the accumulator's parity behind this thread's chunks
                 const int first = first_of(tot >= limit);         // the thread whose four chunks hold the leaving one
                 if (tid == min(first, NT - 1)) {
                     // everything before that thread's chunks is consumed; of its own chunks, those before the leaving one
-                    double steps = tid > 0 && first < NT ? s_tot[tid - 1] : (first < NT ? 0.0 : s_tot[NT - 1]);
+                    uint32_t steps = tid > 0 && first < NT ? s_tot[tid - 1] : (first < NT ? 0u : s_tot[NT - 1]);
                     int taken = first < NT ? tid * EPT : NT * EPT;
                     if (first < NT) {
                         int par = tid > 0 ? s_par[tid - 1] : parity;
 #pragma unroll
                         for (int k = 0; k < EPT; k++) {
-                            const double inc = par ? fk[k].inc1 : fk[k].inc0;
+                            const uint32_t inc = pf_steps(fk[k], par);
                             if (steps + inc >= limit) break;
                             steps += inc;
-                            par = par ? fk[k].b1 : fk[k].b0;
+                            par = pf_parity(fk[k], par);
                             taken++;
                         }
                     }
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const ui
                 }
                 __syncthreads();
                 if (s_res_taken > 0) {
-                    sum = __uint_as_float(sbits + (unsigned)(long long)s_res_steps);
+                    sum = __uint_as_float(sbits + s_res_steps);
                     pos = min(n, pos + (long long)s_res_taken * BR_WCHUNK);
                 }
                 __syncthreads();
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const ui
         const unsigned sb = __float_as_uint(sum);
         const bool zero = sum == 0.f;
         const int e2 = (int)((sb >> 23) & 0xff) - 127;
-        const double lim2 = (double)(0x800000u - (sb & 0x7fffffu));
+        const uint32_t lim2 = 0x800000u - (sb & 0x7fffffu);
         const int parity = (int)(sb & 1u);
         const long long nlim = min(n, (pos / BR_WCHUNK + 1) * BR_WCHUNK);
         const BrRegime g = br_regime(e2);
@@ -678,16 +678,16 @@ __global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const ui
             s_term[tid * EPT + k] = t;
         }
         const ParityFn incl = pf_block_scan(f, s_part);
-        const double tot = parity ? incl.inc1 : incl.inc0;        // steps added by everything up to and including this thread
+        const uint32_t tot = pf_steps(incl, parity);              // steps added by everything up to and including this thread
         s_tot[tid] = tot;
         const int first = first_of(zero ? nonzero : (tot >= lim2));
         if (first == NT) {                                        // everything offered stays inside the binade
-            if (!zero) sum = __uint_as_float(sb + (unsigned)(long long)s_tot[NT - 1]);
+            if (!zero) sum = __uint_as_float(sb + s_tot[NT - 1]);
             pos = nlim;
         } else {
             // that thread's terms hold the one that leaves the binade (or the first non-zero one): the literal sequence
             float ns = sum;
-            if (!zero && first > 0) ns = __uint_as_float(sb + (unsigned)(long long)s_tot[first - 1]);
+            if (!zero && first > 0) ns = __uint_as_float(sb + s_tot[first - 1]);
             long long np = pos + (long long)first * EPT;
 #pragma unroll
             for (int k = 0; k < EPT; k++)
