@@ -655,53 +655,70 @@ __global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const ui
                 // the chunk at pos leaves the binade: replay it below (the accumulator is still in binade e)
             }
         }
-        // ---- term-by-term replay of [pos, next chunk boundary): four consecutive terms per thread, recomputed from the pixels
-        const unsigned sb = __float_as_uint(sum);
-        const bool zero = sum == 0.f;
-        const int e2 = (int)((sb >> 23) & 0xff) - 127;
-        const uint32_t lim2 = 0x800000u - (sb & 0x7fffffu);
-        const int parity = (int)(sb & 1u);
-        const long long nlim = min(n, (pos / BR_WCHUNK + 1) * BR_WCHUNK);
-        const BrRegime g = br_regime(e2);
-        ParityFn f = pf_identity();
-        bool nonzero = false;
+        // ---- term-by-term replay of the rest of the chunk pos stands in.  The chunk's 1024 terms are computed from the pixels
+        // once (four consecutive ones per thread) and stay in LDS while the accumulator works its way through the chunk: every
+        // pass below ends at the term that leaves the current binade (added with the literal float/double sequence) or at the
+        // chunk's end, and only a new chunk costs loads.
+        const long long cbase = pos / BR_WCHUNK * BR_WCHUNK;
+        const long long nlim = min(n, cbase + BR_WCHUNK);
+        double tk[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; k++) {
-            const long long i = pos + (long long)tid * EPT + k;
+            const long long i = cbase + tid * EPT + k;
             double t = 0.0;
             if (i < nlim) {
-                const int x = (int)(i / h), y = (int)(i - (long long)x * h);
+                const int x = (int)((unsigned)i / (unsigned)h), y = (int)i - x * h;      // n <= 2^30 (launch_brightness)
                 t = br_term_of<CN>(br_load_px<CN>(src + (size_t)y * step + (size_t)x * CN));
-                if (zero) nonzero |= t != 0.0;
-                else f = pf_compose(f, br_classify(t, g));
             }
+            tk[k] = t;
             s_term[tid * EPT + k] = t;
         }
-        const ParityFn incl = pf_block_scan(f, s_part);
-        const uint32_t tot = pf_steps(incl, parity);              // steps added by everything up to and including this thread
-        s_tot[tid] = tot;
-        const int first = first_of(zero ? nonzero : (tot >= lim2));
-        if (first == NT) {                                        // everything offered stays inside the binade
-            if (!zero) sum = __uint_as_float(sb + s_tot[NT - 1]);
-            pos = nlim;
-        } else {
-            // that thread's terms hold the one that leaves the binade (or the first non-zero one): the literal sequence
-            float ns = sum;
-            if (!zero && first > 0) ns = __uint_as_float(sb + s_tot[first - 1]);
-            long long np = pos + (long long)first * EPT;
+        while (pos < nlim) {
+            const unsigned sb = __float_as_uint(sum);
+            const bool zero = sum == 0.f;
+            const int e2 = (int)((sb >> 23) & 0xff) - 127;
+            const uint32_t lim2 = 0x800000u - (sb & 0x7fffffu);
+            const int parity = (int)(sb & 1u);
+            const int o = (int)(pos - cbase);                     // terms of the chunk already consumed
+            const BrRegime g = br_regime(e2);
+            ParityFn f = pf_identity();
+            bool nonzero = false;
 #pragma unroll
-            for (int k = 0; k < EPT; k++)
-                if (np < nlim) { ns = (float)__dadd_rn((double)ns, s_term[first * EPT + k]); np++; }
-            sum = ns;
-            pos = np;
+            for (int k = 0; k < EPT; k++) {
+                const int j = tid * EPT + k;
+                if (j >= o && cbase + j < nlim) {
+                    if (zero) nonzero |= tk[k] != 0.0;
+                    else f = pf_compose(f, br_classify(tk[k], g));
+                }
+            }
+            const ParityFn incl = pf_block_scan(f, s_part);
+            const uint32_t tot = pf_steps(incl, parity);          // steps added by everything up to and including this thread
+            s_tot[tid] = tot;
+            const int first = first_of(zero ? nonzero : (tot >= lim2));
+            if (first == NT) {                                    // everything left in the chunk stays inside the binade
+                if (!zero) sum = __uint_as_float(sb + s_tot[NT - 1]);
+                pos = nlim;
+            } else {
+                // that thread's terms hold the one that leaves the binade (or the first non-zero one): the literal sequence
+                float ns = sum;
+                if (!zero && first > 0) ns = __uint_as_float(sb + s_tot[first - 1]);
+#pragma unroll
+                for (int k = 0; k < EPT; k++) {
+                    const int j = first * EPT + k;
+                    if (j >= o && cbase + j < nlim) ns = (float)__dadd_rn((double)ns, s_term[j]);
+                }
+                sum = ns;
+                pos = min(nlim, cbase + (long long)(first + 1) * EPT);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (tid == 0) *out = sum;
 }
 
 int launch_brightness(const View& v, float* host_result, hipStream_t s) {
     const long long n = (long long)v.w * v.h;
+    if (!view_fits(v.w, v.h, v.c, v.step)) return IMP_ERROR_INVALID_ARGS;       // (n <= 2^30: the kernels divide in 32 bits)
     const long long nchunks = (n + BR_WCHUNK - 1) / BR_WCHUNK;
     // binades with summaries: from 2^20 up to the last one the sum can reach (a term is at most 255; u / 2 = 256 in binade
     // 32, so it never leaves that one)
