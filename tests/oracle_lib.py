@@ -289,3 +289,18 @@ def jpeg_coefficients(blob, ci):
     bw, bh = C.c_int(), C.c_int()
     rc = lib.orc_jpeg_coefficients(blob, len(blob), ci, out.ctypes.data, n, bw, bh)
     return rc, (out.reshape(bh.value, bw.value, 8, 8) if rc == 0 else None)
+
+
+def jpeg_encode(arr, quality):
+    """cvEncodeImage(".jpg", frame, {CV_IMWRITE_JPEG_QUALITY, quality}) -> (rc, file bytes or None); arr is H x W x {1,3,4} B,G,R(,A)."""
+    a = np.ascontiguousarray(arr, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    hh, ww, cc = a.shape
+    lib.orc_jpeg_encode_bound.restype = C.c_long
+    cap = lib.orc_jpeg_encode_bound(ww, hh, cc)
+    out = (C.c_ubyte * cap)()
+    n = C.c_long()
+    lib.orc_jpeg_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+    rc = lib.orc_jpeg_encode(a.ctypes.data, ww, hh, cc, ww * cc, int(quality), out, cap, C.byref(n))
+    return rc, (bytes(out[: n.value]) if rc == 0 else None)
