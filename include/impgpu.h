@@ -150,6 +150,21 @@ int   impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_im
  * error), in which case no image is returned. */
 int   impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* sizes, int count,
                                impgpu_image** images, int* codes);
+/* The other end of the request: CvMat* encoded = cvEncodeImage(".jpg", image, basicCoderopt)          bridge.c:704
+ * with basicCoderopt = {CV_IMWRITE_JPEG_QUALITY, quality} (bridge.c:474-486; OpenCV clamps the value to 0..100), for the
+ * frame the operators left in HBM: colour conversion, chroma downsampling, forward DCT, quantisation and Huffman coding run
+ * on the device and the compressed file crosses the link instead of the pixels.  OpenCV 2.4.9's JpegEncoder leaves
+ * everything else at libjpeg's defaults -- baseline, YCbCr 4:2:0 (one gray component for a 1-channel frame), the Annex K
+ * tables, ISLOW DCT, JFIF 1.01 -- and the file is the same, byte for byte, as libjpeg-turbo's.  A 4-channel frame loses
+ * its alpha exactly as in cvEncodeImage (RunJob flattens it first, bridge.c:642-656); an album handle encodes frame 0,
+ * like bridge.c:703.  *length receives the file's size; IMP_ERROR_MALLOC_FAILED = capacity is smaller than that (nothing
+ * is written; impgpu_jpeg_encode_bound(w, h, c) is always enough).  Waits for the device. */
+int   impgpu_image_encode_jpeg(const impgpu_image* image, int quality, unsigned char* out, size_t capacity, size_t* length);
+/* `count` frames (the thumbnails of a request queue) in two launches and two waits; codes[i] / lengths[i] are what
+ * impgpu_image_encode_jpeg would give for frame i. */
+int   impgpu_batch_encode_jpeg(const impgpu_image* const* images, int count, int quality, unsigned char* const* outs,
+                               const size_t* capacities, size_t* lengths, int* codes);
+size_t impgpu_jpeg_encode_bound(int width, int height, int channels);
 /* the SOF header alone (host, no device): the size checks the module makes before decoding */
 int   impgpu_jpeg_info(const unsigned char* blob, size_t size, int* width, int* height, int* channels);
 /* Diagnostics (host, no device): the quantised coefficients of the file's components, MCU-padded planes one after the

@@ -126,6 +126,9 @@ SIGNATURES = {
     "impgpu_image_clone": (C.c_int, [P, PP]),
     "impgpu_image_download": (C.c_int, [P, P, C.c_int]),
     "impgpu_batch_download": (C.c_int, [PP, C.c_int, PP, IP]),
+    "impgpu_image_encode_jpeg": (C.c_int, [P, C.c_int, P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "impgpu_batch_encode_jpeg": (C.c_int, [PP, C.c_int, C.c_int, PP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), IP]),
+    "impgpu_jpeg_encode_bound": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "impgpu_album_upload": (C.c_int, [PP, C.c_int, C.c_int, C.c_int, C.c_int, IP, PP]),
     "impgpu_album_download": (C.c_int, [P, PP, IP]),
     "impgpu_album_count": (C.c_int, [P]),

@@ -21,6 +21,7 @@ SOURCES = [
     "imp_pixel.hip",
     "imp_blur.hip",
     "imp_jpeg.hip",
+    "imp_jpeg_enc.hip",
     "imp_api.cpp",
     "imp_args.cpp",
     "imp_request.cpp",

@@ -1,0 +1,542 @@
+// imp_jpeg_enc.hip -- the encoder's side of the JPEG front: cvEncodeImage(".jpg", image, {CV_IMWRITE_JPEG_QUALITY, q})
+// at bridge.c:704 (q from bridge.c:474-486) for the frame the operator chain leaves in HBM, so that the compressed file
+// crosses the link instead of the pixels.  What OpenCV 2.4.9's JpegEncoder asks libjpeg for: jpeg_set_defaults +
+// jpeg_set_quality(q, TRUE) -- baseline Huffman with the Annex K tables, YCbCr 4:2:0 (one gray component for 1-channel
+// frames), ISLOW forward DCT, no restart markers, JFIF 1.01 -- and the output is the same FILE, byte for byte
+// (oracle/orc_jpeg_enc.c is pinned against Pillow's libjpeg-turbo; tests/test_gpu_jpeg_enc.py compares with both).
+//
+//   host      headers (jcmarker.c order: SOI, APP0, DQT per table, SOF0, DHT per table, SOS), the quantisation tables of
+//             jpeg_quality_scaling, the derived Huffman code tables (built once)
+//   k_jpeg_enc_blocks   one lane per 8x8 block slot of the scan, in MCU order: colour conversion (jccolor.c's fixed-point
+//             tables) on the fly, edge replication (jcsample.c expand_right_edge, jcprepct.c expand_bottom_edge -- the
+//             chroma rows past the last real one repeat THAT row), the 2x2 chroma box with its alternating 1,2 bias
+//             (h2v2_downsample), jfdctint.c's ISLOW DCT in registers, jcdctmgr.c's quantisation; the block goes to HBM as
+//             64 shorts in zigzag order.  Block slots beyond a component's own blocks (jccoefct.c's dummy blocks) are
+//             zero; their DC is their predecessor's and is resolved where it is read.
+//   k_jpeg_enc_huff     one workgroup per image walks its blocks 256 at a time: every lane sizes its block's code
+//             (jchuff.c encode_one_block), a block scan turns the sizes into bit offsets, the lanes OR their bits into an
+//             LDS window (32 bits per ds_or), and the window's whole bytes leave with FF00 stuffing (a second scan over the
+//             FF counts); the last partial byte carries into the next strip, flush_bits' 1-fill and EOI end the file.
+// An image's scan is one serial bit stream, but only the offsets are serial: the two scans.
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "imp_internal.h"
+#include "imp_jpeg_std.h"
+
+namespace imp {
+
+namespace {
+
+struct EncJob {
+    const uint8_t* src;
+    int w, h, c, step;
+    int mcuw, mcuh, bpm, nblocks;       // MCUs across / down, blocks per MCU (6: Y Y Y Y Cb Cr, or 1), block slots in the scan
+    int lbw, lbh, chh;                  // luma's own blocks (width_in_blocks / height_in_blocks), real chroma rows
+    int out_cap;                        // bytes of `out`
+    short* coef;                        // nblocks x 64, zigzag order
+    uint8_t* out;                       // entropy-coded segment + EOI
+};
+struct EncMap { int job, local; };      // workgroup of k_jpeg_enc_blocks -> (image, first block slot)
+struct EncTables {
+    uint16_t q[2][64];                  // natural order
+    uint32_t huff[4][256];              // code << 8 | size : DC luma, AC luma, DC chroma, AC chroma
+};
+
+#define ENC_WIN_WORDS 14336             // 256 blocks x 1658 bits at most, plus the carried byte
+#define ENC_BLOCK_BYTES 432             // what a block can need in the file: 1658 bits, every byte stuffed
+
+// ---------------------------------------------------------------- k_jpeg_enc_blocks
+__device__ __forceinline__ int enc_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// jfdctint.c, one 1-D pass over eight values; PASS = 0 rows (results scaled up by 2^PASS1_BITS), 1 columns
+template <int PASS>
+__device__ __forceinline__ void enc_fdct8(int& d0, int& d1, int& d2, int& d3, int& d4, int& d5, int& d6, int& d7) {
+    const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6, t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    constexpr int SH = PASS ? 13 + 2 : 13 - 2;
+    if (PASS == 0) { d0 = (t10 + t11) << 2; d4 = (t10 - t11) << 2; }
+    else { d0 = enc_descale(t10 + t11, 2); d4 = enc_descale(t10 - t11, 2); }
+    int z1 = (t12 + t13) * 4433;
+    d2 = enc_descale(z1 + t13 * 6270, SH);
+    d6 = enc_descale(z1 + t12 * -15137, SH);
+    z1 = t4 + t7;
+    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    const int z5 = (z3 + z4) * 9633;
+    const int a4 = t4 * 2446, a5 = t5 * 16819, a6 = t6 * 25172, a7 = t7 * 12299;
+    z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+    z3 += z5; z4 += z5;
+    d7 = enc_descale(a4 + z1 + z3, SH);
+    d5 = enc_descale(a5 + z2 + z4, SH);
+    d3 = enc_descale(a6 + z2 + z3, SH);
+    d1 = enc_descale(a7 + z1 + z4, SH);
+}
+
+// jcdctmgr.c: magnitude + half the divisor, integer division, sign back (divisor = 8 q: the DCT's output is scaled by 8)
+__device__ __forceinline__ int enc_quant(int v, int q8) {
+    const int t = abs(v) + (q8 >> 1);
+    int r = (int)((float)t / (float)q8);            // t < 2^17, q8 <= 2040: the quotient is off by one at most
+    if (r * q8 > t) r--;
+    if ((r + 1) * q8 <= t) r++;
+    return v < 0 ? -r : r;
+}
+
+// jccolor.c rgb_ycc_convert on one B,G,R pixel: which = 0 Y, 1 Cb, 2 Cr
+template <int CN>
+__device__ __forceinline__ int enc_sample(const uint8_t* p, int which) {
+    if (CN == 1) return p[0];
+    const int b = p[0], g = p[1], r = p[2];
+    if (which == 0) return (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
+    if (which == 1) return (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16;
+    return (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
+}
+
+template <int CN>
+__device__ __forceinline__ void enc_block(const EncJob& J, const uint16_t* __restrict__ qt, int comp, int bx, int by, short* __restrict__ out) {
+    int d[64];
+    if (comp == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint8_t* row = J.src + (size_t)min(by * 8 + r, J.h - 1) * J.step;
+#pragma unroll
+            for (int i = 0; i < 8; i++) d[r * 8 + i] = enc_sample<CN>(row + (size_t)min(bx * 8 + i, J.w - 1) * CN, 0) - 128;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int cy = min(by * 8 + r, J.chh - 1);          // rows past the last real chroma row repeat that row
+            const uint8_t* r0 = J.src + (size_t)min(2 * cy, J.h - 1) * J.step;
+            const uint8_t* r1 = J.src + (size_t)min(2 * cy + 1, J.h - 1) * J.step;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int cx = bx * 8 + i;
+                const size_t x0 = (size_t)min(2 * cx, J.w - 1) * CN, x1 = (size_t)min(2 * cx + 1, J.w - 1) * CN;
+                const int s = enc_sample<CN>(r0 + x0, comp) + enc_sample<CN>(r0 + x1, comp) + enc_sample<CN>(r1 + x0, comp) +
+                              enc_sample<CN>(r1 + x1, comp) + 1 + (i & 1);       // bias 1, 2, 1, 2, ... along the row (cx and i have the same parity)
+                d[r * 8 + i] = (s >> 2) - 128;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) enc_fdct8<0>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) enc_fdct8<1>(d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i]);
+    const uint16_t* q = qt + (comp ? 64 : 0);
+    constexpr uint8_t ZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    uint32_t* o = (uint32_t*)out;
+#pragma unroll
+    for (int k = 0; k < 64; k += 2) {
+        const int a = enc_quant(d[ZZ[k]], (int)q[ZZ[k]] << 3), b = enc_quant(d[ZZ[k + 1]], (int)q[ZZ[k + 1]] << 3);
+        o[k >> 1] = (uint32_t)(a & 0xffff) | ((uint32_t)b << 16);
+    }
+}
+
+// which component / block a slot of the scan is: false for a dummy slot
+__device__ __forceinline__ bool enc_slot(const EncJob& J, int mcu, int j, int* comp, int* bx, int* by) {
+    const int my = mcu / J.mcuw, mx = mcu - my * J.mcuw;
+    if (J.bpm == 1) { *comp = 0; *bx = mx; *by = my; return true; }
+    if (j >= 4) { *comp = j - 3; *bx = mx; *by = my; return true; }
+    *comp = 0; *bx = mx * 2 + (j & 1); *by = my * 2 + (j >> 1);
+    return *bx < J.lbw && *by < J.lbh;
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_enc_blocks(const EncJob* __restrict__ jobs, const EncMap* __restrict__ map, const EncTables* __restrict__ tabs) {
+    const EncMap m = map[blockIdx.x];
+    const EncJob& J = jobs[m.job];
+    const int b = m.local + (int)threadIdx.x;
+    if (b >= J.nblocks) return;
+    const int mcu = b / J.bpm, j = b - mcu * J.bpm;
+    int comp, bx, by;
+    short* out = J.coef + (size_t)b * 64;
+    if (!enc_slot(J, mcu, j, &comp, &bx, &by)) {
+        int4* o = (int4*)out;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = int4{0, 0, 0, 0};
+        return;
+    }
+    if (J.c == 1) enc_block<1>(J, &tabs->q[0][0], comp, bx, by, out);
+    else if (J.c == 3) enc_block<3>(J, &tabs->q[0][0], comp, bx, by, out);
+    else enc_block<4>(J, &tabs->q[0][0], comp, bx, by, out);
+}
+
+// ---------------------------------------------------------------- k_jpeg_enc_huff
+// DC of block slot (mcu, j): a dummy slot has the DC of its predecessor in the MCU (jccoefct.c: the block to its left at
+// the right edge, MCU_buffer[blkn - 1] for a whole dummy row at the bottom), which ends at a real block: slot 0 always is
+__device__ __forceinline__ int enc_dc_of(const EncJob& J, int mcu, int j) {
+    if (J.bpm == 6 && j < 4) {
+        const int my = mcu / J.mcuw, mx = mcu - my * J.mcuw;
+        while (j > 0 && !(mx * 2 + (j & 1) < J.lbw && my * 2 + (j >> 1) < J.lbh)) j--;
+    }
+    return J.coef[((size_t)mcu * J.bpm + j) * 64];
+}
+
+__device__ __forceinline__ int enc_nbits(int v) { return 32 - __clz(abs(v)); }      // 0 for 0
+
+// inclusive scan of one int per thread over the 256 threads of the block; s_part: 4 words of scratch.  Returns the thread's
+// inclusive prefix, *total = the block's sum.
+__device__ __forceinline__ int enc_block_scan(int v, int* s_part, int* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int p = __shfl_up(v, d);
+        if (lane >= d) v += p;
+    }
+    __syncthreads();
+    if (lane == 63) s_part[wv] = v;
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = s_part[k];
+        if (k < wv) pre += p;
+        tot += p;
+    }
+    *total = tot;
+    return v + pre;
+}
+
+struct EncPut {                          // a lane's write head into the LDS window: bits are ORed in, 32 at a time
+    uint32_t* win;
+    uint64_t acc;
+    int nacc, wpos;
+    __device__ __forceinline__ void start(uint32_t* w, int bit) { win = w; acc = 0; nacc = bit & 31; wpos = bit >> 5; }
+    __device__ __forceinline__ void put(uint32_t code, int len) {      // len <= 16, code < 2^len
+        if (len == 0) return;                                           // (a symbol without a code: cannot occur for 8-bit data)
+        acc |= (uint64_t)code << (64 - nacc - len);
+        nacc += len;
+        if (nacc >= 32) {
+            atomicOr(&win[wpos], (uint32_t)(acc >> 32));
+            acc <<= 32;
+            nacc -= 32;
+            wpos++;
+        }
+    }
+    __device__ __forceinline__ void finish() { if (nacc > 0) atomicOr(&win[wpos], (uint32_t)(acc >> 32)); }
+};
+
+// jchuff.c encode_one_block over a block in zigzag order, held in registers (32 dwords of two coefficients).  EMIT = false:
+// only the number of bits.
+template <bool EMIT>
+__device__ __forceinline__ int enc_code_block(const uint32_t (&cw)[32], int last_dc, int dc, const uint32_t* __restrict__ hdc, const uint32_t* __restrict__ hac, EncPut* P) {
+    int bits = 0;
+    {
+        int t = dc - last_dc, t2 = t;
+        if (t < 0) { t = -t; t2--; }
+        const int n = enc_nbits(t);
+        const uint32_t e = hdc[n];
+        bits += (int)(e & 0xff) + n;
+        if (EMIT) { P->put(e >> 8, (int)(e & 0xff)); if (n) P->put((uint32_t)t2 & ((1u << n) - 1), n); }
+    }
+    int run = 0;
+    const uint32_t zrl = hac[0xF0], eob = hac[0];
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        int t = (short)(cw[k >> 1] >> ((k & 1) * 16));
+        if (t == 0) { run++; continue; }
+        while (run > 15) {
+            bits += (int)(zrl & 0xff);
+            if (EMIT) P->put(zrl >> 8, (int)(zrl & 0xff));
+            run -= 16;
+        }
+        int t2 = t;
+        if (t < 0) { t = -t; t2--; }
+        const int n = enc_nbits(t);
+        const uint32_t e = hac[(run << 4) + n];
+        bits += (int)(e & 0xff) + n;
+        if (EMIT) { P->put(e >> 8, (int)(e & 0xff)); P->put((uint32_t)t2 & ((1u << n) - 1), n); }
+        run = 0;
+    }
+    if (run > 0) {
+        bits += (int)(eob & 0xff);
+        if (EMIT) P->put(eob >> 8, (int)(eob & 0xff));
+    }
+    return bits;
+}
+
+// result[2 * job] = bytes of the entropy-coded segment + EOI (what the file needs after its headers, whether or not it
+// fitted), result[2 * job + 1] = 1 when it did not fit out_cap
+__global__ __launch_bounds__(256) void k_jpeg_enc_huff(const EncJob* __restrict__ jobs, const EncTables* __restrict__ tabs, uint32_t* __restrict__ result) {
+    __shared__ uint32_t s_win[ENC_WIN_WORDS];
+    __shared__ int s_part[4];
+    __shared__ uint32_t s_carry;
+    const EncJob& J = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ENC_WIN_WORDS; i += 256) s_win[i] = 0;
+    __syncthreads();
+    int carry = 0;                      // bits of an unfinished byte at the top of s_win[0]
+    long long out_pos = 0;              // bytes of the segment so far (counted even when they no longer fit)
+    for (int b0 = 0; b0 < J.nblocks; b0 += 256) {
+        const int b = b0 + tid;
+        const bool live = b < J.nblocks;
+        int bits = 0, dc = 0, last_dc = 0;
+        uint32_t cw[32];
+        const uint32_t *hdc = tabs->huff[0], *hac = tabs->huff[1];
+        if (live) {
+            const int mcu = b / J.bpm, j = b - mcu * J.bpm;
+            const uint4* blk = (const uint4*)(J.coef + (size_t)b * 64);
+#pragma unroll
+            for (int v = 0; v < 8; v++) {
+                const uint4 q = blk[v];
+                cw[4 * v] = q.x; cw[4 * v + 1] = q.y; cw[4 * v + 2] = q.z; cw[4 * v + 3] = q.w;
+            }
+            dc = enc_dc_of(J, mcu, j);
+            if (J.bpm == 1) last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, 0) : 0;
+            else if (j >= 4) { last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, j) : 0; hdc = tabs->huff[2]; hac = tabs->huff[3]; }
+            else last_dc = j > 0 ? enc_dc_of(J, mcu, j - 1) : (mcu > 0 ? enc_dc_of(J, mcu - 1, 3) : 0);
+            bits = enc_code_block<false>(cw, last_dc, dc, hdc, hac, nullptr);
+        }
+        int total;
+        const int incl = enc_block_scan(bits, s_part, &total);
+        if (live) {
+            EncPut P;
+            P.start(s_win, carry + incl - bits);
+            enc_code_block<true>(cw, last_dc, dc, hdc, hac, &P);
+            P.finish();
+        }
+        __syncthreads();
+        int nbits = carry + total;
+        const bool last = b0 + 256 >= J.nblocks;
+        if (last && (nbits & 7)) {                              // flush_bits: ones up to the byte boundary
+            if (tid == 0) {
+                const int lb = nbits & 7;
+                atomicOr(&s_win[nbits >> 5], ((1u << (8 - lb)) - 1) << (24 - ((nbits >> 3) & 3) * 8));
+            }
+            nbits = (nbits + 7) & ~7;
+            __syncthreads();
+        }
+        const int nbytes = nbits >> 3;
+        // whole bytes leave with a 00 stuffed behind every FF: a word-aligned run of bytes per thread
+        const int per = ((nbytes + 255) / 256 + 3) & ~3;
+        const int s = min(nbytes, tid * per), e = min(nbytes, s + per);
+        int ff = 0;
+        for (int i = s; i < e; i++) ff += ((s_win[i >> 2] >> (24 - (i & 3) * 8)) & 0xff) == 0xff;
+        int ff_total;
+        const int ff_incl = enc_block_scan(ff, s_part, &ff_total);
+        {
+            long long at = out_pos + s + (ff_incl - ff);
+            for (int i = s; i < e; i++) {
+                const uint32_t v = (s_win[i >> 2] >> (24 - (i & 3) * 8)) & 0xff;
+                if (at < J.out_cap) J.out[at] = (uint8_t)v;
+                at++;
+                if (v == 0xff) { if (at < J.out_cap) J.out[at] = 0; at++; }
+            }
+        }
+        out_pos += nbytes + ff_total;
+        // the unfinished byte moves to the top of a cleared window
+        carry = nbits & 7;
+        if (tid == 0) s_carry = carry ? ((s_win[nbytes >> 2] >> (24 - (nbytes & 3) * 8)) & 0xff) << 24 : 0u;
+        __syncthreads();
+        const int used = (nbits + 31) >> 5;
+        for (int i = tid; i < used; i += 256) s_win[i] = 0;
+        __syncthreads();
+        if (tid == 0) s_win[0] = s_carry;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (out_pos + 2 <= J.out_cap) { J.out[out_pos] = 0xff; J.out[out_pos + 1] = 0xd9; }
+        result[2 * blockIdx.x] = (uint32_t)(out_pos + 2);
+        result[2 * blockIdx.x + 1] = out_pos + 2 > J.out_cap ? 1u : 0u;
+    }
+}
+
+// ---------------------------------------------------------------- host
+const EncTables& enc_static_tables(EncTables* scratch, int quality) {
+    static uint32_t huff[4][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const uint8_t* bits[4] = {JSTD_BITS_DC_LUMA, JSTD_BITS_AC_LUMA, JSTD_BITS_DC_CHROMA, JSTD_BITS_AC_CHROMA};
+        const uint8_t* vals[4] = {JSTD_VALS_DC, JSTD_VALS_AC_LUMA, JSTD_VALS_DC, JSTD_VALS_AC_CHROMA};
+        for (int t = 0; t < 4; t++) {                          // jchuff.c jpeg_make_c_derived_tbl: canonical codes by length
+            std::memset(huff[t], 0, sizeof(huff[t]));
+            uint32_t code = 0;
+            int p = 0;
+            for (int l = 1; l <= 16; l++) {
+                for (int i = 0; i < bits[t][l - 1]; i++, p++) huff[t][vals[t][p]] = (code++ << 8) | (uint32_t)l;
+                code <<= 1;
+            }
+        }
+    });
+    std::memcpy(scratch->huff, huff, sizeof(huff));
+    // jcparam.c jpeg_quality_scaling + jpeg_add_quant_table(force_baseline = TRUE); OpenCV clamps the quality to 0..100
+    int q = quality <= 0 ? 1 : quality > 100 ? 100 : quality;
+    q = q < 50 ? 5000 / q : 200 - q * 2;
+    for (int t = 0; t < 2; t++)
+        for (int i = 0; i < 64; i++) {
+            long v = ((long)(t ? JSTD_Q_CHROMA : JSTD_Q_LUMA)[i] * q + 50L) / 100L;
+            v = v <= 0 ? 1 : v > 255 ? 255 : v;
+            scratch->q[t][JSTD_ZIGZAG[i]] = (uint16_t)v;
+        }
+    return *scratch;
+}
+
+void enc_put(std::vector<uint8_t>& f, int b) { f.push_back((uint8_t)b); }
+void enc_put2(std::vector<uint8_t>& f, int v) { enc_put(f, v >> 8); enc_put(f, v & 255); }
+
+// everything of the file in front of the entropy-coded segment, in jcmarker.c's order
+std::vector<uint8_t> enc_headers(int w, int h, int nc, const EncTables& T) {
+    std::vector<uint8_t> f;
+    f.reserve(640);
+    enc_put2(f, 0xFFD8);
+    enc_put2(f, 0xFFE0); enc_put2(f, 16);
+    for (const char ch : {'J', 'F', 'I', 'F', '\0'}) enc_put(f, ch);
+    enc_put(f, 1); enc_put(f, 1); enc_put(f, 0); enc_put2(f, 1); enc_put2(f, 1); enc_put(f, 0); enc_put(f, 0);
+    const int ntab = nc == 3 ? 2 : 1;
+    for (int t = 0; t < ntab; t++) {
+        enc_put2(f, 0xFFDB); enc_put2(f, 67); enc_put(f, t);
+        for (int i = 0; i < 64; i++) enc_put(f, T.q[t][JSTD_ZIGZAG[i]]);
+    }
+    enc_put2(f, 0xFFC0); enc_put2(f, 8 + 3 * nc); enc_put(f, 8); enc_put2(f, h); enc_put2(f, w); enc_put(f, nc);
+    for (int k = 0; k < nc; k++) { enc_put(f, k + 1); enc_put(f, k == 0 && nc == 3 ? 0x22 : 0x11); enc_put(f, k ? 1 : 0); }
+    const uint8_t* bits[4] = {JSTD_BITS_DC_LUMA, JSTD_BITS_AC_LUMA, JSTD_BITS_DC_CHROMA, JSTD_BITS_AC_CHROMA};
+    const uint8_t* vals[4] = {JSTD_VALS_DC, JSTD_VALS_AC_LUMA, JSTD_VALS_DC, JSTD_VALS_AC_CHROMA};
+    for (int t = 0; t < 2 * ntab; t++) {
+        int n = 0;
+        for (int i = 0; i < 16; i++) n += bits[t][i];
+        enc_put2(f, 0xFFC4); enc_put2(f, 2 + 1 + 16 + n); enc_put(f, ((t & 1) << 4) | (t >> 1));
+        for (int i = 0; i < 16; i++) enc_put(f, bits[t][i]);
+        for (int i = 0; i < n; i++) enc_put(f, vals[t][i]);
+    }
+    enc_put2(f, 0xFFDA); enc_put2(f, 6 + 2 * nc); enc_put(f, nc);
+    for (int k = 0; k < nc; k++) { enc_put(f, k + 1); enc_put(f, k ? 0x11 : 0x00); }
+    enc_put(f, 0); enc_put(f, 63); enc_put(f, 0);
+    return f;
+}
+
+struct EncGeom { int nc, mcuw, mcuh, bpm, nblocks; };
+bool enc_geom(int w, int h, int c, EncGeom* g) {
+    if (w <= 0 || h <= 0 || w > 65500 || h > 65500 || (c != 1 && c != 3 && c != 4)) return false;    // JPEG_MAX_DIMENSION
+    g->nc = c == 1 ? 1 : 3;
+    const int m = c == 1 ? 8 : 16;
+    g->mcuw = (w + m - 1) / m; g->mcuh = (h + m - 1) / m;
+    g->bpm = c == 1 ? 1 : 6;
+    const long long nb = (long long)g->mcuw * g->mcuh * g->bpm;
+    if (nb > (1 << 24)) return false;
+    g->nblocks = (int)nb;
+    return true;
+}
+
+constexpr int ENC_MAX_BATCH = 256;
+
+int encode_group(const impgpu_image* const* images, int count, int quality, unsigned char* const* outs, const size_t* caps,
+                 size_t* lens, int* codes) {
+    hipStream_t s = env_stream();
+    EncTables T;
+    enc_static_tables(&T, quality);
+    std::vector<EncJob> jobs;
+    std::vector<int> owner;                                     // job -> index into images
+    std::vector<EncMap> map;
+    std::vector<std::vector<uint8_t>> heads;
+    size_t coef_bytes = 0, out_bytes = 0;
+    for (int i = 0; i < count; i++) {
+        lens[i] = 0;
+        const impgpu_image* im = images[i];
+        EncGeom g;
+        if (!im || !outs[i] || !enc_geom(im->w, im->h, im->c, &g)) { codes[i] = IMP_ERROR_INVALID_ARGS; continue; }
+        codes[i] = IMP_OK;
+        EncJob J{};
+        J.src = im->d; J.w = im->w; J.h = im->h; J.c = im->c; J.step = im->step;
+        J.mcuw = g.mcuw; J.mcuh = g.mcuh; J.bpm = g.bpm; J.nblocks = g.nblocks;
+        J.lbw = (im->w + 7) / 8; J.lbh = (im->h + 7) / 8; J.chh = (im->h + 1) / 2;
+        const size_t cap = (size_t)g.nblocks * ENC_BLOCK_BYTES + 16;
+        if (cap > 0x7fffffffu) { codes[i] = IMP_ERROR_INVALID_ARGS; continue; }
+        J.out_cap = (int)cap;
+        J.coef = (short*)coef_bytes;                            // offsets for now
+        J.out = (uint8_t*)out_bytes;
+        coef_bytes += (size_t)g.nblocks * 128;
+        out_bytes += (cap + 255) & ~size_t(255);
+        for (int b = 0; b < g.nblocks; b += 256) map.push_back(EncMap{(int)jobs.size(), b});
+        jobs.push_back(J);
+        owner.push_back(i);
+        heads.push_back(enc_headers(im->w, im->h, g.nc, T));
+    }
+    const int nj = (int)jobs.size();
+    if (!nj) return IMP_OK;
+    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr;
+    auto drop = [&]() { dev_free(coef); dev_free(out); dev_free(res); dev_free(side); };
+    if (int rc = dev_alloc(coef_bytes, &coef)) return rc;
+    if (int rc = dev_alloc(out_bytes, &out)) { drop(); return rc; }
+    if (int rc = dev_alloc((size_t)nj * 8, &res)) { drop(); return rc; }
+    for (EncJob& J : jobs) { J.coef = (short*)((uint8_t*)coef + (size_t)J.coef); J.out = (uint8_t*)out + (size_t)J.out; }
+    // side blob: tables | jobs | map
+    const size_t o_jobs = (sizeof(EncTables) + 15) & ~size_t(15), o_map = o_jobs + ((jobs.size() * sizeof(EncJob) + 15) & ~size_t(15));
+    std::vector<uint8_t> blob(o_map + map.size() * sizeof(EncMap));
+    std::memcpy(blob.data(), &T, sizeof(T));
+    std::memcpy(blob.data() + o_jobs, jobs.data(), jobs.size() * sizeof(EncJob));
+    std::memcpy(blob.data() + o_map, map.data(), map.size() * sizeof(EncMap));
+    if (int rc = upload_small(blob.data(), blob.size(), &side, s)) { drop(); return rc; }
+    const uint8_t* sd = (const uint8_t*)side;
+    hipLaunchKernelGGL(k_jpeg_enc_blocks, dim3((unsigned)map.size()), dim3(256), 0, s, (const EncJob*)(sd + o_jobs), (const EncMap*)(sd + o_map), (const EncTables*)sd);
+    hipLaunchKernelGGL(k_jpeg_enc_huff, dim3((unsigned)nj), dim3(256), 0, s, (const EncJob*)(sd + o_jobs), (const EncTables*)sd, (uint32_t*)res);
+    hipError_t e = hipGetLastError();
+    // first wait: how long every segment is; second: exactly those bytes
+    void *pin = nullptr, *token = nullptr;
+    if (e == hipSuccess && stage_begin((size_t)nj * 8, &pin, &token) != IMP_OK) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpyAsync(pin, res, (size_t)nj * 8, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) { set_error("jpeg encode", e); (void)hipStreamSynchronize(s); drop(); return IMP_ERROR_DEVICE; }
+    if (int rc = lane_wait()) { drop(); return rc; }
+    std::vector<uint32_t> seg(2 * (size_t)nj);
+    std::memcpy(seg.data(), pin, seg.size() * 4);
+    size_t fetch = 0;
+    std::vector<size_t> at((size_t)nj, 0);
+    for (int k = 0; k < nj; k++) {
+        const int i = owner[k];
+        lens[i] = heads[k].size() + seg[2 * k];
+        if (seg[2 * k + 1]) { codes[i] = IMP_ERROR_DEVICE; set_error_text("jpeg encode: a segment outgrew its bound"); continue; }
+        if (lens[i] > caps[i]) { codes[i] = IMP_ERROR_MALLOC_FAILED; continue; }       // lens[i] says what it takes
+        at[k] = fetch;
+        fetch += (seg[2 * k] + 63) & ~size_t(63);
+    }
+    if (fetch) {
+        if (stage_begin(fetch, &pin, &token) != IMP_OK) { drop(); return IMP_ERROR_DEVICE; }
+        for (int k = 0; k < nj && e == hipSuccess; k++)
+            if (codes[owner[k]] == IMP_OK)
+                e = hipMemcpyAsync((uint8_t*)pin + at[k], jobs[k].out, seg[2 * k], hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) { set_error("jpeg encode download", e); (void)hipStreamSynchronize(s); drop(); return IMP_ERROR_DEVICE; }
+    }
+    drop();                                                     // stream-ordered: after the copies
+    if (fetch) if (int rc = lane_wait()) return rc;
+    for (int k = 0; k < nj; k++) {
+        const int i = owner[k];
+        if (codes[i] != IMP_OK) continue;
+        std::memcpy(outs[i], heads[k].data(), heads[k].size());
+        std::memcpy(outs[i] + heads[k].size(), (const uint8_t*)pin + at[k], seg[2 * k]);
+    }
+    return IMP_OK;
+}
+
+}  // namespace
+
+}  // namespace imp
+
+using namespace imp;
+
+extern "C" {
+
+size_t impgpu_jpeg_encode_bound(int width, int height, int channels) {
+    EncGeom g;
+    if (!enc_geom(width, height, channels, &g)) return 0;
+    return 1024 + (size_t)g.nblocks * ENC_BLOCK_BYTES;
+}
+
+int impgpu_batch_encode_jpeg(const impgpu_image* const* images, int count, int quality, unsigned char* const* outs,
+                             const size_t* capacities, size_t* lengths, int* codes) {
+    if (count < 0 || (count && (!images || !outs || !capacities || !lengths || !codes))) return IMP_ERROR_INVALID_ARGS;
+    if (!env_ready()) { set_error("impgpu_env_start has not been called", hipErrorNotInitialized); return IMP_ERROR_DEVICE; }
+    TraceRange tr("IMP_STEP_ENCODE");                           // bridge.c:679-710
+    IMP_FAULT_POINT(IMP_STEP_ENCODE);
+    for (int at = 0; at < count; at += ENC_MAX_BATCH) {
+        const int n = count - at < ENC_MAX_BATCH ? count - at : ENC_MAX_BATCH;
+        if (int rc = encode_group(images + at, n, quality, outs + at, capacities + at, lengths + at, codes + at)) return rc;
+    }
+    return IMP_OK;
+}
+
+int impgpu_image_encode_jpeg(const impgpu_image* image, int quality, unsigned char* out, size_t capacity, size_t* length) {
+    if (!image || !out || !length) return IMP_ERROR_INVALID_ARGS;
+    int code = IMP_OK;
+    if (int rc = impgpu_batch_encode_jpeg(&image, 1, quality, &out, &capacity, length, &code)) return rc;
+    return code;
+}
+
+}  // extern "C"

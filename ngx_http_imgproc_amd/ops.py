@@ -13,6 +13,7 @@ from ._lib import lib, CConfig, CJob, ImpError
 
 IMP_OK = 0
 IMP_ERROR_UNSUPPORTED = 1
+IMP_ERROR_MALLOC_FAILED = 2
 IMP_ERROR_DECODE_FAILED = 3
 IMP_ERROR_INVALID_ARGS = 50
 IMP_ERROR_UPSCALE = 51
@@ -146,6 +147,15 @@ class Image:
             raise ImpError(rc, "impgpu_album_download")
         return outs
 
+    def encode_jpeg(self, quality=95):
+        """cvEncodeImage(".jpg", frame, {CV_IMWRITE_JPEG_QUALITY, quality}) (bridge.c:704) on the device -> (code, file bytes or None)."""
+        hh, ww, cc = self.shape
+        cap = lib.impgpu_jpeg_encode_bound(ww, hh, cc)
+        buf = np.empty(max(1, cap), dtype=np.uint8)
+        n = C.c_size_t()
+        rc = lib.impgpu_image_encode_jpeg(self.h, int(quality), buf.ctypes.data, cap, C.byref(n))
+        return rc, (buf[: n.value].tobytes() if rc == 0 else None)
+
     def release(self):
         if self.h:
             lib.impgpu_image_release(C.byref(self.h))
@@ -267,6 +277,22 @@ def batch_decode_jpeg(blobs):
     if rc:
         raise ImpError(rc, "impgpu_batch_decode_jpeg")
     return [(codes[i], Image(handle=imgs[i]) if codes[i] == 0 else None) for i in range(n)]
+
+
+def batch_encode_jpeg(images, quality=95):
+    """impgpu_batch_encode_jpeg -> [(code, file bytes or None)] in the order of `images`."""
+    n = len(images)
+    hs = (C.c_void_p * n)(*[im.h.value for im in images])
+    caps = [lib.impgpu_jpeg_encode_bound(im.shape[1], im.shape[0], im.shape[2]) for im in images]
+    bufs = [np.empty(max(1, c), dtype=np.uint8) for c in caps]
+    outs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    ccaps = (C.c_size_t * n)(*caps)
+    lens = (C.c_size_t * n)()
+    codes = (C.c_int * n)()
+    rc = lib.impgpu_batch_encode_jpeg(hs, n, int(quality), outs, ccaps, lens, codes)
+    if rc:
+        raise ImpError(rc, "impgpu_batch_encode_jpeg")
+    return [(codes[i], bufs[i][: lens[i]].tobytes() if codes[i] == 0 else None) for i in range(n)]
 
 
 def jpeg_info(blob):

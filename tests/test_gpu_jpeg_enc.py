@@ -1,0 +1,105 @@
+"""GPU parity for the JPEG ENCODE end of the request (cvEncodeImage(".jpg") at bridge.c:704): the device writes the same
+FILE, byte for byte, as the oracle -- which is pinned against Pillow's libjpeg-turbo -- and as the committed Pillow files."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import noise_image, smooth_image
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_enc")
+CASES = json.load(open(os.path.join(GOLD, "manifest.json")))["cases"]
+DATA = np.load(os.path.join(GOLD, "enc_cases.npz"))
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%dx%d-q%d" % (c["width"], c["height"], c["channels"], c["quality"]))
+def test_device_writes_the_file_pillow_wrote(gpu, case):
+    i = case["case"]
+    im = gpu.Image(DATA["in_%02d" % i])
+    rc, got = im.encode_jpeg(case["quality"])
+    assert rc == 0
+    assert got == DATA["file_%02d" % i].tobytes()
+    im.release()
+
+
+SIZES = [(1, 1), (7, 9), (8, 8), (16, 16), (17, 33), (24, 40), (31, 257), (100, 75), (126, 224), (224, 126), (255, 255), (480, 640)]
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_encode_matches_oracle(gpu, h, w, c):
+    for q, arr in ((90, smooth_image(h, w, c) if c > 1 and h > 1 and w > 1 else noise_image(h, w, c, 5)), (75, noise_image(h, w, c, 1200 + h + w)), (100, noise_image(h, w, c, 7)),
+                   (3, noise_image(h, w, c, 8))):
+        rc_o, want = orc.jpeg_encode(arr, q)
+        im = gpu.Image(arr)
+        rc, got = im.encode_jpeg(q)
+        assert rc == rc_o == 0
+        assert got == want, (h, w, c, q, len(got), len(want))
+        im.release()
+
+
+def test_extreme_frames(gpu):
+    """Saturated and alternating content: the longest codes, FF bytes in the entropy-coded segment (stuffing), runs of
+    sixteen zeros (ZRL), quality 100 (divisor 8: the largest coefficients)."""
+    h, w = 64, 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames = [np.full((h, w, 3), 255, np.uint8), np.zeros((h, w, 3), np.uint8),
+              np.where(((xx + yy) & 1)[..., None] == 0, 255, 0).astype(np.uint8).repeat(3, axis=2),
+              np.where((xx & 8)[..., None] == 0, 255, 0).astype(np.uint8).repeat(3, axis=2),
+              np.stack([(xx * 255 // (w - 1)), (yy * 255 // (h - 1)), ((xx ^ yy) * 4) % 256], -1).astype(np.uint8)]
+    for arr in frames:
+        for q in (100, 95, 50, 0):
+            rc_o, want = orc.jpeg_encode(arr, q)
+            im = gpu.Image(arr)
+            rc, got = im.encode_jpeg(q)
+            assert rc == rc_o == 0 and got == want, q
+            im.release()
+
+
+def test_full_hd_frame_many_strips(gpu):
+    arr = smooth_image(1080, 1920, 3)
+    arr = (arr.astype(int) + np.random.default_rng(3).integers(-20, 21, arr.shape)).clip(0, 255).astype(np.uint8)
+    rc_o, want = orc.jpeg_encode(arr, 90)
+    im = gpu.Image(arr)
+    rc, got = im.encode_jpeg(90)
+    assert rc == rc_o == 0 and got == want
+    im.release()
+
+
+def test_batch_and_refusals(gpu):
+    rng = np.random.default_rng(5)
+    frames = [noise_image(int(rng.integers(1, 200)), int(rng.integers(1, 300)), int(rng.choice([1, 3, 4])), 1300 + i) for i in range(40)]
+    ims = [gpu.Image(f) for f in frames]
+    res = gpu.batch_encode_jpeg(ims, 85)
+    for f, (code, data) in zip(frames, res):
+        assert code == 0 and data == orc.jpeg_encode(f, 85)[1]
+    # a buffer that is too small: the code says so, the length says what it takes, nothing is written
+    import ctypes as C
+
+    small = (C.c_ubyte * 100)()
+    n = C.c_size_t()
+    rc = gpu.lib.impgpu_image_encode_jpeg(ims[0].h, 85, small, 100, C.byref(n))
+    assert rc == gpu.IMP_ERROR_MALLOC_FAILED and n.value == len(res[0][1]) and bytes(small) == bytes(100)
+    assert gpu.lib.impgpu_image_encode_jpeg(None, 85, small, 100, C.byref(n)) == gpu.IMP_ERROR_INVALID_ARGS
+    for im in ims:
+        im.release()
+
+
+def test_request_end_to_end_jpeg_in_jpeg_out(gpu):
+    """A whole request on the device: JPEG file -> decode -> resize -> JPEG file; the answer equals the reference's host
+    pipeline restated by the oracle (decode, Resize(), encode)."""
+    gold = os.path.join(os.path.dirname(GOLD), "jpeg")
+    blob = open(os.path.join(gold, sorted(f for f in os.listdir(gold) if f.endswith(".jpg"))[0]), "rb").read()
+    rc, im = gpu.Image.decode_jpeg(blob)
+    assert rc == 0
+    assert im.resize("48,0") == 0
+    rc, got = im.encode_jpeg(80)
+    rc_o, dec = orc.jpeg_decode(blob)
+    rc_o2, small = orc.resize(dec, "48,0", 2000, 2000, 0)
+    rc_o3, want = orc.jpeg_encode(small, 80)
+    assert rc == rc_o == rc_o2 == rc_o3 == 0 and got == want
+    im.release()
