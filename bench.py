@@ -378,12 +378,14 @@ def jpeg_pool(n_files):
     return files
 
 
-def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0, world=1, batch=1):
+def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0, world=1, batch=1, out_quality=0):
     """The same request stream with the requests arriving as what they are in production -- JPEG files (bridge.c:376-378,
     :545-552): decode -> resize=224,0 -> download.  decoder = "device": impgpu_image_decode_jpeg (the compressed bytes cross
     the link; Huffman, IDCT, upsampling, colour on the device); "hosthuff": the same with the entropy stage on the calling
     thread (IMPGPU_JPEG_HUFF=host); "host": the reference's structure -- libjpeg-turbo on the calling thread (Pillow's,
-    which releases the GIL) and impgpu_image_upload of the decoded frame."""
+    which releases the GIL) and impgpu_image_upload of the decoded frame.  out_quality > 0: the answer is a JPEG file too
+    (cvEncodeImage at bridge.c:704 with that quality): written on the device (impgpu_batch_encode_jpeg) and only the file is
+    downloaded -- or, for decoder "host", by libjpeg-turbo on the calling thread from the downloaded thumbnail."""
     import ctypes as C
     import io
     import queue
@@ -400,6 +402,8 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
     pending = queue.Queue(maxsize=max(1, queue_depth))
     errors = []
     out_bytes = 224 * 224 * 4 * 4
+    answer_bytes = [0]
+    enc_cap = lib.impgpu_jpeg_encode_bound(224, 224, 3)
 
     def feeder():
         for item in mine:
@@ -413,6 +417,22 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
         hdst = lib.impgpu_host_alloc(out_bytes * max(1, batch))
         if decoder == "host":
             from PIL import Image
+        nb = max(1, batch)
+        files_out = np.empty((nb, enc_cap), dtype=np.uint8) if out_quality and decoder != "host" else None
+        if files_out is not None:
+            e_outs = (C.c_void_p * nb)(*[files_out[k].ctypes.data for k in range(nb)])
+            e_caps = (C.c_size_t * nb)(*[enc_cap] * nb)
+            e_lens = (C.c_size_t * nb)()
+            e_codes = (C.c_int * nb)()
+        sent = 0
+
+        def host_encode(k, ow, oh):                                  # the reference's encoder on the downloaded thumbnail
+            step = (ow * 3 + 3) & ~3
+            a = np.ctypeslib.as_array(C.cast(hdst + out_bytes * k, C.POINTER(C.c_ubyte)), shape=(oh * step,)).reshape(oh, step)[:, : ow * 3].reshape(oh, ow, 3)
+            b = io.BytesIO()
+            Image.fromarray(a).save(b, format="JPEG", quality=out_quality, subsampling=2)
+            return len(b.getvalue())
+
         done = False
         while not done:
             items = []
@@ -460,12 +480,24 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
                                             lib.impgpu_image_device_ptr(o), ow_.value, oh_.value, lib.impgpu_image_step(o))
                 if rc == 0:
                     rc = lib.impgpu_batch_resize_mixed(its, n, 3, 0, None)
-                for k in range(n):
-                    o = C.c_void_p(outs[k])
+                if files_out is not None:
                     if rc == 0:
-                        rc = lib.impgpu_image_download_pinned(o, hdst + out_bytes * k, lib.impgpu_image_step(o))
-                if rc == 0:
-                    rc = lib.impgpu_sync()
+                        rc = lib.impgpu_batch_encode_jpeg(outs, n, out_quality, e_outs, e_caps, e_lens, e_codes)
+                        rc = rc or max(e_codes[:n])
+                        sent += sum(e_lens[:n])
+                else:
+                    for k in range(n):
+                        o = C.c_void_p(outs[k])
+                        if rc == 0:
+                            rc = lib.impgpu_image_download_pinned(o, hdst + out_bytes * k, lib.impgpu_image_step(o))
+                    if rc == 0:
+                        rc = lib.impgpu_sync()
+                    for k in range(n):
+                        o = C.c_void_p(outs[k])
+                        if rc == 0 and out_quality:
+                            sent += host_encode(k, lib.impgpu_image_width(o), lib.impgpu_image_height(o))
+                        elif rc == 0:
+                            sent += lib.impgpu_image_step(o) * lib.impgpu_image_height(o)
                 for k in range(n):
                     o = C.c_void_p(outs[k])
                     if o:
@@ -475,12 +507,19 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
                     one = C.c_void_p(imgs[k])
                     if rc == 0:
                         rc = lib.impgpu_resize(C.byref(one), MIXED_RESIZE, C.byref(cfg.c), 0)
-                    if rc == 0:
+                    if rc == 0 and files_out is not None:
+                        rc = lib.impgpu_image_encode_jpeg(one, out_quality, e_outs[0], enc_cap, e_lens)
+                        sent += e_lens[0]
+                    elif rc == 0:
                         ow = lib.impgpu_image_width(one)
                         rc = lib.impgpu_image_download_pinned(one, hdst + out_bytes * k, (ow * 3 + 3) & ~3)
                     imgs[k] = one
-                if rc == 0:
+                if rc == 0 and files_out is None:
                     rc = lib.impgpu_sync()
+                    for k in range(n):
+                        one = C.c_void_p(imgs[k])
+                        ow, oh = lib.impgpu_image_width(one), lib.impgpu_image_height(one)
+                        sent += host_encode(k, ow, oh) if out_quality else ((ow * 3 + 3) & ~3) * oh
             for k in range(n):
                 one = C.c_void_p(imgs[k])
                 if one:
@@ -489,6 +528,7 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
                 errors.append(((items[0][0], items[0][1]), rc))
                 break
         lib.impgpu_host_free(hdst)
+        answer_bytes[0] += sent                                      # (under the GIL)
 
     threads = [threading.Thread(target=worker) for _ in range(n_threads)]
     feed = threading.Thread(target=feeder, daemon=True)
@@ -502,7 +542,7 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
     if errors:
         raise SystemExit("jpeg_stream failed: %r" % errors[:3])
     return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * 3 for w, h, _ in mine),
-            "file_bytes": sum(len(b) for _, _, b in mine), "numa_node": lib.impgpu_env_numa_node(),
+            "file_bytes": sum(len(b) for _, _, b in mine), "answer_bytes": answer_bytes[0], "numa_node": lib.impgpu_env_numa_node(),
             "threads_bound": bool(NUMA_BIND and lib.impgpu_env_numa_node() >= 0)}
 
 
@@ -524,6 +564,8 @@ def main():
     ap.add_argument("--jpeg", default="", choices=("", "device", "hosthuff", "host", "all"),
                     help="--stream: the requests arrive as JPEG files; where they are decoded (all = the three one after the other)")
     ap.add_argument("--jpeg-batch", type=int, default=1, help="--stream --jpeg: requests a thread takes from the queue and decodes with one impgpu_batch_decode_jpeg call")
+    ap.add_argument("--jpeg-out", type=int, default=0, metavar="Q",
+                    help="--stream --jpeg: the answers are JPEG files of quality Q too (the module's default is 86), encoded where the request was decoded")
     ap.add_argument("--jpeg-files", type=int, default=64, help="--stream --jpeg: distinct files the requests cycle through")
     ap.add_argument("--mixed", type=int, default=0, metavar="N",
                     help="BASELINE configs[4] with the N frames already in HBM: resize=224,0 over mixed sizes, one "
@@ -575,15 +617,15 @@ def main():
         for decoder in (("device", "hosthuff", "host") if args.jpeg == "all" else (args.jpeg,)):
             # untimed prefix: every lane (= thread) meets the common buffer sizes once, so that the timed part measures the
             # steady state of a server, not hipMalloc / hipHostMalloc
-            jpeg_stream(imp, min(args.stream, max(256, 24 * args.threads * args.jpeg_batch)), args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch)
+            jpeg_stream(imp, min(args.stream, max(256, 24 * args.threads * args.jpeg_batch)), args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch, args.jpeg_out)
             if use_dist:
                 dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
-            r = jpeg_stream(imp, args.stream, args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch)
+            r = jpeg_stream(imp, args.stream, args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch, args.jpeg_out)
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier(device_ids=[local_rank])
-            secs, (nreq, nbytes, fbytes) = job_totals(r["seconds"], [r["requests"], r["source_bytes"], r["file_bytes"]], dist if use_dist else None, "cuda")
+            secs, (nreq, nbytes, fbytes, abytes) = job_totals(r["seconds"], [r["requests"], r["source_bytes"], r["file_bytes"], r["answer_bytes"]], dist if use_dist else None, "cuda")
             lines.append({
                 "metric": "requests/sec, mixed-size JPEG request stream (256px-4K) decode + resize=224,0, PCIe-inclusive",
                 "value": round(nreq / secs, 1), "unit": "requests/sec", "n_gpus": world, "higher_is_better": True,
@@ -591,6 +633,8 @@ def main():
                 "data": "synthetic (seeded sizes, photograph-like content, quality-90 4:2:0 JPEG files, %d distinct)" % len(files),
                 "compressed_MB_per_sec": round(fbytes / secs / 1e6, 1), "decoded_MB_per_sec": round(nbytes / secs / 1e6, 1),
                 "bits_per_pixel": round(fbytes * 8 / (nbytes / 3), 2), "seconds": round(secs, 3),
+                "answers": ("JPEG quality %d, encoded on the %s" % (args.jpeg_out, "host" if decoder == "host" else "device")) if args.jpeg_out else "raw B,G,R thumbnails",
+                "answer_bytes_per_request": round(abytes / max(1.0, nreq), 1),
                 "config": {"workload": "BASELINE configs[4] as JPEG files: %d requests, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % int(nreq),
                            "threads_per_gpu": args.threads, "files_per_decode_call": args.jpeg_batch, "host_cores": os.cpu_count(), "queue_depth": args.queue_depth,
                            "numa_node": r["numa_node"], "threads_bound_to_node": r["threads_bound"],

@@ -26,11 +26,19 @@ B="$T/bridge.c"
 # finalize: (bridge.c:714) -- device frames are released on every exit path past the decoder
 sed -i '714a\
 		ImpGpuRelease(\&gpu);' "$B"
-# encoders (bridge.c:680-710) read IplImages: bring the results back right after Step = ENCODE / Code = OK (bridge.c:681)
+# the basic encoder's JPEG case (bridge.c:703-709) is written on the device; its PNG case falls through to cvEncodeImage
+sed -i '702a\
+		if (answer->MIME == IMP_MIME_JPG) {\
+			answer->Code = ImpGpuEncodeJpeg(\&gpu, basicCoderopt[1], req->pool, \&answer->EncodedBytes, \&answer->Length);\
+			goto finalize;\
+		}' "$B"
+# every other encoder (bridge.c:683-710) reads IplImages: bring the results back right after Step = ENCODE / Code = OK (bridge.c:681)
 sed -i '681a\
-	answer->Code = ImpGpuDownload(\&gpu, \&album, req->pool);\
-	if (answer->Code) {\
-		goto finalize;\
+	if (encodeAdvancedIO || answer->MIME != IMP_MIME_JPG) {\
+		answer->Code = ImpGpuDownload(\&gpu, \&album, req->pool);\
+		if (answer->Code) {\
+			goto finalize;\
+		}\
 	}' "$B"
 # text exit (bridge.c:669-670): ASCII() on the device frame
 sed -i '669,670c\

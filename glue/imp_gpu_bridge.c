@@ -194,6 +194,24 @@ int ImpGpuDownload(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool) {
     return rc;
 }
 
+int ImpGpuEncodeJpeg(ImpGpuAlbum* gpu, int quality, ngx_pool_t* pool, u_char** bytes, size_t* length) {
+    /* cvEncodeImage(".jpg", album.Frames[0].Image, basicCoderopt) at bridge.c:703-709 for the frame in HBM: the same file,
+     * and the compressed bytes are all that crosses the link.  The buffer is sized for the worst case and lives in the
+     * request pool like the reference's own copy of the encoder's output. */
+    size_t capacity = impgpu_jpeg_encode_bound(impgpu_image_width(gpu->Handle), impgpu_image_height(gpu->Handle),
+                                               impgpu_image_channels(gpu->Handle));
+    u_char* output = capacity ? ngx_palloc(pool, capacity) : NULL;
+    if (!output) {
+        return IMP_ERROR_MALLOC_FAILED;
+    }
+    int rc = impgpu_image_encode_jpeg(gpu->Handle, quality, output, capacity, length);
+    if (rc) {
+        return rc;
+    }
+    *bytes = output;
+    return IMP_OK;
+}
+
 void ImpGpuRelease(ImpGpuAlbum* gpu) {
     impgpu_image_release(&gpu->Handle);
 }

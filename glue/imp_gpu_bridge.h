@@ -8,7 +8,8 @@
  *   bridge.c:574-656  crop / resize / filter / watermark / flatten loops over the album -> ImpGpuOperators
  *   bridge.c:661      Info()                                -> ImpGpuInfo      (brightness reduced on the device)
  *   bridge.c:669-670  ASCII()                               -> ImpGpuASCII
- *   bridge.c:681      before either encoder runs            -> ImpGpuDownload  (frames back into IplImages)
+ *   bridge.c:681      before an encoder that reads IplImages -> ImpGpuDownload  (frames back into IplImages)
+ *   bridge.c:703-709  cvEncodeImage(".jpg")                 -> ImpGpuEncodeJpeg (the file is written on the device)
  *   bridge.c:714      finalize:                             -> ImpGpuRelease
  *   required.h:117    Config gains `void* WatermarkDevice`  (per-worker handle of the uploaded overlay)
  * Needs nginx, OpenCV 2.4 and FreeImage headers exactly like the files around it, so it is not BUILT in this repository;
@@ -51,6 +52,8 @@ int    ImpGpuOperators(Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool, char* c
 u_char* ImpGpuInfo(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool, int* code); /* bridge.c:283-300; NULL + *code on a device error */
 Memory ImpGpuASCII(ImpGpuAlbum* gpu, char* args, ngx_pool_t* pool);              /* filters.c:488-522 */
 int    ImpGpuDownload(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool);         /* results -> fresh IplImages, one wait */
+/* bridge.c:703-709 when the answer is a JPEG from the basic encoder: the file is written on the device, nothing is downloaded */
+int    ImpGpuEncodeJpeg(ImpGpuAlbum* gpu, int quality, ngx_pool_t* pool, u_char** bytes, size_t* length);
 void   ImpGpuRelease(ImpGpuAlbum* gpu);
 
 #endif

@@ -25,13 +25,14 @@ def test_apply_glue_rewrites_the_operator_segment(tmp_path):
     subprocess.check_call([os.path.join(ROOT, "glue", "apply_glue.sh"), str(work)])
     bridge = (work / "bridge.c").read_text()
     run_job = bridge[bridge.index("RunJob("):]
-    for call in ("ImpGpuDecode(blob, size, &album, &gpu", "ImpGpuOperators(&album, &gpu", "ImpGpuInfo(&gpu", "ImpGpuASCII(&gpu", "ImpGpuDownload(&gpu", "ImpGpuRelease(&gpu"):
+    for call in ("ImpGpuDecode(blob, size, &album, &gpu", "ImpGpuOperators(&album, &gpu", "ImpGpuInfo(&gpu", "ImpGpuASCII(&gpu", "ImpGpuDownload(&gpu", "ImpGpuEncodeJpeg(&gpu, basicCoderopt[1]", "ImpGpuRelease(&gpu"):
         assert run_job.count(call) == 1, call
     for gone in ("Crop(&image", "Resize(&image", "Filter(&image", "Watermark(image", "BlendWithPaper(image", "CV_GRAY2BGR"):
         assert gone not in run_job, gone
     assert "ImpGpuEnvStart(IMP_GPU_WORKER_INDEX);" in bridge and "ImpGpuEnvDestroy();" in bridge
     assert run_job.index("ImpGpuAlbum gpu = { NULL };") < run_job.index("goto finalize")     # declared before every jump to the release
     assert "cvDecodeImage(&rawencoded, -1)" in run_job                                              # the host decoder stays as the fallback
+    assert run_job.index("ImpGpuEncodeJpeg(") < run_job.index("cvEncodeImage(")                       # the host encoder stays for PNG
     assert run_job.count("{") == run_job.count("}")                      # the edit kept the function balanced
     assert "WatermarkDevice;" in (work / "required.h").read_text()
     assert "glue/imp_gpu_bridge.c" in (work / "config").read_text() and "-limpgpu" in (work / "config").read_text()
