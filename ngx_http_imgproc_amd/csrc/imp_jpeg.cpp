@@ -437,7 +437,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     const uint8_t* bytes = buf.data();
     auto word = [bytes](uint32_t i) -> uint32_t {
         const uint8_t* q = bytes + (size_t)i * 4;
-        return ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+        return ((uint32_t)q[3] << 24) | ((uint32_t)q[2] << 16) | ((uint32_t)q[1] << 8) | q[0];      // as a little-endian load
     };
     const uint32_t CB = JPEG_CHUNK_WORDS * 32;
     const size_t n = scan.nchunks;

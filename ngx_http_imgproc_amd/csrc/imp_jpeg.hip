@@ -92,7 +92,11 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // whole refill ahead in a register, so the latency is off the critical path; staging the workgroup's 33 KB in LDS bought
     // nothing and cost two of every three resident workgroups.  (bit 31 of a word = the first bit of the stream: byte swap)
     const uint32_t* __restrict__ words = A.words;
-    auto word = [&](uint32_t i) -> uint32_t { return __builtin_bswap32(__builtin_nontemporal_load(words + i)); };
+    // (a GLOBAL load: the pointer comes out of a table in memory, which makes it a flat one to the compiler, and a flat load
+    // counts as an LDS access too -- every wait for a table read would then wait for the stream word as well)
+    typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
+    const GlobalWords gwords = (GlobalWords)(uintptr_t)words;
+    auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
     uint32_t* rec = A.records + (size_t)b * CTL_REC;
     const uint32_t* prec = rec - CTL_REC;
     __syncthreads();

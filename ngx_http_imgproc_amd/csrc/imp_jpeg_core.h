@@ -73,8 +73,23 @@ IMP_HD inline void jpeg_flag(uint32_t* status, uint32_t bits) {
 #endif
 }
 
+// a coefficient store; on the device a GLOBAL one (through a pointer out of a table it would be a flat store, which counts
+// as an LDS access as well and makes every wait for a table read wait for the stores too)
+IMP_HD inline void jpeg_put_coef(int16_t* base, uint32_t at, int16_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef int16_t __attribute__((address_space(1))) * GlobalCoef;
+    ((GlobalCoef)(uintptr_t)base)[at] = v;
+#else
+    base[at] = v;
+#endif
+}
+
+// the i-th 32-bit word of the stream as memory holds it (first byte in bits 0..7) -> first bit of the stream in bit 31
+IMP_HD inline uint32_t jpeg_be(uint32_t raw) { return __builtin_bswap32(raw); }
+
 // One chunk: every symbol that STARTS before `limit`, from the packed state `entry`.  `word(i)` returns the i-th 32-bit
-// word of the unstuffed stream with its first bit in bit 31.  Reads at most two words past the one holding bit limit-1.
+// word of the unstuffed stream AS LOADED (little-endian: jpeg_be turns it round where it is used, not where it is loaded,
+// so that the load has a whole refill's worth of symbols to arrive).  Reads at most two words past the one holding bit limit-1.
 // `max_slots` ends the walk once that many coefficient slots have been passed: the last chunk of an interval stops after the
 // interval's last MCU like a sequential decoder does, whatever the (up to seven) padding bits behind it look like.
 //
@@ -104,7 +119,7 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
     }
     // bit window: `have` valid bits at the top of buf, never fewer than 32 when a symbol starts; `ahead` = the word after it
     uint32_t widx = p >> 5;
-    uint64_t buf = (((uint64_t)word(widx) << 32) | word(widx + 1)) << (p & 31);
+    uint64_t buf = (((uint64_t)jpeg_be(word(widx)) << 32) | jpeg_be(word(widx + 1))) << (p & 31);
     int have = 64 - (int)(p & 31);
     widx += 2;
     uint32_t ahead = word(widx);
@@ -147,7 +162,7 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
         have -= (int)total;
         p += total;
         if (have <= 32) {
-            buf |= (uint64_t)ahead << (32 - have);
+            buf |= (uint64_t)jpeg_be(ahead) << (32 - have);         // the byte swap HERE: a swap at the load would wait for it there
             have += 32;
             widx++;
             ahead = word(widx);
@@ -159,9 +174,9 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
         if (WRITE) {
             if (isdc) {
                 const int dcv = (ci == 0 ? W->dc0[0] + dcs0 : ci == 1 ? W->dc0[1] + dcs1 : W->dc0[2] + dcs2) + v;
-                if (blk_ok) W->coef[blk] = (int16_t)dcv;
+                if (blk_ok) jpeg_put_coef(W->coef, blk, (int16_t)dcv);
             } else if (size && !over && blk_ok) {
-                W->coef[blk + L.natural[z + run]] = (int16_t)v;
+                jpeg_put_coef(W->coef, blk + L.natural[z + run], (int16_t)v);
             }
         }
         dcs0 += (isdc && ci == 0) ? v : 0;
