@@ -425,7 +425,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     std::vector<JpegHuffTabs> Lv(1);
     JpegHuffTabs& L = Lv[0];
     for (int k = 0; k < 4; k++) {
-        std::memcpy(L.lut[k], tabs[k].lut, sizeof L.lut[k]);
+        for (size_t i = 0; i < sizeof tabs[k].lut / sizeof tabs[k].lut[0]; i++) L.lut[k][i] = jpeg_lut_expand(tabs[k].lut[i]);
         std::memcpy(L.limit[k], tabs[k].limit, sizeof L.limit[k]);
         std::memcpy(L.offs[k], tabs[k].offs, sizeof L.offs[k]);
         std::memcpy(L.vals[k], tabs[k].vals, sizeof L.vals[k]);
@@ -453,8 +453,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
         seg_end[g] = first * CB + scan.seg_bits[sg];
         limit[g] = std::min<uint32_t>((uint32_t)(g + 1) * CB, seg_end[g]);
         entry[g] = jpeg_pack_state((uint32_t)g * CB, 0, 0, 0);
-        dec[g] = jpeg_decode_chunk<false>(L, word, entry[g], limit[g], seg_end[g], F, nullptr);
-        exitst[g] = dec[g].exit;
+        exitst[g] = jpeg_sync_chunk(L, word, entry[g], limit[g], seg_end[g], F);      // the rounds only look for exit states
     }
     int sweeps = 0;
     for (;;) {
@@ -467,8 +466,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
             const uint64_t pred = (prev[g - 1] >> 48) ? jpeg_pack_state((uint32_t)g * CB, 0, 0, 0) : prev[g - 1];
             if (pred == entry[g]) continue;
             entry[g] = pred;
-            dec[g] = jpeg_decode_chunk<false>(L, word, entry[g], limit[g], seg_end[g], F, nullptr);
-            exitst[g] = dec[g].exit;
+            exitst[g] = jpeg_sync_chunk(L, word, entry[g], limit[g], seg_end[g], F);
             changed = true;
         }
         sweeps++;
@@ -477,6 +475,12 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     }
     if (rounds) *rounds = sweeps;
     *status = 0;
+    // every entry state is final: the full walk once per chunk for its slot count and DC differences (k_jpeg_entropy step 3);
+    // it must leave the chunk in the state the lean walk found
+    for (size_t g = 0; g < n; g++) {
+        dec[g] = jpeg_decode_chunk<false>(L, word, entry[g], limit[g], seg_end[g], F, nullptr);
+        if (dec[g].exit != exitst[g]) return IMP_ERROR_DEVICE;
+    }
     uint32_t run_n = 0;
     int run_dc[3] = {0, 0, 0};
     for (size_t g = 0; g < n; g++) {

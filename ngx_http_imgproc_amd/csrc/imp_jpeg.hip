@@ -46,7 +46,7 @@ __device__ bool wait_flag(const uint32_t* flag) {
     return false;
 }
 
-__global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_jpeg_entropy(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map,
+__global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_jpeg_entropy(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map,
                                                       uint32_t* __restrict__ launch_ticket) {
     __shared__ JpegHuffTabs L;
     __shared__ uint64_t s_exit[HB], s_entry[HB];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     struct { const uint32_t *words, *chunk_seg, *seg_first_chunk, *seg_bits; const JpegHuffDev* tables; int16_t* coef; uint32_t *header, *records; } A =
         {J.words, J.chunk_seg, J.seg_first_chunk, J.seg_bits, J.tables, J.coef, J.header, J.records};
     // tables
-    for (int i = t; i < 4 * (1 << JPEG_LOOKBITS); i += HB) L.lut[i >> JPEG_LOOKBITS][i & ((1 << JPEG_LOOKBITS) - 1)] = A.tables[i >> JPEG_LOOKBITS].lut[i & ((1 << JPEG_LOOKBITS) - 1)];
+    for (int i = t; i < 4 * (1 << JPEG_LOOKBITS); i += HB) L.lut[i >> JPEG_LOOKBITS][i & ((1 << JPEG_LOOKBITS) - 1)] = jpeg_lut_expand(A.tables[i >> JPEG_LOOKBITS].lut[i & ((1 << JPEG_LOOKBITS) - 1)]);
     for (int i = t; i < 4 * 18; i += HB) { L.limit[i / 18][i % 18] = A.tables[i / 18].limit[i % 18]; L.offs[i / 18][i % 18] = A.tables[i / 18].offs[i % 18]; }
     for (int i = t; i < 4 * 256; i += HB) L.vals[i >> 8][i & 255] = A.tables[i >> 8].vals[i & 255];
     if (t < 64) L.natural[t] = c_natural[t];
@@ -151,12 +151,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             if (queued == 0) { if (t == 0) atomicMax(&A.header[phase == 0 ? 2 : 3], (uint32_t)round); break; }
             if ((uint32_t)t < queued) {
                 const uint32_t k = s_queue[t];
-                const JpegDecoded d = jpeg_decode_chunk<false>(L, word, s_entry[k], min((g0 + k + 1) * CHUNK_BITS, s_segend[k]), s_segend[k], F, nullptr);
-                s_exit[k] = d.exit;
-                s_n[k] = d.n;
-                s_dc[0][k] = d.dc[0];
-                s_dc[1][k] = d.dc[1];
-                s_dc[2][k] = d.dc[2];
+                s_exit[k] = jpeg_sync_chunk(L, word, s_entry[k], min((g0 + k + 1) * CHUNK_BITS, s_segend[k]), s_segend[k], F);
             }
             __syncthreads();
             if (t == 0) s_queued = 0;
@@ -168,6 +163,16 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         rec[5] = (uint32_t)(s_exit[t] >> 32);
         st_release(rec + 3, 1u);
     }
+    // ---- 3. every entry state is final: one full walk per chunk for what the rounds above left out -- the slots it passes
+    // and its DC differences
+    if (live) {
+        const JpegDecoded cnt = jpeg_decode_chunk<false>(L, word, entry, limit, seg_end, F, nullptr);
+        s_n[t] = cnt.n;
+        s_dc[0][t] = cnt.dc[0];
+        s_dc[1][t] = cnt.dc[1];
+        s_dc[2][t] = cnt.dc[2];
+    }
+    __syncthreads();
     // ---- 4. running totals inside each interval: segmented inclusive scan over (n, dc0, dc1, dc2)
     struct { uint32_t n; int dc[3]; } d = {s_n[t], {s_dc[0][t], s_dc[1][t], s_dc[2][t]}};     // this chunk's own
     s_head[t] = origin ? 1 : 0;

@@ -29,8 +29,17 @@ IMP_HD inline uint32_t jpeg_lut_entry(uint32_t len, uint32_t sym, bool is_dc) {
     return len | (size << 5) | (run << 9) | (eob << 13);
 }
 
+// The same entry as the lanes read it, with the two sums the resynchronising rounds live on worked out once: bits 16..20 =
+// code length + value bits (what the symbol takes from the stream), bits 21..27 = how far the coefficient index moves
+// (run + 1; 64 for an end of block: "to the block's end" and "past it" are the same thing to the index).  0 stays 0.
+IMP_HD inline uint32_t jpeg_lut_expand(uint32_t e) {
+    if ((e & 31) == 0) return 0;
+    const uint32_t total = (e & 31) + ((e >> 5) & 15), adv = ((e >> 13) & 1) ? 64u : ((e >> 9) & 15) + 1;
+    return e | (total << 16) | (adv << 21);
+}
+
 struct JpegHuffTabs {                       // the four tables as a decoder lane reads them (LDS on the device)
-    uint16_t lut[4][1 << JPEG_LOOKBITS];    // JpegHuffDev::lut
+    uint32_t lut[4][1 << JPEG_LOOKBITS];    // jpeg_lut_expand(JpegHuffDev::lut)
     uint32_t limit[4][18];
     int32_t offs[4][18];
     uint8_t vals[4][256];
@@ -206,6 +215,63 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
     r.dc[1] = dcs1;
     r.dc[2] = dcs2;
     return r;
+}
+
+// The same walk for the rounds that only look for the chunk's EXIT state (every round but the last two): no values, no
+// counts, no coefficient addresses -- a symbol is a table read, two shifts and two additions.  Returns exactly the exit
+// state jpeg_decode_chunk<false> (without a slot budget) returns for the same entry.
+template <class WordFn>
+IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint64_t entry, uint32_t limit, uint32_t seg_end, const JpegFrame& F) {
+    uint32_t p = (uint32_t)entry;
+    uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
+    if ((uint32_t)(entry >> 48)) return entry;
+    if (p >= limit) return entry;
+    const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
+    uint32_t dc_sel = 0, ac_sel = 0;
+    for (uint32_t k = 0; k < 6; k++) {
+        const uint32_t ci = k < nluma ? 0u : (k - nluma + 1 < 3 ? k - nluma + 1 : 2u);
+        dc_sel |= (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]) << k;
+        ac_sel |= (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]) << k;
+    }
+    uint32_t widx = p >> 5;
+    uint64_t buf = (((uint64_t)jpeg_be(word(widx)) << 32) | jpeg_be(word(widx + 1))) << (p & 31);
+    int have = 64 - (int)(p & 31);
+    widx += 2;
+    uint32_t ahead = word(widx);
+    uint32_t fl = 0;
+    while (p < limit) {
+        const bool isdc = z == 0;
+        const uint32_t tab = isdc ? ((dc_sel >> c) & 1) : 2 + ((ac_sel >> c) & 1);
+        const uint32_t peek = (uint32_t)(buf >> 48);
+        uint32_t e = L.lut[tab][peek >> (16 - JPEG_LOOKBITS)];
+        if ((e & 31) == 0) {                                        // a code longer than the table's index (rare)
+            uint32_t len = JPEG_LOOKBITS + 1;
+            for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= L.limit[tab][l] ? 1u : 0u;
+            if (peek >= L.limit[tab][16]) {
+                fl = (seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID;
+                break;
+            }
+            const uint32_t sym = L.vals[tab][(uint32_t)(L.offs[tab][len] + (int)(peek >> (16 - len))) & 255];
+            e = jpeg_lut_expand(jpeg_lut_entry(len, sym, isdc));
+        }
+        const uint32_t total = (e >> 16) & 31, adv = e >> 21;
+        if (p + total > seg_end) { fl = JPEG_FL_END; break; }
+        buf <<= total;
+        have -= (int)total;
+        p += total;
+        if (have <= 32) {
+            buf |= (uint64_t)jpeg_be(ahead) << (32 - have);
+            have += 32;
+            widx++;
+            ahead = word(widx);
+        }
+        z += adv;
+        if (z >= 64) {
+            z = 0;
+            c = c + 1 == bpm ? 0 : c + 1;
+        }
+    }
+    return jpeg_pack_state(p, c, z, fl);
 }
 
 }  // namespace imp
