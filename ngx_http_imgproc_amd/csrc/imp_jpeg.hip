@@ -100,6 +100,8 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     uint32_t* rec = A.records + (size_t)b * CTL_REC;
     const uint32_t* prec = rec - CTL_REC;
     __syncthreads();
+    auto stamp = [&](int k) { if (t == 0) rec[12 + k] = (uint32_t)wall_clock64(); };     // 100 MHz
+    stamp(0);
 
     // ---- 1./2. Every lane decodes its chunk from a guessed state (its first bit, start of a block) -- exact only for the
     // first chunk of an interval -- and then pulls its predecessor's exit state, re-decoding whenever that differs from the
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     s_dc[0][t] = s_dc[1][t] = s_dc[2][t] = 0;
     if (t == 0) { s_pred = none; s_queued = 0; }
     for (int phase = 0; phase < 3; phase++) {
+        stamp(1 + 2 * phase);                                       // 1, 3, 5: the phase's rounds start (after the wait: 2, 4 below)
         if (phase > 0) {
             const int at = phase == 1 ? 0 : 3;                      // tentative, then final
             if (phase == 1 && t == HB - 1 && b + 1 < nblocks) {
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                 if (wait_flag(prec + at)) s_pred = (uint64_t)prec[at + 1] | ((uint64_t)prec[at + 2] << 32);
                 else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
             }
+            stamp(2 * phase + 2);                                   // 4, 6: the predecessor's state has arrived
         }
         for (int round = 0; round <= HB + 1; round++) {
             __syncthreads();
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         rec[5] = (uint32_t)(s_exit[t] >> 32);
         st_release(rec + 3, 1u);
     }
+    stamp(7);
     // ---- 3. every entry state is final: one full walk per chunk for what the rounds above left out -- the slots it passes
     // and its DC differences
     if (live) {
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         s_dc[2][t] = cnt.dc[2];
     }
     __syncthreads();
+    stamp(8);
     // ---- 4. running totals inside each interval: segmented inclusive scan over (n, dc0, dc1, dc2)
     struct { uint32_t n; int dc[3]; } d = {s_n[t], {s_dc[0][t], s_dc[1][t], s_dc[2][t]}};     // this chunk's own
     s_head[t] = origin ? 1 : 0;
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         rec[7] = incl_n; rec[8] = (uint32_t)incl_dc0; rec[9] = (uint32_t)incl_dc1; rec[10] = (uint32_t)incl_dc2;
         st_release(rec + 6, 1u);
     }
+    stamp(9);
     if (!live) return;
     // ---- 5. decode once more, now knowing where every coefficient goes.  The last chunk of an interval walks with the
     // interval's remaining slots as a budget -- a sequential decoder stops after the last MCU and never looks at the padding
@@ -231,6 +238,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         if ((fle & JPEG_FL_INVALID) || pe > seg_end || seg_end - pe >= 8) atomicOr(&A.header[1], JPEG_ST_BAD_CODE);
         if (base_n + e.n != slots_here) atomicOr(&A.header[1], JPEG_ST_BAD_COUNT);
     }
+    stamp(10);
 }
 
 // ---------------------------------------------------------------- pixels

@@ -101,7 +101,7 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
     }
     sw.mark();                                                      // [1] unstuffing copy / host entropy decoding
     void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr;
-    size_t njobs = 0;
+    size_t njobs = 0, ctl_total = 0;
     uint32_t* mailbox = lane_mailbox();
     if (live == 0) { (void)stage_upload(token, nullptr, 0); goto done; }
     if (!mailbox) { rc = IMP_ERROR_DEVICE; goto fail; }
@@ -141,6 +141,7 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         rc = dev_alloc(side, &d_side);
         if (!rc) rc = dev_alloc(coef_total, &d_coef);
         if (!rc && on_device) rc = dev_alloc(words_total, &d_words);
+        ctl_total = ctl_words;
         if (!rc && on_device) rc = dev_alloc(ctl_words * sizeof(uint32_t), &d_ctl);
         if (rc) goto fail;
         std::vector<uint8_t> blob(side);
@@ -208,6 +209,31 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
     if (on_device) {
         rc = lane_wait();
         if (rc) goto fail;
+        if (sw.on && !std::strcmp(std::getenv("IMPGPU_JPEG_TRACE"), "2")) {
+            // the workgroups' clocks at their phase boundaries (k_jpeg_entropy's stamp()), microseconds since the launch's
+            // first workgroup started: wg: start | rounds0 | wait1 rounds1 | wait2 rounds2 | count scan carry write
+            std::vector<uint32_t> ctl(ctl_total);
+            if (hipMemcpy(ctl.data(), d_ctl, ctl_total * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+                uint32_t t0 = 0;
+                bool have = false;
+                for (const Prep& p : P)
+                    if (!p.code)
+                        for (unsigned b = 0; b < jpeg_entropy_blocks(p.F.nchunks); b++) {
+                            const uint32_t v = ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 12];
+                            if (!have || (int32_t)(v - t0) < 0) { t0 = v; have = true; }
+                        }
+                for (const Prep& p : P) {
+                    if (p.code) continue;
+                    const unsigned nb = jpeg_entropy_blocks(p.F.nchunks);
+                    for (unsigned b = 0; b < nb; b++) {
+                        const uint32_t* r = &ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 12];
+                        std::fprintf(stderr, "wg %dx%d %u/%u:", p.H.width, p.H.height, b, nb);
+                        for (int k = 0; k <= 10; k++) std::fprintf(stderr, " %.1f", r[k] ? (double)(int32_t)(r[k] - t0) / 100.0 : -1.0);
+                        std::fprintf(stderr, "\n");
+                    }
+                }
+            }
+        }
         size_t j = 0;
         for (Prep& p : P) {
             if (p.code) continue;
