@@ -174,8 +174,9 @@ __device__ __forceinline__ int enc_dc_of(const EncJob& J, int mcu, int j) {
 
 __device__ __forceinline__ int enc_nbits(int v) { return 32 - __clz(abs(v)); }      // 0 for 0
 
-// inclusive scan of one int per thread over the 256 threads of the block; s_part: 4 words of scratch.  Returns the thread's
-// inclusive prefix, *total = the block's sum.
+// inclusive scan of one int per thread over the NT threads of the block; s_part: NT / 64 words of scratch.  Returns the
+// thread's inclusive prefix, *total = the block's sum.
+template <int NT>
 __device__ __forceinline__ int enc_block_scan(int v, int* s_part, int* total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -188,7 +189,7 @@ __device__ __forceinline__ int enc_block_scan(int v, int* s_part, int* total) {
     __syncthreads();
     int pre = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NT / 64; k++) {
         const int p = s_part[k];
         if (k < wv) pre += p;
         tot += p;
@@ -255,19 +256,27 @@ __device__ __forceinline__ int enc_code_block(const uint32_t (&cw)[32], int last
     return bits;
 }
 
-// result[2 * job] = bytes of the entropy-coded segment + EOI (what the file needs after its headers, whether or not it
-// fitted), result[2 * job + 1] = 1 when it did not fit out_cap
-__global__ __launch_bounds__(256) void k_jpeg_enc_huff(const EncJob* __restrict__ jobs, const EncTables* __restrict__ tabs, uint32_t* __restrict__ result) {
+// result[4 * job] = bytes of the entropy-coded segment + EOI (what the file needs after its headers, whether or not it
+// fitted), [4 * job + 1] = 1 when it did not fit out_cap, [4 * job + 2] = where the workgroup put a copy of the segment in
+// `compact` (0xffffffff: it did not fit there).  The compact area is what the host fetches: the segments of a whole batch
+// back to back (in the order the workgroups finish), one copy instead of one per image.  result[4 * njobs] = its cursor.
+// NT threads take NT blocks per pass.  NT = 256: whatever the blocks hold, a pass fits the window.  NT = 1024 (frames of more
+// than 256 blocks): a pass takes the blocks from the front whose code still fits -- all 1024 unless they average more than
+// 447 bits, which photographs do not come near -- and the rest come again in the next pass.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__ jobs, const EncTables* __restrict__ tabs, uint32_t* __restrict__ result,
+                                                      uint8_t* __restrict__ compact, uint32_t compact_cap) {
     __shared__ uint32_t s_win[ENC_WIN_WORDS];
-    __shared__ int s_part[4];
+    __shared__ int s_part[NT / 64], s_cnt[NT / 64], s_top[NT / 64];
     __shared__ uint32_t s_carry;
     const EncJob& J = jobs[blockIdx.x];
     const int tid = threadIdx.x;
-    for (int i = tid; i < ENC_WIN_WORDS; i += 256) s_win[i] = 0;
+    for (int i = tid; i < ENC_WIN_WORDS; i += NT) s_win[i] = 0;
     __syncthreads();
     int carry = 0;                      // bits of an unfinished byte at the top of s_win[0]
     long long out_pos = 0;              // bytes of the segment so far (counted even when they no longer fit)
-    for (int b0 = 0; b0 < J.nblocks; b0 += 256) {
+    int taken = 0;
+    for (int b0 = 0; b0 < J.nblocks; b0 += taken) {
         const int b = b0 + tid;
         const bool live = b < J.nblocks;
         int bits = 0, dc = 0, last_dc = 0;
@@ -288,8 +297,21 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_huff(const EncJob* __restrict_
             bits = enc_code_block<false>(cw, last_dc, dc, hdc, hac, nullptr);
         }
         int total;
-        const int incl = enc_block_scan(bits, s_part, &total);
-        if (live) {
+        const int incl = enc_block_scan<NT>(bits, s_part, &total);
+        bool mine = live;
+        taken = min(NT, J.nblocks - b0);
+        if (NT > 256) {
+            // the blocks whose code still fits the window form a prefix (the offsets grow): how many, and where their bits end
+            mine = live && carry + incl <= ENC_WIN_WORDS * 32 - 64;
+            const unsigned long long bal = __ballot(mine);
+            const int cnt = __popcll(bal), top = __shfl(incl, cnt > 0 ? cnt - 1 : 0);
+            if ((tid & 63) == 0) { s_cnt[tid >> 6] = cnt; s_top[tid >> 6] = cnt > 0 ? top : 0; }
+            __syncthreads();
+            taken = 0; total = 0;
+#pragma unroll
+            for (int k = 0; k < NT / 64; k++) { taken += s_cnt[k]; total = max(total, s_top[k]); }
+        }
+        if (mine) {
             EncPut P;
             P.start(s_win, carry + incl - bits);
             enc_code_block<true>(cw, last_dc, dc, hdc, hac, &P);
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_huff(const EncJob* __restrict_
         }
         __syncthreads();
         int nbits = carry + total;
-        const bool last = b0 + 256 >= J.nblocks;
+        const bool last = b0 + taken >= J.nblocks;
         if (last && (nbits & 7)) {                              // flush_bits: ones up to the byte boundary
             if (tid == 0) {
                 const int lb = nbits & 7;
@@ -308,12 +330,12 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_huff(const EncJob* __restrict_
         }
         const int nbytes = nbits >> 3;
         // whole bytes leave with a 00 stuffed behind every FF: a word-aligned run of bytes per thread
-        const int per = ((nbytes + 255) / 256 + 3) & ~3;
+        const int per = ((nbytes + NT - 1) / NT + 3) & ~3;
         const int s = min(nbytes, tid * per), e = min(nbytes, s + per);
         int ff = 0;
         for (int i = s; i < e; i++) ff += ((s_win[i >> 2] >> (24 - (i & 3) * 8)) & 0xff) == 0xff;
         int ff_total;
-        const int ff_incl = enc_block_scan(ff, s_part, &ff_total);
+        const int ff_incl = enc_block_scan<NT>(ff, s_part, &ff_total);
         {
             long long at = out_pos + s + (ff_incl - ff);
             for (int i = s; i < e; i++) {
@@ -329,15 +351,33 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_huff(const EncJob* __restrict_
         if (tid == 0) s_carry = carry ? ((s_win[nbytes >> 2] >> (24 - (nbytes & 3) * 8)) & 0xff) << 24 : 0u;
         __syncthreads();
         const int used = (nbits + 31) >> 5;
-        for (int i = tid; i < used; i += 256) s_win[i] = 0;
+        for (int i = tid; i < used; i += NT) s_win[i] = 0;
         __syncthreads();
         if (tid == 0) s_win[0] = s_carry;
         __syncthreads();
     }
+    const uint32_t len = (uint32_t)(out_pos + 2);
+    const bool fits = out_pos + 2 <= J.out_cap;
     if (tid == 0) {
-        if (out_pos + 2 <= J.out_cap) { J.out[out_pos] = 0xff; J.out[out_pos + 1] = 0xd9; }
-        result[2 * blockIdx.x] = (uint32_t)(out_pos + 2);
-        result[2 * blockIdx.x + 1] = out_pos + 2 > J.out_cap ? 1u : 0u;
+        if (fits) { J.out[out_pos] = 0xff; J.out[out_pos + 1] = 0xd9; }
+        uint32_t at = 0xffffffffu;
+        if (fits) {
+            at = atomicAdd(&result[4 * gridDim.x], (len + 15u) & ~15u);
+            if (at > compact_cap || len > compact_cap - at) at = 0xffffffffu;
+        }
+        result[4 * blockIdx.x] = len;
+        result[4 * blockIdx.x + 1] = fits ? 0u : 1u;
+        result[4 * blockIdx.x + 2] = at;
+        s_carry = at;
+    }
+    __threadfence_block();
+    __syncthreads();                                                // (also: every lane's bytes of the segment are written)
+    const uint32_t at = s_carry;
+    if (at != 0xffffffffu) {
+        __threadfence();
+        const uint4* src = (const uint4*)J.out;                     // both 16-byte aligned
+        uint4* dst = (uint4*)(compact + at);
+        for (uint32_t i = tid; i < (len + 15u) / 16u; i += NT) dst[i] = src[i];
     }
 }
 
@@ -453,11 +493,18 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     }
     const int nj = (int)jobs.size();
     if (!nj) return IMP_OK;
-    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr;
+    // what the host will fetch in its one copy: 32 bytes per block slot (a photograph at quality 90 needs about 13) and the
+    // results in front; a batch that needs more than that costs a second copy and wait for the segments that did not fit
+    size_t compact_cap = 0;
+    for (const EncJob& J : jobs) compact_cap += std::min((size_t)J.out_cap, (size_t)J.nblocks * 32 + 256);
+    compact_cap = (compact_cap + 255) & ~size_t(255);
+    if (compact_cap > 0xfffffff0u) compact_cap = 0xfffffff0u & ~size_t(255);
+    const size_t res_bytes = (((size_t)nj * 4 + 1) * 4 + 255) & ~size_t(255);
+    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr;          // res = results | compact area
     auto drop = [&]() { dev_free(coef); dev_free(out); dev_free(res); dev_free(side); };
     if (int rc = dev_alloc(coef_bytes, &coef)) return rc;
     if (int rc = dev_alloc(out_bytes, &out)) { drop(); return rc; }
-    if (int rc = dev_alloc((size_t)nj * 8, &res)) { drop(); return rc; }
+    if (int rc = dev_alloc(res_bytes + compact_cap, &res)) { drop(); return rc; }
     for (EncJob& J : jobs) { J.coef = (short*)((uint8_t*)coef + (size_t)J.coef); J.out = (uint8_t*)out + (size_t)J.out; }
     // side blob: tables | jobs | map
     const size_t o_jobs = (sizeof(EncTables) + 15) & ~size_t(15), o_map = o_jobs + ((jobs.size() * sizeof(EncJob) + 15) & ~size_t(15));
@@ -467,41 +514,37 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     std::memcpy(blob.data() + o_map, map.data(), map.size() * sizeof(EncMap));
     if (int rc = upload_small(blob.data(), blob.size(), &side, s)) { drop(); return rc; }
     const uint8_t* sd = (const uint8_t*)side;
+    hipError_t e = hipMemsetAsync((uint8_t*)res + (size_t)nj * 16, 0, 4, s);           // the compact area's cursor
     hipLaunchKernelGGL(k_jpeg_enc_blocks, dim3((unsigned)map.size()), dim3(256), 0, s, (const EncJob*)(sd + o_jobs), (const EncMap*)(sd + o_map), (const EncTables*)sd);
-    hipLaunchKernelGGL(k_jpeg_enc_huff, dim3((unsigned)nj), dim3(256), 0, s, (const EncJob*)(sd + o_jobs), (const EncTables*)sd, (uint32_t*)res);
-    hipError_t e = hipGetLastError();
-    // ONE wait in the common case: every segment's length comes back together with its first `guess` bytes (32 per block
-    // slot: a photograph at quality 90 needs about 13); only a segment longer than that costs a second copy and wait
-    std::vector<size_t> at((size_t)nj), guess((size_t)nj);
-    size_t total = ((size_t)nj * 8 + 63) & ~size_t(63);
-    for (int k = 0; k < nj; k++) {
-        guess[k] = std::min((size_t)jobs[k].out_cap, (size_t)jobs[k].nblocks * 32 + 256);
-        at[k] = total;
-        total += (guess[k] + 63) & ~size_t(63);
-    }
+    bool wide = false;                                          // any frame of more than 256 block slots: 1024 per pass
+    for (const EncJob& J : jobs) wide = wide || J.nblocks > 256;
+    if (wide) hipLaunchKernelGGL(k_jpeg_enc_huff<1024>, dim3((unsigned)nj), dim3(1024), 0, s, (const EncJob*)(sd + o_jobs), (const EncTables*)sd, (uint32_t*)res,
+                                 (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
+    else hipLaunchKernelGGL(k_jpeg_enc_huff<256>, dim3((unsigned)nj), dim3(256), 0, s, (const EncJob*)(sd + o_jobs), (const EncTables*)sd, (uint32_t*)res,
+                            (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
+    if (e == hipSuccess) e = hipGetLastError();
     void *pin = nullptr, *token = nullptr;
-    if (e == hipSuccess && stage_begin(total, &pin, &token) != IMP_OK) e = hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemcpyAsync(pin, res, (size_t)nj * 8, hipMemcpyDeviceToHost, s);
-    for (int k = 0; k < nj && e == hipSuccess; k++)
-        e = hipMemcpyAsync((uint8_t*)pin + at[k], jobs[k].out, guess[k], hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && stage_begin(res_bytes + compact_cap, &pin, &token) != IMP_OK) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpyAsync(pin, res, res_bytes + compact_cap, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) { set_error("jpeg encode", e); (void)hipStreamSynchronize(s); drop(); return IMP_ERROR_DEVICE; }
     if (int rc = lane_wait()) { drop(); return rc; }
     const uint32_t* seg = (const uint32_t*)pin;
+    const uint8_t* compact = (const uint8_t*)pin + res_bytes;
     size_t more = 0;
     std::vector<size_t> at2((size_t)nj, 0);
     for (int k = 0; k < nj; k++) {
         const int i = owner[k];
-        lens[i] = heads[k].size() + seg[2 * k];
-        if (seg[2 * k + 1]) { codes[i] = IMP_ERROR_DEVICE; set_error_text("jpeg encode: a segment outgrew its bound"); continue; }
+        lens[i] = heads[k].size() + seg[4 * k];
+        if (seg[4 * k + 1]) { codes[i] = IMP_ERROR_DEVICE; set_error_text("jpeg encode: a segment outgrew its bound"); continue; }
         if (lens[i] > caps[i]) { codes[i] = IMP_ERROR_MALLOC_FAILED; continue; }       // lens[i] says what it takes
-        if (seg[2 * k] > guess[k]) { at2[k] = more; more += (seg[2 * k] - guess[k] + 63) & ~size_t(63); }
+        if (seg[4 * k + 2] == 0xffffffffu) { at2[k] = more; more += (seg[4 * k] + 63) & ~size_t(63); }
     }
     void* pin2 = nullptr;
     if (more) {
         if (stage_begin(more, &pin2, &token) != IMP_OK) { drop(); return IMP_ERROR_DEVICE; }
         for (int k = 0; k < nj && e == hipSuccess; k++)
-            if (codes[owner[k]] == IMP_OK && seg[2 * k] > guess[k])
-                e = hipMemcpyAsync((uint8_t*)pin2 + at2[k], jobs[k].out + guess[k], seg[2 * k] - guess[k], hipMemcpyDeviceToHost, s);
+            if (codes[owner[k]] == IMP_OK && seg[4 * k + 2] == 0xffffffffu)
+                e = hipMemcpyAsync((uint8_t*)pin2 + at2[k], jobs[k].out, seg[4 * k], hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) { set_error("jpeg encode download", e); (void)hipStreamSynchronize(s); drop(); return IMP_ERROR_DEVICE; }
     }
     drop();                                                     // stream-ordered: after the copies
@@ -509,10 +552,9 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     for (int k = 0; k < nj; k++) {
         const int i = owner[k];
         if (codes[i] != IMP_OK) continue;
-        const size_t n = seg[2 * k], first = std::min(n, guess[k]);
+        const uint8_t* from = seg[4 * k + 2] == 0xffffffffu ? (const uint8_t*)pin2 + at2[k] : compact + seg[4 * k + 2];
         std::memcpy(outs[i], heads[k].data(), heads[k].size());
-        std::memcpy(outs[i] + heads[k].size(), (const uint8_t*)pin + at[k], first);
-        if (n > first) std::memcpy(outs[i] + heads[k].size() + first, (const uint8_t*)pin2 + at2[k], n - first);
+        std::memcpy(outs[i] + heads[k].size(), from, seg[4 * k]);
     }
     return IMP_OK;
 }

@@ -17,7 +17,13 @@ python bench.py --mixed 4096 --steps 10 --channels 3 > $O/r03_mixed_bgr.json 2>/
   JPEG_MODE=device JPEG_BATCH=64 tools/jpeg_stream.sh 8192 1 2 4 8 16
   JPEG_MODE=hosthuff JPEG_BATCH=16 tools/jpeg_stream.sh 2048 4 8 16
   JPEG_MODE=host JPEG_BATCH=1 tools/jpeg_stream.sh 512 1 4 8 16 ) > $O/r03_jpeg_stream.txt 2>&1
-python bench.py --stream 8192 --threads 8 --jpeg device --jpeg-batch 64 > $O/r03_jpeg_stream_line.json 2>/dev/null
+python bench.py --stream 8192 --threads 4 --jpeg device --jpeg-batch 64 > $O/r03_jpeg_stream_line.json 2>/dev/null
+# 4b. ... with JPEG answers as well (cvEncodeImage at bridge.c:704 on the device), against the reference's structure (host codecs at both ends)
+( JPEG_MODE=device JPEG_BATCH=64 JPEG_OUT=86 tools/jpeg_stream.sh 8192 1 4 8
+  JPEG_MODE=host JPEG_BATCH=1 JPEG_OUT=86 tools/jpeg_stream.sh 512 8 16 ) > $O/r03_jpeg_out_stream.txt 2>&1
+python tools/jpeg_enc_probe.py > $O/r03_jpeg_enc_probe.txt 2>&1
+python tools/album_probe.py > $O/r03_album_probe.txt 2>&1
+python tools/jpeg_wg_trace.py 2> $O/r03_jpeg_wg_trace.txt
 # 5. one decode at a time: latency per file, next to Pillow on one core
 python tools/jpeg_probe.py 40 > $O/r03_jpeg_probe.txt 2>&1
 python tools/jpeg_batch_probe.py 256 > $O/r03_jpeg_batch_probe.txt 2>&1
