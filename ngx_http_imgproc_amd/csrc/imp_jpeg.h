@@ -106,8 +106,9 @@ struct JpegJob {
     uint8_t* dst;                            // the frame
     int dstep;
 };
-constexpr int JPEG_CTL_REC = 24;             // [0..2] tentative exit state (flag, lo, hi), [3..5] final exit state, [6..10] totals (flag, n, dc0..2),
-                                             // [12..23] the workgroup's clock at its phase boundaries, low words of wall_clock64() (IMPGPU_JPEG_TRACE=2 prints them)
+constexpr int JPEG_CTL_REC = 24;             // [0..1] the tentative exit state, one 64-bit word kept up to date by the last lane (0 = nothing yet), [3..5] final exit
+                                             // state (flag, lo, hi), [6..10] totals (flag, n, dc0..2), [12..22] the workgroup's clock at its phase boundaries, low words
+                                             // of wall_clock64() (IMPGPU_JPEG_TRACE=2 prints them)
 constexpr int JPEG_TILE_W = 256, JPEG_TILE_H = 64;   // pixels a workgroup of the pixel kernel produces
 struct JpegMapEntry { uint32_t job, local; };
 inline unsigned jpeg_entropy_blocks(unsigned nchunks) { return (nchunks + JPEG_HUFF_BLOCK - 1) / JPEG_HUFF_BLOCK; }

@@ -111,6 +111,13 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     // entry state turns out to be), which lets all workgroups run their fix-up at the same time instead of one after the
     // other, and FINALLY once its own entry state is final.  The chain of final states is then a flag and a compare per
     // workgroup; only a workgroup whose tentative input was wrong converges once more.
+    // The tentative state is not published once but KEPT UP TO DATE: the last lane stores its exit state (one 64-bit word,
+    // 0 = nothing yet) after every round that changed it, and lane 0 of the next workgroup looks at it at the top of every
+    // round -- so the correction a workgroup's first chunks need from its predecessor happens during the rounds its slowest
+    // chunks need anyway, not in a phase of its own after them.
+    uint64_t* const tent = (uint64_t*)(rec + 0);
+    const uint64_t* const ptent = (const uint64_t*)(prec + 0);
+    uint64_t published = 0;                                         // (lane HB - 1)
     const bool chained = origin || !live;                           // (read by lane 0 only) nothing to wait for
     const uint64_t guess = jpeg_pack_state(g * CHUNK_BITS, 0, 0, 0);
     const uint64_t none = ~0ull;                                    // "no state": its flag bits are set
@@ -123,20 +130,31 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     if (t == 0) { s_pred = none; s_queued = 0; }
     for (int phase = 0; phase < 3; phase++) {
         stamp(1 + 2 * phase);                                       // 1, 3, 5: the phase's rounds start (after the wait: 2, 4 below)
-        if (phase > 0) {
-            const int at = phase == 1 ? 0 : 3;                      // tentative, then final
-            if (phase == 1 && t == HB - 1 && b + 1 < nblocks) {
-                rec[1] = (uint32_t)s_exit[t];
-                rec[2] = (uint32_t)(s_exit[t] >> 32);
-                st_release(rec + 0, 1u);
-            }
-            if (t == 0 && !chained) {
-                if (wait_flag(prec + at)) s_pred = (uint64_t)prec[at + 1] | ((uint64_t)prec[at + 2] << 32);
-                else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
-            }
-            stamp(2 * phase + 2);                                   // 4, 6: the predecessor's state has arrived
+        if (phase == 1 && t == HB - 1 && b + 1 < nblocks && !published) {
+            // its rounds are over and the last lane never had a state worth handing on (an undecodable pattern): say so, the
+            // next workgroup then starts from its own guess instead of waiting
+            published = s_exit[t];
+            __hip_atomic_store(tent, published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (phase == 1 && t == 0 && !chained) {                     // a predecessor that has not said anything yet: wait for its first word
+            uint64_t v = 0;
+            for (int spin = 0; spin < (1 << 21) && !v; spin++) {
+                v = __hip_atomic_load(ptent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!v) __builtin_amdgcn_s_sleep(16);
+            }
+            if (v) s_pred = v;
+            else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
+        }
+        if (phase == 2 && t == 0 && !chained) {                     // the predecessor's FINAL state
+            if (wait_flag(prec + 3)) s_pred = (uint64_t)prec[4] | ((uint64_t)prec[5] << 32);
+            else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
+        }
+        if (phase > 0) stamp(2 * phase + 2);                        // 4, 6: the predecessor's state has arrived
         for (int round = 0; round <= HB + 1; round++) {
+            if (phase < 2 && t == 0 && !chained) {
+                const uint64_t v = __hip_atomic_load(ptent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v) s_pred = v;
+            }
             __syncthreads();
             uint64_t want = t > 0 ? s_exit[t - 1] : s_pred;
             // a predecessor with nothing to hand on (none yet, or it ran into an undecodable pattern -- a wrong guess,
@@ -159,6 +177,13 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
             }
             __syncthreads();
             if (t == 0) s_queued = 0;
+            if (t == HB - 1 && b + 1 < nblocks) {
+                const uint64_t mine = s_exit[t];
+                if (mine != published && !(mine >> 48)) {
+                    __hip_atomic_store(tent, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    published = mine;
+                }
+            }
         }
     }
     __syncthreads();
