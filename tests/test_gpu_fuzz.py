@@ -175,3 +175,45 @@ def test_resize_one_axis_grows_the_other_shrinks(gpu):
             assert im.resize(args) == rc_o == 0
             assert np.array_equal(im.numpy(), want), (c, sh, sw, args)
             im.release()
+
+
+@settings(max_examples=120 * SCALE, **COMMON)
+@given(w=st.integers(1, 200), h=st.integers(1, 150), c=st.sampled_from([1, 3, 4]), q=st.integers(0, 100), kind=st.integers(0, 3),
+       seed=st.integers(0, 1000))
+def test_jpeg_encode_any_frame(gpu, w, h, c, q, kind, seed):
+    """cvEncodeImage(".jpg") on the device: the same file, byte for byte, as the oracle (itself pinned against libjpeg-turbo)
+    for any geometry (every padding and dummy-block rule), channel count, quality and kind of content."""
+    if kind == 0:
+        arr = noise_image(h, w, c, seed)
+    elif kind == 1:
+        arr = smooth_image(h, w, c) if c > 1 and h > 1 and w > 1 else noise_image(h, w, c, seed)
+    elif kind == 2:                                       # blocky: long zero runs, end-of-block everywhere
+        arr = np.repeat(np.repeat(noise_image((h + 7) // 8, (w + 7) // 8, c, seed), 8, axis=0), 8, axis=1)[:h, :w]
+    else:                                                 # extremes only: the longest codes, FF bytes in the segment
+        arr = (noise_image(h, w, c, seed) > 127).astype(np.uint8) * 255
+    rc_o, want = orc.jpeg_encode(arr, q)
+    im = gpu.Image(arr)
+    rc, got = im.encode_jpeg(q)
+    im.release()
+    assert rc == rc_o == 0 and got == want, (w, h, c, q, kind)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(n=st.integers(1, 9), w=st.integers(1, 120), h=st.integers(1, 90), c=st.sampled_from([1, 3, 4]), pick=st.integers(0, 5), seed=st.integers(0, 1000))
+def test_album_is_the_per_frame_loop(gpu, n, w, h, c, pick, seed):
+    """An album handle through an operator: every frame equals the single-image call on that frame."""
+    frames = [noise_image(h, w, c, seed * 16 + i) for i in range(n)]
+    ops = [("resize", "%d,0" % max(1, w // 2)), ("resize", "%d,%d,up" % (w + 3, h + 2)), ("filter", "gamma=1.7"), ("filter", "rotate=90"),
+           ("filter", "blur=1.2"), ("crop", "1,1")]
+    kind, arg = ops[pick]
+    al = gpu.Image.album(frames)
+    rc_a = getattr(al, kind)(arg)
+    outs = al.frames() if rc_a == 0 else []
+    for i, f in enumerate(frames):
+        im = gpu.Image(f)
+        rc = getattr(im, kind)(arg)
+        assert rc == rc_a, (kind, arg, rc, rc_a)
+        if rc == 0:
+            assert np.array_equal(im.numpy(), outs[i]), (kind, arg, i)
+        im.release()
+    al.release()
