@@ -239,7 +239,10 @@ IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint6
     widx += 2;
     uint32_t ahead = word(widx);
     uint32_t fl = 0;
-    while (p < limit) {
+    // ONE way out of the loop, at its bottom: an ending (the interval's padding, an undecodable pattern) takes nothing from
+    // the stream and pulls `limit` down to zero instead of jumping out -- every extra exit of a divergent loop costs a
+    // handful of scalar instructions per symbol for its execution-mask bookkeeping
+    do {
         const bool isdc = z == 0;
         const uint32_t tab = isdc ? ((dc_sel >> c) & 1) : 2 + ((ac_sel >> c) & 1);
         const uint32_t peek = (uint32_t)(buf >> 48);
@@ -247,15 +250,17 @@ IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint6
         if ((e & 31) == 0) {                                        // a code longer than the table's index (rare)
             uint32_t len = JPEG_LOOKBITS + 1;
             for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= L.limit[tab][l] ? 1u : 0u;
-            if (peek >= L.limit[tab][16]) {
-                fl = (seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID;
-                break;
-            }
+            const bool none = peek >= L.limit[tab][16];             // no code starts with these 16 bits
             const uint32_t sym = L.vals[tab][(uint32_t)(L.offs[tab][len] + (int)(peek >> (16 - len))) & 255];
-            e = jpeg_lut_expand(jpeg_lut_entry(len, sym, isdc));
+            e = none ? 0u : jpeg_lut_expand(jpeg_lut_entry(len, sym, isdc));
+            fl = none ? ((seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID) : fl;
         }
-        const uint32_t total = (e >> 16) & 31, adv = e >> 21;
-        if (p + total > seg_end) { fl = JPEG_FL_END; break; }
+        uint32_t total = (e >> 16) & 31, adv = e >> 21;
+        const bool pad = fl == 0 && p + total > seg_end;            // the interval's padding, not a symbol
+        fl = pad ? JPEG_FL_END : fl;
+        total = fl ? 0u : total;
+        adv = fl ? 0u : adv;
+        limit = fl ? 0u : limit;
         buf <<= total;
         have -= (int)total;
         p += total;
@@ -266,11 +271,11 @@ IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint6
             ahead = word(widx);
         }
         z += adv;
-        if (z >= 64) {
-            z = 0;
-            c = c + 1 == bpm ? 0 : c + 1;
-        }
-    }
+        const bool ended = z >= 64;
+        const uint32_t cn = c + 1 == bpm ? 0u : c + 1;
+        z = ended ? 0u : z;
+        c = ended ? cn : c;
+    } while (p < limit);
     return jpeg_pack_state(p, c, z, fl);
 }
 
