@@ -571,6 +571,7 @@ __global__ __launch_bounds__(64 * BR_FOLD_WAVES) void k_brightness_fold(const ui
 
 // inclusive scan of one ParityFn per thread over a block of BR_WALK_WAVES waves; s_part: that many entries of shared scratch
 #define BR_WALK_WAVES 4
+#define BR_HEAD 64                                                  // terms k_brightness_walk adds one by one before it starts scanning
 #define BR_WALK_EPT (BR_WCHUNK / (64 * BR_WALK_WAVES))            // 4 consecutive terms (or chunk summaries) per thread
 __device__ __forceinline__ ParityFn pf_block_scan(ParityFn f, ParityFn* s_part) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -607,6 +608,19 @@ __global__ __launch_bounds__(64 * BR_WALK_WAVES) void k_brightness_walk(const ui
         for (int k = 0; k < BR_WALK_WAVES; k++) first = min(first, s_first[k]);
         return first;
     };
+    // The first terms are added with the literal sequence by every thread for itself: a dozen binades go by in the first few
+    // dozen terms (the sum passes 2^13 within ~64 of them), and a block-wide pass per crossing would cost twenty times this.
+    {
+        const int head = (int)min(n, (long long)BR_HEAD);
+        if (tid < head) {
+            const int x = tid / h, y = tid - x * h;
+            s_term[tid] = br_term_of<CN>(br_load_px<CN>(src + (size_t)y * step + (size_t)x * CN));
+        }
+        __syncthreads();
+        for (int i = 0; i < head; i++) sum = (float)__dadd_rn((double)sum, s_term[i]);
+        pos = head;
+        __syncthreads();                                          // (s_term is the replay's chunk buffer next)
+    }
     while (pos < n) {
         {
             const unsigned sbits = __float_as_uint(sum);
