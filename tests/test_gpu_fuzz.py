@@ -3,7 +3,7 @@ kernel variant (gather, LDS-tiled, rolling 2x, vector AREA for BGR / BGRA, integ
 chains through run_ops, random watermark placements.  Bit-exact against the oracle."""
 import numpy as np
 import pytest
-from hypothesis import given, settings, strategies as st, HealthCheck
+from hypothesis import assume, given, settings, strategies as st, HealthCheck
 
 import oracle_lib as orc
 from conftest import noise_image, smooth_image
@@ -217,3 +217,49 @@ def test_album_is_the_per_frame_loop(gpu, n, w, h, c, pick, seed):
             assert np.array_equal(im.numpy(), outs[i]), (kind, arg, i)
         im.release()
     al.release()
+
+
+def _pil_jpeg(arr, **kw):
+    import io
+
+    Image = pytest.importorskip("PIL.Image")
+    b = io.BytesIO()
+    (Image.fromarray(arr[:, :, 0], "L") if arr.shape[2] == 1 else Image.fromarray(arr)).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+@settings(max_examples=120 * SCALE, **COMMON)
+@given(w=st.integers(1, 700), h=st.integers(1, 500), sub=st.sampled_from(["4:4:4", "4:2:2", "4:2:0", "gray"]), q=st.integers(20, 100),
+       rst=st.sampled_from([0, 0, 1, 3, 8, 40]), kind=st.integers(0, 2), opt=st.booleans(), flips=st.integers(0, 2), seed=st.integers(0, 10000))
+def test_jpeg_decode_any_file(gpu, w, h, sub, q, rst, kind, opt, flips, seed):
+    """Any baseline file (size, sampling, quality, restart interval, optimised tables, content), intact or with a few bytes
+    flipped: the device gives the oracle's verdict and, when that is OK, the oracle's pixels (the oracle = libjpeg-turbo's)."""
+    c = 1 if sub == "gray" else 3
+    if kind == 0:
+        arr = noise_image(h, w, c, seed)
+    elif kind == 1:
+        arr = smooth_image(h, w, c) if c > 1 and h > 1 and w > 1 else noise_image(h, w, c, seed)
+    else:
+        arr = np.repeat(np.repeat(noise_image((h + 15) // 16, (w + 15) // 16, c, seed), 16, axis=0), 16, axis=1)[:h, :w]
+    kw = dict(quality=q, optimize=opt)
+    if c == 3:
+        kw["subsampling"] = sub
+    if rst:
+        kw["restart_marker_blocks"] = rst
+    try:
+        blob = bytearray(_pil_jpeg(arr, **kw))
+    except OSError:                      # Pillow's own buffer estimate (noise at quality 100 with optimised tables): not a case
+        assume(False)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for _ in range(flips):
+        blob[int(rng.integers(2, len(blob)))] = int(rng.integers(0, 256))
+    blob = bytes(blob)
+    rc_o, want = orc.jpeg_decode(blob)
+    rc, im = gpu.Image.decode_jpeg(blob)
+    if rc_o == 0:
+        assert rc == 0, (w, h, sub, q, rst, kind, opt, flips, seed, gpu.lib.impgpu_last_error())
+        got = im.numpy()
+        im.release()
+        assert np.array_equal(got, want), (w, h, sub, q, rst, kind, opt, flips, seed)
+    else:
+        assert rc != 0, (w, h, sub, q, rst, kind, opt, flips, seed, rc_o)
