@@ -170,3 +170,32 @@ def test_mixed_batch_from_c(tmp_path, c):
         got = np.fromfile(tmp_path / ("o%d.raw" % i), dtype=np.uint8).reshape(dh, dw, c)
         interp = orc.INTER_CUBIC if (dw > sw or dh > sh) else orc.INTER_AREA
         assert np.array_equal(got, orc.cv_resize(frames[i], dw, dh, interp)), geoms[i]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,uri,ext", [
+    ("c420_q90_dri4_95x51", "/a.jpg?resize=40", "jpg"),                               # the module's default quality, 86
+    ("c444_q90_48x40", "/a.jpg?crop=1,1,c,c&filter-gamma=1.5&quality=70", "jpg"),
+    ("gray_q90_57x43", "/a.jpg?resize=30,0&filter-rotate=90&quality=100", "jpg"),      # gray file: 3 channels after the operator segment
+    ("c420_q92_opt_120x90", "/a.jpg?quality=0", "jpg"),
+])
+def test_jpeg_in_jpeg_out_from_c(tmp_path, name, uri, ext):
+    """tests/c/jpeg_harness.c: decode on the device, the operator segment, encode on the device -- from C99; the file it
+    writes is the oracle's (decode, chain, encode: each pinned or restated as DESIGN §2 says), byte for byte."""
+    from test_gpu_chain import oracle_chain
+
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+    src = os.path.join(ROOT, "tests", "golden", "jpeg", name + ".jpg")
+    out = tmp_path / "out.jpg"
+    p = subprocess.run([os.path.join(ROOT, "tests", "c", "_build", "jpeg_harness"), src, uri, ext, str(out)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    f = {k: int(v) for k, v in (kv.split("=") for kv in p.stdout.split())}
+    rc_o, q = orc.parse_request(uri, ext, 5)
+    rc_d, frame = orc.jpeg_decode(open(src, "rb").read())
+    rc_w, step_w, want = oracle_chain(frame, crop=q["crop"], gravity=q["gravity"], resize=q["resize"], simple=q["simple"],
+                                      filters=q["filters"], flatten=q["need_flatten"])
+    quality = int(q["quality"]) if q.get("quality") not in (None, "") else 86
+    rc_e, file_want = orc.jpeg_encode(want, quality)
+    assert rc_o == rc_d == rc_w == rc_e == 0 and f["code"] == 0 and f["step"] == 8
+    assert (f["h"], f["w"], f["c"]) == want.shape
+    assert out.read_bytes() == file_want
