@@ -103,3 +103,31 @@ def test_request_end_to_end_jpeg_in_jpeg_out(gpu):
     rc_o3, want = orc.jpeg_encode(small, 80)
     assert rc == rc_o == rc_o2 == rc_o3 == 0 and got == want
     im.release()
+
+
+def test_encodes_from_several_threads(gpu):
+    """Every thread has its own lane (stream, pool, staging); the shared pieces are the code tables (built once) and the device."""
+    import threading
+
+    frames = [noise_image(40 + 7 * i, 90 + 11 * i, [3, 1, 4][i % 3], 1400 + i) for i in range(8)]
+    wants = [orc.jpeg_encode(f, 80 + i)[1] for i, f in enumerate(frames)]
+    errors = []
+
+    def worker(i):
+        try:
+            im = gpu.Image(frames[i])
+            for _ in range(25):
+                rc, got = im.encode_jpeg(80 + i)
+                if rc != 0 or got != wants[i]:
+                    errors.append((i, rc))
+                    break
+            im.release()
+        except Exception as e:          # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
