@@ -145,7 +145,9 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
         blk_ok = my < (uint32_t)F.mcuy;
         blk = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
     }
-    while (p < limit && n < max_slots) {
+    // (one way out of the loop, at its bottom -- see jpeg_sync_chunk: an ending skips the rest of the body instead of jumping out)
+    bool go = n < max_slots;
+    while (go) {
         const uint32_t ci = (comp_of >> (2 * c)) & 3;
         const bool isdc = z == 0;
         const uint32_t tab = isdc ? ((dc_sel >> c) & 1) : 2 + ((ac_sel >> c) & 1);
@@ -154,57 +156,58 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
         if ((e & 31) == 0) {                                        // a code longer than the table's index: its length from
             uint32_t len = JPEG_LOOKBITS + 1;                       // the canonical limits, its symbol from the value list
             for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= L.limit[tab][l] ? 1u : 0u;
-            if (peek >= L.limit[tab][16]) {                         // no code starts with these 16 bits
-                fl = (seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID;   // (the 1-bits that pad an interval are no code either)
-                break;
-            }
+            const bool none = peek >= L.limit[tab][16];             // no code starts with these 16 bits
             const uint32_t sym = L.vals[tab][(uint32_t)(L.offs[tab][len] + (int)(peek >> (16 - len))) & 255];
-            e = jpeg_lut_entry(len, sym, isdc);
+            e = none ? 0u : jpeg_lut_entry(len, sym, isdc);
+            fl = none ? ((seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID) : fl;   // (the 1-bits that pad an interval are no code either)
         }
         const uint32_t len = e & 31, size = (e >> 5) & 15, run = (e >> 9) & 15, eob = (e >> 13) & 1;
         const uint32_t total = len + size;
-        if (p + total > seg_end) { fl = JPEG_FL_END; break; }       // the interval's padding, not a symbol
-        // the value: `size` bits after the code, negative when its first bit is 0 (T.81 F.2.2.1)
-        const uint32_t vb = (uint32_t)(buf >> 32) << len;
-        const int v = (int)((vb >> 1) >> (31 - size)) + ((int)(~vb) >> 31 & (1 - (1 << size)));
-        buf <<= total;
-        have -= (int)total;
-        p += total;
-        if (have <= 32) {
-            buf |= (uint64_t)jpeg_be(ahead) << (32 - have);         // the byte swap HERE: a swap at the load would wait for it there
-            have += 32;
-            widx++;
-            ahead = word(widx);
-        }
-        uint32_t adv = eob ? 64 - z : run + 1;
-        const bool over = z + adv > 64;                             // a run that leaves the block: damaged
-        adv = over ? 64 - z : adv;
-        damaged |= over ? 1u : 0u;
-        if (WRITE) {
-            if (isdc) {
-                const int dcv = (ci == 0 ? W->dc0[0] + dcs0 : ci == 1 ? W->dc0[1] + dcs1 : W->dc0[2] + dcs2) + v;
-                if (blk_ok) jpeg_put_coef(W->coef, blk, (int16_t)dcv);
-            } else if (size && !over && blk_ok) {
-                jpeg_put_coef(W->coef, blk + L.natural[z + run], (int16_t)v);
+        if (fl == 0 && p + total > seg_end) fl = JPEG_FL_END;       // the interval's padding, not a symbol
+        if (fl == 0) {
+            // the value: `size` bits after the code, negative when its first bit is 0 (T.81 F.2.2.1)
+            const uint32_t vb = (uint32_t)(buf >> 32) << len;
+            const int v = (int)((vb >> 1) >> (31 - size)) + ((int)(~vb) >> 31 & (1 - (1 << size)));
+            buf <<= total;
+            have -= (int)total;
+            p += total;
+            if (have <= 32) {
+                buf |= (uint64_t)jpeg_be(ahead) << (32 - have);     // the byte swap HERE: a swap at the load would wait for it there
+                have += 32;
+                widx++;
+                ahead = word(widx);
             }
-        }
-        dcs0 += (isdc && ci == 0) ? v : 0;
-        dcs1 += (isdc && ci == 1) ? v : 0;
-        dcs2 += (isdc && ci == 2) ? v : 0;
-        z += adv;
-        n += adv;
-        if (z >= 64) {                                              // next block
-            z = 0;
-            c++;
+            uint32_t adv = eob ? 64 - z : run + 1;
+            const bool over = z + adv > 64;                         // a run that leaves the block: damaged
+            adv = over ? 64 - z : adv;
+            damaged |= over ? 1u : 0u;
             if (WRITE) {
-                if (c == bpm) { mx++; if (mx == (uint32_t)F.mcux) { mx = 0; my++; } }
+                if (isdc) {
+                    const int dcv = (ci == 0 ? W->dc0[0] + dcs0 : ci == 1 ? W->dc0[1] + dcs1 : W->dc0[2] + dcs2) + v;
+                    if (blk_ok) jpeg_put_coef(W->coef, blk, (int16_t)dcv);
+                } else if (size && !over && blk_ok) {
+                    jpeg_put_coef(W->coef, blk + L.natural[z + run], (int16_t)v);
+                }
             }
-            c = c == bpm ? 0 : c;
-            if (WRITE) {
-                blk_ok = my < (uint32_t)F.mcuy;
-                blk = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
+            dcs0 += (isdc && ci == 0) ? v : 0;
+            dcs1 += (isdc && ci == 1) ? v : 0;
+            dcs2 += (isdc && ci == 2) ? v : 0;
+            z += adv;
+            n += adv;
+            if (z >= 64) {                                          // next block
+                z = 0;
+                c++;
+                if (WRITE) {
+                    if (c == bpm) { mx++; if (mx == (uint32_t)F.mcux) { mx = 0; my++; } }
+                }
+                c = c == bpm ? 0 : c;
+                if (WRITE) {
+                    blk_ok = my < (uint32_t)F.mcuy;
+                    blk = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
+                }
             }
         }
+        go = fl == 0 && p < limit && n < max_slots;
     }
     if (WRITE) {
         if (damaged || (fl & JPEG_FL_INVALID)) jpeg_flag(W->status, JPEG_ST_BAD_CODE);
