@@ -155,3 +155,27 @@ def test_album_entry_points_check_their_arguments_before_the_device():
     assert not h.value
     assert lib.impgpu_album_download(None, ptrs, None) == INV
     assert lib.impgpu_album_count(None) == 0
+
+
+def test_jpeg_codec_entry_points_check_their_arguments_before_the_device():
+    import ctypes as C
+
+    import ngx_http_imgproc_amd as imp
+
+    lib = imp.lib
+    INV = imp.IMP_ERROR_INVALID_ARGS
+    n = C.c_size_t()
+    buf = (C.c_ubyte * 64)()
+    assert lib.impgpu_image_encode_jpeg(None, 90, buf, 64, C.byref(n)) == INV
+    assert lib.impgpu_batch_encode_jpeg(None, 3, 90, None, None, None, None) == INV
+    assert lib.impgpu_batch_encode_jpeg(None, -1, 90, None, None, None, None) == INV
+    assert lib.impgpu_batch_encode_jpeg(None, 0, 90, None, None, None, None) == imp.IMP_ERROR_DEVICE    # nothing to do, but no env either
+    # the bound is a host computation: what a block can take in the file, every byte stuffed, plus the headers
+    assert lib.impgpu_jpeg_encode_bound(224, 126, 3) == 1024 + 14 * 8 * 6 * 432
+    assert lib.impgpu_jpeg_encode_bound(17, 9, 1) == 1024 + 3 * 2 * 432
+    assert lib.impgpu_jpeg_encode_bound(0, 9, 3) == 0 and lib.impgpu_jpeg_encode_bound(9, 9, 2) == 0 and lib.impgpu_jpeg_encode_bound(70000, 9, 3) == 0
+    h = C.c_void_p()
+    assert lib.impgpu_image_decode_jpeg(None, 10, C.byref(h)) == INV
+    codes = (C.c_int * 2)()
+    imgs = (C.c_void_p * 2)()
+    assert lib.impgpu_batch_decode_jpeg(None, None, 2, imgs, codes) == INV
