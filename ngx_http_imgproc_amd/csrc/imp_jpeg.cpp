@@ -207,7 +207,21 @@ size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs) {
 // Copies the entropy-coded bytes out of the file: FF 00 becomes FF, fill FFs go, an RSTn marker closes the interval (the
 // rest of its chunk is filled with 1-bits, exactly what the encoder pads the last byte with) and the next one starts on a
 // chunk boundary.  Stops at EOI, at any other marker, or at the end of the file.
+size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
+    if (const char* s = std::getenv("IMPGPU_JPEG_CHUNK_WORDS")) {
+        const int w = std::atoi(s);
+        if (w == 8 || w == 16 || w == 32) return (size_t)w * 4;
+    }
+    // measured, one request at a time (profiles/r03_request_latency.txt; 256 / 512 / 1024 bits): 640x480 0.77 / 0.76 / 0.89 ms,
+    // 720p 0.83 / 0.84 / 0.94, 1080p 0.90 / 0.84 / 0.95, 4K 1.45 / 1.24 / 1.24; a queue's worth of files (28 MB) is a little
+    // faster on 1024
+    if (launch_bytes > (size_t(4) << 20)) return JPEG_CHUNK_BYTES;
+    return file_bytes <= (size_t(96) << 10) ? 32 : 64;
+}
+
 int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uint8_t* out, size_t cap, JpegScan* scan) {
+    const size_t CBY = scan->chunk_bytes;                                // 128, 64 or 32
+    if (CBY != 128 && CBY != 64 && CBY != 32) return IMP_ERROR_INVALID_ARGS;
     scan->seg_first_chunk.clear();
     scan->seg_bits.clear();
     const size_t total_mcus = (size_t)H.mcux * H.mcuy;
@@ -217,9 +231,9 @@ int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uin
     bool done = false, closed = false;
     auto close_segment = [&]() -> bool {
         if (o == seg_begin) return false;                             // an interval with no data
-        scan->seg_first_chunk.push_back((uint32_t)(seg_begin / JPEG_CHUNK_BYTES));
+        scan->seg_first_chunk.push_back((uint32_t)(seg_begin / CBY));
         scan->seg_bits.push_back((uint32_t)((o - seg_begin) * 8));
-        const size_t padded = (o + JPEG_CHUNK_BYTES - 1) / JPEG_CHUNK_BYTES * JPEG_CHUNK_BYTES;
+        const size_t padded = (o + CBY - 1) / CBY * CBY;
         std::memset(out + o, 0xFF, padded - o);
         o = seg_begin = padded;
         return true;
@@ -253,10 +267,10 @@ int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uin
     }
     if (!closed && !close_segment()) return IMP_ERROR_DECODE_FAILED;
     if (scan->seg_first_chunk.size() != want_segs) return IMP_ERROR_DECODE_FAILED;
-    scan->nchunks = o / JPEG_CHUNK_BYTES;
+    scan->nchunks = o / CBY;
     if (o + JPEG_CHUNK_BYTES > cap) return IMP_ERROR_DECODE_FAILED;
     std::memset(out + o, 0xFF, JPEG_CHUNK_BYTES);                     // guard chunk: a lane may look 64 bits past its own
-    if ((uint64_t)scan->nchunks * JPEG_CHUNK_BYTES * 8 >= (1ull << 32)) return IMP_ERROR_UNSUPPORTED;   // bit positions are 32-bit
+    if ((uint64_t)scan->nchunks * CBY * 8 >= (1ull << 32)) return IMP_ERROR_UNSUPPORTED;   // bit positions are 32-bit
     return IMP_OK;
 }
 
@@ -317,7 +331,7 @@ int jpeg_host_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, int
     const size_t total_mcus = (size_t)H.mcux * H.mcuy;
     const size_t per_seg = H.restart_interval ? (size_t)H.restart_interval : total_mcus;
     for (size_t sg = 0; sg < scan.seg_first_chunk.size(); sg++) {
-        BitFeed b{buf.data(), (size_t)scan.seg_first_chunk[sg] * JPEG_CHUNK_BYTES, 0};
+        BitFeed b{buf.data(), (size_t)scan.seg_first_chunk[sg] * scan.chunk_bytes, 0};
         b.end = b.at + scan.seg_bits[sg] / 8;
         int pred[3] = {0, 0, 0};
         const size_t m0 = sg * per_seg, m1 = m0 + per_seg < total_mcus ? m0 + per_seg : total_mcus;
@@ -353,7 +367,7 @@ int jpeg_host_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, int
             }
         }
         // what is left of the interval must be the encoder's padding: fewer than 8 bits
-        const long long consumed = (long long)(b.at - (size_t)scan.seg_first_chunk[sg] * JPEG_CHUNK_BYTES) * 8 + b.fed_past - b.have;
+        const long long consumed = (long long)(b.at - (size_t)scan.seg_first_chunk[sg] * scan.chunk_bytes) * 8 + b.fed_past - b.have;
         if ((long long)scan.seg_bits[sg] - consumed >= 8) return IMP_ERROR_DECODE_FAILED;
     }
     return IMP_OK;
@@ -419,6 +433,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     const size_t nsegs = H.restart_interval ? (total_mcus + H.restart_interval - 1) / H.restart_interval : 1;
     std::vector<uint8_t> buf(jpeg_scan_capacity(size - H.scan_begin, nsegs));
     JpegScan scan;
+    scan.chunk_bytes = jpeg_chunk_bytes_for(size - H.scan_begin, size - H.scan_begin);      // as a lone request would be cut
     if (int rc = jpeg_prepare_scan(blob, size, H, buf.data(), buf.size(), &scan)) return rc;
     std::vector<JpegHuffDev> tabs(4);
     if (int rc = jpeg_build_tables(H, dc_ids, ac_ids, tabs.data())) return rc;
@@ -434,12 +449,13 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     for (int k = 0; k < F.bpm; k++) jpeg_block_steps(F, k, &L.blk_base[k], &L.blk_dx[k], &L.blk_dy[k]);
     F.nchunks = (unsigned)scan.nchunks;
     F.nsegs = (unsigned)scan.seg_first_chunk.size();
+    F.chunk_bits = (unsigned)scan.chunk_bytes * 8;
     const uint8_t* bytes = buf.data();
     auto word = [bytes](uint32_t i) -> uint32_t {
         const uint8_t* q = bytes + (size_t)i * 4;
         return ((uint32_t)q[3] << 24) | ((uint32_t)q[2] << 16) | ((uint32_t)q[1] << 8) | q[0];      // as a little-endian load
     };
-    const uint32_t CB = JPEG_CHUNK_WORDS * 32;
+    const uint32_t CB = (uint32_t)scan.chunk_bytes * 8;
     const size_t n = scan.nchunks;
     std::vector<uint32_t> meta;
     jpeg_scan_meta(scan, &meta);

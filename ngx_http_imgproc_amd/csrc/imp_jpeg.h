@@ -8,8 +8,8 @@
 namespace imp {
 
 constexpr int JPEG_LOOKBITS = 10;            // codes up to this length resolve with one LDS lookup
-constexpr int JPEG_CHUNK_WORDS = 32;         // a decoder lane owns 1024 bits of the unstuffed stream
-constexpr int JPEG_CHUNK_BYTES = JPEG_CHUNK_WORDS * 4;
+constexpr int JPEG_CHUNK_WORDS = 32;         // a decoder lane owns 1024 bits of the unstuffed stream -- or 512 / 256 for a launch too
+constexpr int JPEG_CHUNK_BYTES = JPEG_CHUNK_WORDS * 4;   // small to fill the device (JpegScan::chunk_bytes, chosen by jpeg_chunk_bytes_for)
 constexpr int JPEG_HUFF_BLOCK = 256;         // chunks (= lanes) per workgroup of the entropy kernel
 
 struct JpegHuffSpec {                        // a DHT table as the file gives it
@@ -61,6 +61,7 @@ struct JpegFrame {
     int slots_per_seg;                       // restart_interval * bpm * 64 coefficient slots (whole scan when no DRI)
     unsigned total_slots;                    // mcux * mcuy * bpm * 64
     unsigned nchunks, nsegs;
+    unsigned chunk_bits;                     // 1024, 512 or 256: what a lane of the entropy kernel owns
 };
 
 // The entropy-coded segment made ready for the device: FF00 unstuffed, restart intervals cut at their RSTn markers, every
@@ -69,7 +70,15 @@ struct JpegScan {
     std::vector<uint32_t> seg_first_chunk;   // per interval
     std::vector<uint32_t> seg_bits;          // per interval: payload length in bits (8 * bytes)
     size_t nchunks = 0;                      // chunks holding payload (the trailing guard chunk is not counted)
+    size_t chunk_bytes = JPEG_CHUNK_BYTES;   // IN: 128, 64 or 32
 };
+// How a launch's files are cut: 128-byte chunks fill the device when there are many of them; a small launch (a lone request,
+// up to 4 MB of entropy-coded data)
+// is a chain of per-chunk walks that nothing else overlaps with, so its counting and writing walks -- which touch every
+// chunk once -- finish sooner on shorter chunks, while the resynchronising rounds take the same time either way (a round's
+// length and the number of rounds trade against each other).  launch_bytes = entropy-coded bytes of the whole launch.
+// IMPGPU_JPEG_CHUNK_WORDS = 8 | 16 | 32 overrides (A/B).
+size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes);
 // worst-case bytes jpeg_prepare_scan writes for `scan_bytes` of entropy-coded data and `nsegs` intervals
 size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs);
 int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uint8_t* out, size_t cap, JpegScan* scan);

@@ -19,9 +19,7 @@ namespace imp {
 namespace {
 
 constexpr int HB = JPEG_HUFF_BLOCK;
-constexpr int CW = JPEG_CHUNK_WORDS;
 
-constexpr unsigned CHUNK_BITS = CW * 32;
 constexpr int CTL_REC = JPEG_CTL_REC;
 
 __constant__ uint8_t c_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -75,6 +73,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     for (int i = t; i < 4 * 256; i += HB) L.vals[i >> 8][i & 255] = A.tables[i >> 8].vals[i & 255];
     if (t < 64) L.natural[t] = c_natural[t];
     if (t < F.bpm) jpeg_block_steps(F, t, &L.blk_base[t], &L.blk_dx[t], &L.blk_dy[t]);
+    const uint32_t CHUNK_BITS = F.chunk_bits;                       // 1024, 512 or 256 (jpeg_chunk_bytes_for)
     const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
     const uint32_t nblocks = (F.nchunks + HB - 1) / HB;
     const uint32_t g0 = b * HB, g = g0 + (uint32_t)t;

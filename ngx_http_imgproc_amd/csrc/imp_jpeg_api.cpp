@@ -81,15 +81,19 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
     void* token = nullptr;
     int rc = stage_begin(on_device ? words_total : coef_total, &host, &token);
     if (rc) return rc;
-    size_t live = 0;
+    size_t live = 0, launch_bytes = 0;
+    for (int i = 0; i < count; i++)
+        if (!P[(size_t)i].code) launch_bytes += sizes[i] - P[(size_t)i].H.scan_begin;
     for (int i = 0; i < count; i++) {
         Prep& p = P[(size_t)i];
         if (p.code) continue;
         if (on_device) {
+            p.scan.chunk_bytes = jpeg_chunk_bytes_for(sizes[i] - p.H.scan_begin, launch_bytes);
             p.code = jpeg_prepare_scan(blobs[i], sizes[i], p.H, (uint8_t*)host + p.words_off, p.words_cap, &p.scan);
             if (!p.code) {
                 p.F.nchunks = (unsigned)p.scan.nchunks;
                 p.F.nsegs = (unsigned)p.scan.seg_first_chunk.size();
+                p.F.chunk_bits = (unsigned)p.scan.chunk_bytes * 8;
             }
         } else {
             int16_t* planes = (int16_t*)((uint8_t*)host + p.coef_off);
