@@ -50,7 +50,7 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     __shared__ uint64_t s_exit[HB], s_entry[HB];
     __shared__ uint32_t s_segend[HB];
     __shared__ uint8_t s_queue[HB];
-    __shared__ uint32_t s_queued;
+    __shared__ uint32_t s_queued[2];            // the round's queue length; two, so that one barrier less per round is needed
     __shared__ uint32_t s_n[HB];
     __shared__ int s_dc[3][HB];
     __shared__ uint8_t s_head[HB];              // 1 = an interval starts in or before this chunk (inside the workgroup)
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     s_segend[t] = seg_end;
     s_n[t] = 0;
     s_dc[0][t] = s_dc[1][t] = s_dc[2][t] = 0;
-    if (t == 0) { s_pred = none; s_queued = 0; }
+    if (t == 0) { s_pred = none; s_queued[0] = s_queued[1] = 0; }
+    __syncthreads();
     for (int phase = 0; phase < 3; phase++) {
         stamp(1 + 2 * phase);                                       // 1, 3, 5: the phase's rounds start (after the wait: 2, 4 below)
         if (phase == 1 && t == HB - 1 && b + 1 < nblocks && !published) {
@@ -154,7 +155,9 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                 const uint64_t v = __hip_atomic_load(ptent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (v) s_pred = v;
             }
-            __syncthreads();
+            // (every exit state of the round before is in place: its closing barrier -- or the one in front of the phases --
+            // has been passed; two barriers per round, not three: at 256-bit chunks a round is short enough for that to show)
+            const int q = round & 1;
             uint64_t want = t > 0 ? s_exit[t - 1] : s_pred;
             // a predecessor with nothing to hand on (none yet, or it ran into an undecodable pattern -- a wrong guess,
             // normally): the lane's own guess.  Otherwise that dead state would travel a chunk per round to the interval's end.
@@ -165,17 +168,17 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
             if (live && want != entry) {
                 entry = want;
                 s_entry[t] = want;
-                s_queue[atomicAdd(&s_queued, 1u)] = (uint8_t)t;
+                s_queue[atomicAdd(&s_queued[q], 1u)] = (uint8_t)t;
             }
+            if (t == 0) s_queued[q ^ 1] = 0;                        // (last read before the barrier that closed the round before)
             __syncthreads();
-            const uint32_t queued = s_queued;
+            const uint32_t queued = s_queued[q];
             if (queued == 0) { if (t == 0) atomicMax(&A.header[phase == 0 ? 2 : 3], (uint32_t)round); break; }
             if ((uint32_t)t < queued) {
                 const uint32_t k = s_queue[t];
                 s_exit[k] = jpeg_sync_chunk(L, word, s_entry[k], min((g0 + k + 1) * CHUNK_BITS, s_segend[k]), s_segend[k], F);
             }
             __syncthreads();
-            if (t == 0) s_queued = 0;
             if (t == HB - 1 && b + 1 < nblocks) {
                 const uint64_t mine = s_exit[t];
                 if (mine != published && !(mine >> 48)) {
