@@ -230,11 +230,15 @@ IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint6
     if ((uint32_t)(entry >> 48)) return entry;
     if (p >= limit) return entry;
     const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
-    uint32_t dc_sel = 0, ac_sel = 0;
+    // per block of the MCU, four bits: the table its DC symbol is read with (0 / 1) and, two bits up, the table of its AC
+    // symbols (2 / 3) -- one shift and one mask per symbol pick the table; and, four bits each again, the block that follows
+    uint32_t tabsel = 0, nextc = 0;
     for (uint32_t k = 0; k < 6; k++) {
         const uint32_t ci = k < nluma ? 0u : (k - nluma + 1 < 3 ? k - nluma + 1 : 2u);
-        dc_sel |= (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]) << k;
-        ac_sel |= (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]) << k;
+        const uint32_t dct = (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]);
+        const uint32_t act = 2u + (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]);
+        tabsel |= (dct | (act << 2)) << (4 * k);
+        nextc |= (k + 1 == bpm ? 0u : k + 1) << (4 * k);
     }
     uint32_t widx = p >> 5;
     uint64_t buf = (((uint64_t)jpeg_be(word(widx)) << 32) | jpeg_be(word(widx + 1))) << (p & 31);
@@ -247,7 +251,7 @@ IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint6
     // handful of scalar instructions per symbol for its execution-mask bookkeeping
     do {
         const bool isdc = z == 0;
-        const uint32_t tab = isdc ? ((dc_sel >> c) & 1) : 2 + ((ac_sel >> c) & 1);
+        const uint32_t tab = (tabsel >> (4 * c + (isdc ? 0u : 2u))) & 3;
         const uint32_t peek = (uint32_t)(buf >> 48);
         uint32_t e = L.lut[tab][peek >> (16 - JPEG_LOOKBITS)];
         if ((e & 31) == 0) {                                        // a code longer than the table's index (rare)
@@ -275,7 +279,7 @@ IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint6
         }
         z += adv;
         const bool ended = z >= 64;
-        const uint32_t cn = c + 1 == bpm ? 0u : c + 1;
+        const uint32_t cn = (nextc >> (4 * c)) & 15;
         z = ended ? 0u : z;
         c = ended ? cn : c;
     } while (p < limit);
