@@ -12,10 +12,18 @@ using namespace imp;
 
 namespace {
 
-bool host_entropy_requested() {
-    // A/B switch, read per call (a getenv is nothing next to a decode): "host" = entropy decoding on the calling thread
+// Where the entropy stage of a launch runs.  The device's takes a chain of rounds that costs a few hundred microseconds
+// however small the file is; the calling thread's takes 6 ns per byte.  One request at a time (tools/jpeg_tiny_probe.py,
+// frame complete, ms: device / calling thread / libjpeg-turbo on one core) -- 64x64 0.24 / 0.05 / 0.04, 320x240 0.48 / 0.15 /
+// 0.20, 640x480 0.73 / 0.54 / 0.85, 800x600 0.65 / 0.85 / 1.29, 1080p 0.76 / 3.5 / 5.4 -- they cross near 100 KB of
+// entropy-coded data, so a launch smaller than that keeps its Huffman decoding on the thread that is about to sleep in the
+// wait anyway (dequantisation, IDCT, upsampling and colour stay on the device either way), and everything larger -- every
+// batch -- is the device's.  IMPGPU_JPEG_HUFF = device | host forces one (read per call: a getenv is nothing next to a decode).
+bool entropy_on_device(size_t launch_bytes) {
     const char* s = std::getenv("IMPGPU_JPEG_HUFF");
-    return s && !std::strcmp(s, "host");
+    if (s && !std::strcmp(s, "host")) return false;
+    if (s && !std::strcmp(s, "device")) return true;
+    return launch_bytes >= (size_t(100) << 10);
 }
 
 // IMPGPU_JPEG_TRACE=1: one line per call on stderr with the host's share of it, in microseconds
@@ -52,7 +60,6 @@ struct Prep {                                       // one file on its way to th
 
 int decode_group(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
     Stopwatch sw;
-    const bool on_device = !host_entropy_requested();
     hipStream_t s = env_stream();
     if (!s) return IMP_ERROR_DEVICE;
     std::vector<Prep> P((size_t)count);
@@ -74,6 +81,10 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         p.coef_off = coef_total;
         coef_total += align_up((size_t)p.F.total_slots * sizeof(int16_t), 256);
     }
+    size_t launch_bytes = 0;
+    for (int i = 0; i < count; i++)
+        if (!P[(size_t)i].code) launch_bytes += sizes[i] - P[(size_t)i].H.scan_begin;
+    const bool on_device = entropy_on_device(launch_bytes);
     sw.mark();                                                      // [0] headers
     // ---- the compressed bytes: FF00 unstuffing while they are copied into pinned memory -- the only pass the host makes
     // over them (device entropy stage), or the whole entropy decoding into pinned coefficient planes (A/B path)
@@ -81,9 +92,7 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
     void* token = nullptr;
     int rc = stage_begin(on_device ? words_total : coef_total, &host, &token);
     if (rc) return rc;
-    size_t live = 0, launch_bytes = 0;
-    for (int i = 0; i < count; i++)
-        if (!P[(size_t)i].code) launch_bytes += sizes[i] - P[(size_t)i].H.scan_begin;
+    size_t live = 0;
     for (int i = 0; i < count; i++) {
         Prep& p = P[(size_t)i];
         if (p.code) continue;

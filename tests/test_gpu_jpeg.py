@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
 MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
 EXPECTED = np.load(os.path.join(GOLD, "expected_bgr.npz"))
-MODES = ["device", "host"]      # IMPGPU_JPEG_HUFF: where the entropy decoding runs (host = the A/B path)
+MODES = ["device", "host", "auto"]      # IMPGPU_JPEG_HUFF: where the entropy decoding runs; auto (unset) = by the size of the launch
 
 
 def golden_blob(name):
@@ -35,7 +35,10 @@ def encode(arr, **kw):
 
 @pytest.fixture(params=MODES)
 def huff(request, monkeypatch):
-    monkeypatch.setenv("IMPGPU_JPEG_HUFF", request.param)
+    if request.param == "auto":
+        monkeypatch.delenv("IMPGPU_JPEG_HUFF", raising=False)
+    else:
+        monkeypatch.setenv("IMPGPU_JPEG_HUFF", request.param)
     return request.param
 
 
