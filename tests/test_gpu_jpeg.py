@@ -33,6 +33,13 @@ def encode(arr, **kw):
     return b.getvalue()
 
 
+@pytest.fixture(autouse=True)
+def _device_entropy_unless_a_test_says_otherwise(monkeypatch):
+    """Unset, a lone small file's Huffman stage runs on the calling thread (decode_group's size rule): the files of this
+    module are small, and it is the DEVICE's entropy stage they are here to test."""
+    monkeypatch.setenv("IMPGPU_JPEG_HUFF", "device")
+
+
 @pytest.fixture(params=MODES)
 def huff(request, monkeypatch):
     if request.param == "auto":
