@@ -19,6 +19,7 @@
 //             FF counts); the last partial byte carries into the next strip, flush_bits' 1-fill and EOI end the file.
 // An image's scan is one serial bit stream, but only the offsets are serial: the two scans.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -37,6 +38,13 @@ struct EncJob {
     int out_cap;                        // bytes of `out`
     short* coef;                        // nblocks x 64, zigzag order
     uint8_t* out;                       // entropy-coded segment + EOI
+    // large frames only (k_jpeg_enc_pack / k_jpeg_enc_stuff): the unstuffed bit stream (zeroed), one (sum, flag) record per
+    // 256-block segment and one per 16 KB chunk of the stream (zeroed), [0] = the stream's bytes once it is complete
+    uint32_t* ustream;
+    uint32_t* seg_rec;
+    uint32_t* chunk_rec;
+    uint32_t* ubytes;
+    int nseg, nchunk;
 };
 struct EncMap { int job, local; };      // workgroup of k_jpeg_enc_blocks -> (image, first block slot)
 struct EncTables {
@@ -259,13 +267,13 @@ __device__ __forceinline__ int enc_code_block(const uint32_t (&cw)[32], int last
 // result[4 * job] = bytes of the entropy-coded segment + EOI (what the file needs after its headers, whether or not it
 // fitted), [4 * job + 1] = 1 when it did not fit out_cap, [4 * job + 2] = where the workgroup put a copy of the segment in
 // `compact` (0xffffffff: it did not fit there).  The compact area is what the host fetches: the segments of a whole batch
-// back to back (in the order the workgroups finish), one copy instead of one per image.  result[4 * njobs] = its cursor.
+// back to back (in the order the workgroups finish), one copy instead of one per image.  *cursor = how far it is filled.
 // NT threads take NT blocks per pass.  NT = 256: whatever the blocks hold, a pass fits the window.  NT = 1024 (frames of more
 // than 256 blocks): a pass takes the blocks from the front whose code still fits -- all 1024 unless they average more than
 // 447 bits, which photographs do not come near -- and the rest come again in the next pass.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__ jobs, const EncTables* __restrict__ tabs, uint32_t* __restrict__ result,
-                                                      uint8_t* __restrict__ compact, uint32_t compact_cap) {
+                                                      uint32_t* __restrict__ cursor, uint8_t* __restrict__ compact, uint32_t compact_cap) {
     __shared__ uint32_t s_win[ENC_WIN_WORDS];
     __shared__ int s_part[NT / 64], s_cnt[NT / 64], s_top[NT / 64];
     __shared__ uint32_t s_carry;
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__
         if (fits) { J.out[out_pos] = 0xff; J.out[out_pos + 1] = 0xd9; }
         uint32_t at = 0xffffffffu;
         if (fits) {
-            at = atomicAdd(&result[4 * gridDim.x], (len + 15u) & ~15u);
+            at = atomicAdd(cursor, (len + 15u) & ~15u);
             if (at > compact_cap || len > compact_cap - at) at = 0xffffffffu;
         }
         result[4 * blockIdx.x] = len;
@@ -378,6 +386,146 @@ __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__
         const uint4* src = (const uint4*)J.out;                     // both 16-byte aligned
         uint4* dst = (uint4*)(compact + at);
         for (uint32_t i = tid; i < (len + 15u) / 16u; i += NT) dst[i] = src[i];
+    }
+}
+
+// ---------------------------------------------------------------- large frames: many workgroups per image
+// One workgroup walking a whole 1080p frame takes 1.6 ms (48 passes of 1024 blocks).  A large frame is cut instead into
+// segments of 256 blocks, one workgroup each, in two launches:
+//   k_jpeg_enc_pack   sizes its blocks, publishes the segment's bit count, adds up the counts of the segments before it (they
+//                     run at the same time: a segment's count does not depend on anything), and ORs its code into the
+//                     image's UNSTUFFED stream at that bit offset -- through the LDS window, whole words to memory, only the
+//                     two words it may share with its neighbours as atomics;
+//   k_jpeg_enc_stuff  one workgroup per 16 KB of that stream: counts its FF bytes, publishes, adds up the chunks before it,
+//                     and writes its bytes with the 00s behind their FFs where they belong; the chunk that holds the last
+//                     byte adds EOI and the verdict.
+// Workgroups take a ticket when they start (never blockIdx): the ones a workgroup waits for are then always running.
+struct EncSeg { int job, local; };
+
+__device__ __forceinline__ uint32_t enc_sum_before(const uint32_t* __restrict__ rec, int upto, int* s_part) {
+    // sum of rec[2 * p] over p < upto, each read once its flag rec[2 * p + 1] is up (the same bounded, relaxed poll as the
+    // decoder's chain); all threads of the block get the sum
+    uint32_t acc = 0;
+    for (int p = threadIdx.x; p < upto; p += 256) {
+        bool up = false;
+        for (int spin = 0; spin < (1 << 22) && !up; spin++) {
+            up = __hip_atomic_load(&rec[2 * p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (!up) __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        acc += __hip_atomic_load(&rec[2 * p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int total;
+    (void)enc_block_scan<256>((int)acc, s_part, &total);
+    return (uint32_t)total;
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_enc_pack(const EncJob* __restrict__ jobs, const EncSeg* __restrict__ map, const EncTables* __restrict__ tabs,
+                                                       uint32_t* __restrict__ ticket) {
+    __shared__ uint32_t s_win[ENC_WIN_WORDS];
+    __shared__ int s_part[4];
+    __shared__ uint32_t s_ticket;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    for (int i = tid; i < ENC_WIN_WORDS; i += 256) s_win[i] = 0;
+    __syncthreads();
+    const EncSeg me = map[s_ticket];
+    const EncJob& J = jobs[me.job];
+    const int sg = me.local, b = sg * 256 + tid;
+    const bool live = b < J.nblocks;
+    int bits = 0, dc = 0, last_dc = 0;
+    uint32_t cw[32];
+    const uint32_t *hdc = tabs->huff[0], *hac = tabs->huff[1];
+    if (live) {
+        const int mcu = b / J.bpm, j = b - mcu * J.bpm;
+        const uint4* blk = (const uint4*)(J.coef + (size_t)b * 64);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const uint4 q = blk[v];
+            cw[4 * v] = q.x; cw[4 * v + 1] = q.y; cw[4 * v + 2] = q.z; cw[4 * v + 3] = q.w;
+        }
+        dc = enc_dc_of(J, mcu, j);
+        if (J.bpm == 1) last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, 0) : 0;
+        else if (j >= 4) { last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, j) : 0; hdc = tabs->huff[2]; hac = tabs->huff[3]; }
+        else last_dc = j > 0 ? enc_dc_of(J, mcu, j - 1) : (mcu > 0 ? enc_dc_of(J, mcu - 1, 3) : 0);
+        bits = enc_code_block<false>(cw, last_dc, dc, hdc, hac, nullptr);
+    }
+    int total;
+    const int incl = enc_block_scan<256>(bits, s_part, &total);
+    if (tid == 0) {
+        __hip_atomic_store(&J.seg_rec[2 * sg], (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&J.seg_rec[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                // (s_part is free again)
+    const uint32_t base = enc_sum_before(J.seg_rec, sg, s_part);    // bits of the image in front of this segment
+    const int lead = (int)(base & 31u);
+    if (live) {
+        EncPut P;
+        P.start(s_win, lead + incl - bits);
+        enc_code_block<true>(cw, last_dc, dc, hdc, hac, &P);
+        P.finish();
+    }
+    __syncthreads();
+    int nbits = lead + total;
+    if (sg == J.nseg - 1) {                                         // the image's last segment: flush_bits' ones, and the stream's length
+        const uint32_t all = base + (uint32_t)total;
+        if (tid == 0) {
+            if (all & 7u) atomicOr(&s_win[nbits >> 5], ((1u << (8 - (all & 7u))) - 1) << (24 - ((nbits >> 3) & 3) * 8));
+            J.ubytes[0] = (all + 7u) >> 3;
+        }
+        nbits = (nbits + 7) & ~7;
+        __syncthreads();
+    }
+    const int nwords = (nbits + 31) >> 5;
+    uint32_t* U = J.ustream + (base >> 5);
+    for (int i = tid; i < nwords; i += 256) {
+        const uint32_t v = s_win[i];
+        if (i == 0 || i == nwords - 1) { if (v) atomicOr(&U[i], v); }
+        else U[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_enc_stuff(const EncJob* __restrict__ jobs, const EncSeg* __restrict__ map, uint32_t* __restrict__ result,
+                                                        uint32_t* __restrict__ ticket) {
+    __shared__ int s_part[4];
+    __shared__ uint32_t s_ticket;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const EncSeg me = map[s_ticket];
+    const EncJob& J = jobs[me.job];
+    const int ck = me.local;
+    const uint32_t nbytes = J.ubytes[0];
+    const uint32_t c0 = (uint32_t)ck * 16384u;
+    // a chunk past the stream's end (the grid is sized for the worst case) still publishes: nothing in it
+    const uint32_t s = min(nbytes, c0 + (uint32_t)tid * 64u), e = min(nbytes, s + 64u);
+    const uint32_t* U = J.ustream;
+    int ff = 0;
+    for (uint32_t i = s; i < e; i++) ff += ((U[i >> 2] >> (24 - (i & 3) * 8)) & 0xff) == 0xff;
+    int total;
+    const int incl = enc_block_scan<256>(ff, s_part, &total);
+    if (tid == 0) {
+        __hip_atomic_store(&J.chunk_rec[2 * ck], (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&J.chunk_rec[2 * ck + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (c0 >= nbytes) return;                                       // (uniform)
+    const uint32_t before = enc_sum_before(J.chunk_rec, ck, s_part);
+    long long at = (long long)s + before + (incl - ff);
+    for (uint32_t i = s; i < e; i++) {
+        const uint32_t v = (U[i >> 2] >> (24 - (i & 3) * 8)) & 0xff;
+        if (at < J.out_cap) J.out[at] = (uint8_t)v;
+        at++;
+        if (v == 0xff) { if (at < J.out_cap) J.out[at] = 0; at++; }
+    }
+    if (e == nbytes && s < e) {                                     // the lane that wrote the stream's last byte
+        const long long len = at + 2;
+        const bool fits = len <= J.out_cap;
+        if (fits) { J.out[at] = 0xff; J.out[at + 1] = 0xd9; }
+        const int r = me.job;
+        result[4 * r] = (uint32_t)len;
+        result[4 * r + 1] = fits ? 0u : 1u;
+        result[4 * r + 2] = 0xffffffffu;                            // fetched from its own region, not from the compact area
     }
 }
 
@@ -459,69 +607,121 @@ bool enc_geom(int w, int h, int c, EncGeom* g) {
 
 constexpr int ENC_MAX_BATCH = 256;
 
+constexpr int ENC_BIG_BLOCKS = 2048;                            // frames of more block slots than this take the many-workgroup path
+
 int encode_group(const impgpu_image* const* images, int count, int quality, unsigned char* const* outs, const size_t* caps,
                  size_t* lens, int* codes) {
     hipStream_t s = env_stream();
     EncTables T;
     enc_static_tables(&T, quality);
-    std::vector<EncJob> jobs;
+    static const bool one_wg = std::getenv("IMPGPU_JPEG_ENC_ONE_WG") != nullptr;       // A/B: every frame through k_jpeg_enc_huff
+    std::vector<EncJob> jobs;                                   // small frames first, then the large ones
     std::vector<int> owner;                                     // job -> index into images
-    std::vector<EncMap> map;
     std::vector<std::vector<uint8_t>> heads;
-    size_t coef_bytes = 0, out_bytes = 0;
-    for (int i = 0; i < count; i++) {
-        lens[i] = 0;
-        const impgpu_image* im = images[i];
-        EncGeom g;
-        if (!im || !outs[i] || !enc_geom(im->w, im->h, im->c, &g)) { codes[i] = IMP_ERROR_INVALID_ARGS; continue; }
-        codes[i] = IMP_OK;
-        EncJob J{};
-        J.src = im->d; J.w = im->w; J.h = im->h; J.c = im->c; J.step = im->step;
-        J.mcuw = g.mcuw; J.mcuh = g.mcuh; J.bpm = g.bpm; J.nblocks = g.nblocks;
-        J.lbw = (im->w + 7) / 8; J.lbh = (im->h + 7) / 8; J.chh = (im->h + 1) / 2;
-        const size_t cap = (size_t)g.nblocks * ENC_BLOCK_BYTES + 16;
-        if (cap > 0x7fffffffu) { codes[i] = IMP_ERROR_INVALID_ARGS; continue; }
-        J.out_cap = (int)cap;
-        J.coef = (short*)coef_bytes;                            // offsets for now
-        J.out = (uint8_t*)out_bytes;
-        coef_bytes += (size_t)g.nblocks * 128;
-        out_bytes += (cap + 255) & ~size_t(255);
-        for (int b = 0; b < g.nblocks; b += 256) map.push_back(EncMap{(int)jobs.size(), b});
-        jobs.push_back(J);
-        owner.push_back(i);
-        heads.push_back(enc_headers(im->w, im->h, g.nc, T));
-    }
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < count; i++) {
+            const impgpu_image* im = images[i];
+            EncGeom g;
+            if (pass == 0) {
+                lens[i] = 0;
+                codes[i] = (!im || !outs[i] || !enc_geom(im->w, im->h, im->c, &g)) ? IMP_ERROR_INVALID_ARGS : IMP_OK;
+                if (codes[i] == IMP_OK && (size_t)g.nblocks * ENC_BLOCK_BYTES + 16 > 0x7fffffffu) codes[i] = IMP_ERROR_INVALID_ARGS;
+            }
+            if (codes[i] != IMP_OK) continue;
+            (void)enc_geom(im->w, im->h, im->c, &g);
+            const bool big = !one_wg && g.nblocks > ENC_BIG_BLOCKS && (uint64_t)g.nblocks * 1658u < (1ull << 32);
+            if (big != (pass == 1)) continue;
+            EncJob J{};
+            J.src = im->d; J.w = im->w; J.h = im->h; J.c = im->c; J.step = im->step;
+            J.mcuw = g.mcuw; J.mcuh = g.mcuh; J.bpm = g.bpm; J.nblocks = g.nblocks;
+            J.lbw = (im->w + 7) / 8; J.lbh = (im->h + 7) / 8; J.chh = (im->h + 1) / 2;
+            J.out_cap = (int)((size_t)g.nblocks * ENC_BLOCK_BYTES + 16);
+            if (big) {
+                J.nseg = (g.nblocks + 255) / 256;
+                J.nchunk = (int)(((size_t)g.nblocks * 1658 / 8 + 8 + 16383) / 16384);
+            }
+            jobs.push_back(J);
+            owner.push_back(i);
+            heads.push_back(enc_headers(im->w, im->h, g.nc, T));
+        }
     const int nj = (int)jobs.size();
     if (!nj) return IMP_OK;
+    int nsmall = 0;
+    while (nsmall < nj && jobs[nsmall].nseg == 0) nsmall++;
+    // device memory: coefficient blocks | segments | for the large frames: unstuffed streams, records, tickets (one area, zeroed)
+    std::vector<EncMap> map;
+    std::vector<EncSeg> pack_map, stuff_map;
+    size_t coef_bytes = 0, out_bytes = 0, aux_bytes = 16;        // aux: [0] [1] = the two tickets
+    std::vector<size_t> o_coef((size_t)nj), o_out((size_t)nj), o_u((size_t)nj), o_seg((size_t)nj), o_chk((size_t)nj), o_ub((size_t)nj);
+    for (int k = 0; k < nj; k++) {
+        const EncJob& J = jobs[k];
+        o_coef[k] = coef_bytes; coef_bytes += (size_t)J.nblocks * 128;
+        o_out[k] = out_bytes; out_bytes += ((size_t)J.out_cap + 255) & ~size_t(255);
+        for (int b = 0; b < J.nblocks; b += 256) map.push_back(EncMap{k, b});
+        if (J.nseg) {
+            o_ub[k] = aux_bytes; aux_bytes += 16;
+            o_seg[k] = aux_bytes; aux_bytes += (size_t)J.nseg * 8;
+            o_chk[k] = aux_bytes; aux_bytes += (size_t)J.nchunk * 8;
+            aux_bytes = (aux_bytes + 255) & ~size_t(255);
+            o_u[k] = aux_bytes; aux_bytes += ((size_t)J.nchunk * 16384 + 64 + 255) & ~size_t(255);
+            for (int g = 0; g < J.nseg; g++) pack_map.push_back(EncSeg{k, g});
+            for (int g = 0; g < J.nchunk; g++) stuff_map.push_back(EncSeg{k, g});
+        }
+    }
     // what the host will fetch in its one copy: 32 bytes per block slot (a photograph at quality 90 needs about 13) and the
-    // results in front; a batch that needs more than that costs a second copy and wait for the segments that did not fit
+    // results in front; a batch that needs more than that costs a second copy and wait for the segments that did not fit.
+    // (Large frames are fetched from their own regions once their length is known: they are worth a copy of their own.)
     size_t compact_cap = 0;
-    for (const EncJob& J : jobs) compact_cap += std::min((size_t)J.out_cap, (size_t)J.nblocks * 32 + 256);
+    for (int k = 0; k < nsmall; k++) compact_cap += std::min((size_t)jobs[k].out_cap, (size_t)jobs[k].nblocks * 32 + 256);
     compact_cap = (compact_cap + 255) & ~size_t(255);
     if (compact_cap > 0xfffffff0u) compact_cap = 0xfffffff0u & ~size_t(255);
     const size_t res_bytes = (((size_t)nj * 4 + 1) * 4 + 255) & ~size_t(255);
-    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr;          // res = results | compact area
-    auto drop = [&]() { dev_free(coef); dev_free(out); dev_free(res); dev_free(side); };
+    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr, *aux = nullptr;      // res = results | compact area
+    auto drop = [&]() { dev_free(coef); dev_free(out); dev_free(res); dev_free(side); dev_free(aux); };
     if (int rc = dev_alloc(coef_bytes, &coef)) return rc;
     if (int rc = dev_alloc(out_bytes, &out)) { drop(); return rc; }
     if (int rc = dev_alloc(res_bytes + compact_cap, &res)) { drop(); return rc; }
-    for (EncJob& J : jobs) { J.coef = (short*)((uint8_t*)coef + (size_t)J.coef); J.out = (uint8_t*)out + (size_t)J.out; }
-    // side blob: tables | jobs | map
-    const size_t o_jobs = (sizeof(EncTables) + 15) & ~size_t(15), o_map = o_jobs + ((jobs.size() * sizeof(EncJob) + 15) & ~size_t(15));
-    std::vector<uint8_t> blob(o_map + map.size() * sizeof(EncMap));
+    if (nsmall < nj) if (int rc = dev_alloc(aux_bytes, &aux)) { drop(); return rc; }
+    for (int k = 0; k < nj; k++) {
+        EncJob& J = jobs[k];
+        J.coef = (short*)((uint8_t*)coef + o_coef[k]);
+        J.out = (uint8_t*)out + o_out[k];
+        if (J.nseg) {
+            J.ustream = (uint32_t*)((uint8_t*)aux + o_u[k]);
+            J.seg_rec = (uint32_t*)((uint8_t*)aux + o_seg[k]);
+            J.chunk_rec = (uint32_t*)((uint8_t*)aux + o_chk[k]);
+            J.ubytes = (uint32_t*)((uint8_t*)aux + o_ub[k]);
+        }
+    }
+    // side blob: tables | jobs | map | segment map | chunk map
+    auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+    const size_t o_jobs = up16(sizeof(EncTables)), o_map = o_jobs + up16(jobs.size() * sizeof(EncJob)),
+                 o_pack = o_map + up16(map.size() * sizeof(EncMap)), o_stuff = o_pack + up16(pack_map.size() * sizeof(EncSeg));
+    std::vector<uint8_t> blob(o_stuff + stuff_map.size() * sizeof(EncSeg) + 16);
     std::memcpy(blob.data(), &T, sizeof(T));
     std::memcpy(blob.data() + o_jobs, jobs.data(), jobs.size() * sizeof(EncJob));
     std::memcpy(blob.data() + o_map, map.data(), map.size() * sizeof(EncMap));
+    if (!pack_map.empty()) std::memcpy(blob.data() + o_pack, pack_map.data(), pack_map.size() * sizeof(EncSeg));
+    if (!stuff_map.empty()) std::memcpy(blob.data() + o_stuff, stuff_map.data(), stuff_map.size() * sizeof(EncSeg));
     if (int rc = upload_small(blob.data(), blob.size(), &side, s)) { drop(); return rc; }
     const uint8_t* sd = (const uint8_t*)side;
-    hipError_t e = hipMemsetAsync((uint8_t*)res + (size_t)nj * 16, 0, 4, s);           // the compact area's cursor
-    hipLaunchKernelGGL(k_jpeg_enc_blocks, dim3((unsigned)map.size()), dim3(256), 0, s, (const EncJob*)(sd + o_jobs), (const EncMap*)(sd + o_map), (const EncTables*)sd);
-    bool wide = false;                                          // any frame of more than 256 block slots: 1024 per pass
-    for (const EncJob& J : jobs) wide = wide || J.nblocks > 256;
-    if (wide) hipLaunchKernelGGL(k_jpeg_enc_huff<1024>, dim3((unsigned)nj), dim3(1024), 0, s, (const EncJob*)(sd + o_jobs), (const EncTables*)sd, (uint32_t*)res,
-                                 (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
-    else hipLaunchKernelGGL(k_jpeg_enc_huff<256>, dim3((unsigned)nj), dim3(256), 0, s, (const EncJob*)(sd + o_jobs), (const EncTables*)sd, (uint32_t*)res,
-                            (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
+    const EncJob* djobs = (const EncJob*)(sd + o_jobs);
+    uint32_t* cursor = (uint32_t*)res + (size_t)nj * 4;
+    hipError_t e = hipMemsetAsync(cursor, 0, 4, s);             // the compact area's cursor
+    if (e == hipSuccess && aux) e = hipMemsetAsync(aux, 0, aux_bytes, s);
+    hipLaunchKernelGGL(k_jpeg_enc_blocks, dim3((unsigned)map.size()), dim3(256), 0, s, djobs, (const EncMap*)(sd + o_map), (const EncTables*)sd);
+    if (nsmall) {
+        bool wide = false;                                      // any frame of more than 256 block slots: 1024 per pass
+        for (int k = 0; k < nsmall; k++) wide = wide || jobs[k].nblocks > 256;
+        if (wide) hipLaunchKernelGGL(k_jpeg_enc_huff<1024>, dim3((unsigned)nsmall), dim3(1024), 0, s, djobs, (const EncTables*)sd, (uint32_t*)res, cursor,
+                                     (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
+        else hipLaunchKernelGGL(k_jpeg_enc_huff<256>, dim3((unsigned)nsmall), dim3(256), 0, s, djobs, (const EncTables*)sd, (uint32_t*)res, cursor,
+                                (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
+    }
+    if (nsmall < nj) {
+        hipLaunchKernelGGL(k_jpeg_enc_pack, dim3((unsigned)pack_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_pack), (const EncTables*)sd, (uint32_t*)aux);
+        hipLaunchKernelGGL(k_jpeg_enc_stuff, dim3((unsigned)stuff_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_stuff), (uint32_t*)res, (uint32_t*)aux + 1);
+    }
     if (e == hipSuccess) e = hipGetLastError();
     void *pin = nullptr, *token = nullptr;
     if (e == hipSuccess && stage_begin(res_bytes + compact_cap, &pin, &token) != IMP_OK) e = hipErrorOutOfMemory;

@@ -131,3 +131,28 @@ def test_encodes_from_several_threads(gpu):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("h,w,c,q,kind", [(767, 1023, 3, 92, "smooth"), (900, 1200, 1, 75, "noise"), (1080, 1920, 4, 100, "noise"), (2160, 3840, 3, 86, "smooth"),
+                                         (401, 3001, 3, 50, "noise"), (3001, 401, 3, 0, "smooth")])
+def test_large_frames_many_workgroups(gpu, h, w, c, q, kind):
+    """Frames of more than 2048 block slots: k_jpeg_enc_pack + k_jpeg_enc_stuff, a workgroup per 256 blocks / per 16 KB of the
+    stream.  Sizes that leave partial segments, partial chunks and dummy blocks; noise at quality 100 (FF bytes everywhere)."""
+    arr = noise_image(h, w, c, 1500 + h) if kind == "noise" else smooth_image(h, w, c)
+    if kind == "smooth":
+        arr = (arr.astype(int) + np.random.default_rng(h).integers(-9, 10, arr.shape)).clip(0, 255).astype(np.uint8)
+    rc_o, want = orc.jpeg_encode(arr, q)
+    im = gpu.Image(arr)
+    rc, got = im.encode_jpeg(q)
+    im.release()
+    assert rc == rc_o == 0
+    assert got == want, (h, w, c, q, len(got), len(want))
+
+
+def test_batch_of_large_and_small_frames(gpu):
+    frames = [noise_image(40, 50, 3, 1), smooth_image(1080, 1920, 3), noise_image(9, 9, 1, 2), smooth_image(700, 900, 4), noise_image(126, 224, 3, 3)]
+    ims = [gpu.Image(f) for f in frames]
+    for (code, data), f in zip(gpu.batch_encode_jpeg(ims, 88), frames):
+        assert code == 0 and data == orc.jpeg_encode(f, 88)[1]
+    for im in ims:
+        im.release()

@@ -2,7 +2,7 @@
 against the reference's loop shape (one impgpu_run_ops per frame).  Wall time per request, uploads and downloads included."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import ngx_http_imgproc_amd as gpu
 
 gpu.env_start(0)

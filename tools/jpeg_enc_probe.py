@@ -1,7 +1,7 @@
 """JPEG encode on the device against Pillow (libjpeg-turbo) on this host: one thumbnail, a batch of thumbnails, one 1080p frame."""
 import io, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import ngx_http_imgproc_amd as gpu
 from ngx_http_imgproc_amd.workloads import photo_like
 
