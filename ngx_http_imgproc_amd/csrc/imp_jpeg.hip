@@ -33,13 +33,16 @@ __device__ __forceinline__ void st_release(uint32_t* p, uint32_t v) { __hip_atom
 // the XCD's whole L2 every time round, and hundreds of waiting waves doing that every few hundred cycles took every
 // kernel on the device down with them (a request stream got slower with every thread added).  One acquire fence after
 // the flag has been seen orders the payload reads behind it.
+#ifndef JPEG_POLL_SLEEP
+#define JPEG_POLL_SLEEP 2      // x 64 cycles between two looks at a flag of the chain (16: 4K lone file 13 % slower; A/B with -DJPEG_POLL_SLEEP=)
+#endif
 __device__ bool wait_flag(const uint32_t* flag) {
     for (int spin = 0; spin < (1 << 21); spin++) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             return true;
         }
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(JPEG_POLL_SLEEP);
     }
     return false;
 }
