@@ -172,9 +172,13 @@ int   impgpu_jpeg_info(const unsigned char* blob, size_t size, int* width, int* 
 /* Diagnostics (host, no device): the quantised coefficients of the file's components, MCU-padded planes one after the
  * other, blocks in raster order, 64 shorts each in row-major order.  how = 0: a plain sequential entropy decoder;
  * how = 1: the device's chunk-parallel scheme executed lane by lane on the host (same code as the kernel's lanes).
- * info[0] = shorts written, [1] = the scheme's status word, [2] = sweeps to the fixed point, [3..5] = first short of
- * each component's plane, [6..8] / [9..11] = blocks per row / column. */
+ * info[0] = shorts written, [1] = the scheme's status word, [2] = chunks whose true entry state was not among their
+ * walks' (how = 1), [3..5] = first short of each component's plane, [6..8] / [9..11] = blocks per row / column.
+ * impgpu_jpeg_sync_stats: more about the calling thread's last how = 1 call -- stats[0] = chunks, [1] = the same misses,
+ * [2] = repair walks (speculative ones included), [3] = chunks reached by an explicit state ("chase"), [4] = chunk bits,
+ * [5] = overlap bits, [6] = walks per chunk. */
 int   impgpu_jpeg_coefficients(const unsigned char* blob, size_t size, int how, short* out, size_t capacity, int* info);
+void  impgpu_jpeg_sync_stats(int stats[8]);
 int   impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int step,
                         impgpu_image** out);               /* borrow memory already in HBM */
 int   impgpu_image_clone(const impgpu_image* src, impgpu_image** out);

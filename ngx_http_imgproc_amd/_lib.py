@@ -115,6 +115,7 @@ SIGNATURES = {
     "impgpu_batch_decode_jpeg": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, PP, IP]),
     "impgpu_jpeg_info": (C.c_int, [C.c_char_p, C.c_size_t, IP, IP, IP]),
     "impgpu_jpeg_coefficients": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, P, C.c_size_t, IP]),
+    "impgpu_jpeg_sync_stats": (None, [IP]),
     "impgpu_host_alloc": (P, [C.c_size_t]),
     "impgpu_host_free": (None, [P]),
     "impgpu_image_upload_pinned": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, PP]),

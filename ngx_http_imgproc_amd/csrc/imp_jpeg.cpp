@@ -7,6 +7,7 @@
 // the host -- reading the marker segments (a few hundred bytes) and removing the FF00 stuffing while the scan is copied into
 // pinned memory; Huffman decoding, dequantisation, IDCT, upsampling and colour conversion run on the device.
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <algorithm>
 #include "imp_jpeg_core.h"
@@ -219,6 +220,19 @@ size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
     return file_bytes <= (size_t(96) << 10) ? 32 : 64;
 }
 
+unsigned jpeg_overlap_bits_for(unsigned chunk_bits, size_t scan_bytes, size_t total_blocks) {
+    if (const char* s = std::getenv("IMPGPU_JPEG_OVERLAP")) {
+        const int v = std::atoi(s);
+        if (v >= 0 && v <= 1 << 20) return (unsigned)v;
+    }
+    // tools/jpeg_sync_probe.py: with five blocks' worth of bits in front of the chunk 97.5-99.5 % of a photograph's chunks find
+    // their true entry state among their walks' (quality 50-90, 1-2.5 bits per pixel); with two or three, four in five
+    (void)chunk_bits;
+    const size_t bits_per_block = total_blocks ? scan_bytes * 8 / total_blocks : 64;
+    const size_t want = (5 * bits_per_block + 63) / 64 * 64;
+    return (unsigned)(want < 256 ? 256 : want > 1024 ? 1024 : want);
+}
+
 int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uint8_t* out, size_t cap, JpegScan* scan) {
     const size_t CBY = scan->chunk_bytes;                                // 128, 64 or 32
     if (CBY != 128 && CBY != 64 && CBY != 32) return IMP_ERROR_INVALID_ARGS;
@@ -423,9 +437,18 @@ void jpeg_scan_meta(const JpegScan& scan, std::vector<uint32_t>* meta) {
 }
 
 // ---- the device's entropy stage, lane by lane on the host (diagnostics and CPU tests only; see imp_jpeg_core.h).
-// Same chunk decoder, same rule (a chunk's entry state is its predecessor's exit state, iterate until nothing changes), same
-// totals, same verdict; the workgroup structure (rounds inside a workgroup, a chain between workgroups) is only a schedule of
-// this fixed-point iteration and is not modelled.  *rounds receives the number of sweeps the fixed point took.
+// The same three steps as the kernels (imp_jpeg.hip), with the very same walks:
+//   k_jpeg_sync   one jpeg_span_walk per (chunk, block of the MCU) from `overlap` bits in front of the chunk; a chunk's true
+//                 entry state is SELECTED among its walks' `in` states by comparing them with its predecessor's true exit --
+//                 on the device a scan over per-chunk maps, here the plain recurrence -- and only a chunk none of whose
+//                 walks had fallen into step by its first bit ("miss") is walked again from the true state
+//   k_jpeg_write  one full walk per chunk from its true entry: coefficients to their places, DC terms summed up inside the
+//                 chunk only
+//   k_jpeg_dcfix  the DC predictors at the chunk's entry (a prefix sum over the interval's chunks) added to the DC terms of
+//                 the blocks that begin in the chunk
+// *rounds receives the number of misses.
+static thread_local int g_sync_stats[8];
+
 int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, const JpegFrame& F0, const int dc_ids[2],
                          const int ac_ids[2], int16_t* coef, unsigned* status, int* rounds) {
     JpegFrame F = F0;
@@ -450,79 +473,146 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     F.nchunks = (unsigned)scan.nchunks;
     F.nsegs = (unsigned)scan.seg_first_chunk.size();
     F.chunk_bits = (unsigned)scan.chunk_bytes * 8;
+    F.overlap_bits = jpeg_overlap_bits_for(F.chunk_bits, size - H.scan_begin, (size_t)F.total_slots / 64);
     const uint8_t* bytes = buf.data();
     auto word = [bytes](uint32_t i) -> uint32_t {
         const uint8_t* q = bytes + (size_t)i * 4;
         return ((uint32_t)q[3] << 24) | ((uint32_t)q[2] << 16) | ((uint32_t)q[1] << 8) | q[0];      // as a little-endian load
     };
-    const uint32_t CB = (uint32_t)scan.chunk_bytes * 8;
+    const uint32_t CB = F.chunk_bits, B = (uint32_t)F.bpm;
     const size_t n = scan.nchunks;
     std::vector<uint32_t> meta;
     jpeg_scan_meta(scan, &meta);
-    std::vector<uint64_t> entry(n), exitst(n);
-    std::vector<JpegDecoded> dec(n);
-    std::vector<uint32_t> seg_end(n), limit(n);
+    // ---- k_jpeg_sync
+    std::vector<uint64_t> entry(n);
+    std::vector<uint32_t> slots(n), seg_end(n), limit(n);
     std::vector<char> origin(n);
+    struct Cand {
+        uint64_t in[6], out[6], rep_out[6];
+        uint32_t n[6], rep_n[6];
+        uint32_t map, via;                                           // via: bit k = the map's entry k comes from a repair walk
+        bool exact;
+    };
+    std::vector<Cand> cand(n);
+    // A. the walks
     for (size_t g = 0; g < n; g++) {
         const uint32_t sg = meta[g], first = scan.seg_first_chunk[sg];
         origin[g] = first == g;
         seg_end[g] = first * CB + scan.seg_bits[sg];
         limit[g] = std::min<uint32_t>((uint32_t)(g + 1) * CB, seg_end[g]);
-        entry[g] = jpeg_pack_state((uint32_t)g * CB, 0, 0, 0);
-        exitst[g] = jpeg_sync_chunk(L, word, entry[g], limit[g], seg_end[g], F);      // the rounds only look for exit states
-    }
-    int sweeps = 0;
-    for (;;) {
-        std::vector<uint64_t> prev = exitst;                          // every lane reads last round's states (as the kernel does)
-        bool changed = false;
-        for (size_t g = 1; g < n; g++) {
-            if (origin[g]) continue;
-            // a predecessor that ran into an undecodable pattern (a wrong guess, normally) has nothing to hand on: the lane
-            // falls back to its own guess, otherwise that dead state would travel one chunk per sweep to the interval's end
-            const uint64_t pred = (prev[g - 1] >> 48) ? jpeg_pack_state((uint32_t)g * CB, 0, 0, 0) : prev[g - 1];
-            if (pred == entry[g]) continue;
-            entry[g] = pred;
-            exitst[g] = jpeg_sync_chunk(L, word, entry[g], limit[g], seg_end[g], F);
-            changed = true;
+        const uint32_t start = (uint32_t)g * CB, seg_start = first * CB;
+        const uint32_t p0 = start - seg_start > F.overlap_bits ? start - F.overlap_bits : seg_start;
+        Cand& c = cand[g];
+        c.exact = p0 == seg_start;                                   // the walk starts where the interval does: no guess
+        for (uint32_t k = 0; k < 6; k++) { c.in[k] = c.out[k] = c.rep_out[k] = JPEG_STATE_NONE; c.n[k] = c.rep_n[k] = 0; }
+        for (uint32_t k = 0; k < (c.exact ? 1u : B); k++) {
+            const JpegSpan sp = jpeg_span_walk(L, word, jpeg_pack_state(p0, k, 0, 0), start, limit[g], seg_end[g], F);
+            c.in[k] = sp.in; c.out[k] = sp.out; c.n[k] = sp.n;
         }
-        sweeps++;
-        if (!changed) break;
-        if ((size_t)sweeps > n + 1) return IMP_ERROR_DECODE_FAILED;   // cannot happen: sweep k settles chunk k of an interval
     }
-    if (rounds) *rounds = sweeps;
-    *status = 0;
-    // every entry state is final: the full walk once per chunk for its slot count and DC differences (k_jpeg_entropy step 3);
-    // it must leave the chunk in the state the lean walk found
+    // B. the maps: a predecessor's exit that is one of the chunk's `in` states selects that walk; one that is not is decoded
+    // on from (a "repair" walk) and, almost always, joins one of the chunk's walks before the chunk ends
+    int repairs = 0, chases = 0, misses = 0;
     for (size_t g = 0; g < n; g++) {
-        dec[g] = jpeg_decode_chunk<false>(L, word, entry[g], limit[g], seg_end[g], F, nullptr);
-        if (dec[g].exit != exitst[g]) return IMP_ERROR_DEVICE;
+        Cand& c = cand[g];
+        c.map = jpeg_map_const(0);
+        c.via = 0;
+        if (c.exact) continue;
+        const Cand& pr = cand[g - 1];
+        c.map = 0;
+        for (uint32_t k = 0; k < 6; k++) {
+            const uint64_t E = pr.out[k];
+            uint32_t v = JPEG_MAP_FAIL, via = 0;
+            uint32_t twin = 6;
+            for (uint32_t k2 = 0; k2 < k && twin == 6; k2++) if (pr.out[k2] == E) twin = k2;
+            if (E == JPEG_STATE_NONE) {
+            } else if (twin < 6) {
+                v = jpeg_map_at(c.map, twin); via = (c.via >> twin) & 1;
+                c.rep_out[k] = c.rep_out[twin]; c.rep_n[k] = c.rep_n[twin];
+            } else {
+                for (uint32_t k1 = 0; k1 < B && v == JPEG_MAP_FAIL; k1++) if (c.in[k1] == E) v = k1;
+                if (v == JPEG_MAP_FAIL) {
+                    const JpegSpan sp = jpeg_span_walk(L, word, E, (uint32_t)g * CB, limit[g], seg_end[g], F);
+                    c.rep_out[k] = sp.out; c.rep_n[k] = sp.n;
+                    via = 1;
+                    repairs++;
+                    for (uint32_t k1 = 0; k1 < B && v == JPEG_MAP_FAIL; k1++) if (c.out[k1] == sp.out) v = k1;
+                }
+            }
+            c.map |= v << (4 * k);
+            c.via |= via << k;
+        }
     }
+    // C. along the chain (on the device: a scan over the maps inside a workgroup, a look-back between workgroups).  Where
+    // even the repair walk joined nothing, its exit is carried on as an explicit state (a "chase") until it joins.
+    {
+        bool explicit_state = false;
+        uint64_t S = 0;
+        uint32_t idx = 0;                                            // which of the predecessor's exits is the true one
+        for (size_t g = 0; g < n; g++) {
+            Cand& c = cand[g];
+            if (c.exact) { entry[g] = c.in[0]; slots[g] = c.n[0]; idx = 0; explicit_state = false; continue; }
+            if (explicit_state) {
+                chases++;
+                uint32_t k1 = 6;
+                for (uint32_t k = 0; k < B && k1 == 6; k++) if (c.in[k] == S) k1 = k;
+                if (k1 < 6) { entry[g] = S; slots[g] = c.n[k1]; idx = k1; explicit_state = false; continue; }
+                const JpegSpan sp = jpeg_span_walk(L, word, S, (uint32_t)g * CB, limit[g], seg_end[g], F);
+                entry[g] = S; slots[g] = sp.n;
+                for (uint32_t k = 0; k < B && k1 == 6; k++) if (c.out[k] == sp.out) k1 = k;
+                if (k1 < 6) { idx = k1; explicit_state = false; } else S = sp.out;
+                continue;
+            }
+            const uint32_t v = jpeg_map_at(c.map, idx);
+            if (!((c.via >> idx) & 1)) {
+                if (v == JPEG_MAP_FAIL) return IMP_ERROR_DEVICE;     // (the true exit of a chunk is never "no candidate")
+                entry[g] = c.in[v]; slots[g] = c.n[v]; idx = v;
+            } else {
+                misses++;
+                entry[g] = cand[g - 1].out[idx]; slots[g] = c.rep_n[idx];
+                if (v != JPEG_MAP_FAIL) idx = v;
+                else { S = c.rep_out[idx]; explicit_state = true; }
+            }
+        }
+    }
+    g_sync_stats[0] = (int)n; g_sync_stats[1] = misses; g_sync_stats[2] = repairs; g_sync_stats[3] = chases;
+    g_sync_stats[4] = (int)CB; g_sync_stats[5] = (int)F.overlap_bits; g_sync_stats[6] = (int)B; g_sync_stats[7] = 0;
+    if (rounds) *rounds = misses;
+    *status = 0;
+    // ---- k_jpeg_write
+    std::vector<JpegDecoded> dec(n);
+    std::vector<uint32_t> slot0(n);
     uint32_t run_n = 0;
-    int run_dc[3] = {0, 0, 0};
     for (size_t g = 0; g < n; g++) {
         const uint32_t sg = meta[g];
-        if (origin[g]) { run_n = 0; run_dc[0] = run_dc[1] = run_dc[2] = 0; }
+        if (origin[g]) run_n = 0;
         JpegWriteCtx W;
         W.coef = coef;
-        W.slot0 = sg * (uint32_t)F.slots_per_seg + run_n;
-        W.dc0[0] = run_dc[0]; W.dc0[1] = run_dc[1]; W.dc0[2] = run_dc[2];
+        W.slot0 = slot0[g] = sg * (uint32_t)F.slots_per_seg + run_n;
+        W.dc0[0] = W.dc0[1] = W.dc0[2] = 0;                          // DC terms relative to the chunk's entry; k_jpeg_dcfix adds the rest
         W.status = status;
         const uint32_t base_n = run_n;
-        run_n += dec[g].n;
-        for (int k = 0; k < 3; k++) run_dc[k] += dec[g].dc[k];
+        run_n += slots[g];
         const size_t last = (sg + 1 < F.nsegs ? scan.seg_first_chunk[sg + 1] : n) - 1;
-        uint32_t budget = 0xffffffffu, end_n = run_n;
-        if (g == last) {                                             // (see k_jpeg_entropy step 5)
-            const uint32_t want = std::min<uint32_t>((uint32_t)F.slots_per_seg, F.total_slots - sg * (uint32_t)F.slots_per_seg);
-            budget = want >= base_n ? want - base_n : 0u;
-            const JpegDecoded e = jpeg_decode_chunk<false>(L, word, entry[g], limit[g], seg_end[g], F, nullptr, budget);
-            const uint32_t pe = (uint32_t)e.exit, fle = (uint32_t)(e.exit >> 48);
+        const uint32_t want = std::min<uint32_t>((uint32_t)F.slots_per_seg, F.total_slots - sg * (uint32_t)F.slots_per_seg);
+        const bool closes = g == last;
+        dec[g] = JpegDecoded{};
+        if (!closes && run_n > want) { *status |= JPEG_ST_OVERRUN; continue; }
+        // the last chunk of an interval walks with the interval's remaining slots as a budget and gives the verdict
+        const uint32_t budget = closes ? (want >= base_n ? want - base_n : 0u) : 0xffffffffu;
+        dec[g] = jpeg_decode_chunk<true>(L, word, entry[g], limit[g], seg_end[g], F, &W, budget);
+        if (closes) {
+            const uint32_t pe = (uint32_t)dec[g].exit, fle = (uint32_t)(dec[g].exit >> 48);
             if ((fle & JPEG_FL_INVALID) || pe > seg_end[g] || seg_end[g] - pe >= 8) *status |= JPEG_ST_BAD_CODE;
-            if (base_n + e.n != want) *status |= JPEG_ST_BAD_COUNT;
-            end_n = base_n + e.n;
-        }
-        if (end_n > (uint32_t)F.slots_per_seg) { *status |= JPEG_ST_OVERRUN; continue; }
-        (void)jpeg_decode_chunk<true>(L, word, entry[g], limit[g], seg_end[g], F, &W, budget);
+            if (base_n + dec[g].n != want) *status |= JPEG_ST_BAD_COUNT;
+        } else if (dec[g].n != slots[g]) *status |= JPEG_ST_BAD_COUNT;      // the lean walk and the full walk disagree: cannot happen
+    }
+    // ---- k_jpeg_dcfix
+    int run_dc[3] = {0, 0, 0};
+    for (size_t g = 0; g < n; g++) {
+        if (origin[g]) run_dc[0] = run_dc[1] = run_dc[2] = 0;
+        jpeg_dc_fixup(L, F, coef, slot0[g], entry[g], dec[g].ndc, run_dc);
+        for (int k = 0; k < 3; k++) run_dc[k] += dec[g].dc[k];
     }
     return IMP_OK;
 }
@@ -540,6 +630,10 @@ int impgpu_jpeg_info(const unsigned char* blob, size_t size, int* width, int* he
     if (height) *height = H.height;
     if (channels) *channels = H.ncomp;
     return IMP_OK;
+}
+
+void impgpu_jpeg_sync_stats(int stats[8]) {
+    if (stats) for (int i = 0; i < 8; i++) stats[i] = g_sync_stats[i];
 }
 
 int impgpu_jpeg_coefficients(const unsigned char* blob, size_t size, int how, short* out, size_t capacity, int* info) {

@@ -62,6 +62,7 @@ struct JpegFrame {
     unsigned total_slots;                    // mcux * mcuy * bpm * 64
     unsigned nchunks, nsegs;
     unsigned chunk_bits;                     // 1024, 512 or 256: what a lane of the entropy kernel owns
+    unsigned overlap_bits;                   // how far in front of its chunk a walk of k_jpeg_sync starts (jpeg_overlap_bits_for)
 };
 
 // The entropy-coded segment made ready for the device: FF00 unstuffed, restart intervals cut at their RSTn markers, every
@@ -79,6 +80,10 @@ struct JpegScan {
 // length and the number of rounds trade against each other).  launch_bytes = entropy-coded bytes of the whole launch.
 // IMPGPU_JPEG_CHUNK_WORDS = 8 | 16 | 32 overrides (A/B).
 size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes);
+// How far in front of its chunk a synchronising walk starts: long enough to hold a block end or two of THIS file (its
+// entropy-coded bytes over its blocks), so that one of the walks has fallen into step with the true decoder by the chunk's
+// first bit.  IMPGPU_JPEG_OVERLAP (bits) overrides (A/B).
+unsigned jpeg_overlap_bits_for(unsigned chunk_bits, size_t scan_bytes, size_t total_blocks);
 // worst-case bytes jpeg_prepare_scan writes for `scan_bytes` of entropy-coded data and `nsegs` intervals
 size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs);
 int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uint8_t* out, size_t cap, JpegScan* scan);

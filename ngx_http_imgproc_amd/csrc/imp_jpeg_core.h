@@ -65,6 +65,7 @@ struct JpegDecoded {
     uint64_t exit;
     uint32_t n;          // coefficient slots passed
     int dc[3];           // sum of the DC differences met, per component
+    uint32_t ndc;        // DC symbols met = blocks that begin in the chunk
 };
 
 struct JpegWriteCtx {
@@ -112,6 +113,7 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
     JpegDecoded r;
     r.exit = entry;
     r.n = 0;
+    r.ndc = 0;
     r.dc[0] = r.dc[1] = r.dc[2] = 0;
     uint32_t p = (uint32_t)entry;
     uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
@@ -132,7 +134,7 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
     int have = 64 - (int)(p & 31);
     widx += 2;
     uint32_t ahead = word(widx);
-    uint32_t fl = 0, n = 0, damaged = 0;
+    uint32_t fl = 0, n = 0, damaged = 0, ndc = 0;
     int dcs0 = 0, dcs1 = 0, dcs2 = 0;
     // where the coefficients go (WRITE): MCU coordinates are carried along, a block's address is base + mx*dx + my*dy
     uint32_t mx = 0, my = 0, blk = 0;
@@ -189,6 +191,7 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
                     jpeg_put_coef(W->coef, blk + L.natural[z + run], (int16_t)v);
                 }
             }
+            ndc += isdc ? 1u : 0u;
             dcs0 += (isdc && ci == 0) ? v : 0;
             dcs1 += (isdc && ci == 1) ? v : 0;
             dcs2 += (isdc && ci == 2) ? v : 0;
@@ -214,6 +217,7 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
     }
     r.exit = jpeg_pack_state(p, c, z, fl);
     r.n = n;
+    r.ndc = ndc;
     r.dc[0] = dcs0;
     r.dc[1] = dcs1;
     r.dc[2] = dcs2;
@@ -285,5 +289,127 @@ IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint6
     } while (p < limit);
     return jpeg_pack_state(p, c, z, fl);
 }
+
+// The write walk (jpeg_decode_chunk<true> with dc0 = 0) leaves every DC term relative to its chunk's entry; this adds the
+// predictors at the entry (`base`, per component) to the `ndc` blocks that begin in the chunk.  Same block walk as the
+// decoder's: MCU coordinates carried along, a block's address is base + mx*dx + my*dy.
+IMP_HD inline void jpeg_dc_fixup(const JpegHuffTabs& L, const JpegFrame& F, int16_t* coef, uint32_t slot0, uint64_t entry, uint32_t ndc, const int base[3]) {
+    const uint32_t z = (uint32_t)(entry >> 40) & 0xff;
+    const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
+    const uint32_t gb = (slot0 >> 6) + (z ? 1u : 0u);               // a chunk entered in mid-block begins with the next block's DC term
+    const uint32_t mcu = gb / bpm;
+    uint32_t c = gb - mcu * bpm, my = mcu / (uint32_t)F.mcux, mx = mcu - my * (uint32_t)F.mcux;
+    for (uint32_t j = 0; j < ndc; j++) {
+        const int add = c < nluma ? base[0] : (c - nluma == 0 ? base[1] : base[2]);
+        if (my < (uint32_t)F.mcuy && add) {
+            const uint32_t at = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
+            coef[at] = (int16_t)(coef[at] + add);
+        }
+        c++;
+        if (c == bpm) { c = 0; mx++; if (mx == (uint32_t)F.mcux) { mx = 0; my++; } }
+    }
+}
+
+// Round 4: the walk of the phase-parallel scheme (k_jpeg_sync).  It starts `overlap` bits BEFORE the chunk it belongs to, in
+// a guessed state (that bit, start of block k of the MCU), and reports two states: `in`, the first state it reaches at or
+// behind bit `cross` (the chunk's first bit), and `out`, the first at or behind `limit` -- plus the coefficient slots passed
+// by the symbols that start in [cross, limit).  A state is everything the decoder's future depends on, so whenever a
+// predecessor's `out` equals a walk's `in` the walk's `out` IS what decoding on from the predecessor's state gives: the
+// successor is SELECTED, not decoded again.  With one walk per block of the MCU (six for 4:2:0) the true state is almost
+// always among the `in`s once the overlap holds a block end or two -- bit position and coefficient index fall into step by
+// themselves, and every block phase is being tried.  Same symbol step as jpeg_sync_chunk.
+struct JpegSpan {
+    uint64_t in, out;
+    uint32_t n;
+};
+template <class WordFn>
+IMP_HD inline JpegSpan jpeg_span_walk(const JpegHuffTabs& L, WordFn word, uint64_t entry, uint32_t cross, uint32_t limit, uint32_t seg_end, const JpegFrame& F) {
+    JpegSpan r;
+    r.in = r.out = entry;
+    r.n = 0;
+    uint32_t p = (uint32_t)entry;
+    uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
+    if ((uint32_t)(entry >> 48)) return r;                          // a dead state stays what it is
+    const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
+    uint32_t tabsel = 0, nextc = 0;
+    for (uint32_t k = 0; k < 6; k++) {
+        const uint32_t ci = k < nluma ? 0u : (k - nluma + 1 < 3 ? k - nluma + 1 : 2u);
+        const uint32_t dct = (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]);
+        const uint32_t act = 2u + (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]);
+        tabsel |= (dct | (act << 2)) << (4 * k);
+        nextc |= (k + 1 == bpm ? 0u : k + 1) << (4 * k);
+    }
+    uint32_t widx = p >> 5;
+    uint64_t buf = (((uint64_t)jpeg_be(word(widx)) << 32) | jpeg_be(word(widx + 1))) << (p & 31);
+    int have = 64 - (int)(p & 31);
+    widx += 2;
+    uint32_t ahead = word(widx);
+    uint32_t fl = 0, n = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int stage = 0; stage < 2; stage++) {
+        uint32_t target = stage ? limit : cross;
+        n = 0;
+        while (p < target) {                                        // (an ending pulls `target` down to zero: one way out)
+            const bool isdc = z == 0;
+            const uint32_t tab = (tabsel >> (4 * c + (isdc ? 0u : 2u))) & 3;
+            const uint32_t peek = (uint32_t)(buf >> 48);
+            uint32_t e = L.lut[tab][peek >> (16 - JPEG_LOOKBITS)];
+            if ((e & 31) == 0) {                                    // a code longer than the table's index (rare)
+                uint32_t len = JPEG_LOOKBITS + 1;
+                for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= L.limit[tab][l] ? 1u : 0u;
+                const bool none = peek >= L.limit[tab][16];         // no code starts with these 16 bits
+                const uint32_t sym = L.vals[tab][(uint32_t)(L.offs[tab][len] + (int)(peek >> (16 - len))) & 255];
+                e = none ? 0u : jpeg_lut_expand(jpeg_lut_entry(len, sym, isdc));
+                fl = none ? ((seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID) : fl;
+            }
+            uint32_t total = (e >> 16) & 31, adv = e >> 21;
+            const bool pad = fl == 0 && p + total > seg_end;        // the interval's padding, not a symbol
+            fl = pad ? JPEG_FL_END : fl;
+            total = fl ? 0u : total;
+            adv = fl ? 0u : adv;
+            target = fl ? 0u : target;
+            buf <<= total;
+            have -= (int)total;
+            p += total;
+            if (have <= 32) {
+                buf |= (uint64_t)jpeg_be(ahead) << (32 - have);
+                have += 32;
+                widx++;
+                ahead = word(widx);
+            }
+            const uint32_t room = 64 - z;                           // (jpeg_decode_chunk counts a run that leaves its block up to the block's end)
+            n += adv < room ? adv : room;
+            z += adv;
+            const bool ended = z >= 64;
+            const uint32_t cn = (nextc >> (4 * c)) & 15;
+            z = ended ? 0u : z;
+            c = ended ? cn : c;
+        }
+        if (stage == 0) r.in = jpeg_pack_state(p, c, z, fl);
+    }
+    r.out = jpeg_pack_state(p, c, z, fl);
+    r.n = n;
+    return r;
+}
+
+// ---- maps: which of a chunk's six exit candidates follows from each of its predecessor's six (a nibble each; FAIL = not
+// known).  Composing them along the chain is the scan that replaces the rounds of re-decoding.
+constexpr uint32_t JPEG_MAP_FAIL = 15u;
+constexpr uint64_t JPEG_STATE_NONE = ~0ull;                         // "no candidate here" (its flag bits are set: a dead state)
+IMP_HD inline uint32_t jpeg_map_at(uint32_t m, uint32_t k) { return (m >> (4 * k)) & 15u; }
+IMP_HD inline uint32_t jpeg_map_const(uint32_t k) { return k * 0x111111u; }
+IMP_HD inline uint32_t jpeg_map_then(uint32_t first, uint32_t second) {      // `first`, then `second`
+    uint32_t r = 0;
+    for (uint32_t k = 0; k < 6; k++) {
+        const uint32_t v = jpeg_map_at(first, k);
+        const uint32_t w = (second >> (4 * (v & 7))) & 15u;         // (v & 7: a FAIL must not shift by 60)
+        r |= (v == JPEG_MAP_FAIL ? JPEG_MAP_FAIL : w) << (4 * k);
+    }
+    return r;
+}
+// every input leads to the same known output: what comes before the chunk no longer matters
+IMP_HD inline bool jpeg_map_is_const(uint32_t m) { return (m & 0xffffffu) == jpeg_map_const(m & 15u) && (m & 15u) != JPEG_MAP_FAIL; }
 
 }  // namespace imp
