@@ -195,6 +195,42 @@ int jpeg_build_table(const JpegHuffSpec& spec, bool is_dc, JpegHuffDev* out) {
     }
     out->limit[0] = 0;
     out->limit[17] = 0x10000;
+    // Second level: the codes longer than the first level's index, grouped by their first JPEG_LOOKBITS bits; a group's
+    // entry in the first level says where its sub-table starts and how many more bits index it.  (A long code met by ANY lane
+    // of a wave sends the whole wave through the long-code path: with the limit walk that path was most of the walk's
+    // instructions.)  A table whose long codes need more room than there is keeps the limit walk.
+    {
+        struct Long { unsigned code; int len; uint8_t sym; };
+        std::vector<Long> longs;
+        unsigned cd = 0;
+        int idx = 0;
+        for (int l = 1; l <= 16; l++) {
+            for (unsigned k = 0; k < spec.bits[l]; k++, idx++)
+                if (l > JPEG_LOOKBITS) longs.push_back(Long{cd + k, l, spec.vals[idx]});
+            cd = (cd + spec.bits[l]) << 1;
+        }
+        unsigned next = 0;
+        bool fits = true;
+        std::vector<std::pair<unsigned, unsigned>> pointers;         // (first-level index, entry)
+        for (size_t a = 0; a < longs.size() && fits;) {
+            const unsigned prefix = longs[a].code >> (longs[a].len - JPEG_LOOKBITS);
+            size_t b = a;
+            int maxlen = 0;
+            while (b < longs.size() && (longs[b].code >> (longs[b].len - JPEG_LOOKBITS)) == prefix) { maxlen = std::max(maxlen, longs[b].len); b++; }
+            const unsigned nb = (unsigned)(maxlen - JPEG_LOOKBITS);
+            if (next + (1u << nb) > (unsigned)JPEG_SUB_ENTRIES || nb > 7) { fits = false; break; }
+            for (size_t i = a; i < b; i++) {
+                const unsigned rem = (unsigned)(longs[i].len - JPEG_LOOKBITS);
+                const unsigned lo = (longs[i].code & ((1u << rem) - 1)) << (nb - rem);
+                for (unsigned f = 0; f < (1u << (nb - rem)); f++) out->sub[next + lo + f] = (uint16_t)jpeg_lut_entry((uint32_t)longs[i].len, longs[i].sym, is_dc);
+            }
+            pointers.push_back({prefix, 0x8000u | (nb << 12) | ((next >> 1) << 5)});
+            next += std::max(2u, 1u << nb);
+            a = b;
+        }
+        if (fits) for (auto& pr : pointers) out->lut[pr.first] = (uint16_t)pr.second;
+        else std::memset(out->sub, 0, sizeof out->sub);
+    }
     if (is_dc)
         for (int i = 0; i < spec.nvals; i++)
             if (spec.vals[i] > 15) return IMP_ERROR_DECODE_FAILED;
@@ -202,7 +238,7 @@ int jpeg_build_table(const JpegHuffSpec& spec, bool is_dc, JpegHuffDev* out) {
 }
 
 size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs) {
-    return scan_bytes + (nsegs + 2) * JPEG_CHUNK_BYTES;
+    return scan_bytes + (nsegs + 2) * JPEG_CHUNK_BYTES_MAX;
 }
 
 // Copies the entropy-coded bytes out of the file: FF 00 becomes FF, fill FFs go, an RSTn marker closes the interval (the
@@ -211,12 +247,12 @@ size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs) {
 size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
     if (const char* s = std::getenv("IMPGPU_JPEG_CHUNK_WORDS")) {
         const int w = std::atoi(s);
-        if (w == 8 || w == 16 || w == 32) return (size_t)w * 4;
+        if (w == 8 || w == 16 || w == 32 || w == 64) return (size_t)w * 4;
     }
     // measured, one request at a time (profiles/r03_request_latency.txt; 256 / 512 / 1024 bits): 640x480 0.77 / 0.76 / 0.89 ms,
     // 720p 0.83 / 0.84 / 0.94, 1080p 0.90 / 0.84 / 0.95, 4K 1.45 / 1.24 / 1.24; a queue's worth of files (28 MB) is a little
     // faster on 1024
-    if (launch_bytes > (size_t(4) << 20)) return JPEG_CHUNK_BYTES;
+    if (launch_bytes > (size_t(4) << 20)) return JPEG_CHUNK_BYTES_MAX;    // (a walk's overlap weighs half as much on 2048 bits as on 1024)
     return file_bytes <= (size_t(96) << 10) ? 32 : 64;
 }
 
@@ -234,8 +270,8 @@ unsigned jpeg_overlap_bits_for(unsigned chunk_bits, size_t scan_bytes, size_t to
 }
 
 int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uint8_t* out, size_t cap, JpegScan* scan) {
-    const size_t CBY = scan->chunk_bytes;                                // 128, 64 or 32
-    if (CBY != 128 && CBY != 64 && CBY != 32) return IMP_ERROR_INVALID_ARGS;
+    const size_t CBY = scan->chunk_bytes;                                // 256, 128, 64 or 32
+    if (CBY != 256 && CBY != 128 && CBY != 64 && CBY != 32) return IMP_ERROR_INVALID_ARGS;
     scan->seg_first_chunk.clear();
     scan->seg_bits.clear();
     const size_t total_mcus = (size_t)H.mcux * H.mcuy;
@@ -255,7 +291,7 @@ int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uin
     while (!done) {
         const uint8_t* ff = at < size ? (const uint8_t*)std::memchr(blob + at, 0xFF, size - at) : nullptr;
         const size_t run = (ff ? (size_t)(ff - blob) : size) - at;
-        if (o + run + 2 * JPEG_CHUNK_BYTES > cap) return IMP_ERROR_DECODE_FAILED;
+        if (o + run + 2 * JPEG_CHUNK_BYTES_MAX > cap) return IMP_ERROR_DECODE_FAILED;
         std::memcpy(out + o, blob + at, run);
         o += run;
         at += run;
@@ -464,12 +500,14 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     JpegHuffTabs& L = Lv[0];
     for (int k = 0; k < 4; k++) {
         for (size_t i = 0; i < sizeof tabs[k].lut / sizeof tabs[k].lut[0]; i++) L.lut[k][i] = jpeg_lut_expand(tabs[k].lut[i]);
+        for (size_t i = 0; i < (size_t)JPEG_SUB_ENTRIES; i++) L.sub[k][i] = jpeg_lut_expand(tabs[k].sub[i]);
         std::memcpy(L.limit[k], tabs[k].limit, sizeof L.limit[k]);
         std::memcpy(L.offs[k], tabs[k].offs, sizeof L.offs[k]);
         std::memcpy(L.vals[k], tabs[k].vals, sizeof L.vals[k]);
     }
-    std::memcpy(L.natural, kNatural, 64);
-    for (int k = 0; k < F.bpm; k++) jpeg_block_steps(F, k, &L.blk_base[k], &L.blk_dx[k], &L.blk_dy[k]);
+    JpegBlockTabs K;
+    std::memcpy(K.natural, kNatural, 64);
+    for (int k = 0; k < F.bpm; k++) jpeg_block_steps(F, k, &K.blk_base[k], &K.blk_dx[k], &K.blk_dy[k]);
     F.nchunks = (unsigned)scan.nchunks;
     F.nsegs = (unsigned)scan.seg_first_chunk.size();
     F.chunk_bits = (unsigned)scan.chunk_bytes * 8;
@@ -600,7 +638,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
         if (!closes && run_n > want) { *status |= JPEG_ST_OVERRUN; continue; }
         // the last chunk of an interval walks with the interval's remaining slots as a budget and gives the verdict
         const uint32_t budget = closes ? (want >= base_n ? want - base_n : 0u) : 0xffffffffu;
-        dec[g] = jpeg_decode_chunk<true>(L, word, entry[g], limit[g], seg_end[g], F, &W, budget);
+        dec[g] = jpeg_write_chunk(L, K, word, entry[g], limit[g], seg_end[g], F, &W, budget);
         if (closes) {
             const uint32_t pe = (uint32_t)dec[g].exit, fle = (uint32_t)(dec[g].exit >> 48);
             if ((fle & JPEG_FL_INVALID) || pe > seg_end[g] || seg_end[g] - pe >= 8) *status |= JPEG_ST_BAD_CODE;
@@ -611,7 +649,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     int run_dc[3] = {0, 0, 0};
     for (size_t g = 0; g < n; g++) {
         if (origin[g]) run_dc[0] = run_dc[1] = run_dc[2] = 0;
-        jpeg_dc_fixup(L, F, coef, slot0[g], entry[g], dec[g].ndc, run_dc);
+        jpeg_dc_fixup(K, F, coef, slot0[g], entry[g], dec[g].ndc, run_dc);
         for (int k = 0; k < 3; k++) run_dc[k] += dec[g].dc[k];
     }
     return IMP_OK;
@@ -644,7 +682,8 @@ int impgpu_jpeg_coefficients(const unsigned char* blob, size_t size, int how, sh
     int dc_ids[2], ac_ids[2];
     if (int rc = jpeg_frame_setup(H, &F, dc_ids, ac_ids)) return rc;
     if ((size_t)F.total_slots > capacity) return IMP_ERROR_INVALID_ARGS;
-    std::memset(out, 0, (size_t)F.total_slots * sizeof(short));
+    // (how = 1: the planes start out as garbage -- the write walk has to put every coefficient of every block there itself)
+    std::memset(out, how == 0 ? 0 : 0x5a, (size_t)F.total_slots * sizeof(short));
     unsigned status = 0;
     int rounds = 0;
     int rc;

@@ -7,10 +7,14 @@
 
 namespace imp {
 
-constexpr int JPEG_LOOKBITS = 10;            // codes up to this length resolve with one LDS lookup
+#ifndef JPEG_LOOKBITS_N
+#define JPEG_LOOKBITS_N 10                   // (A/B builds: -DJPEG_LOOKBITS_N=9)
+#endif
+constexpr int JPEG_SUB_ENTRIES = 256;        // second-level entries per table (the Annex K tables need 128 or fewer)
+constexpr int JPEG_LOOKBITS = JPEG_LOOKBITS_N;   // codes up to this length resolve with one LDS lookup
 constexpr int JPEG_CHUNK_WORDS = 32;         // a decoder lane owns 1024 bits of the unstuffed stream -- or 512 / 256 for a launch too
+constexpr int JPEG_CHUNK_BYTES_MAX = 256;    // the longest chunk jpeg_prepare_scan cuts
 constexpr int JPEG_CHUNK_BYTES = JPEG_CHUNK_WORDS * 4;   // small to fill the device (JpegScan::chunk_bytes, chosen by jpeg_chunk_bytes_for)
-constexpr int JPEG_HUFF_BLOCK = 256;         // chunks (= lanes) per workgroup of the entropy kernel
 
 struct JpegHuffSpec {                        // a DHT table as the file gives it
     bool present = false;
@@ -45,7 +49,9 @@ int jpeg_parse(const uint8_t* blob, size_t size, JpegHeader* H);
 
 // One Huffman table as the kernels read it.
 struct JpegHuffDev {
-    uint16_t lut[1 << JPEG_LOOKBITS];        // jpeg_lut_entry() of the code a JPEG_LOOKBITS-bit peek starts with; length 0 = a longer code
+    uint16_t lut[1 << JPEG_LOOKBITS];        // jpeg_lut_entry() of the code a JPEG_LOOKBITS-bit peek starts with; length 0 = a longer code:
+                                             // 0x8000 | nb << 12 | (off / 2) << 5 = look in sub[off + the next nb bits], or 0 = walk the limits
+    uint16_t sub[JPEG_SUB_ENTRIES];          // second level: jpeg_lut_entry() of the codes longer than JPEG_LOOKBITS (0 = no such code)
     uint32_t limit[18];                      // limit[l]: 16-bit left-aligned peeks below it start with a code of length <= l
     int32_t offs[18];                        // symbol index = offs[l] + (peek16 >> (16 - l))
     uint8_t vals[256];
@@ -62,7 +68,7 @@ struct JpegFrame {
     unsigned total_slots;                    // mcux * mcuy * bpm * 64
     unsigned nchunks, nsegs;
     unsigned chunk_bits;                     // 1024, 512 or 256: what a lane of the entropy kernel owns
-    unsigned overlap_bits;                   // how far in front of its chunk a walk of k_jpeg_sync starts (jpeg_overlap_bits_for)
+    unsigned overlap_bits;                   // how far in front of its chunk a walk of k_jpeg_select starts (jpeg_overlap_bits_for)
 };
 
 // The entropy-coded segment made ready for the device: FF00 unstuffed, restart intervals cut at their RSTn markers, every
@@ -71,7 +77,7 @@ struct JpegScan {
     std::vector<uint32_t> seg_first_chunk;   // per interval
     std::vector<uint32_t> seg_bits;          // per interval: payload length in bits (8 * bytes)
     size_t nchunks = 0;                      // chunks holding payload (the trailing guard chunk is not counted)
-    size_t chunk_bytes = JPEG_CHUNK_BYTES;   // IN: 128, 64 or 32
+    size_t chunk_bytes = JPEG_CHUNK_BYTES;   // IN: 256, 128, 64 or 32
 };
 // How a launch's files are cut: 128-byte chunks fill the device when there are many of them; a small launch (a lone request,
 // up to 4 MB of entropy-coded data)
@@ -102,10 +108,10 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
                          const int ac_ids[2], int16_t* coef, unsigned* status, int* rounds);
 
 // ---- imp_jpeg.hip
-// status word the entropy kernel leaves behind: 0 = every interval decoded to exactly its MCUs
+// status word the entropy kernels leave behind: 0 = every interval decoded to exactly its MCUs
 constexpr unsigned JPEG_ST_BAD_CODE = 1u, JPEG_ST_BAD_COUNT = 2u, JPEG_ST_CHAIN_TIMEOUT = 4u, JPEG_ST_OVERRUN = 8u;
-// One file of a launch.  Both kernels take a table of these plus a map from workgroup number to (job, workgroup within
-// the job), so any number of files -- a request, an album, a queue's worth of requests -- costs the same two launches.
+// One file of a launch.  All kernels take a table of these plus a map from workgroup number to (job, workgroup within
+// the job), so any number of files -- a request, an album, a queue's worth of requests -- costs the same few launches.
 struct JpegJob {
     JpegFrame F;
     const uint32_t* words;                   // the prepared scan
@@ -114,20 +120,54 @@ struct JpegJob {
     const uint32_t* seg_bits;
     const JpegHuffDev* tables;               // [0..1] DC, [2..3] AC
     const uint16_t* qt;                      // [3][64] natural order: the components' quantisation tables
-    int16_t* coef;                           // the MCU-padded coefficient planes (zeroed before the entropy launch)
-    uint32_t* header;                        // 4 words, zeroed: [1] status, [2] / [3] most rounds a workgroup took before / after the hand-over
-    uint32_t* records;                       // JPEG_CTL_REC words per workgroup of the job, zeroed: the chain
+    int16_t* coef;                           // the MCU-padded coefficient planes (every block written whole by k_jpeg_write)
+    uint32_t* header;                        // 4 words, zeroed: [1] status, [2] repair walks, [3] chunks reached by a chase
+    uint32_t* records;                       // JPEG_CTL_REC words per workgroup of k_jpeg_select, zeroed: the chain
+    uint64_t *cand_in, *cand_out;            // [bpm][nchunks], k_jpeg_walks -> k_jpeg_select: the state of walk k of a chunk at its first bit / behind its last
+    uint32_t* cand_n;                        // ... and the coefficient slots passed between the two
+    uint8_t* cand_nib;                       // [bpm][nchunks], k_jpeg_mend -> k_jpeg_select: candidate k of the chunk before leads into walk (nib & 15) of this one
+                                             // (15 = none); | 16 = found by a repair walk; 32 | k2 = the same state as candidate k2: its answer
+    uint64_t* rep_out;                       // ... the repair walk's exit state and slot count
+    uint32_t* rep_n;
+    struct JpegHuffTabs* tabs;               // the tables as the decoder lanes read them (written by k_jpeg_walks)
+    uint32_t* ext_idx;                       // [bpm][nchunks]: the record of a candidate whose repair walk joined nothing (valid where cand_nib == 15 | 16)
+    uint32_t* ext;                           // records of JPEG_EXT_WORDS words: [0] chunk, [1] candidate, [2] steps, [3] joined candidate of the last step's chunk
+                                             // (14 = the chain ended at an interval's end, 15 = not joined), then per step {entry state (2), slots};
+                                             // the last two words: the state behind the last step when not joined
+    uint32_t* ext_count;                     // records handed out (zeroed with the control area)
+    uint32_t ext_cap;
+    uint64_t* chunk_entry;                   // per chunk, k_jpeg_select -> k_jpeg_write: the decoder state at its first symbol
+    uint32_t* chunk_n;                       // ... and the coefficient slots its symbols pass
+    uint32_t* chunk_slot0;                   // per chunk, k_jpeg_write -> k_jpeg_dcfix: the slot of its first symbol
+    int* chunk_dc;                           // ... and [4]: its DC differences summed per component, its DC symbols
+    int* wg_dc;                              // [8] per workgroup of k_jpeg_write: the sums over its chunks [0..2]; its clock at start and end [4], [5]
+    int16_t* dcadd;                          // per block, in scan order, k_jpeg_dcfix -> k_jpeg_pixels: what its DC term in the planes lacks
+                                             // (null: the planes hold absolute DC terms -- the host's entropy stage)
     uint8_t* dst;                            // the frame
     int dstep;
 };
-constexpr int JPEG_CTL_REC = 24;             // [0..1] the tentative exit state, one 64-bit word kept up to date by the last lane (0 = nothing yet), [3..5] final exit
-                                             // state (flag, lo, hi), [6..10] totals (flag, n, dc0..2), [12..22] the workgroup's clock at its phase boundaries, low words
-                                             // of wall_clock64() (IMPGPU_JPEG_TRACE=2 prints them)
+// a workgroup's record in the chain of k_jpeg_select (words):
+//   [1] 1 = its map is in [2]; 2 = its final word is in [3..5]
+//   [2] the composed map of its chunks: which candidate of its last chunk follows from each candidate of its predecessor's
+//   [3] the final word: 0..5 = that candidate of its last chunk is the true exit state; 15 = the state in [4..5] is;
+//       13 = the next chunk is step [5] of record [4]
+//   [6] coefficient slots passed by its chunks      [20..31] its clock at the phase boundaries (IMPGPU_JPEG_TRACE=2)
+constexpr int JPEG_EXT_STEPS = 6, JPEG_EXT_WORDS = 4 + 3 * JPEG_EXT_STEPS + 2;
+constexpr int JPEG_CTL_REC = 32;
+constexpr int JPEG_SYNC_BLOCK = 256;         // lanes per workgroup of k_jpeg_select: (chunk, block of the MCU) pairs
+#ifndef JPEG_HUFF_BLOCK_N
+#define JPEG_HUFF_BLOCK_N 256
+#endif
+constexpr int JPEG_HUFF_BLOCK = JPEG_HUFF_BLOCK_N;         // chunks (= lanes) per workgroup of k_jpeg_write / k_jpeg_dcfix
 constexpr int JPEG_TILE_W = 256, JPEG_TILE_H = 64;   // pixels a workgroup of the pixel kernel produces
 struct JpegMapEntry { uint32_t job, local; };
+inline unsigned jpeg_sync_chunks_per_block(int bpm) { return (unsigned)JPEG_SYNC_BLOCK / (unsigned)bpm; }   // 256, 85, 64, 42
+inline unsigned jpeg_sync_blocks(unsigned nchunks, int bpm) { const unsigned c = jpeg_sync_chunks_per_block(bpm); return (nchunks + c - 1) / c; }
 inline unsigned jpeg_entropy_blocks(unsigned nchunks) { return (nchunks + JPEG_HUFF_BLOCK - 1) / JPEG_HUFF_BLOCK; }
-// `ticket` = one zeroed word per launch; block_map in job-major order (a job's workgroups in increasing order)
-int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* block_map, unsigned total_blocks, uint32_t* ticket, hipStream_t s);
+// `ticket` = one zeroed word per launch; both maps in job-major order (a job's workgroups in increasing order):
+// sync_map for k_jpeg_select (jpeg_sync_blocks per job), chunk_map for k_jpeg_write and k_jpeg_dcfix (jpeg_entropy_blocks)
+int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* sync_map, unsigned sync_blocks, const JpegMapEntry* chunk_map,
+                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s);
 // dequantise + ISLOW IDCT + fancy upsampling + YCbCr->BGR, coefficient planes -> frames; all jobs of one sampling class
 int launch_jpeg_pixels(int hs, int vs, int ncomp, const JpegJob* jobs, const JpegMapEntry* tile_map, unsigned total_tiles, hipStream_t s);
 

@@ -1,26 +1,30 @@
 // imp_jpeg.hip -- device side of the JPEG front (imp_jpeg.h): what libjpeg does under cvDecodeImage at bridge.c:545-552.
 //
-//   k_jpeg_entropy   Huffman decoding of a whole scan in ONE launch.  The unstuffed stream is cut into 1024-bit chunks, one
-//                    per lane.  Only the first chunk of a restart interval starts at a known decoder state; every other lane
-//                    starts at its chunk's first bit in a guessed state and relies on the self-synchronisation of Huffman
-//                    codes: lane t takes over the state lane t-1 leaves behind and re-decodes its chunk until nothing in the
-//                    workgroup changes (a fixed point: every chunk's entry state is its predecessor's exit state, and the
-//                    first chunk of an interval is exact, so by induction all are).  Workgroups take tickets, so a
-//                    workgroup may wait for its predecessor's exit state and running totals (coefficient slots, DC sums)
-//                    -- a chained scan.  With the totals known every lane decodes its chunk once more and scatters the
-//                    non-zero coefficients into the (zeroed) planes, DC terms already integrated.
-//   k_jpeg_pixels    dequantisation, libjpeg's ISLOW 8x8 IDCT (jidctint.c), fancy chroma upsampling (jdsample.c) and
-//                    YCbCr -> B,G,R (jdcolor.c) for a 256x64 pixel tile per workgroup; the planes live only in LDS.
+// Huffman decoding of any number of scans in three launches.  The unstuffed stream of a file is cut into chunks of 256 ...
+// 1024 bits.  A Huffman stream has no random access, but a decoder started at a wrong bit falls into step with the true one
+// after a few symbols; what does NOT fall into step by itself is the block within the MCU (luma or chroma tables?), which a
+// guessing decoder only learns by derailing at the next luma/chroma boundary.  So:
+//   k_jpeg_sync    a lane per (chunk, block of the MCU): it starts `overlap` bits in FRONT of its chunk as if block k of an MCU
+//                  began there, and notes the state it is in at the chunk's first bit and at its last.  The true entry state
+//                  of a chunk is then SELECTED, not decoded: it is the walk whose state at the first bit equals the
+//                  predecessor's true exit state -- per chunk a map from the predecessor's six exit candidates to its own
+//                  six, composed along the chain by a scan inside the workgroup and a look-back between workgroups (which
+//                  take tickets, so the one waited for is always running already).  The few predecessor states no walk
+//                  arrived in are decoded on from ("repair": they almost always join a walk before the chunk ends); what
+//                  even that leaves open is carried forward as an explicit state by one lane ("chase").  Round 3 re-decoded
+//                  in rounds instead, one chunk of progress per round: 9-14 + 2-6 rounds for a 4:2:0 file.
+//   k_jpeg_write   a lane per chunk decodes it once from its true entry state; a block belongs to the chunk it begins in, whose
+//                  lane writes all 64 of its coefficients (zeros, then the others), so nothing has to be cleared
+//                  beforehand; DC terms are summed up inside the chunk only
+//   k_jpeg_dcfix   adds the DC predictors at a chunk's entry (a prefix sum over the interval's chunks) to its blocks
+//   k_jpeg_pixels  dequantisation, libjpeg's ISLOW 8x8 IDCT (jidctint.c), fancy chroma upsampling (jdsample.c) and
+//                  YCbCr -> B,G,R (jdcolor.c) for a 256x64 pixel tile per workgroup; the planes live only in LDS.
 // Integer arithmetic throughout; tests/test_gpu_jpeg.py compares with the Pillow-pinned oracle bit for bit.
 #include "imp_jpeg_core.h"
 
 namespace imp {
 
 namespace {
-
-constexpr int HB = JPEG_HUFF_BLOCK;
-
-constexpr int CTL_REC = JPEG_CTL_REC;
 
 __constant__ uint8_t c_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -36,30 +40,172 @@ __device__ __forceinline__ void st_release(uint32_t* p, uint32_t v) { __hip_atom
 #ifndef JPEG_POLL_SLEEP
 #define JPEG_POLL_SLEEP 2      // x 64 cycles between two looks at a flag of the chain (16: 4K lone file 13 % slower; A/B with -DJPEG_POLL_SLEEP=)
 #endif
-__device__ bool wait_flag(const uint32_t* flag) {
+__device__ uint32_t wait_flag_ge(const uint32_t* flag, uint32_t want) {
     for (int spin = 0; spin < (1 << 21); spin++) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= want) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            return true;
+            return v;
         }
         __builtin_amdgcn_s_sleep(JPEG_POLL_SLEEP);
     }
-    return false;
+    return 0;
 }
 
-__global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_jpeg_entropy(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map,
-                                                      uint32_t* __restrict__ launch_ticket) {
+// the Huffman tables of a job into LDS as a decoder lane reads them
+__device__ __forceinline__ void load_tables(JpegHuffTabs& L, const JpegHuffDev* tables, int t, int nthreads) {
+    for (int i = t; i < 4 * (1 << JPEG_LOOKBITS); i += nthreads) L.lut[i >> JPEG_LOOKBITS][i & ((1 << JPEG_LOOKBITS) - 1)] = jpeg_lut_expand(tables[i >> JPEG_LOOKBITS].lut[i & ((1 << JPEG_LOOKBITS) - 1)]);
+    for (int i = t; i < 4 * JPEG_SUB_ENTRIES; i += nthreads) L.sub[i / JPEG_SUB_ENTRIES][i % JPEG_SUB_ENTRIES] = jpeg_lut_expand(tables[i / JPEG_SUB_ENTRIES].sub[i % JPEG_SUB_ENTRIES]);
+    for (int i = t; i < 4 * 18; i += nthreads) { L.limit[i / 18][i % 18] = tables[i / 18].limit[i % 18]; L.offs[i / 18][i % 18] = tables[i / 18].offs[i % 18]; }
+    for (int i = t; i < 4 * 256; i += nthreads) L.vals[i >> 8][i & 255] = tables[i >> 8].vals[i & 255];
+}
+__device__ __forceinline__ void load_block_tables(JpegBlockTabs& K, const JpegFrame& F, int t) {
+    if (t < 64) K.natural[t] = c_natural[t];
+    if (t < F.bpm) jpeg_block_steps(F, t, &K.blk_base[t], &K.blk_dx[t], &K.blk_dy[t]);
+}
+
+constexpr int SB = JPEG_SYNC_BLOCK;
+
+// The walks, and nothing else: a lane per (chunk, block of the MCU), results to memory.  No barrier, no other workgroup is
+// waited for -- the instruction stream of a table-driven decoder saturates the vector unit as long as nothing else holds the
+// workgroup's slots (as ONE kernel with the selection the workgroups of a compute unit went through their latency-bound
+// phases together, and the unit idled a third of the time).
+__global__ __launch_bounds__(SB) void k_jpeg_walks(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
     __shared__ JpegHuffTabs L;
-    __shared__ uint64_t s_exit[HB], s_entry[HB];
-    __shared__ uint32_t s_segend[HB];
-    __shared__ uint8_t s_queue[HB];
-    __shared__ uint32_t s_queued[2];            // the round's queue length; two, so that one barrier less per round is needed
-    __shared__ uint32_t s_n[HB];
-    __shared__ int s_dc[3][HB];
-    __shared__ uint8_t s_head[HB];              // 1 = an interval starts in or before this chunk (inside the workgroup)
-    __shared__ uint32_t s_ticket;
-    __shared__ uint64_t s_pred;
-    __shared__ uint32_t s_carry[4];
+    const int t = threadIdx.x;
+    const JpegMapEntry me = block_map[blockIdx.x];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    const JpegFrame& F = J.F;           // (a reference: scalar loads from the table; a copy of the struct would live in scratch memory)
+    load_tables(L, J.tables, t, SB);
+    const uint32_t CHUNK_BITS = F.chunk_bits, OVERLAP = F.overlap_bits;
+    const uint32_t B = (uint32_t)F.bpm, CPW = (uint32_t)SB / B;     // walks per chunk, chunks per workgroup
+    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
+    const uint32_t g0 = b * CPW;
+    const uint32_t nlive = min(CPW, F.nchunks - g0);
+    const uint32_t k = (uint32_t)t / CPW, j = (uint32_t)t - k * CPW;
+    const uint32_t g = g0 + j;
+    // The stream is read straight from memory: a lane walks its own lines, and the decoder keeps the next word a whole refill
+    // ahead in a register.  (bit 31 of a word = the first bit of the stream: byte swap.)  A GLOBAL load: the pointer comes out
+    // of a table in memory, which makes it a flat one to the compiler, and a flat load counts as an LDS access too -- every
+    // wait for a table read would then wait for the stream word as well.
+    typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
+    const GlobalWords gwords = (GlobalWords)(uintptr_t)J.words;
+    auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
+    __syncthreads();
+    // (the tables as the lanes read them, for k_jpeg_mend)
+    if (b == 0) for (int i = t; i < (int)(sizeof(JpegHuffTabs) / 4); i += SB) ((uint32_t*)J.tabs)[i] = ((const uint32_t*)&L)[i];
+    if (k >= B || j >= nlive) return;
+    const uint32_t seg = J.chunk_seg[g], first = J.seg_first_chunk[seg];
+    const uint32_t seg_start = first * CHUNK_BITS, seg_end = seg_start + J.seg_bits[seg];
+    const uint32_t start = g * CHUNK_BITS, limit = min(start + CHUNK_BITS, seg_end);
+    const uint32_t p0 = start - seg_start > OVERLAP ? start - OVERLAP : seg_start;
+    const bool exact = p0 == seg_start;                             // the walk starts where the interval does: nothing to guess
+    JpegSpan sp;
+    sp.in = sp.out = JPEG_STATE_NONE;
+    sp.n = 0;
+    if (!exact || k == 0) sp = jpeg_span_walk(L, word, jpeg_pack_state(p0, k, 0, 0), start, limit, seg_end, F);
+    const size_t at = (size_t)k * F.nchunks + g;                    // [k][chunk]: a wave's stores are neighbours
+    J.cand_in[at] = sp.in;
+    J.cand_out[at] = sp.out;
+    J.cand_n[at] = sp.n;
+}
+
+// Which walk of a chunk does each exit candidate of the chunk before it lead into?  A lane per (chunk, candidate k): the same
+// state as an earlier candidate -> that one's answer ("twin"); one of the chunk's `in` states -> that walk; otherwise the
+// lane decodes the chunk once more from the candidate state (a "repair" walk -- one chunk in twenty needs one for some
+// candidate) and looks which of the chunk's walks it has joined by the end.  No barrier, nothing waited for: the few lanes
+// that walk are latency-bound and alone in their waves, so the kernel is as long as one walk however many there are.
+__global__ __launch_bounds__(SB) void k_jpeg_mend(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
+    __shared__ JpegHuffTabs L;
+    const int t = threadIdx.x;
+    const JpegMapEntry me = block_map[blockIdx.x];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    const JpegFrame& F = J.F;
+    for (int i = t; i < (int)(sizeof(JpegHuffTabs) / 4); i += SB) ((uint32_t*)&L)[i] = ((const uint32_t*)J.tabs)[i];
+    const uint32_t CHUNK_BITS = F.chunk_bits, OVERLAP = F.overlap_bits;
+    const uint32_t B = (uint32_t)F.bpm, CPW = (uint32_t)SB / B;
+    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
+    const uint32_t g0 = b * CPW;
+    const uint32_t nlive = min(CPW, F.nchunks - g0);
+    const uint32_t k = (uint32_t)t / CPW, j = (uint32_t)t - k * CPW;
+    const uint32_t g = g0 + j;
+    typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
+    const GlobalWords gwords = (GlobalWords)(uintptr_t)J.words;
+    auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
+    __syncthreads();
+    if (k >= B || j >= nlive) return;
+    const uint32_t seg = J.chunk_seg[g], first = J.seg_first_chunk[seg];
+    const uint32_t seg_start = first * CHUNK_BITS, seg_end = seg_start + J.seg_bits[seg];
+    const uint32_t start = g * CHUNK_BITS, limit = min(start + CHUNK_BITS, seg_end);
+    const size_t N = F.nchunks, at = (size_t)k * N + g;
+    uint32_t nib = JPEG_MAP_FAIL | 64u;                             // bit 6: the chunk's one walk started with its interval -- nothing to select
+    if (start - seg_start > OVERLAP) {
+        nib = JPEG_MAP_FAIL;
+        const uint64_t E = J.cand_out[at - 1];
+        int twin = -1;
+        for (uint32_t k2 = 0; k2 < k && twin < 0; k2++) if (J.cand_out[(size_t)k2 * N + g - 1] == E) twin = (int)k2;
+        if (E == JPEG_STATE_NONE) {
+        } else if (twin >= 0) nib = 32u | (uint32_t)twin;           // bit 5: the answer is candidate `twin`'s
+        else {
+            for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_in[(size_t)k1 * N + g] == E) nib = k1;
+            if (nib == JPEG_MAP_FAIL) {
+                const JpegSpan sp = jpeg_span_walk(L, word, E, start, limit, seg_end, F);
+                for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_out[(size_t)k1 * N + g] == sp.out) nib = k1;
+                J.rep_out[at] = sp.out;
+                J.rep_n[at] = sp.n;
+                atomicAdd(&J.header[2], 1u);
+                if (nib == JPEG_MAP_FAIL) {
+                    // It has joined none of the chunk's walks: they are all out of step here, and those of the next chunk tend
+                    // to be too.  Decode on, chunk by chunk, until the state IS one of a chunk's candidates, and leave what was
+                    // found on the way -- every chunk's entry state and slot count -- in a record k_jpeg_select can follow
+                    // without decoding anything (it used to: one lane, a chunk at a time, its successors waiting).
+                    const uint32_t r = atomicAdd(J.ext_count, 1u);
+                    uint32_t* R = r < J.ext_cap ? J.ext + (size_t)r * JPEG_EXT_WORDS : nullptr;
+                    J.ext_idx[at] = R ? r : 0xffffffffu;
+                    if (R) {
+                        uint64_t S = sp.out;
+                        uint32_t count = 0, joined = 15;
+                        for (uint32_t m = 0; m < (uint32_t)JPEG_EXT_STEPS; m++) {
+                            const uint32_t gc = g + 1 + m;
+                            if (gc >= F.nchunks) { joined = 14; break; }
+                            const uint32_t seg2 = J.chunk_seg[gc], first2 = J.seg_first_chunk[seg2];
+                            const uint32_t sstart2 = first2 * CHUNK_BITS, send2 = sstart2 + J.seg_bits[seg2];
+                            const uint32_t start2 = gc * CHUNK_BITS, limit2 = min(start2 + CHUNK_BITS, send2);
+                            if (start2 - sstart2 <= OVERLAP) { joined = 14; break; }          // a chunk that selects nothing: the chain ends here
+                            uint32_t k1 = JPEG_MAP_FAIL, nn = 0;
+                            for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && J.cand_in[(size_t)i * N + gc] == S) { k1 = i; nn = J.cand_n[(size_t)i * N + gc]; }
+                            uint64_t out = S;
+                            if (k1 == JPEG_MAP_FAIL) {
+                                const JpegSpan s2 = jpeg_span_walk(L, word, S, start2, limit2, send2, F);
+                                nn = s2.n;
+                                out = s2.out;
+                                for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && J.cand_out[(size_t)i * N + gc] == out) k1 = i;
+                            }
+                            R[4 + 3 * count] = (uint32_t)S; R[5 + 3 * count] = (uint32_t)(S >> 32); R[6 + 3 * count] = nn;
+                            count++;
+                            if (k1 != JPEG_MAP_FAIL) { joined = k1; break; }
+                            S = out;
+                        }
+                        R[0] = g; R[1] = k; R[2] = count; R[3] = joined;
+                        R[4 + 3 * JPEG_EXT_STEPS] = (uint32_t)S; R[5 + 3 * JPEG_EXT_STEPS] = (uint32_t)(S >> 32);   // (not joined: where it stands)
+                    }
+                }
+                nib |= 16u;                                         // bit 4: this answer comes from a repair walk
+            }
+        }
+    }
+    J.cand_nib[at] = (uint8_t)nib;
+}
+
+__global__ __launch_bounds__(SB) void k_jpeg_select(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map, uint32_t* __restrict__ launch_ticket) {
+    __shared__ uint64_t s_in[SB], s_out[SB], s_rep_out[SB];         // [k * CPW + j]: walk k of the workgroup's j-th chunk
+    __shared__ uint64_t s_pout[6];                                  // the exit candidates of the chunk in front of the workgroup
+    __shared__ uint32_t s_n[SB], s_rep_n[SB];
+    __shared__ uint32_t s_res_n[SB];                                // [j]
+    __shared__ uint32_t s_map[SB], s_scan[2][SB];                   // [j]: the chunk's map; the scan's two buffers
+    __shared__ uint8_t s_nib[SB], s_exact[SB], s_own[SB];           // s_own: the candidate whose answer this one shares (a twin's), else itself
+    __shared__ uint32_t s_ticket, s_jf, s_mode, s_idx0, s_fin, s_chases, s_ext, s_ei, s_from;
+    __shared__ uint64_t s_S;
     const int t = threadIdx.x;
     // workgroups are numbered in the order they START (a ticket), never by blockIdx: the one a workgroup waits for is then
     // always running already
@@ -67,21 +213,304 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     __syncthreads();
     const JpegMapEntry me = block_map[__builtin_amdgcn_readfirstlane(s_ticket)];
     const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
-    const JpegFrame& F = J.F;           // (a reference: scalar loads from the table; a copy of the struct would live in scratch memory)
+    const JpegFrame& F = J.F;
+    struct { const uint32_t *words, *chunk_seg, *seg_first_chunk, *seg_bits; const JpegHuffDev* tables; uint32_t *header, *records; uint64_t* chunk_entry; uint32_t* chunk_n; } A =
+        {J.words, J.chunk_seg, J.seg_first_chunk, J.seg_bits, J.tables, J.header, J.records, J.chunk_entry, J.chunk_n};
+    const uint32_t CHUNK_BITS = F.chunk_bits;
+    const uint32_t B = (uint32_t)F.bpm, CPW = (uint32_t)SB / B;     // walks per chunk, chunks per workgroup
+    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
+    const uint32_t nblocks = (F.nchunks + CPW - 1) / CPW;
+    const uint32_t g0 = b * CPW;
+    const uint32_t nlive = min(CPW, F.nchunks - g0), jl = nlive - 1;
+    const uint32_t k = (uint32_t)t / CPW, j = (uint32_t)t - k * CPW;
+    const bool lane_ok = k < B && j < nlive;
+    const uint32_t g = g0 + j;
+    uint32_t* rec = A.records + (size_t)b * JPEG_CTL_REC;
+    const uint32_t* prec = rec - JPEG_CTL_REC;
+    auto stamp = [&](int i) { if (t == 0) rec[20 + i] = (uint32_t)wall_clock64(); };     // 100 MHz
+    stamp(0);
+    typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
+    const GlobalWords gwords = (GlobalWords)(uintptr_t)A.words;
+    auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
+    if (t == 0) { s_ext = 0xffffffffu; s_ei = 0; s_from = 0; s_jf = 0xffffffffu; s_mode = 0; s_idx0 = 0; s_fin = 0; s_chases = 0; s_S = 0; }
+
+    // ---- A. what the walks found (k_jpeg_walks) and where each of the predecessor's candidates leads (k_jpeg_mend), this
+    // workgroup's chunks and the one in front of them
+    uint64_t my_in = JPEG_STATE_NONE, my_out = JPEG_STATE_NONE, my_rep_out = JPEG_STATE_NONE;
+    uint32_t my_n = 0, my_rep_n = 0, my_nib = JPEG_MAP_FAIL;
+    if (lane_ok) {
+        const size_t at = (size_t)k * F.nchunks + g;
+        my_in = J.cand_in[at]; my_out = J.cand_out[at]; my_n = J.cand_n[at];
+        my_nib = J.cand_nib[at];
+        if (k == 0) s_exact[j] = (my_nib & 64u) ? 1 : 0;
+        if (my_nib & 16u) { my_rep_out = J.rep_out[at]; my_rep_n = J.rep_n[at]; }
+    }
+    s_in[t] = my_in;
+    s_out[t] = my_out;
+    s_n[t] = my_n;
+    s_rep_out[t] = my_rep_out;
+    s_rep_n[t] = my_rep_n;
+    s_nib[t] = (uint8_t)my_nib;
+    s_own[t] = (uint8_t)((my_nib & 32u) ? (my_nib & 7u) : k);
+    if (t < 6) s_pout[t] = (g0 > 0 && (uint32_t)t < B) ? J.cand_out[(size_t)t * F.nchunks + g0 - 1] : JPEG_STATE_NONE;
+    __syncthreads();
+    stamp(1);
+    if (lane_ok && (my_nib & 32u)) {                                // a twin: the answer of the earlier candidate with the same state
+        const uint32_t tw = (my_nib & 7u) * CPW + j;
+        s_nib[t] = s_nib[tw];
+        s_rep_out[t] = s_rep_out[tw];
+        s_rep_n[t] = s_rep_n[tw];
+    }
+    __syncthreads();
+    stamp(2);
+    if ((uint32_t)t < nlive) {                                      // (t = j from here on)
+        uint32_t m = 0;
+        // (a file with fewer than six blocks per MCU: the unused inputs repeat input 0, so that "every input leads to the same
+        // output" can be seen from the whole word)
+        for (uint32_t i = 0; i < 6; i++) m |= ((uint32_t)s_nib[(i < B ? i : 0u) * CPW + t] & 15u) << (4 * i);
+        m = s_exact[t] ? jpeg_map_const(0) : m;
+        s_map[t] = m;
+        s_scan[0][t] = m;
+    }
+    __syncthreads();
+    stamp(3);
+    // ---- C. inclusive scan: P[j] = which candidate of chunk j follows from each candidate of the chunk in front of the workgroup
+    int cur = 0;
+    for (uint32_t ofs = 1; ofs < nlive; ofs <<= 1) {
+        if ((uint32_t)t < nlive) {
+            const uint32_t mine = s_scan[cur][t];
+            s_scan[cur ^ 1][t] = (uint32_t)t >= ofs ? jpeg_map_then(s_scan[cur][t - ofs], mine) : mine;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (b + 1 < nblocks) { rec[2] = s_scan[cur][jl]; st_release(rec + 1, 1u); }
+        // ---- which of the predecessor's candidates is the true one?  Look back over the maps of the workgroups before, nearest
+        // first, until what comes before no longer matters (a constant map: the usual case after ONE) or a final word is met.
+        if (!s_exact[0]) {
+            uint32_t acc = 0x543210u, idx0 = 0, mode = 2;           // mode 2 = not known yet
+            for (int w = (int)b - 1; w >= 0 && mode == 2; w--) {
+                const uint32_t* r = A.records + (size_t)w * JPEG_CTL_REC;
+                const uint32_t have = wait_flag_ge(r + 1, 1u);
+                if (!have) break;
+                if (have == 2) {
+                    const uint32_t kind = r[3];
+                    if (kind < 6) { const uint32_t x = jpeg_map_at(acc, kind); if (x != JPEG_MAP_FAIL) { idx0 = x; mode = 0; } }
+                    else if (w == (int)b - 1) {
+                        if (kind == 13) { s_ext = r[4]; s_ei = r[5]; mode = 3; }
+                        else { s_S = (uint64_t)r[4] | ((uint64_t)r[5] << 32); mode = 1; }
+                    }
+                    break;                                          // nothing to learn behind a final word
+                }
+                acc = jpeg_map_then(r[2], acc);
+                if (jpeg_map_is_const(acc)) { idx0 = acc & 15u; mode = 0; }
+            }
+            if (mode == 2) {                                        // the maps do not say: the predecessor's final word, then
+                if (wait_flag_ge(prec + 1, 2u)) {
+                    const uint32_t kind = prec[3];
+                    if (kind < 6) { idx0 = kind; mode = 0; }
+                    else if (kind == 13) { s_ext = prec[4]; s_ei = prec[5]; mode = 3; }
+                    else { s_S = (uint64_t)prec[4] | ((uint64_t)prec[5] << 32); mode = 1; }
+                } else {
+                    atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
+                    s_S = JPEG_STATE_NONE;                          // a dead state: every chunk behind it stays empty, the verdict is "refused"
+                    mode = 1;
+                }
+            }
+            s_idx0 = idx0;
+            s_mode = mode;
+        }
+    }
+    __syncthreads();
+    stamp(4);
+    // ---- D / E.  Every chunk picks its true walk from the scan; where the chain leaves the candidates (a repair walk that joined
+    // nothing, or a predecessor that hands on a record or a state), ONE lane follows it up to the chunk where the state is a
+    // candidate again, and the chunks behind that are scanned and picked once more by all.
+    uint32_t mode = s_mode, idx0 = s_idx0, from = 0;                // chunks below `from` are settled
+    for (;;) {
+        if ((uint32_t)t >= from && (uint32_t)t < nlive) {
+            uint32_t idx_in = JPEG_MAP_FAIL;                        // which candidate of the chunk before is the true one
+            if (mode == 0) idx_in = t == 0 ? idx0 : jpeg_map_at(s_scan[cur][t - 1], idx0);
+            uint64_t ent = JPEG_STATE_NONE;
+            uint32_t n = 0;
+            bool known = false;
+            if (s_exact[t]) { ent = s_in[t]; n = s_n[t]; known = true; }
+            else if (idx_in != JPEG_MAP_FAIL) {
+                const uint32_t nb = s_nib[idx_in * CPW + t], v = nb & 15u;
+                if (!(nb & 16u)) {
+                    if (v != JPEG_MAP_FAIL) { ent = s_in[v * CPW + t]; n = s_n[v * CPW + t]; known = true; }
+                    else atomicMin(&s_jf, (uint32_t)t > 0 ? (uint32_t)t - 1 : 0u);   // (cannot happen: a true exit state is never "no candidate")
+                } else {
+                    ent = t > 0 ? s_out[idx_in * CPW + t - 1] : s_pout[idx_in];
+                    n = s_rep_n[idx_in * CPW + t];
+                    known = true;
+                    if (v == JPEG_MAP_FAIL) atomicMin(&s_jf, (uint32_t)t);            // its exit joined no walk: follow it from here
+                }
+            }
+            if (known) { A.chunk_entry[g0 + t] = ent; s_res_n[t] = n; }
+        }
+        __syncthreads();
+        const uint32_t jf = s_jf;
+        if (mode == 0 && jf == 0xffffffffu) {                       // everything picked
+            if (t == 0) { s_fin = jpeg_map_at(s_scan[cur][jl], idx0); s_S = 0; }   // (a constant map when an interval starts inside the workgroup)
+            break;
+        }
+        if (t == 0) {
+            // A candidate whose repair walk joined nothing has a record (k_jpeg_mend) of the chunks behind it: their entry states
+            // and slot counts, up to the chunk where the state is a candidate again.  Only where there is no record (or it ends
+            // unjoined) is an explicit state decoded on from, with the tables read from memory.
+            const JpegHuffCompact& L = *(const JpegHuffCompact*)A.tables;
+            const size_t N = F.nchunks;
+            uint32_t jn = 0, idx = 0, chases = 0, ei = 0, rcount = 0, rjoined = 15;
+            bool expl = true;
+            uint64_t S = JPEG_STATE_NONE;
+            const uint32_t* R = nullptr;                            // the record being followed
+            uint32_t Rno = 0xffffffffu;
+            auto open_record = [&](uint32_t kk, uint32_t jj) {      // candidate kk of the chunk before jj left a record?
+                const uint32_t r = J.ext_idx[(size_t)s_own[kk * CPW + jj] * N + g0 + jj];
+                if (r < J.ext_cap) { Rno = r; R = J.ext + (size_t)r * JPEG_EXT_WORDS; ei = 0; rcount = R[2]; rjoined = R[3]; }
+            };
+            auto close_record = [&]() {
+                if (rjoined < 6) { idx = rjoined; expl = false; }
+                else { S = (uint64_t)R[4 + 3 * JPEG_EXT_STEPS] | ((uint64_t)R[5 + 3 * JPEG_EXT_STEPS] << 32); expl = true; }
+                R = nullptr;
+            };
+            if (mode == 1) S = s_S;
+            else if (mode == 3) { Rno = s_ext; R = J.ext + (size_t)Rno * JPEG_EXT_WORDS; ei = s_ei; rcount = R[2]; rjoined = R[3]; }
+            else {
+                const uint32_t idx_in = jf == 0 ? idx0 : jpeg_map_at(s_scan[cur][jf - 1], idx0);
+                S = s_rep_out[idx_in * CPW + jf];
+                open_record(idx_in, jf);
+                jn = jf + 1;
+            }
+            uint32_t jj = jn;
+            for (; jj < nlive; jj++) {
+                if (s_exact[jj]) { expl = false; idx = 0; R = nullptr; break; }   // an interval begins: the scan has the rest
+                if (R && ei >= rcount) close_record();
+                if (!R && !expl) break;                             // the state is candidate `idx` of chunk jj - 1 again
+                uint64_t ent;
+                uint32_t n;
+                chases++;
+                if (R) {
+                    ent = (uint64_t)R[4 + 3 * ei] | ((uint64_t)R[5 + 3 * ei] << 32);
+                    n = R[6 + 3 * ei];
+                    ei++;
+                } else {
+                    ent = S;
+                    uint32_t k1 = JPEG_MAP_FAIL;
+                    for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && s_in[i * CPW + jj] == S) k1 = i;
+                    if (k1 != JPEG_MAP_FAIL) { n = s_n[k1 * CPW + jj]; idx = k1; expl = false; }
+                    else {
+                        const uint32_t gg = g0 + jj, seg = A.chunk_seg[gg];
+                        const uint32_t seg_end = A.seg_first_chunk[seg] * CHUNK_BITS + A.seg_bits[seg];
+                        const JpegSpan sp = jpeg_span_walk(L, word, S, gg * CHUNK_BITS, min((gg + 1) * CHUNK_BITS, seg_end), seg_end, F);
+                        atomicAdd(&A.header[0], 1u);                // (diagnostics: walks this kernel had to do itself)
+                        n = sp.n;
+                        for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && s_out[i * CPW + jj] == sp.out) k1 = i;
+                        if (k1 != JPEG_MAP_FAIL) { idx = k1; expl = false; } else S = sp.out;
+                    }
+                }
+                A.chunk_entry[g0 + jj] = ent;
+                s_res_n[jj] = n;
+            }
+            if (jj >= nlive) {                                      // the workgroup's end: what the next one starts from --
+                if (R && ei >= rcount) close_record();
+                if (R) { s_fin = 13u; s_S = (uint64_t)Rno | ((uint64_t)ei << 32); }   // a record to go on with,
+                else { s_fin = expl ? 15u : idx; s_S = S; }                            // a state, or a candidate of the last chunk
+            }
+            s_from = jj;
+            s_idx0 = idx;
+            s_jf = 0xffffffffu;
+            s_chases += chases;
+        }
+        __syncthreads();
+        from = s_from;
+        if (from >= nlive) break;
+        // scan the rest again: in front of chunk `from` stands candidate s_idx0 of the chunk before it, whatever came before
+        idx0 = s_idx0;
+        mode = 0;
+        if ((uint32_t)t < nlive) s_scan[0][t] = (uint32_t)t < from ? jpeg_map_const(idx0) : s_map[t];
+        cur = 0;
+        __syncthreads();
+        for (uint32_t ofs = 1; ofs < nlive; ofs <<= 1) {
+            if ((uint32_t)t < nlive) {
+                const uint32_t mine = s_scan[cur][t];
+                s_scan[cur ^ 1][t] = (uint32_t)t >= ofs ? jpeg_map_then(s_scan[cur][t - ofs], mine) : mine;
+            }
+            cur ^= 1;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // the final word for whoever looks back this far, the slot counts for k_jpeg_write
+    uint32_t total = 0;
+    if ((uint32_t)t < nlive) { const uint32_t n = s_res_n[t]; A.chunk_n[g0 + t] = n; total = n; }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+    if ((t & 63) == 0) s_scan[0][t >> 6] = total;
+    __syncthreads();
+    if (t == 0) {
+        rec[6] = s_scan[0][0] + s_scan[0][1] + s_scan[0][2] + s_scan[0][3];
+        if (b + 1 < nblocks) {
+            rec[3] = s_fin;
+            rec[4] = (uint32_t)s_S;
+            rec[5] = (uint32_t)(s_S >> 32);
+            st_release(rec + 1, 2u);
+        }
+        if (s_chases) atomicAdd(&A.header[3], s_chases);
+    }
+    stamp(5);
+}
+
+constexpr int HB = JPEG_HUFF_BLOCK;
+
+// Sum of x[c] over the chunks c in [first, g0) -- g0 = the workgroup's first chunk, first = where the interval it belongs to
+// began -- by all lanes: the chunks of whole groups of `per` come as the group totals `tot[w * stride]`, the ragged ends one by one.
+template <class T>
+__device__ T sum_before(const T* x, int xstride, const T* tot, int stride, uint32_t per, uint32_t first, uint32_t g0, int t, T* s_acc) {
+    if (t == 0) *s_acc = 0;
+    __syncthreads();
+    T part = 0;
+    const uint32_t wf = first / per, w0 = g0 / per;
+    if (wf == w0) {
+        for (uint32_t c = first + (uint32_t)t; c < g0; c += HB) part += x[(size_t)c * xstride];
+    } else {
+        for (uint32_t c = first + (uint32_t)t; c < (wf + 1) * per; c += HB) part += x[(size_t)c * xstride];
+        for (uint32_t w = wf + 1 + (uint32_t)t; w < w0; w += HB) part += tot[(size_t)w * stride];
+        for (uint32_t c = w0 * per + (uint32_t)t; c < g0; c += HB) part += x[(size_t)c * xstride];
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((t & 63) == 0 && part) atomicAdd(s_acc, part);
+    __syncthreads();
+    return *s_acc;
+}
+
+__global__ __launch_bounds__(HB) void k_jpeg_write(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
+    __shared__ JpegHuffCompact L;                                   // (the tables as the host built them: this walk reads nothing the widened form adds)
+    __shared__ JpegBlockTabs K;
+    __shared__ uint32_t s_n[HB];
+    __shared__ uint8_t s_head[HB];                                  // 1 = an interval starts in or before this chunk (inside the workgroup)
+    __shared__ uint32_t s_carry;
+    __shared__ int s_tot[4];
+    __shared__ __attribute__((aligned(16))) int16_t s_stage[HB][64];      // per lane: the block it is decoding
+    __shared__ uint32_t s_list[HB / 64][128];                       // per wave: its complete blocks {where in LDS, where in the planes}
+    const int t = threadIdx.x;
+    const uint32_t clock0 = (uint32_t)wall_clock64();
+    for (int i = t; i < HB * 64 / 8; i += HB) ((uint4*)&s_stage[0][0])[i] = make_uint4(0, 0, 0, 0);
+    const JpegMapEntry me = block_map[blockIdx.x];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    const JpegFrame& F = J.F;
     struct { const uint32_t *words, *chunk_seg, *seg_first_chunk, *seg_bits; const JpegHuffDev* tables; int16_t* coef; uint32_t *header, *records; } A =
         {J.words, J.chunk_seg, J.seg_first_chunk, J.seg_bits, J.tables, J.coef, J.header, J.records};
-    // tables
-    for (int i = t; i < 4 * (1 << JPEG_LOOKBITS); i += HB) L.lut[i >> JPEG_LOOKBITS][i & ((1 << JPEG_LOOKBITS) - 1)] = jpeg_lut_expand(A.tables[i >> JPEG_LOOKBITS].lut[i & ((1 << JPEG_LOOKBITS) - 1)]);
-    for (int i = t; i < 4 * 18; i += HB) { L.limit[i / 18][i % 18] = A.tables[i / 18].limit[i % 18]; L.offs[i / 18][i % 18] = A.tables[i / 18].offs[i % 18]; }
-    for (int i = t; i < 4 * 256; i += HB) L.vals[i >> 8][i & 255] = A.tables[i >> 8].vals[i & 255];
-    if (t < 64) L.natural[t] = c_natural[t];
-    if (t < F.bpm) jpeg_block_steps(F, t, &L.blk_base[t], &L.blk_dx[t], &L.blk_dy[t]);
-    const uint32_t CHUNK_BITS = F.chunk_bits;                       // 1024, 512 or 256 (jpeg_chunk_bytes_for)
+    for (int i = t; i < (int)(sizeof(JpegHuffCompact) / 4); i += HB) ((uint32_t*)&L)[i] = ((const uint32_t*)A.tables)[i];
+    load_block_tables(K, F, t);
+    if (t < 4) s_tot[t] = 0;
+    const uint32_t CHUNK_BITS = F.chunk_bits;
     const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
-    const uint32_t nblocks = (F.nchunks + HB - 1) / HB;
     const uint32_t g0 = b * HB, g = g0 + (uint32_t)t;
     const bool live = g < F.nchunks;
-    uint32_t seg = 0, first = 0, seg_end = 0, limit = 0;
+    uint32_t seg = 0, first = 0, seg_end = 0, limit = 0, own_n = 0;
+    uint64_t entry = JPEG_STATE_NONE;
     bool origin = false;
     if (live) {
         seg = A.chunk_seg[g];
@@ -89,186 +518,131 @@ __global__ __launch_bounds__(HB) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         origin = first == g;
         seg_end = first * CHUNK_BITS + A.seg_bits[seg];
         limit = min((g + 1) * CHUNK_BITS, seg_end);
+        entry = J.chunk_entry[g];
+        own_n = J.chunk_n[g];
     }
-    // The stream is read straight from memory: a lane walks its own 128-byte line, and the decoder keeps the next word a
-    // whole refill ahead in a register, so the latency is off the critical path; staging the workgroup's 33 KB in LDS bought
-    // nothing and cost two of every three resident workgroups.  (bit 31 of a word = the first bit of the stream: byte swap)
-    const uint32_t* __restrict__ words = A.words;
-    // (a GLOBAL load: the pointer comes out of a table in memory, which makes it a flat one to the compiler, and a flat load
-    // counts as an LDS access too -- every wait for a table read would then wait for the stream word as well)
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
-    const GlobalWords gwords = (GlobalWords)(uintptr_t)words;
+    const GlobalWords gwords = (GlobalWords)(uintptr_t)A.words;
     auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
-    uint32_t* rec = A.records + (size_t)b * CTL_REC;
-    const uint32_t* prec = rec - CTL_REC;
-    __syncthreads();
-    auto stamp = [&](int k) { if (t == 0) rec[12 + k] = (uint32_t)wall_clock64(); };     // 100 MHz
-    stamp(0);
-
-    // ---- 1./2. Every lane decodes its chunk from a guessed state (its first bit, start of a block) -- exact only for the
-    // first chunk of an interval -- and then pulls its predecessor's exit state, re-decoding whenever that differs from the
-    // state it started from, until nothing changes in the workgroup.  Lane 0's predecessor is the previous workgroup's last
-    // lane.  A workgroup publishes its last exit state twice: TENTATIVELY as soon as its own lanes agree (Huffman codes
-    // resynchronise within a few chunks, so that state is almost always the true one already, whatever the workgroup's own
-    // entry state turns out to be), which lets all workgroups run their fix-up at the same time instead of one after the
-    // other, and FINALLY once its own entry state is final.  The chain of final states is then a flag and a compare per
-    // workgroup; only a workgroup whose tentative input was wrong converges once more.
-    // The tentative state is not published once but KEPT UP TO DATE: the last lane stores its exit state (one 64-bit word,
-    // 0 = nothing yet) after every round that changed it, and lane 0 of the next workgroup looks at it at the top of every
-    // round -- so the correction a workgroup's first chunks need from its predecessor happens during the rounds its slowest
-    // chunks need anyway, not in a phase of its own after them.
-    uint64_t* const tent = (uint64_t*)(rec + 0);
-    const uint64_t* const ptent = (const uint64_t*)(prec + 0);
-    uint64_t published = 0;                                         // (lane HB - 1)
-    const bool chained = origin || !live;                           // (read by lane 0 only) nothing to wait for
-    const uint64_t guess = jpeg_pack_state(g * CHUNK_BITS, 0, 0, 0);
-    const uint64_t none = ~0ull;                                    // "no state": its flag bits are set
-    uint64_t entry = none;
-    s_exit[t] = none;
-    s_entry[t] = none;
-    s_segend[t] = seg_end;
-    s_n[t] = 0;
-    s_dc[0][t] = s_dc[1][t] = s_dc[2][t] = 0;
-    if (t == 0) { s_pred = none; s_queued[0] = s_queued[1] = 0; }
-    __syncthreads();
-    for (int phase = 0; phase < 3; phase++) {
-        stamp(1 + 2 * phase);                                       // 1, 3, 5: the phase's rounds start (after the wait: 2, 4 below)
-        if (phase == 1 && t == HB - 1 && b + 1 < nblocks && !published) {
-            // its rounds are over and the last lane never had a state worth handing on (an undecodable pattern): say so, the
-            // next workgroup then starts from its own guess instead of waiting
-            published = s_exit[t];
-            __hip_atomic_store(tent, published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (phase == 1 && t == 0 && !chained) {                     // a predecessor that has not said anything yet: wait for its first word
-            uint64_t v = 0;
-            for (int spin = 0; spin < (1 << 21) && !v; spin++) {
-                v = __hip_atomic_load(ptent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!v) __builtin_amdgcn_s_sleep(16);
-            }
-            if (v) s_pred = v;
-            else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
-        }
-        if (phase == 2 && t == 0 && !chained) {                     // the predecessor's FINAL state
-            if (wait_flag(prec + 3)) s_pred = (uint64_t)prec[4] | ((uint64_t)prec[5] << 32);
-            else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
-        }
-        if (phase > 0) stamp(2 * phase + 2);                        // 4, 6: the predecessor's state has arrived
-        for (int round = 0; round <= HB + 1; round++) {
-            if (phase < 2 && t == 0 && !chained) {
-                const uint64_t v = __hip_atomic_load(ptent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v) s_pred = v;
-            }
-            // (every exit state of the round before is in place: its closing barrier -- or the one in front of the phases --
-            // has been passed; two barriers per round, not three: at 256-bit chunks a round is short enough for that to show)
-            const int q = round & 1;
-            uint64_t want = t > 0 ? s_exit[t - 1] : s_pred;
-            // a predecessor with nothing to hand on (none yet, or it ran into an undecodable pattern -- a wrong guess,
-            // normally): the lane's own guess.  Otherwise that dead state would travel a chunk per round to the interval's end.
-            if (origin || (want >> 48)) want = guess;
-            // The chunks whose entry state changed are queued and the queue is worked off by the first lanes of the
-            // workgroup: after the first round or two only a few chunks per workgroup still move (the ones that take long to
-            // synchronise), and they should keep one wave busy, not four.
-            if (live && want != entry) {
-                entry = want;
-                s_entry[t] = want;
-                s_queue[atomicAdd(&s_queued[q], 1u)] = (uint8_t)t;
-            }
-            if (t == 0) s_queued[q ^ 1] = 0;                        // (last read before the barrier that closed the round before)
-            __syncthreads();
-            const uint32_t queued = s_queued[q];
-            if (queued == 0) { if (t == 0) atomicMax(&A.header[phase == 0 ? 2 : 3], (uint32_t)round); break; }
-            if ((uint32_t)t < queued) {
-                const uint32_t k = s_queue[t];
-                s_exit[k] = jpeg_sync_chunk(L, word, s_entry[k], min((g0 + k + 1) * CHUNK_BITS, s_segend[k]), s_segend[k], F);
-            }
-            __syncthreads();
-            if (t == HB - 1 && b + 1 < nblocks) {
-                const uint64_t mine = s_exit[t];
-                if (mine != published && !(mine >> 48)) {
-                    __hip_atomic_store(tent, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    published = mine;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (t == HB - 1 && b + 1 < nblocks) {                           // the final exit state
-        rec[4] = (uint32_t)s_exit[t];
-        rec[5] = (uint32_t)(s_exit[t] >> 32);
-        st_release(rec + 3, 1u);
-    }
-    stamp(7);
-    // ---- 3. every entry state is final: one full walk per chunk for what the rounds above left out -- the slots it passes
-    // and its DC differences
-    if (live) {
-        const JpegDecoded cnt = jpeg_decode_chunk<false>(L, word, entry, limit, seg_end, F, nullptr);
-        s_n[t] = cnt.n;
-        s_dc[0][t] = cnt.dc[0];
-        s_dc[1][t] = cnt.dc[1];
-        s_dc[2][t] = cnt.dc[2];
-    }
-    __syncthreads();
-    stamp(8);
-    // ---- 4. running totals inside each interval: segmented inclusive scan over (n, dc0, dc1, dc2)
-    struct { uint32_t n; int dc[3]; } d = {s_n[t], {s_dc[0][t], s_dc[1][t], s_dc[2][t]}};     // this chunk's own
+    // ---- the slot of every chunk's first symbol: running totals inside each interval (a segmented scan), plus what the
+    // interval had passed before this workgroup's first chunk (k_jpeg_sync left its workgroups' totals in their records)
+    s_n[t] = own_n;
     s_head[t] = origin ? 1 : 0;
     __syncthreads();
     for (int ofs = 1; ofs < HB; ofs <<= 1) {
         uint32_t n2 = 0, h2 = 0;
-        int a0 = 0, a1 = 0, a2 = 0;
         const bool take = t >= ofs;
-        if (take) { n2 = s_n[t - ofs]; a0 = s_dc[0][t - ofs]; a1 = s_dc[1][t - ofs]; a2 = s_dc[2][t - ofs]; h2 = s_head[t - ofs]; }
+        if (take) { n2 = s_n[t - ofs]; h2 = s_head[t - ofs]; }
         const uint32_t myh = s_head[t];
         __syncthreads();
         if (take) {
-            if (!myh) { s_n[t] += n2; s_dc[0][t] += a0; s_dc[1][t] += a1; s_dc[2][t] += a2; }
+            if (!myh) s_n[t] += n2;
             s_head[t] = (uint8_t)(myh | h2);
         }
         __syncthreads();
     }
-    // the previous workgroup's totals for the interval that runs into this one
-    if (t == 0) {
-        s_carry[0] = s_carry[1] = s_carry[2] = s_carry[3] = 0;
-        if (!chained) {
-            if (wait_flag(prec + 6)) { s_carry[0] = prec[7]; s_carry[1] = prec[8]; s_carry[2] = prec[9]; s_carry[3] = prec[10]; }
-            else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
+    const uint32_t first0 = A.seg_first_chunk[A.chunk_seg[g0]];
+    const uint32_t carry = sum_before<uint32_t>(J.chunk_n, 1, A.records + 6, JPEG_CTL_REC, (uint32_t)SB / (uint32_t)F.bpm, first0, g0, t, &s_carry);
+    const bool open = !s_head[t];                                   // still in the interval that began in an earlier workgroup
+    const uint32_t incl_n = s_n[t] + (open ? carry : 0u);
+    // ---- decode, now knowing where every coefficient goes.  The last chunk of an interval walks with the interval's
+    // remaining slots as a budget -- a sequential decoder stops after the last MCU and never looks at the padding bits, which
+    // in a damaged file need not be the 1-bits an encoder writes -- and gives the verdict: it must end inside the padding
+    // with exactly the interval's slots decoded.
+    JpegDecoded e;
+    uint32_t slot0 = 0;
+    {
+        const uint32_t last_chunk_of_seg = live ? (seg + 1 < F.nsegs ? A.seg_first_chunk[seg + 1] : F.nchunks) - 1 : 0u;
+        const uint32_t base_n = incl_n - own_n;
+        const uint32_t slots_here = min((uint32_t)F.slots_per_seg, F.total_slots - seg * (uint32_t)F.slots_per_seg);
+        const bool closes = g == last_chunk_of_seg;
+        JpegWriteCtx W;
+        W.coef = A.coef;
+        W.slot0 = slot0 = seg * (uint32_t)F.slots_per_seg + base_n;
+        W.dc0[0] = W.dc0[1] = W.dc0[2] = 0;                         // relative to the chunk's entry: k_jpeg_dcfix adds the rest
+        W.status = &A.header[1];
+        W.stage = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&s_stage[t][0];
+        W.list = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&s_list[t >> 6][0];
+        const bool overrun = live && !closes && incl_n > slots_here;              // would write outside the interval
+        if (overrun) atomicOr(&A.header[1], JPEG_ST_OVERRUN);
+        const uint32_t budget = closes ? (slots_here >= base_n ? slots_here - base_n : 0u) : 0xffffffffu;
+        // (every lane of the wave takes part: finished blocks are written out by the lanes together)
+        e = jpeg_write_chunk(L, K, word, entry, limit, seg_end, F, &W, budget, live && !overrun);
+        if (live && !overrun) {
+            if (closes) {
+                const uint32_t pe = (uint32_t)e.exit, fle = (uint32_t)(e.exit >> 48);
+                if ((fle & JPEG_FL_INVALID) || pe > seg_end || seg_end - pe >= 8) atomicOr(&A.header[1], JPEG_ST_BAD_CODE);
+                if (base_n + e.n != slots_here) atomicOr(&A.header[1], JPEG_ST_BAD_COUNT);
+            } else if (e.n != own_n) atomicOr(&A.header[1], JPEG_ST_BAD_COUNT);   // the two walks disagree: cannot happen
         }
     }
+    if (live) {
+        J.chunk_slot0[g] = slot0;
+        int* d = J.chunk_dc + (size_t)g * 4;
+        d[0] = e.dc[0]; d[1] = e.dc[1]; d[2] = e.dc[2]; d[3] = (int)e.ndc;
+    }
+    // the workgroup's DC sums, for the look-back of k_jpeg_dcfix
+    int d0 = e.dc[0], d1 = e.dc[1], d2 = e.dc[2];
+    for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_down(d0, o, 64); d1 += __shfl_down(d1, o, 64); d2 += __shfl_down(d2, o, 64); }
+    if ((t & 63) == 0) { atomicAdd(&s_tot[0], d0); atomicAdd(&s_tot[1], d1); atomicAdd(&s_tot[2], d2); }
     __syncthreads();
-    const bool open = !s_head[t];                                   // still in the interval that began in an earlier workgroup
-    const uint32_t incl_n = s_n[t] + (open ? s_carry[0] : 0u);
-    const int incl_dc0 = s_dc[0][t] + (open ? (int)s_carry[1] : 0), incl_dc1 = s_dc[1][t] + (open ? (int)s_carry[2] : 0),
-              incl_dc2 = s_dc[2][t] + (open ? (int)s_carry[3] : 0);
-    if (t == HB - 1 && b + 1 < nblocks) {
-        rec[7] = incl_n; rec[8] = (uint32_t)incl_dc0; rec[9] = (uint32_t)incl_dc1; rec[10] = (uint32_t)incl_dc2;
-        st_release(rec + 6, 1u);
+    if (t < 3) J.wg_dc[(size_t)b * 8 + t] = s_tot[t];
+    if (t == 0) { J.wg_dc[(size_t)b * 8 + 4] = (int)clock0; J.wg_dc[(size_t)b * 8 + 5] = (int)(uint32_t)wall_clock64(); }   // (IMPGPU_JPEG_TRACE=2)
+}
+
+__global__ __launch_bounds__(HB) void k_jpeg_dcfix(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
+    __shared__ int s_dc[3][HB];
+    __shared__ uint8_t s_head[HB];
+    __shared__ int s_carry[3];
+    const int t = threadIdx.x;
+    const JpegMapEntry me = block_map[blockIdx.x];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    const JpegFrame& F = J.F;
+    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
+    const uint32_t g0 = b * HB, g = g0 + (uint32_t)t;
+    const bool live = g < F.nchunks;
+    int own[3] = {0, 0, 0};
+    uint32_t ndc = 0;
+    bool origin = false;
+    if (live) {
+        origin = J.seg_first_chunk[J.chunk_seg[g]] == g;
+        const int* d = J.chunk_dc + (size_t)g * 4;
+        own[0] = d[0]; own[1] = d[1]; own[2] = d[2]; ndc = (uint32_t)d[3];
     }
-    stamp(9);
-    if (!live) return;
-    // ---- 5. decode once more, now knowing where every coefficient goes.  The last chunk of an interval walks with the
-    // interval's remaining slots as a budget -- a sequential decoder stops after the last MCU and never looks at the padding
-    // bits, which in a damaged file need not be the 1-bits an encoder writes -- and gives the verdict: it must end inside
-    // the padding with exactly the interval's slots decoded.
-    const uint32_t last_chunk_of_seg = (seg + 1 < F.nsegs ? A.seg_first_chunk[seg + 1] : F.nchunks) - 1;
-    const uint32_t base_n = incl_n - d.n;
-    const uint32_t slots_here = min((uint32_t)F.slots_per_seg, F.total_slots - seg * (uint32_t)F.slots_per_seg);
-    const bool closes = g == last_chunk_of_seg;
-    JpegWriteCtx W;
-    W.coef = A.coef;
-    W.slot0 = seg * (uint32_t)F.slots_per_seg + base_n;
-    W.dc0[0] = incl_dc0 - d.dc[0];
-    W.dc0[1] = incl_dc1 - d.dc[1];
-    W.dc0[2] = incl_dc2 - d.dc[2];
-    W.status = &A.header[1];
-    if (!closes && incl_n > slots_here) { atomicOr(&A.header[1], JPEG_ST_OVERRUN); return; }   // would write outside the interval
-    const uint32_t budget = closes ? (slots_here >= base_n ? slots_here - base_n : 0u) : 0xffffffffu;
-    const JpegDecoded e = jpeg_decode_chunk<true>(L, word, entry, limit, seg_end, F, &W, budget);
-    if (closes) {
-        const uint32_t pe = (uint32_t)e.exit, fle = (uint32_t)(e.exit >> 48);
-        if ((fle & JPEG_FL_INVALID) || pe > seg_end || seg_end - pe >= 8) atomicOr(&A.header[1], JPEG_ST_BAD_CODE);
-        if (base_n + e.n != slots_here) atomicOr(&A.header[1], JPEG_ST_BAD_COUNT);
+    s_dc[0][t] = own[0]; s_dc[1][t] = own[1]; s_dc[2][t] = own[2];
+    s_head[t] = origin ? 1 : 0;
+    __syncthreads();
+    for (int ofs = 1; ofs < HB; ofs <<= 1) {
+        int a0 = 0, a1 = 0, a2 = 0;
+        uint32_t h2 = 0;
+        const bool take = t >= ofs;
+        if (take) { a0 = s_dc[0][t - ofs]; a1 = s_dc[1][t - ofs]; a2 = s_dc[2][t - ofs]; h2 = s_head[t - ofs]; }
+        const uint32_t myh = s_head[t];
+        __syncthreads();
+        if (take) {
+            if (!myh) { s_dc[0][t] += a0; s_dc[1][t] += a1; s_dc[2][t] += a2; }
+            s_head[t] = (uint8_t)(myh | h2);
+        }
+        __syncthreads();
     }
-    stamp(10);
+    const uint32_t first0 = J.seg_first_chunk[J.chunk_seg[g0]];
+    int carry[3];
+    for (int i = 0; i < 3; i++) carry[i] = sum_before<int>(J.chunk_dc + i, 4, J.wg_dc + i, 8, (uint32_t)HB, first0, g0, t, &s_carry[i]);
+    if (!live || ndc == 0) return;
+    const bool open = !s_head[t];
+    int base[3];
+    for (int i = 0; i < 3; i++) base[i] = s_dc[i][t] - own[i] + (open ? carry[i] : 0);
+    // the blocks that begin in the chunk are neighbours in the scan: their predictors go to a side array indexed by the
+    // block's number there (k_jpeg_pixels adds them) -- a short each, side by side, where adding them to the DC terms in the
+    // planes was a 2-byte read-modify-write into a line of its own per block
+    const uint32_t z = (uint32_t)(J.chunk_entry[g] >> 40) & 0xff;
+    const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2, nblocks = F.total_slots >> 6;
+    const uint32_t gb = (J.chunk_slot0[g] >> 6) + (z ? 1u : 0u);
+    uint32_t c = gb % bpm;
+    for (uint32_t i = 0; i < ndc && gb + i < nblocks; i++) {
+        J.dcadd[gb + i] = (int16_t)(c < nluma ? base[0] : (c - nluma == 0 ? base[1] : base[2]));
+        c = c + 1 == bpm ? 0 : c + 1;
+    }
 }
 
 // ---------------------------------------------------------------- pixels
@@ -326,12 +700,14 @@ __device__ __forceinline__ void idct8(const int in[8], int out[8], const int shi
 __device__ __forceinline__ uint32_t sat_u8(int v) { return (uint32_t)min(max(v, 0), 255); }
 
 // one block: 64 coefficients at `blk` (natural order) -> 8 rows of 8 samples at out[0..7][0..7] in LDS
-__device__ void idct_block_to_lds(const int16_t* blk, const uint16_t* q, uint8_t* out, int pitch) {
+// (`dcadd`: what k_jpeg_dcfix found the block's DC term to lack -- the planes hold it relative to its chunk's entry)
+__device__ void idct_block_to_lds(const int16_t* blk, const uint16_t* q, uint8_t* out, int pitch, int dcadd) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     int ws[64];
     v4i raw[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) raw[k] = *(const v4i*)(blk + 8 * k);     // a row: eight shorts
+    raw[0][0] = (raw[0][0] & (int)0xffff0000) | ((raw[0][0] + dcadd) & 0xffff);   // (16-bit, like the JCOEF libjpeg stores)
 #pragma unroll
     for (int x = 0; x < 8; x++) {
         int in[8], o[8];
@@ -368,6 +744,7 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(const JpegJob* __restrict__
     const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
     const JpegFrame& F = J.F;
     const int16_t* __restrict__ coef = J.coef;
+    const int16_t* __restrict__ dcadd = J.dcadd;                    // (null when the host decoded the entropy stage: absolute DC terms)
     uint8_t* __restrict__ dst = J.dst;
     const int dstep = J.dstep;
     if (t < 64 * NC) s_q[t >> 6][t & 63] = J.qt[t];
@@ -376,16 +753,21 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(const JpegJob* __restrict__
     const int tile_y = (int)__builtin_amdgcn_readfirstlane(me.local) / tiles_x, tile_x = (int)__builtin_amdgcn_readfirstlane(me.local) - tile_y * tiles_x;
     {   // luma: one block per lane
         const int bx = tile_x * (TILE_W / 8) + (t & 31), by = tile_y * (TILE_H / 8) + (t >> 5);
-        if (bx < F.bw[0] && by < F.bh[0])
-            idct_block_to_lds(coef + F.coef_off[0] + ((size_t)by * F.bw[0] + bx) * 64, s_q[0], s_y + (t >> 5) * 8 * YP + (t & 31) * 8, YP);
+        if (bx < F.bw[0] && by < F.bh[0]) {
+            // the block's number in the scan: MCU by MCU, the luma blocks of an MCU row by row, then Cb, Cr
+            const int gb = ((by / VS) * F.mcux + bx / HS) * F.bpm + (by % VS) * HS + bx % HS;
+            idct_block_to_lds(coef + F.coef_off[0] + ((size_t)by * F.bw[0] + bx) * 64, s_q[0], s_y + (t >> 5) * 8 * YP + (t & 31) * 8, YP, dcadd ? dcadd[gb] : 0);
+        }
     }
     const int cbx0 = tile_x * (TILE_W / 8 / HS) - (HS == 2 ? 1 : 0), cby0 = tile_y * (TILE_H / 8 / VS) - (VS == 2 ? 1 : 0);
     if constexpr (NC == 3) {
         for (int i = t; i < 2 * CBW * CBH; i += 256) {
             const int ci = i >= CBW * CBH ? 2 : 1, j = i - (ci - 1) * CBW * CBH;
             const int lx = j % CBW, ly = j / CBW, bx = cbx0 + lx, by = cby0 + ly;
-            if (bx >= 0 && by >= 0 && bx < F.bw[ci] && by < F.bh[ci])
-                idct_block_to_lds(coef + F.coef_off[ci] + ((size_t)by * F.bw[ci] + bx) * 64, s_q[ci], s_c[ci - 1] + ly * 8 * CP + lx * 8, CP);
+            if (bx >= 0 && by >= 0 && bx < F.bw[ci] && by < F.bh[ci]) {
+                const int gb = (by * F.mcux + bx) * F.bpm + HS * VS + ci - 1;
+                idct_block_to_lds(coef + F.coef_off[ci] + ((size_t)by * F.bw[ci] + bx) * 64, s_q[ci], s_c[ci - 1] + ly * 8 * CP + lx * 8, CP, dcadd ? dcadd[gb] : 0);
+            }
         }
     }
     __syncthreads();
@@ -485,9 +867,14 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(const JpegJob* __restrict__
 
 }  // namespace
 
-int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* block_map, unsigned total_blocks, uint32_t* ticket, hipStream_t s) {
-    if (total_blocks == 0) return IMP_OK;
-    hipLaunchKernelGGL(k_jpeg_entropy, dim3(total_blocks), dim3(HB), 0, s, jobs, block_map, ticket);
+int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* sync_map, unsigned sync_blocks, const JpegMapEntry* chunk_map,
+                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s) {
+    if (sync_blocks == 0) return IMP_OK;
+    hipLaunchKernelGGL(k_jpeg_walks, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map);
+    hipLaunchKernelGGL(k_jpeg_mend, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map);
+    hipLaunchKernelGGL(k_jpeg_select, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map, ticket);
+    hipLaunchKernelGGL(k_jpeg_write, dim3(chunk_blocks), dim3(HB), 0, s, jobs, chunk_map);
+    hipLaunchKernelGGL(k_jpeg_dcfix, dim3(chunk_blocks), dim3(HB), 0, s, jobs, chunk_map);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }

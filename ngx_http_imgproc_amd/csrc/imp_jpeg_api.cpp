@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include "imp_jpeg.h"
+#include "imp_jpeg_core.h"
 
 using namespace imp;
 
@@ -54,11 +54,19 @@ struct Prep {                                       // one file on its way to th
     size_t words_off = 0, words_cap = 0;            // bytes, in the staging buffer and in the device copy alike
     size_t coef_off = 0;                            // bytes in the coefficient area
     size_t side_tables = 0, side_qt = 0, side_meta = 0;   // byte offsets in the side blob
-    size_t ctl_header = 0, ctl_records = 0;         // word offsets in the control area
+    size_t ctl_header = 0, ctl_records = 0, ctl_ext = 0;   // word offsets in the control area
+    size_t work_off = 0;                            // bytes in the per-chunk work area (entry states, slot counts, DC sums)
     impgpu_image* im = nullptr;
 };
 
-int decode_group(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
+// A file whose blocks average more bits than this keeps its Huffman stage on the calling thread even inside a launch that is
+// the device's: blocks that long seldom end inside a walk's overlap, so their chunks are reached one after the other by an
+// explicit state (tools/jpeg_sync_probe.py: 4.5 % of the chunks at 210 bits per block, a quality-98 photograph; 25-70 % for
+// white noise), and a 4 MB file of noise would hold a workgroup chain for most of a second where the host needs 25 ms.
+constexpr size_t DENSE_BITS_PER_BLOCK = 200;
+constexpr int CODE_DEFERRED = -0x7fff;              // internal: "decode this one in the host-entropy group"
+
+int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes, int force_host) {
     Stopwatch sw;
     hipStream_t s = env_stream();
     if (!s) return IMP_ERROR_DEVICE;
@@ -75,7 +83,12 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         if (p.code) continue;
         const size_t total_mcus = (size_t)p.H.mcux * p.H.mcuy;
         p.nsegs = p.H.restart_interval ? (total_mcus + p.H.restart_interval - 1) / p.H.restart_interval : 1;
-        p.words_cap = align_up(jpeg_scan_capacity(sizes[i] - p.H.scan_begin, p.nsegs), JPEG_CHUNK_BYTES);
+        // Refused before anything is sized by what the header claims: an interval needs a data byte and its marker, a block a DC
+        // code and an end-of-block code -- a few hundred bytes that announce 30000 x 30000 pixels, or a restart interval of one
+        // MCU on a frame of 2^30, would otherwise have pinned and device memory allocated by the gigabyte before the decode fails.
+        const size_t scan_bytes = sizes[i] - p.H.scan_begin;
+        if (p.nsegs > scan_bytes / 3 + 1 || (size_t)p.F.total_slots / 64 > 4 * scan_bytes + 64) { p.code = IMP_ERROR_DECODE_FAILED; continue; }
+        p.words_cap = align_up(jpeg_scan_capacity(scan_bytes, p.nsegs), JPEG_CHUNK_BYTES_MAX);
         p.words_off = words_total;
         words_total += p.words_cap;
         p.coef_off = coef_total;
@@ -84,7 +97,12 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
     size_t launch_bytes = 0;
     for (int i = 0; i < count; i++)
         if (!P[(size_t)i].code) launch_bytes += sizes[i] - P[(size_t)i].H.scan_begin;
-    const bool on_device = entropy_on_device(launch_bytes);
+    const bool on_device = !force_host && entropy_on_device(launch_bytes);
+    if (on_device && !std::getenv("IMPGPU_JPEG_HUFF"))
+        for (int i = 0; i < count; i++) {
+            Prep& p = P[(size_t)i];
+            if (!p.code && (sizes[i] - p.H.scan_begin) * 8 > DENSE_BITS_PER_BLOCK * ((size_t)p.F.total_slots / 64)) p.code = CODE_DEFERRED;
+        }
     sw.mark();                                                      // [0] headers
     // ---- the compressed bytes: FF00 unstuffing while they are copied into pinned memory -- the only pass the host makes
     // over them (device entropy stage), or the whole entropy decoding into pinned coefficient planes (A/B path)
@@ -103,6 +121,7 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
                 p.F.nchunks = (unsigned)p.scan.nchunks;
                 p.F.nsegs = (unsigned)p.scan.seg_first_chunk.size();
                 p.F.chunk_bits = (unsigned)p.scan.chunk_bytes * 8;
+                p.F.overlap_bits = jpeg_overlap_bits_for(p.F.chunk_bits, sizes[i] - p.H.scan_begin, (size_t)p.F.total_slots / 64);
             }
         } else {
             int16_t* planes = (int16_t*)((uint8_t*)host + p.coef_off);
@@ -113,7 +132,7 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         if (!p.code) live++;
     }
     sw.mark();                                                      // [1] unstuffing copy / host entropy decoding
-    void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr;
+    void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr, *d_work = nullptr;
     size_t njobs = 0, ctl_total = 0;
     uint32_t* mailbox = lane_mailbox();
     if (live == 0) { (void)stage_upload(token, nullptr, 0); goto done; }
@@ -121,7 +140,7 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
     {
         // ---- the side blob: per job its tables, quantisers and interval arrays, then the job table and the workgroup maps
         size_t side = 0, ctl_words = 4;                             // control: [0] ticket, then the jobs' headers, then their records
-        size_t total_blocks = 0;
+        size_t total_blocks = 0, sync_blocks = 0, work = 0;
         size_t tiles[5] = {0, 0, 0, 0, 0};                          // per sampling class
         auto klass = [](const JpegFrame& F) { return F.ncomp == 1 ? 0 : F.hs == 1 ? (F.vs == 1 ? 1 : 3) : (F.vs == 1 ? 2 : 4); };
         for (Prep& p : P) {
@@ -138,8 +157,16 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
                 p.side_meta = side;
                 side += align_up((p.scan.nchunks + 2 * p.scan.seg_first_chunk.size()) * sizeof(uint32_t), 64);
                 p.ctl_records = ctl_words;
-                ctl_words += (size_t)jpeg_entropy_blocks(p.F.nchunks) * JPEG_CTL_REC;
+                ctl_words += (size_t)jpeg_sync_blocks(p.F.nchunks, p.F.bpm) * JPEG_CTL_REC;
+                p.ctl_ext = ctl_words;
+                ctl_words += 4;
+                sync_blocks += jpeg_sync_blocks(p.F.nchunks, p.F.bpm);
                 total_blocks += jpeg_entropy_blocks(p.F.nchunks);
+                // per chunk: entry state (8 bytes), slots, first slot, DC sums [4]; per workgroup of k_jpeg_write: DC sums [4];
+                // per chunk and block of the MCU: what its walk found (two states, a slot count)
+                p.work_off = work;
+                work += align_up((size_t)p.F.nchunks * (32 + 40 * (size_t)p.F.bpm) + (size_t)jpeg_entropy_blocks(p.F.nchunks) * 32 + sizeof(JpegHuffTabs) + 64 +
+                                 ((size_t)p.F.nchunks / 8 + 16) * JPEG_EXT_WORDS * 4 + align_up((size_t)p.F.total_slots / 64 * 2, 64) + 64, 256);
             }
             p.side_qt = side;
             side += align_up(3 * 64 * sizeof(uint16_t), 64);
@@ -149,20 +176,24 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         side += align_up(njobs * sizeof(JpegJob), 64);
         const size_t side_blocks = side;
         side += align_up(total_blocks * sizeof(JpegMapEntry), 64);
+        const size_t side_sync = side;
+        side += align_up(sync_blocks * sizeof(JpegMapEntry), 64);
         size_t side_tiles[5];
         for (int k = 0; k < 5; k++) { side_tiles[k] = side; side += align_up(tiles[k] * sizeof(JpegMapEntry), 64); }
         rc = dev_alloc(side, &d_side);
         if (!rc) rc = dev_alloc(coef_total, &d_coef);
         if (!rc && on_device) rc = dev_alloc(words_total, &d_words);
+        if (!rc && on_device) rc = dev_alloc(work, &d_work);
         ctl_total = ctl_words;
         if (!rc && on_device) rc = dev_alloc(ctl_words * sizeof(uint32_t), &d_ctl);
         if (rc) goto fail;
         std::vector<uint8_t> blob(side);
         JpegJob* jobs = (JpegJob*)(blob.data() + side_jobs);
         JpegMapEntry* bmap = (JpegMapEntry*)(blob.data() + side_blocks);
+        JpegMapEntry* smap = (JpegMapEntry*)(blob.data() + side_sync);
         JpegMapEntry* tmap[5];
         for (int k = 0; k < 5; k++) tmap[k] = (JpegMapEntry*)(blob.data() + side_tiles[k]);
-        size_t j = 0, nb = 0, nt[5] = {0, 0, 0, 0, 0};
+        size_t j = 0, nb = 0, ns = 0, nt[5] = {0, 0, 0, 0, 0};
         std::vector<uint32_t> meta;
         for (Prep& p : P) {
             if (p.code) continue;
@@ -181,7 +212,27 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
                 J.tables = (const JpegHuffDev*)((uint8_t*)d_side + p.side_tables);
                 J.header = (uint32_t*)d_ctl + p.ctl_header;
                 J.records = (uint32_t*)d_ctl + p.ctl_records;
+                uint8_t* wk = (uint8_t*)d_work + p.work_off;
+                J.chunk_entry = (uint64_t*)wk;
+                J.chunk_n = (uint32_t*)(wk + (size_t)p.F.nchunks * 8);
+                J.chunk_slot0 = (uint32_t*)(wk + (size_t)p.F.nchunks * 12);
+                J.chunk_dc = (int*)(wk + (size_t)p.F.nchunks * 16);
+                J.wg_dc = (int*)(wk + (size_t)p.F.nchunks * 32);
+                uint8_t* cd = wk + (size_t)p.F.nchunks * 32 + (size_t)jpeg_entropy_blocks(p.F.nchunks) * 32;
+                J.cand_in = (uint64_t*)cd;
+                J.cand_out = (uint64_t*)(cd + (size_t)p.F.nchunks * 8 * (size_t)p.F.bpm);
+                J.rep_out = (uint64_t*)(cd + (size_t)p.F.nchunks * 16 * (size_t)p.F.bpm);
+                J.cand_n = (uint32_t*)(cd + (size_t)p.F.nchunks * 24 * (size_t)p.F.bpm);
+                J.rep_n = (uint32_t*)(cd + (size_t)p.F.nchunks * 28 * (size_t)p.F.bpm);
+                J.cand_nib = (uint8_t*)(cd + (size_t)p.F.nchunks * 32 * (size_t)p.F.bpm);       // (a byte each; the four-byte arrays go on at 36)
+                J.ext_idx = (uint32_t*)(cd + (size_t)p.F.nchunks * 36 * (size_t)p.F.bpm);
+                J.tabs = (JpegHuffTabs*)(cd + (size_t)p.F.nchunks * 40 * (size_t)p.F.bpm);
+                J.ext = (uint32_t*)((uint8_t*)J.tabs + align_up(sizeof(JpegHuffTabs), 64));
+                J.ext_cap = (uint32_t)(p.F.nchunks / 8 + 16);
+                J.ext_count = (uint32_t*)d_ctl + p.ctl_ext;
+                J.dcadd = (int16_t*)((uint8_t*)J.ext + align_up((size_t)J.ext_cap * JPEG_EXT_WORDS * 4, 64));
                 for (unsigned b = 0; b < jpeg_entropy_blocks(p.F.nchunks); b++) bmap[nb++] = JpegMapEntry{(uint32_t)j, b};
+                for (unsigned b = 0; b < jpeg_sync_blocks(p.F.nchunks, p.F.bpm); b++) smap[ns++] = JpegMapEntry{(uint32_t)j, b};
             }
             uint16_t* qt3 = (uint16_t*)(blob.data() + p.side_qt);
             for (int c = 0; c < p.H.ncomp; c++) std::memcpy(qt3 + 64 * c, p.H.qt[p.H.comp[c].tq], 64 * sizeof(uint16_t));
@@ -200,13 +251,14 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         token = nullptr;
         if (rc) goto fail;
         if (on_device) {
-            if (hipMemsetAsync(d_ctl, 0, ctl_words * sizeof(uint32_t), s) != hipSuccess || hipMemsetAsync(d_coef, 0, coef_total, s) != hipSuccess) {
+            // (the coefficient planes are zeroed by k_jpeg_sync itself, on the side)
+            if (hipMemsetAsync(d_ctl, 0, ctl_words * sizeof(uint32_t), s) != hipSuccess) {
                 set_error("hipMemsetAsync(jpeg)", hipGetLastError());
                 rc = IMP_ERROR_DEVICE;
                 goto fail;
             }
-            rc = launch_jpeg_entropy((const JpegJob*)((uint8_t*)d_side + side_jobs), (const JpegMapEntry*)((uint8_t*)d_side + side_blocks),
-                                     (unsigned)total_blocks, (uint32_t*)d_ctl, s);
+            rc = launch_jpeg_entropy((const JpegJob*)((uint8_t*)d_side + side_jobs), (const JpegMapEntry*)((uint8_t*)d_side + side_sync), (unsigned)sync_blocks,
+                                     (const JpegMapEntry*)((uint8_t*)d_side + side_blocks), (unsigned)total_blocks, (uint32_t*)d_ctl, s);
             if (rc) goto fail;
             // the kernel's verdicts (did every interval decode to exactly its MCUs?) are read before a frame is handed on
             const hipError_t e = hipMemcpyAsync(mailbox, (uint32_t*)d_ctl + 4, njobs * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
@@ -223,25 +275,34 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         rc = lane_wait();
         if (rc) goto fail;
         if (sw.on && !std::strcmp(std::getenv("IMPGPU_JPEG_TRACE"), "2")) {
-            // the workgroups' clocks at their phase boundaries (k_jpeg_entropy's stamp()), microseconds since the launch's
-            // first workgroup started: wg: start | rounds0 | wait1 rounds1 | wait2 rounds2 | count scan carry write
+            // the workgroups' clocks at their phase boundaries (k_jpeg_sync's stamp()), microseconds since the launch's
+            // first workgroup started: wg: start | walks | candidates exchanged | maps | scan + look-back | done
             std::vector<uint32_t> ctl(ctl_total);
             if (hipMemcpy(ctl.data(), d_ctl, ctl_total * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
                 uint32_t t0 = 0;
                 bool have = false;
                 for (const Prep& p : P)
                     if (!p.code)
-                        for (unsigned b = 0; b < jpeg_entropy_blocks(p.F.nchunks); b++) {
-                            const uint32_t v = ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 12];
+                        for (unsigned b = 0; b < jpeg_sync_blocks(p.F.nchunks, p.F.bpm); b++) {
+                            const uint32_t v = ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 20];
                             if (!have || (int32_t)(v - t0) < 0) { t0 = v; have = true; }
                         }
+                for (const Prep& p : P) {                          // k_jpeg_write: every workgroup's start and end
+                    if (p.code) continue;
+                    const unsigned nb2 = jpeg_entropy_blocks(p.F.nchunks);
+                    std::vector<int> wg((size_t)nb2 * 8);
+                    if (hipMemcpy(wg.data(), (uint8_t*)d_work + p.work_off + (size_t)p.F.nchunks * 32, wg.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
+                    for (unsigned b = 0; b < nb2; b++)
+                        std::fprintf(stderr, "ww %dx%d %u/%u: %.1f %.1f\n", p.H.width, p.H.height, b, nb2, (double)(int32_t)((uint32_t)wg[8 * b + 4] - t0) / 100.0,
+                                     (double)(int32_t)((uint32_t)wg[8 * b + 5] - t0) / 100.0);
+                }
                 for (const Prep& p : P) {
                     if (p.code) continue;
-                    const unsigned nb = jpeg_entropy_blocks(p.F.nchunks);
+                    const unsigned nb = jpeg_sync_blocks(p.F.nchunks, p.F.bpm);
                     for (unsigned b = 0; b < nb; b++) {
-                        const uint32_t* r = &ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 12];
+                        const uint32_t* r = &ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 20];
                         std::fprintf(stderr, "wg %dx%d %u/%u:", p.H.width, p.H.height, b, nb);
-                        for (int k = 0; k <= 10; k++) std::fprintf(stderr, " %.1f", r[k] ? (double)(int32_t)(r[k] - t0) / 100.0 : -1.0);
+                        for (int k = 0; k <= 5; k++) std::fprintf(stderr, " %.1f", r[k] ? (double)(int32_t)(r[k] - t0) / 100.0 : -1.0);
                         std::fprintf(stderr, "\n");
                     }
                 }
@@ -251,7 +312,7 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         for (Prep& p : P) {
             if (p.code) continue;
             const uint32_t status = mailbox[4 * j + 1];
-            if (sw.on) std::fprintf(stderr, "jpeg %dx%d: rounds %u + %u, status %u\n", p.H.width, p.H.height, mailbox[4 * j + 2], mailbox[4 * j + 3], status);
+            if (sw.on) std::fprintf(stderr, "jpeg %dx%d: %u chunks of %u bits (overlap %u), %u repair walks, %u chunks chased, %u walks in k_jpeg_select, status %u\n", p.H.width, p.H.height, p.F.nchunks, p.F.chunk_bits, p.F.overlap_bits, mailbox[4 * j + 2], mailbox[4 * j + 3], mailbox[4 * j + 0], status);
             if (status) {
                 char text[96];
                 std::snprintf(text, sizeof text, "jpeg entropy stage refused the scan (status 0x%x)", status);
@@ -270,6 +331,7 @@ done:
     dev_free(d_coef);
     dev_free(d_side);
     dev_free(d_ctl);
+    dev_free(d_work);
     for (int i = 0; i < count; i++) {
         Prep& p = P[(size_t)i];
         if (p.code && p.im) { image_delete(p.im); p.im = nullptr; }
@@ -284,11 +346,28 @@ fail:
     dev_free(d_coef);
     dev_free(d_side);
     dev_free(d_ctl);
+    dev_free(d_work);
     for (int i = 0; i < count; i++) {
         if (P[(size_t)i].im) image_delete(P[(size_t)i].im);
         images[i] = nullptr;
         codes[i] = P[(size_t)i].code ? P[(size_t)i].code : rc;
     }
+    return rc;
+}
+
+int decode_group(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
+    if (int rc = decode_group_as(blobs, sizes, count, images, codes, 0)) return rc;
+    std::vector<int> late;
+    for (int i = 0; i < count; i++) if (codes[i] == CODE_DEFERRED) late.push_back(i);
+    if (late.empty()) return IMP_OK;
+    std::vector<const unsigned char*> b2(late.size());
+    std::vector<size_t> s2(late.size());
+    std::vector<impgpu_image*> i2(late.size(), nullptr);
+    std::vector<int> c2(late.size(), IMP_OK);
+    for (size_t k = 0; k < late.size(); k++) { b2[k] = blobs[late[k]]; s2[k] = sizes[late[k]]; }
+    const int rc = decode_group_as(b2.data(), s2.data(), (int)late.size(), i2.data(), c2.data(), 1);
+    for (size_t k = 0; k < late.size(); k++) { images[late[k]] = rc ? nullptr : i2[k]; codes[late[k]] = rc ? rc : c2[k]; }
+    if (rc) for (int i = 0; i < count; i++) if (images[i]) { impgpu_image_release(&images[i]); codes[i] = rc; }
     return rc;
 }
 

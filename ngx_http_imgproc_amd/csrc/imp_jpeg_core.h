@@ -33,22 +33,43 @@ IMP_HD inline uint32_t jpeg_lut_entry(uint32_t len, uint32_t sym, bool is_dc) {
 // code length + value bits (what the symbol takes from the stream), bits 21..27 = how far the coefficient index moves
 // (run + 1; 64 for an end of block: "to the block's end" and "past it" are the same thing to the index).  0 stays 0.
 IMP_HD inline uint32_t jpeg_lut_expand(uint32_t e) {
-    if ((e & 31) == 0) return 0;
+    if ((e & 31) == 0) return e;                                    // no code of this length: 0, or the pointer to the second level
     const uint32_t total = (e & 31) + ((e >> 5) & 15), adv = ((e >> 13) & 1) ? 64u : ((e >> 9) & 15) + 1;
     return e | (total << 16) | (adv << 21);
 }
 
 struct JpegHuffTabs {                       // the four tables as a decoder lane reads them (LDS on the device)
     uint32_t lut[4][1 << JPEG_LOOKBITS];    // jpeg_lut_expand(JpegHuffDev::lut)
+    uint32_t sub[4][JPEG_SUB_ENTRIES];      // jpeg_lut_expand(JpegHuffDev::sub)
     uint32_t limit[4][18];
     int32_t offs[4][18];
     uint8_t vals[4][256];
+};
+struct JpegBlockTabs {                      // where the coefficients go (k_jpeg_write, k_jpeg_dcfix)
     uint8_t natural[64];                    // zig-zag position -> position in the 8x8 block
     uint32_t blk_base[8];                   // per block of the MCU: its first coefficient in MCU (0,0), in shorts
     uint32_t blk_dx[8], blk_dy[8];          // ... and how far the same block is in the next MCU / the next MCU row
 };
 
-// blk_base / blk_dx / blk_dy of JpegHuffTabs from the frame geometry (luma blocks first, then Cb, Cr)
+// How a walk reads its tables: the expanded form above (LDS of the kernels that walk a lot), or the four tables as the host
+// built them, widened entry by entry (k_jpeg_select: 12 KB instead of 22, for the few walks of a chase).
+struct JpegHuffCompact { JpegHuffDev t[4]; };
+IMP_HD inline uint32_t jpeg_tab_first(const JpegHuffTabs& L, uint32_t tab, uint32_t i) { return L.lut[tab][i]; }
+IMP_HD inline uint32_t jpeg_tab_second(const JpegHuffTabs& L, uint32_t tab, uint32_t i) { return L.sub[tab][i]; }
+IMP_HD inline uint32_t jpeg_tab_limit(const JpegHuffTabs& L, uint32_t tab, int l) { return L.limit[tab][l]; }
+IMP_HD inline int32_t jpeg_tab_offs(const JpegHuffTabs& L, uint32_t tab, uint32_t l) { return L.offs[tab][l]; }
+IMP_HD inline uint32_t jpeg_tab_val(const JpegHuffTabs& L, uint32_t tab, uint32_t i) { return L.vals[tab][i]; }
+IMP_HD inline uint32_t jpeg_tab_first_raw(const JpegHuffTabs& L, uint32_t tab, uint32_t i) { return L.lut[tab][i]; }
+IMP_HD inline uint32_t jpeg_tab_second_raw(const JpegHuffTabs& L, uint32_t tab, uint32_t i) { return L.sub[tab][i]; }
+IMP_HD inline uint32_t jpeg_tab_first_raw(const JpegHuffCompact& L, uint32_t tab, uint32_t i) { return L.t[tab].lut[i]; }
+IMP_HD inline uint32_t jpeg_tab_second_raw(const JpegHuffCompact& L, uint32_t tab, uint32_t i) { return L.t[tab].sub[i]; }
+IMP_HD inline uint32_t jpeg_tab_first(const JpegHuffCompact& L, uint32_t tab, uint32_t i) { return jpeg_lut_expand(L.t[tab].lut[i]); }
+IMP_HD inline uint32_t jpeg_tab_second(const JpegHuffCompact& L, uint32_t tab, uint32_t i) { return jpeg_lut_expand(L.t[tab].sub[i]); }
+IMP_HD inline uint32_t jpeg_tab_limit(const JpegHuffCompact& L, uint32_t tab, int l) { return L.t[tab].limit[l]; }
+IMP_HD inline int32_t jpeg_tab_offs(const JpegHuffCompact& L, uint32_t tab, uint32_t l) { return L.t[tab].offs[l]; }
+IMP_HD inline uint32_t jpeg_tab_val(const JpegHuffCompact& L, uint32_t tab, uint32_t i) { return L.t[tab].vals[i]; }
+
+// blk_base / blk_dx / blk_dy of JpegBlockTabs from the frame geometry (luma blocks first, then Cb, Cr)
 IMP_HD inline void jpeg_block_steps(const JpegFrame& F, int k, uint32_t* base, uint32_t* dx, uint32_t* dy) {
     const int nluma = F.bpm == 1 ? 1 : F.bpm - 2;
     int ci = 0, bx = 0, by = 0;
@@ -73,7 +94,43 @@ struct JpegWriteCtx {
     uint32_t slot0;      // absolute slot (within the scan) of the chunk's first symbol
     int dc0[3];          // DC predictors at the chunk's entry
     uint32_t* status;
+    // device only: where the lane builds the block it is decoding (64 zeroed shorts in LDS) and where its wave lists the
+    // blocks that are complete (64 x {LDS byte address, first short in the planes}); byte addresses in LDS
+    uint32_t stage, list;
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef int16_t __attribute__((address_space(3))) * JpegLdsShort;
+typedef uint32_t __attribute__((address_space(3))) * JpegLdsWord;
+typedef int __attribute__((ext_vector_type(4))) JpegV4;
+typedef JpegV4 __attribute__((address_space(3))) * JpegLdsV4;
+typedef JpegV4 __attribute__((address_space(1))) * JpegGlobalV4;
+// The complete blocks of a wave leave together: eight lanes per block, 16 bytes each -- one store instruction writes eight
+// whole 128-byte lines, where a 2-byte store per coefficient and lane was 64 partial lines per instruction (70 % of the
+// kernel's time), and the buffers go back to zero on the way.  Every lane of the wave must call this together.
+__device__ __forceinline__ void jpeg_flush_blocks(const JpegWriteCtx* W, bool ready, uint32_t at) {
+    const uint64_t mask = __ballot(ready);
+    if (mask == 0) return;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    JpegLdsWord list = (JpegLdsWord)(uintptr_t)W->list;
+    if (ready) { list[2 * rank] = W->stage; list[2 * rank + 1] = at; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t nready = (uint32_t)__popcll(mask);
+    const JpegV4 zero = {0, 0, 0, 0};
+    for (uint32_t base = 0; base < nready; base += 8) {
+        const uint32_t i = base + (lane >> 3), part = lane & 7;
+        if (i < nready) {
+            const uint32_t src = list[2 * i], dst = list[2 * i + 1];
+            JpegLdsV4 q = (JpegLdsV4)(uintptr_t)(src + part * 16);
+            const JpegV4 v = *q;
+            *q = zero;
+            ((JpegGlobalV4)(uintptr_t)(W->coef + dst))[part] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+#endif
 
 IMP_HD inline void jpeg_flag(uint32_t* status, uint32_t bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -97,19 +154,52 @@ IMP_HD inline void jpeg_put_coef(int16_t* base, uint32_t at, int16_t v) {
 // the i-th 32-bit word of the stream as memory holds it (first byte in bits 0..7) -> first bit of the stream in bit 31
 IMP_HD inline uint32_t jpeg_be(uint32_t raw) { return __builtin_bswap32(raw); }
 
-// One chunk: every symbol that STARTS before `limit`, from the packed state `entry`.  `word(i)` returns the i-th 32-bit
-// word of the unstuffed stream AS LOADED (little-endian: jpeg_be turns it round where it is used, not where it is loaded,
-// so that the load has a whole refill's worth of symbols to arrive).  Reads at most two words past the one holding bit limit-1.
+// The decoder's view of the stream: the next 32 bits, out of two consecutive words (first bit of the stream in bit 31) of which
+// 32 - sh bits of w0 are used up; sh = 0 .. 31, 0 = all of w0, the view is w1.  One v_alignbit_b32 on the device (a 64-bit
+// shift register was a quarter-rate v_lshlrev_b64 per symbol).  Consuming n bits: sh -= n, and below zero the words move up.
+IMP_HD inline uint32_t jpeg_window(uint32_t w0, uint32_t w1, int sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
+#else
+    return sh ? (w0 << (32 - sh)) | (w1 >> sh) : w1;
+#endif
+}
+
+// a whole block of zeros (the block's owner writes them just before its coefficients: no fill of the planes beforehand, and
+// every 128-byte line leaves the cache completely written -- 2-byte stores into lines zeroed long before cost a
+// read-modify-write each in memory, 70 % of the write kernel's time when it was built that way)
+IMP_HD inline void jpeg_zero_block(int16_t* base, uint32_t at) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef int __attribute__((ext_vector_type(4))) v4i;
+    typedef v4i __attribute__((address_space(1))) * GlobalV4;
+    GlobalV4 q = (GlobalV4)(uintptr_t)(base + at);
+    const v4i zero = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = zero;
+#else
+    for (int i = 0; i < 64; i++) base[at + i] = 0;
+#endif
+}
+
+// One chunk, decoded for good: every symbol that STARTS before `limit`, from the packed state `entry` (its true one, found
+// by k_jpeg_sync).  `word(i)` returns the i-th 32-bit word of the unstuffed stream AS LOADED (little-endian: jpeg_be turns it
+// round where it is used, not where it is loaded, so that the load has a whole refill's worth of symbols to arrive).
 // `max_slots` ends the walk once that many coefficient slots have been passed: the last chunk of an interval stops after the
 // interval's last MCU like a sequential decoder does, whatever the (up to seven) padding bits behind it look like.
+//
+// A BLOCK BELONGS TO THE CHUNK IT BEGINS IN: that lane zeroes its 64 coefficients, writes its non-zero ones and, if the block
+// runs past `limit`, decodes on to the block's end; the lane of the next chunk decodes those symbols too (it has to get
+// past them) but stores nothing until a block begins.  So every block of the planes is written by exactly one lane, whole.
+// Returned: slots and DC symbols / sums of the symbols that start before `limit` only.  DC terms are written relative to
+// the chunk's entry (dc0 = 0: jpeg_dc_fixup adds the predictors).
 //
 // Written for a SIMT lane: one loop, one table read per symbol, selects instead of branches, no array indexed by a run-time
 // value (those live in scratch memory on the device), the next stream word always one step ahead in a register.  A
 // symbol is (code length, value bits, zero run, end-of-block) straight out of the table; DC and AC symbols, ZRL and EOB all
 // take the same few instructions: the coefficient index moves by run + 1, or to the block's end.
-template <bool WRITE, class WordFn>
-IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, uint64_t entry, uint32_t limit, uint32_t seg_end,
-                                            const JpegFrame& F, const JpegWriteCtx* W, uint32_t max_slots = 0xffffffffu) {
+template <class Tabs, class WordFn>
+IMP_HD inline JpegDecoded jpeg_write_chunk(const Tabs& L, const JpegBlockTabs& K, WordFn word, uint64_t entry, uint32_t limit, uint32_t seg_end,
+                                           const JpegFrame& F, const JpegWriteCtx* W, uint32_t max_slots = 0xffffffffu, bool active = true) {
     JpegDecoded r;
     r.exit = entry;
     r.n = 0;
@@ -117,8 +207,11 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
     r.dc[0] = r.dc[1] = r.dc[2] = 0;
     uint32_t p = (uint32_t)entry;
     uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
-    if ((uint32_t)(entry >> 48)) return r;                          // nothing can follow an invalid / ended predecessor
-    if (p >= limit) return r;
+    // nothing can follow an invalid / ended predecessor.  (No early return: on the device every lane of the wave has to reach
+    // the loop below, where finished blocks are written out by the lanes together -- `active` = this lane has a chunk at all.)
+    bool ok = active && (uint32_t)(entry >> 48) == 0 && p < limit;
+    p = ok ? p : 0u;
+    c = ok ? c : 0u;
     const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
     // per block of the MCU: its component (two bits each) and whether it takes the second DC / AC table (a bit each)
     uint32_t comp_of = 0, dc_sel = 0, ac_sel = 0;
@@ -128,39 +221,59 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
         dc_sel |= (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]) << k;
         ac_sel |= (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]) << k;
     }
-    // bit window: `have` valid bits at the top of buf, never fewer than 32 when a symbol starts; `ahead` = the word after it
-    uint32_t widx = p >> 5;
-    uint64_t buf = (((uint64_t)jpeg_be(word(widx)) << 32) | jpeg_be(word(widx + 1))) << (p & 31);
-    int have = 64 - (int)(p & 31);
-    widx += 2;
-    uint32_t ahead = word(widx);
+    // the bit window (jpeg_window); `ahead` = the word after it, as loaded
+    const uint32_t widx = p >> 5, bit = p & 31;
+    uint32_t w0 = bit ? jpeg_be(word(widx)) : 0u, w1 = jpeg_be(word(widx + (bit ? 1u : 0u))), nxt = widx + (bit ? 2u : 1u);
+    int sh = bit ? 32 - (int)bit : 0;
+    uint32_t ahead = word(nxt);
     uint32_t fl = 0, n = 0, damaged = 0, ndc = 0;
     int dcs0 = 0, dcs1 = 0, dcs2 = 0;
-    // where the coefficients go (WRITE): MCU coordinates are carried along, a block's address is base + mx*dx + my*dy
+    // where the coefficients go: MCU coordinates are carried along, a block's address is base + mx*dx + my*dy
     uint32_t mx = 0, my = 0, blk = 0;
     bool blk_ok = false;
-    if (WRITE) {
+    bool own = false;                                               // the block being decoded began in this chunk
+    if (ok) {
         const uint32_t gb = W->slot0 >> 6, mcu = gb / bpm;
         my = mcu / (uint32_t)F.mcux;
         mx = mcu - my * (uint32_t)F.mcux;
-        if (gb - mcu * bpm != c || (W->slot0 & 63) != z) { jpeg_flag(W->status, JPEG_ST_BAD_COUNT); return r; }
+        if (gb - mcu * bpm != c || (W->slot0 & 63) != z) { jpeg_flag(W->status, JPEG_ST_BAD_COUNT); ok = false; }
         blk_ok = my < (uint32_t)F.mcuy;
-        blk = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
+        blk = K.blk_base[c] + mx * K.blk_dx[c] + my * K.blk_dy[c];
     }
-    // (one way out of the loop, at its bottom -- see jpeg_sync_chunk: an ending skips the rest of the body instead of jumping out)
-    bool go = n < max_slots;
+    // (one way out of the loop, at its bottom: an ending skips the rest of the body instead of jumping out -- every extra exit
+    // of a divergent loop costs a handful of scalar instructions per symbol for its execution-mask bookkeeping)
+    bool go = ok && n < max_slots;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // on the device the whole wave stays in the loop until its last lane is done: finished blocks leave cooperatively
+    JpegLdsShort stage = (JpegLdsShort)(uintptr_t)W->stage;
+    bool dirty = false;                                             // the block buffer holds coefficients not yet written out
+    while (__any(go)) {
+        bool ready = false;
+        uint32_t ready_at = 0;
+        if (go) {
+#else
     while (go) {
+        {
+#endif
         const uint32_t ci = (comp_of >> (2 * c)) & 3;
         const bool isdc = z == 0;
         const uint32_t tab = isdc ? ((dc_sel >> c) & 1) : 2 + ((ac_sel >> c) & 1);
-        const uint32_t peek = (uint32_t)(buf >> 48);
-        uint32_t e = L.lut[tab][peek >> (16 - JPEG_LOOKBITS)];
-        if ((e & 31) == 0) {                                        // a code longer than the table's index: its length from
-            uint32_t len = JPEG_LOOKBITS + 1;                       // the canonical limits, its symbol from the value list
-            for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= L.limit[tab][l] ? 1u : 0u;
-            const bool none = peek >= L.limit[tab][16];             // no code starts with these 16 bits
-            const uint32_t sym = L.vals[tab][(uint32_t)(L.offs[tab][len] + (int)(peek >> (16 - len))) & 255];
-            e = none ? 0u : jpeg_lut_entry(len, sym, isdc);
+        const uint32_t win = jpeg_window(w0, w1, sh), peek = win >> 16;
+        // (only the entry as the host built it is read here -- length, value bits, run, end-of-block: its low 16 bits)
+        uint32_t e = jpeg_tab_first_raw(L, tab, peek >> (16 - JPEG_LOOKBITS));
+        if ((e & 31) == 0) {                                        // a code longer than the table's index
+            bool none;
+            if (e & 0x8000u) {                                      // ... in the second level, indexed by the bits that follow
+                const uint32_t nb = (e >> 12) & 7, off = ((e >> 5) & 127) << 1;
+                e = jpeg_tab_second_raw(L, tab, off + ((win >> (32 - JPEG_LOOKBITS - nb)) & ((1u << nb) - 1)));
+                none = e == 0;
+            } else {                                                // ... or (a table with too many of them) its length from the
+                uint32_t len = JPEG_LOOKBITS + 1;                   // canonical limits, its symbol from the value list
+                for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= jpeg_tab_limit(L, tab, l) ? 1u : 0u;
+                none = peek >= jpeg_tab_limit(L, tab, 16);          // no code starts with these 16 bits
+                const uint32_t sym = jpeg_tab_val(L, tab, (uint32_t)(jpeg_tab_offs(L, tab, len) + (int)(peek >> (16 - len))) & 255);
+                e = none ? 0u : jpeg_lut_entry(len, sym, isdc);
+            }
             fl = none ? ((seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID) : fl;   // (the 1-bits that pad an interval are no code either)
         }
         const uint32_t len = e & 31, size = (e >> 5) & 15, run = (e >> 9) & 15, eob = (e >> 13) & 1;
@@ -168,54 +281,71 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
         if (fl == 0 && p + total > seg_end) fl = JPEG_FL_END;       // the interval's padding, not a symbol
         if (fl == 0) {
             // the value: `size` bits after the code, negative when its first bit is 0 (T.81 F.2.2.1)
-            const uint32_t vb = (uint32_t)(buf >> 32) << len;
+            const uint32_t vb = win << len;
             const int v = (int)((vb >> 1) >> (31 - size)) + ((int)(~vb) >> 31 & (1 - (1 << size)));
-            buf <<= total;
-            have -= (int)total;
+            const bool counted = p < limit;                         // (not so for the symbols that finish a block behind the chunk's end)
             p += total;
-            if (have <= 32) {
-                buf |= (uint64_t)jpeg_be(ahead) << (32 - have);     // the byte swap HERE: a swap at the load would wait for it there
-                have += 32;
-                widx++;
-                ahead = word(widx);
+            sh -= (int)total;
+            if (sh < 0) {
+                w0 = w1;
+                w1 = jpeg_be(ahead);                                // the byte swap HERE: a swap at the load would wait for it there
+                sh += 32;
+                nxt++;
+                ahead = word(nxt);
             }
             uint32_t adv = eob ? 64 - z : run + 1;
             const bool over = z + adv > 64;                         // a run that leaves the block: damaged
             adv = over ? 64 - z : adv;
             damaged |= over ? 1u : 0u;
-            if (WRITE) {
-                if (isdc) {
-                    const int dcv = (ci == 0 ? W->dc0[0] + dcs0 : ci == 1 ? W->dc0[1] + dcs1 : W->dc0[2] + dcs2) + v;
-                    if (blk_ok) jpeg_put_coef(W->coef, blk, (int16_t)dcv);
-                } else if (size && !over && blk_ok) {
-                    jpeg_put_coef(W->coef, blk + L.natural[z + run], (int16_t)v);
+            if (isdc) {
+                own = true;
+                const int dcv = (ci == 0 ? W->dc0[0] + dcs0 : ci == 1 ? W->dc0[1] + dcs1 : W->dc0[2] + dcs2) + v;
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (blk_ok) { stage[0] = (int16_t)dcv; dirty = true; }
+#else
+                if (blk_ok) {
+                    jpeg_zero_block(W->coef, blk);
+                    jpeg_put_coef(W->coef, blk, (int16_t)dcv);
                 }
+#endif
+            } else if (size && !over && blk_ok && own) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                stage[K.natural[z + run]] = (int16_t)v;
+#else
+                jpeg_put_coef(W->coef, blk + K.natural[z + run], (int16_t)v);
+#endif
             }
             ndc += isdc ? 1u : 0u;
             dcs0 += (isdc && ci == 0) ? v : 0;
             dcs1 += (isdc && ci == 1) ? v : 0;
             dcs2 += (isdc && ci == 2) ? v : 0;
             z += adv;
-            n += adv;
+            n += counted ? adv : 0u;
             if (z >= 64) {                                          // next block
+#if defined(__HIP_DEVICE_COMPILE__)
+                ready = dirty;
+                ready_at = blk;
+                dirty = false;
+#endif
                 z = 0;
                 c++;
-                if (WRITE) {
-                    if (c == bpm) { mx++; if (mx == (uint32_t)F.mcux) { mx = 0; my++; } }
-                }
+                if (c == bpm) { mx++; if (mx == (uint32_t)F.mcux) { mx = 0; my++; } }
                 c = c == bpm ? 0 : c;
-                if (WRITE) {
-                    blk_ok = my < (uint32_t)F.mcuy;
-                    blk = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
-                }
+                blk_ok = my < (uint32_t)F.mcuy;
+                blk = K.blk_base[c] + mx * K.blk_dx[c] + my * K.blk_dy[c];
             }
         }
-        go = fl == 0 && p < limit && n < max_slots;
+        go = fl == 0 && n < max_slots && (p < limit || (own && z != 0));
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        jpeg_flush_blocks(W, ready, ready_at);
+#endif
     }
-    if (WRITE) {
-        if (damaged || (fl & JPEG_FL_INVALID)) jpeg_flag(W->status, JPEG_ST_BAD_CODE);
-    }
-    r.exit = jpeg_pack_state(p, c, z, fl);
+#if defined(__HIP_DEVICE_COMPILE__)
+    jpeg_flush_blocks(W, dirty, blk);                               // (a block cut short by an ending: what there is of it)
+#endif
+    if (damaged || (fl & JPEG_FL_INVALID)) jpeg_flag(W->status, JPEG_ST_BAD_CODE);
+    if (ok) r.exit = jpeg_pack_state(p, c, z, fl);
     r.n = n;
     r.ndc = ndc;
     r.dc[0] = dcs0;
@@ -224,76 +354,10 @@ IMP_HD inline JpegDecoded jpeg_decode_chunk(const JpegHuffTabs& L, WordFn word, 
     return r;
 }
 
-// The same walk for the rounds that only look for the chunk's EXIT state (every round but the last two): no values, no
-// counts, no coefficient addresses -- a symbol is a table read, two shifts and two additions.  Returns exactly the exit
-// state jpeg_decode_chunk<false> (without a slot budget) returns for the same entry.
-template <class WordFn>
-IMP_HD inline uint64_t jpeg_sync_chunk(const JpegHuffTabs& L, WordFn word, uint64_t entry, uint32_t limit, uint32_t seg_end, const JpegFrame& F) {
-    uint32_t p = (uint32_t)entry;
-    uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
-    if ((uint32_t)(entry >> 48)) return entry;
-    if (p >= limit) return entry;
-    const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
-    // per block of the MCU, four bits: the table its DC symbol is read with (0 / 1) and, two bits up, the table of its AC
-    // symbols (2 / 3) -- one shift and one mask per symbol pick the table; and, four bits each again, the block that follows
-    uint32_t tabsel = 0, nextc = 0;
-    for (uint32_t k = 0; k < 6; k++) {
-        const uint32_t ci = k < nluma ? 0u : (k - nluma + 1 < 3 ? k - nluma + 1 : 2u);
-        const uint32_t dct = (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]);
-        const uint32_t act = 2u + (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]);
-        tabsel |= (dct | (act << 2)) << (4 * k);
-        nextc |= (k + 1 == bpm ? 0u : k + 1) << (4 * k);
-    }
-    uint32_t widx = p >> 5;
-    uint64_t buf = (((uint64_t)jpeg_be(word(widx)) << 32) | jpeg_be(word(widx + 1))) << (p & 31);
-    int have = 64 - (int)(p & 31);
-    widx += 2;
-    uint32_t ahead = word(widx);
-    uint32_t fl = 0;
-    // ONE way out of the loop, at its bottom: an ending (the interval's padding, an undecodable pattern) takes nothing from
-    // the stream and pulls `limit` down to zero instead of jumping out -- every extra exit of a divergent loop costs a
-    // handful of scalar instructions per symbol for its execution-mask bookkeeping
-    do {
-        const bool isdc = z == 0;
-        const uint32_t tab = (tabsel >> (4 * c + (isdc ? 0u : 2u))) & 3;
-        const uint32_t peek = (uint32_t)(buf >> 48);
-        uint32_t e = L.lut[tab][peek >> (16 - JPEG_LOOKBITS)];
-        if ((e & 31) == 0) {                                        // a code longer than the table's index (rare)
-            uint32_t len = JPEG_LOOKBITS + 1;
-            for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= L.limit[tab][l] ? 1u : 0u;
-            const bool none = peek >= L.limit[tab][16];             // no code starts with these 16 bits
-            const uint32_t sym = L.vals[tab][(uint32_t)(L.offs[tab][len] + (int)(peek >> (16 - len))) & 255];
-            e = none ? 0u : jpeg_lut_expand(jpeg_lut_entry(len, sym, isdc));
-            fl = none ? ((seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID) : fl;
-        }
-        uint32_t total = (e >> 16) & 31, adv = e >> 21;
-        const bool pad = fl == 0 && p + total > seg_end;            // the interval's padding, not a symbol
-        fl = pad ? JPEG_FL_END : fl;
-        total = fl ? 0u : total;
-        adv = fl ? 0u : adv;
-        limit = fl ? 0u : limit;
-        buf <<= total;
-        have -= (int)total;
-        p += total;
-        if (have <= 32) {
-            buf |= (uint64_t)jpeg_be(ahead) << (32 - have);
-            have += 32;
-            widx++;
-            ahead = word(widx);
-        }
-        z += adv;
-        const bool ended = z >= 64;
-        const uint32_t cn = (nextc >> (4 * c)) & 15;
-        z = ended ? 0u : z;
-        c = ended ? cn : c;
-    } while (p < limit);
-    return jpeg_pack_state(p, c, z, fl);
-}
-
-// The write walk (jpeg_decode_chunk<true> with dc0 = 0) leaves every DC term relative to its chunk's entry; this adds the
+// The write walk (jpeg_write_chunk with dc0 = 0) leaves every DC term relative to its chunk's entry; this adds the
 // predictors at the entry (`base`, per component) to the `ndc` blocks that begin in the chunk.  Same block walk as the
 // decoder's: MCU coordinates carried along, a block's address is base + mx*dx + my*dy.
-IMP_HD inline void jpeg_dc_fixup(const JpegHuffTabs& L, const JpegFrame& F, int16_t* coef, uint32_t slot0, uint64_t entry, uint32_t ndc, const int base[3]) {
+IMP_HD inline void jpeg_dc_fixup(const JpegBlockTabs& K, const JpegFrame& F, int16_t* coef, uint32_t slot0, uint64_t entry, uint32_t ndc, const int base[3]) {
     const uint32_t z = (uint32_t)(entry >> 40) & 0xff;
     const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
     const uint32_t gb = (slot0 >> 6) + (z ? 1u : 0u);               // a chunk entered in mid-block begins with the next block's DC term
@@ -302,7 +366,7 @@ IMP_HD inline void jpeg_dc_fixup(const JpegHuffTabs& L, const JpegFrame& F, int1
     for (uint32_t j = 0; j < ndc; j++) {
         const int add = c < nluma ? base[0] : (c - nluma == 0 ? base[1] : base[2]);
         if (my < (uint32_t)F.mcuy && add) {
-            const uint32_t at = L.blk_base[c] + mx * L.blk_dx[c] + my * L.blk_dy[c];
+            const uint32_t at = K.blk_base[c] + mx * K.blk_dx[c] + my * K.blk_dy[c];
             coef[at] = (int16_t)(coef[at] + add);
         }
         c++;
@@ -317,20 +381,23 @@ IMP_HD inline void jpeg_dc_fixup(const JpegHuffTabs& L, const JpegFrame& F, int1
 // predecessor's `out` equals a walk's `in` the walk's `out` IS what decoding on from the predecessor's state gives: the
 // successor is SELECTED, not decoded again.  With one walk per block of the MCU (six for 4:2:0) the true state is almost
 // always among the `in`s once the overlap holds a block end or two -- bit position and coefficient index fall into step by
-// themselves, and every block phase is being tried.  Same symbol step as jpeg_sync_chunk.
+// themselves, and every block phase is being tried.  
 struct JpegSpan {
     uint64_t in, out;
     uint32_t n;
 };
-template <class WordFn>
-IMP_HD inline JpegSpan jpeg_span_walk(const JpegHuffTabs& L, WordFn word, uint64_t entry, uint32_t cross, uint32_t limit, uint32_t seg_end, const JpegFrame& F) {
+template <class Tabs, class WordFn>
+IMP_HD inline JpegSpan jpeg_span_walk(const Tabs& L, WordFn word, uint64_t entry, uint32_t cross, uint32_t limit, uint32_t seg_end, const JpegFrame& F) {
     JpegSpan r;
     r.in = r.out = entry;
     r.n = 0;
     uint32_t p = (uint32_t)entry;
     uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
     if ((uint32_t)(entry >> 48)) return r;                          // a dead state stays what it is
+    (void)seg_end;
     const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
+    // per block of the MCU, four bits: the table its DC symbol is read with (0 / 1) and, two bits up, the table of its AC
+    // symbols (2 / 3) -- one shift and one mask per symbol pick the table; and, four bits each again, the block that follows
     uint32_t tabsel = 0, nextc = 0;
     for (uint32_t k = 0; k < 6; k++) {
         const uint32_t ci = k < nluma ? 0u : (k - nluma + 1 < 3 ? k - nluma + 1 : 2u);
@@ -339,58 +406,62 @@ IMP_HD inline JpegSpan jpeg_span_walk(const JpegHuffTabs& L, WordFn word, uint64
         tabsel |= (dct | (act << 2)) << (4 * k);
         nextc |= (k + 1 == bpm ? 0u : k + 1) << (4 * k);
     }
-    uint32_t widx = p >> 5;
-    uint64_t buf = (((uint64_t)jpeg_be(word(widx)) << 32) | jpeg_be(word(widx + 1))) << (p & 31);
-    int have = 64 - (int)(p & 31);
-    widx += 2;
-    uint32_t ahead = word(widx);
-    uint32_t fl = 0, n = 0;
+    const uint32_t widx = p >> 5, bit = p & 31;
+    uint32_t w0 = bit ? jpeg_be(word(widx)) : 0u, w1 = jpeg_be(word(widx + (bit ? 1u : 0u))), nxt = widx + (bit ? 2u : 1u);
+    int sh = bit ? 32 - (int)bit : 0;
+    uint32_t ahead = word(nxt);                                     // (as loaded: the byte swap where it is used, so that the load has a refill's time to arrive)
+    uint32_t fl = 0, blocks = 0, z0 = z;
+    // No look at the interval's end here (the write walk does that): only an interval's LAST chunk could meet the padding,
+    // and its exit state and slot count are never used -- the chunk behind it starts a new interval.
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
     for (int stage = 0; stage < 2; stage++) {
-        uint32_t target = stage ? limit : cross;
-        n = 0;
+        uint32_t target = fl ? 0u : (stage ? limit : cross);
+        blocks = 0;
+        z0 = z;
         while (p < target) {                                        // (an ending pulls `target` down to zero: one way out)
-            const bool isdc = z == 0;
-            const uint32_t tab = (tabsel >> (4 * c + (isdc ? 0u : 2u))) & 3;
-            const uint32_t peek = (uint32_t)(buf >> 48);
-            uint32_t e = L.lut[tab][peek >> (16 - JPEG_LOOKBITS)];
-            if ((e & 31) == 0) {                                    // a code longer than the table's index (rare)
-                uint32_t len = JPEG_LOOKBITS + 1;
-                for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= L.limit[tab][l] ? 1u : 0u;
-                const bool none = peek >= L.limit[tab][16];         // no code starts with these 16 bits
-                const uint32_t sym = L.vals[tab][(uint32_t)(L.offs[tab][len] + (int)(peek >> (16 - len))) & 255];
-                e = none ? 0u : jpeg_lut_expand(jpeg_lut_entry(len, sym, isdc));
-                fl = none ? ((seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID) : fl;
+            const uint32_t win = jpeg_window(w0, w1, sh);
+            const uint32_t tab = (tabsel >> (4 * c + (z == 0 ? 0u : 2u))) & 3;
+            uint32_t e = jpeg_tab_first(L, tab, win >> (32 - JPEG_LOOKBITS));
+            if ((e >> 16) == 0) {                                   // a code longer than the table's index
+                bool none;
+                if (e & 0x8000u) {                                  // ... in the second level, indexed by the bits that follow
+                    const uint32_t nb = (e >> 12) & 7, off = ((e >> 5) & 127) << 1;
+                    e = jpeg_tab_second(L, tab, off + ((win >> (32 - JPEG_LOOKBITS - nb)) & ((1u << nb) - 1)));
+                    none = e == 0;
+                } else {                                            // ... or (a table with too many of them) by the canonical limits
+                    const uint32_t peek = win >> 16;
+                    uint32_t len = JPEG_LOOKBITS + 1;
+                    for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= jpeg_tab_limit(L, tab, l) ? 1u : 0u;
+                    none = peek >= jpeg_tab_limit(L, tab, 16);                // no code starts with these 16 bits
+                    const uint32_t sym = jpeg_tab_val(L, tab, (uint32_t)(jpeg_tab_offs(L, tab, len) + (int)(peek >> (16 - len))) & 255);
+                    e = none ? 0u : jpeg_lut_expand(jpeg_lut_entry(len, sym, z == 0));
+                }
+                fl = none ? JPEG_FL_INVALID : fl;
+                target = none ? 0u : target;
             }
-            uint32_t total = (e >> 16) & 31, adv = e >> 21;
-            const bool pad = fl == 0 && p + total > seg_end;        // the interval's padding, not a symbol
-            fl = pad ? JPEG_FL_END : fl;
-            total = fl ? 0u : total;
-            adv = fl ? 0u : adv;
-            target = fl ? 0u : target;
-            buf <<= total;
-            have -= (int)total;
+            const uint32_t total = (e >> 16) & 31, adv = e >> 21;
             p += total;
-            if (have <= 32) {
-                buf |= (uint64_t)jpeg_be(ahead) << (32 - have);
-                have += 32;
-                widx++;
-                ahead = word(widx);
+            sh -= (int)total;
+            if (sh < 0) {
+                w0 = w1;
+                w1 = jpeg_be(ahead);
+                sh += 32;
+                nxt++;
+                ahead = word(nxt);
             }
-            const uint32_t room = 64 - z;                           // (jpeg_decode_chunk counts a run that leaves its block up to the block's end)
-            n += adv < room ? adv : room;
             z += adv;
             const bool ended = z >= 64;
             const uint32_t cn = (nextc >> (4 * c)) & 15;
+            blocks += ended ? 1u : 0u;
             z = ended ? 0u : z;
             c = ended ? cn : c;
         }
         if (stage == 0) r.in = jpeg_pack_state(p, c, z, fl);
     }
     r.out = jpeg_pack_state(p, c, z, fl);
-    r.n = n;
+    r.n = 64u * blocks + z - z0;                                    // (every block passed counts 64, whatever its last run claimed)
     return r;
 }
 

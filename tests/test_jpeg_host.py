@@ -74,7 +74,7 @@ def test_chunk_parallel_scheme_on_larger_frames(sub):
         nchunks = len(blob) // 128
         st = (C.c_int * 8)()
         lib.impgpu_jpeg_sync_stats(st)
-        assert st[1] == info[2] and st[0] >= nchunks
+        assert st[1] == info[2] and st[0] >= nchunks // 2          # (chunks of up to 256 bytes)
         if kind == "smooth":
             assert st[1] <= max(4, st[0] // 10), "no self-synchronisation: %d misses for %d chunks" % (st[1], st[0])
         rc, got, _ = product_coefficients(blob, 0)

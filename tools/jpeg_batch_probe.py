@@ -28,6 +28,7 @@ for rep in range(6):
     t0 = time.perf_counter()
     rc = lib.impgpu_batch_decode_jpeg(blobs, sizes, B, imgs, codes)
     t1 = time.perf_counter()
+    assert rc == 0 and not any(codes), (rc, list(codes))
     for k in range(B):
         one = C.c_void_p(imgs[k])
         lib.impgpu_resize(C.byref(one), MIXED_RESIZE, C.byref(cfg.c), 0)

@@ -9,5 +9,5 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SALU
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_jpeg/p$i -- python3 $R/tools/jpeg_pmc_probe.py > $R/gpurun_out/pmc_jpeg/p$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_jpeg/p$i.log; exit 1; }
 done
-python3 $R/tools/pmc_table.py $R/gpurun_out/pmc_jpeg > $R/gpurun_out/r03_jpeg_sq_counters.txt
-grep -c . $R/gpurun_out/r03_jpeg_sq_counters.txt
+python3 $R/tools/pmc_table.py $R/gpurun_out/pmc_jpeg > $R/gpurun_out/${OUT:-r04_jpeg_sq_counters.txt}
+grep -c . $R/gpurun_out/${OUT:-r04_jpeg_sq_counters.txt}
