@@ -546,6 +546,109 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
             "threads_bound": bool(NUMA_BIND and lib.impgpu_env_numa_node() >= 0)}
 
 
+def jpeg_stream_native(n_requests, n_threads, files, batch, out_quality, device):
+    """The same stream driven by C threads over the C ABI (tests/c/stream_harness.c) -- what a pool of nginx workers is.  The
+    Python driver above holds the interpreter's lock for a millisecond per batch and hands it over in 5 ms slices: with more
+    than two threads it measures that (device idle 45-50 % of the time, tools/trace_busy.py), not the library."""
+    import struct
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "c", "_build", "stream_harness")
+    if not os.path.exists(exe):
+        raise SystemExit("tests/c/_build/stream_harness is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        f.write(struct.pack("<I", len(files)))
+        for _, _, b in files:
+            f.write(struct.pack("<I", len(b)))
+            f.write(b)
+        pool = f.name
+    try:
+        warm = max(2048, 8 * n_threads * batch)
+        env = dict(os.environ, IMPGPU_DEVICE=str(device))
+        out = subprocess.run([exe, pool, str(n_requests), str(n_threads), str(batch), str(out_quality), str(warm)], env=env, capture_output=True, text=True)
+        if out.returncode:
+            raise SystemExit("stream_harness failed (%d): %s" % (out.returncode, out.stderr[-400:]))
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    finally:
+        os.unlink(pool)
+    src = 0
+    for i in range(n_requests):
+        w, h, _ = files[i % len(files)]
+        src += w * h * 3
+    return {"requests": r["requests"], "seconds": r["seconds"], "source_bytes": src, "file_bytes": r["file_bytes"], "answer_bytes": r["answer_bytes"],
+            "numa_node": r["numa_node"], "threads_bound": r["numa_node"] >= 0}
+
+
+def jpeg_stage_profile(imp, files, batch, out_quality, reps=6):
+    """Where a batch's time goes, one thread, nothing else on the device: the decode call's own stages
+    (impgpu_jpeg_stage_times: host clock and stream events), then the resize, the encoder / the download timed around their
+    calls.  Microseconds per call of `batch` files; the median of `reps`."""
+    import ctypes as C
+    import numpy as np
+    from ngx_http_imgproc_amd import ResizeItem
+    from ngx_http_imgproc_amd.workloads import MIXED_RESIZE
+
+    lib = imp.lib
+    n = min(batch, len(files)) if batch > 1 else 1
+    cfg = imp.Config()
+    items = [files[i % len(files)] for i in range(n)]
+    blobs = (C.c_char_p * n)(*[b for _, _, b in items])
+    sizes = (C.c_size_t * n)(*[len(b) for _, _, b in items])
+    enc_cap = lib.impgpu_jpeg_encode_bound(224, 224, 3)
+    host = np.empty((n, max(enc_cap, 224 * 224 * 16)), dtype=np.uint8)
+    datas = (C.c_void_p * n)(*[host[k].ctypes.data for k in range(n)])
+    caps = (C.c_size_t * n)(*[enc_cap] * n)
+    lens = (C.c_size_t * n)()
+    codes = (C.c_int * n)()
+    steps = (C.c_int * n)()
+    names = ["headers", "unstuff", "job_tables", "enqueue", "wait", "upload", "walks", "mend", "select", "write", "dcfix", "pixels"]
+    rows = []
+    lib.impgpu_jpeg_profile(1)
+    try:
+        for _ in range(reps + 2):
+            imgs = (C.c_void_p * n)()
+            outs = (C.c_void_p * n)()
+            assert lib.impgpu_batch_decode_jpeg(blobs, sizes, n, imgs, codes) == 0 and not any(codes)
+            st = (C.c_double * 16)()
+            lib.impgpu_jpeg_stage_times(st, 16)
+            its = (ResizeItem * n)()
+            ow, oh, ip = C.c_int(), C.c_int(), C.c_int()
+            for k in range(n):
+                one = C.c_void_p(imgs[k])
+                sw_, sh_ = lib.impgpu_image_width(one), lib.impgpu_image_height(one)
+                lib.impgpu_resize_geometry(sw_, sh_, MIXED_RESIZE, C.byref(cfg.c), 0, ow, oh, ip)
+                o = C.c_void_p()
+                assert lib.impgpu_image_create(ow.value, oh.value, 3, C.byref(o)) == 0
+                outs[k] = o
+                steps[k] = lib.impgpu_image_step(o)
+                its[k] = ResizeItem(lib.impgpu_image_device_ptr(one), sw_, sh_, lib.impgpu_image_step(one), lib.impgpu_image_device_ptr(o), ow.value, oh.value, steps[k])
+            lib.impgpu_sync()
+            t0 = time.perf_counter()
+            assert lib.impgpu_batch_resize_mixed(its, n, 3, 0, None) == 0
+            lib.impgpu_sync()
+            t1 = time.perf_counter()
+            if out_quality:
+                assert lib.impgpu_batch_encode_jpeg(outs, n, out_quality, datas, caps, lens, codes) == 0
+            else:
+                assert lib.impgpu_batch_download(outs, n, datas, steps) == 0
+            t2 = time.perf_counter()
+            for k in range(n):
+                for arr in (imgs, outs):
+                    one = C.c_void_p(arr[k])
+                    lib.impgpu_image_release(C.byref(one))
+            rows.append(list(st)[:12] + [(t1 - t0) * 1e6, (t2 - t1) * 1e6])
+    finally:
+        lib.impgpu_jpeg_profile(0)
+    med = np.median(np.array(rows[2:]), axis=0)
+    out = {nm: round(float(v), 1) for nm, v in zip(names, med[:12])}
+    out["entropy"] = round(float(sum(med[6:11])), 1)
+    out["resize"] = round(float(med[12]), 1)
+    out["encode" if out_quality else "download"] = round(float(med[13]), 1)
+    out["files_per_call"] = n
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -567,6 +670,7 @@ def main():
     ap.add_argument("--jpeg-out", type=int, default=0, metavar="Q",
                     help="--stream --jpeg: the answers are JPEG files of quality Q too (the module's default is 86), encoded where the request was decoded")
     ap.add_argument("--jpeg-files", type=int, default=64, help="--stream --jpeg: distinct files the requests cycle through")
+    ap.add_argument("--native", action="store_true", help="--stream --jpeg device: the request threads are C threads (tests/c/stream_harness.c), not Python's")
     ap.add_argument("--mixed", type=int, default=0, metavar="N",
                     help="BASELINE configs[4] with the N frames already in HBM: resize=224,0 over mixed sizes, one "
                          "impgpu_batch_resize_mixed call per step (and, for comparison, one launch per frame)")
@@ -617,11 +721,18 @@ def main():
         for decoder in (("device", "hosthuff", "host") if args.jpeg == "all" else (args.jpeg,)):
             # untimed prefix: every lane (= thread) meets the common buffer sizes once, so that the timed part measures the
             # steady state of a server, not hipMalloc / hipHostMalloc
-            jpeg_stream(imp, min(args.stream, max(256, 24 * args.threads * args.jpeg_batch)), args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch, args.jpeg_out)
+            native = args.native and decoder == "device"
+            stages = jpeg_stage_profile(imp, files, args.jpeg_batch, args.jpeg_out) if decoder == "device" else None
+            if not native:
+                jpeg_stream(imp, min(args.stream, max(256, 24 * args.threads * args.jpeg_batch)), args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch, args.jpeg_out)
             if use_dist:
                 dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
-            r = jpeg_stream(imp, args.stream, args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch, args.jpeg_out)
+            if native:
+                share = len(range(rank, args.stream, world))
+                r = jpeg_stream_native(share, args.threads, files, args.jpeg_batch, args.jpeg_out, local_rank)
+            else:
+                r = jpeg_stream(imp, args.stream, args.threads, args.queue_depth, decoder, files, rank, world, args.jpeg_batch, args.jpeg_out)
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier(device_ids=[local_rank])
@@ -635,6 +746,13 @@ def main():
                 "bits_per_pixel": round(fbytes * 8 / (nbytes / 3), 2), "seconds": round(secs, 3),
                 "answers": ("JPEG quality %d, encoded on the %s" % (args.jpeg_out, "host" if decoder == "host" else "device")) if args.jpeg_out else "raw B,G,R thumbnails",
                 "answer_bytes_per_request": round(abytes / max(1.0, nreq), 1),
+                "driver": "C threads over the C ABI (tests/c/stream_harness.c)" if native else "Python threads (ctypes)",
+                # what the stream moves at the least: the file in, its coefficient planes once, the decoded pixels once, the answer out
+                "roofline": (lambda alg: {"bound": "hbm", "achieved": round(alg / secs / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / secs / 8e12, 4),
+                                          "traffic": None, "algorithmic_bytes_per_request": round(alg / max(1.0, nreq)),
+                                          "link": {"compressed_GB_per_s": round(fbytes / secs / 1e9, 2), "measured_link_GB_per_s": 55.0, "frac": round(fbytes / secs / 55e9, 3)}})(
+                    fbytes + abytes + nbytes + sum(((w + 15) // 16) * ((h + 15) // 16) * 6 * 128 for w, h, _ in files) * (nreq / len(files))),
+                "stages_us_per_call": stages,
                 "config": {"workload": "BASELINE configs[4] as JPEG files: %d requests, long side log-uniform 256..3840, resize=224,0 (INTER_AREA)" % int(nreq),
                            "threads_per_gpu": args.threads, "files_per_decode_call": args.jpeg_batch, "host_cores": os.cpu_count(), "queue_depth": args.queue_depth,
                            "numa_node": r["numa_node"], "threads_bound_to_node": r["threads_bound"],

@@ -152,6 +152,14 @@ int   impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_im
  * error), in which case no image is returned. */
 int   impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* sizes, int count,
                                impgpu_image** images, int* codes);
+/* Where a decode call's time goes (per-stage timing): impgpu_jpeg_profile(1) makes every later decode call leave
+ * its stages with the calling thread, impgpu_jpeg_stage_times reads the last call's, in microseconds:
+ * [0] marker segments, [1] FF00 unstuffing into pinned memory, [2] tables + job table, [3] enqueue, [4] wait for the verdicts
+ * (host clock); [5] upload, [6] k_jpeg_walks, [7] k_jpeg_mend, [8] k_jpeg_select, [9] k_jpeg_write, [10] k_jpeg_dcfix,
+ * [11] verdict copy + k_jpeg_pixels (events on the stream; the call then also waits for the pixels); [12] files decoded.
+ * Returns the previous setting / IMP_OK. */
+int   impgpu_jpeg_profile(int on);
+int   impgpu_jpeg_stage_times(double* microseconds, int n);
 /* The other end of the request: CvMat* encoded = cvEncodeImage(".jpg", image, basicCoderopt)          bridge.c:704
  * with basicCoderopt = {CV_IMWRITE_JPEG_QUALITY, quality} (bridge.c:474-486; OpenCV clamps the value to 0..100), for the
  * frame the operators left in HBM: colour conversion, chroma downsampling, forward DCT, quantisation and Huffman coding run

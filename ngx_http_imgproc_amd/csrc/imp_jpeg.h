@@ -166,8 +166,9 @@ inline unsigned jpeg_sync_blocks(unsigned nchunks, int bpm) { const unsigned c =
 inline unsigned jpeg_entropy_blocks(unsigned nchunks) { return (nchunks + JPEG_HUFF_BLOCK - 1) / JPEG_HUFF_BLOCK; }
 // `ticket` = one zeroed word per launch; both maps in job-major order (a job's workgroups in increasing order):
 // sync_map for k_jpeg_select (jpeg_sync_blocks per job), chunk_map for k_jpeg_write and k_jpeg_dcfix (jpeg_entropy_blocks)
+// `marks`: null, or five events recorded behind k_jpeg_walks, _mend, _select, _write, _dcfix (impgpu_jpeg_profile)
 int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* sync_map, unsigned sync_blocks, const JpegMapEntry* chunk_map,
-                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s);
+                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s, hipEvent_t* marks = nullptr);
 // dequantise + ISLOW IDCT + fancy upsampling + YCbCr->BGR, coefficient planes -> frames; all jobs of one sampling class
 int launch_jpeg_pixels(int hs, int vs, int ncomp, const JpegJob* jobs, const JpegMapEntry* tile_map, unsigned total_tiles, hipStream_t s);
 

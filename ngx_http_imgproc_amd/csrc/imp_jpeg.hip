@@ -868,13 +868,19 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(const JpegJob* __restrict__
 }  // namespace
 
 int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* sync_map, unsigned sync_blocks, const JpegMapEntry* chunk_map,
-                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s) {
+                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s, hipEvent_t* marks) {
     if (sync_blocks == 0) return IMP_OK;
+    auto mark = [&](int i) { if (marks) (void)hipEventRecord(marks[i], s); };
     hipLaunchKernelGGL(k_jpeg_walks, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map);
+    mark(0);
     hipLaunchKernelGGL(k_jpeg_mend, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map);
+    mark(1);
     hipLaunchKernelGGL(k_jpeg_select, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map, ticket);
+    mark(2);
     hipLaunchKernelGGL(k_jpeg_write, dim3(chunk_blocks), dim3(HB), 0, s, jobs, chunk_map);
+    mark(3);
     hipLaunchKernelGGL(k_jpeg_dcfix, dim3(chunk_blocks), dim3(HB), 0, s, jobs, chunk_map);
+    mark(4);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }

@@ -2,6 +2,7 @@
 // for JPEG blobs (bridge.c:545-552) with everything but marker parsing and FF00 unstuffing on the device (imp_jpeg.h).
 // One file or many, the device sees the same thing: a table of jobs, one entropy launch, one pixel launch per sampling
 // class, one wait for all verdicts.
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,13 +27,18 @@ bool entropy_on_device(size_t launch_bytes) {
     return launch_bytes >= (size_t(100) << 10);
 }
 
+// impgpu_jpeg_profile(1): every decode call leaves its stages' durations with the calling thread (impgpu_jpeg_stage_times) --
+// the host's from its clock, the device's from events recorded between the kernels
+std::atomic<int> g_profile{0};
+thread_local double t_stage[16];
+
 // IMPGPU_JPEG_TRACE=1: one line per call on stderr with the host's share of it, in microseconds
 struct Stopwatch {
     bool on;
     std::chrono::steady_clock::time_point t0;
     double marks[8] = {};
     int n = 0;
-    Stopwatch() : on(std::getenv("IMPGPU_JPEG_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    Stopwatch() : on(std::getenv("IMPGPU_JPEG_TRACE") != nullptr || g_profile.load(std::memory_order_relaxed)), t0(std::chrono::steady_clock::now()) {}
     void mark() {
         if (!on || n >= 8) return;
         const auto t = std::chrono::steady_clock::now();
@@ -133,6 +139,8 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
     }
     sw.mark();                                                      // [1] unstuffing copy / host entropy decoding
     void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr, *d_work = nullptr;
+    bool profile = g_profile.load(std::memory_order_relaxed) != 0;
+    hipEvent_t ev[8] = {};
     size_t njobs = 0, ctl_total = 0;
     uint32_t* mailbox = lane_mailbox();
     if (live == 0) { (void)stage_upload(token, nullptr, 0); goto done; }
@@ -246,6 +254,10 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
             j++;
         }
         sw.mark();                                                  // [2] tables + job table
+        if (profile && on_device) {
+            for (int i = 0; i < 8; i++) if (hipEventCreate(&ev[i]) != hipSuccess) { ev[i] = nullptr; profile = false; }
+            if (profile) (void)hipEventRecord(ev[0], s);
+        }
         rc = upload_to(d_side, blob.data(), side, s);
         if (!rc) rc = stage_upload(token, on_device ? d_words : d_coef, on_device ? words_total : coef_total);
         token = nullptr;
@@ -257,8 +269,9 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
                 rc = IMP_ERROR_DEVICE;
                 goto fail;
             }
+            if (profile) (void)hipEventRecord(ev[1], s);
             rc = launch_jpeg_entropy((const JpegJob*)((uint8_t*)d_side + side_jobs), (const JpegMapEntry*)((uint8_t*)d_side + side_sync), (unsigned)sync_blocks,
-                                     (const JpegMapEntry*)((uint8_t*)d_side + side_blocks), (unsigned)total_blocks, (uint32_t*)d_ctl, s);
+                                     (const JpegMapEntry*)((uint8_t*)d_side + side_blocks), (unsigned)total_blocks, (uint32_t*)d_ctl, s, profile ? ev + 2 : nullptr);
             if (rc) goto fail;
             // the kernel's verdicts (did every interval decode to exactly its MCUs?) are read before a frame is handed on
             const hipError_t e = hipMemcpyAsync(mailbox, (uint32_t*)d_ctl + 4, njobs * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
@@ -269,12 +282,13 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
             rc = launch_jpeg_pixels(KH[k], KV[k], KN[k], (const JpegJob*)((uint8_t*)d_side + side_jobs),
                                     (const JpegMapEntry*)((uint8_t*)d_side + side_tiles[k]), (unsigned)tiles[k], s);
         if (rc) goto fail;
+        if (profile && on_device) (void)hipEventRecord(ev[7], s);
     }
     sw.mark();                                                      // [3] enqueue
     if (on_device) {
         rc = lane_wait();
         if (rc) goto fail;
-        if (sw.on && !std::strcmp(std::getenv("IMPGPU_JPEG_TRACE"), "2")) {
+        if (const char* tr = std::getenv("IMPGPU_JPEG_TRACE"); tr && !std::strcmp(tr, "2")) {
             // the workgroups' clocks at their phase boundaries (k_jpeg_sync's stamp()), microseconds since the launch's
             // first workgroup started: wg: start | walks | candidates exchanged | maps | scan + look-back | done
             std::vector<uint32_t> ctl(ctl_total);
@@ -312,7 +326,7 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
         for (Prep& p : P) {
             if (p.code) continue;
             const uint32_t status = mailbox[4 * j + 1];
-            if (sw.on) std::fprintf(stderr, "jpeg %dx%d: %u chunks of %u bits (overlap %u), %u repair walks, %u chunks chased, %u walks in k_jpeg_select, status %u\n", p.H.width, p.H.height, p.F.nchunks, p.F.chunk_bits, p.F.overlap_bits, mailbox[4 * j + 2], mailbox[4 * j + 3], mailbox[4 * j + 0], status);
+            if (sw.on && std::getenv("IMPGPU_JPEG_TRACE")) std::fprintf(stderr, "jpeg %dx%d: %u chunks of %u bits (overlap %u), %u repair walks, %u chunks chased, %u walks in k_jpeg_select, status %u\n", p.H.width, p.H.height, p.F.nchunks, p.F.chunk_bits, p.F.overlap_bits, mailbox[4 * j + 2], mailbox[4 * j + 3], mailbox[4 * j + 0], status);
             if (status) {
                 char text[96];
                 std::snprintf(text, sizeof text, "jpeg entropy stage refused the scan (status 0x%x)", status);
@@ -323,10 +337,21 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
         }
     }
     sw.mark();                                                      // [4] wait for the verdicts
-    if (sw.on)
+    if (g_profile.load(std::memory_order_relaxed)) {
+        for (int i = 0; i < 16; i++) t_stage[i] = 0;
+        for (int i = 0; i < 5; i++) t_stage[i] = sw.marks[i];
+        if (profile && on_device && hipEventSynchronize(ev[7]) == hipSuccess)
+            for (int i = 0; i < 7; i++) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) t_stage[5 + i] = 1e3 * ms;
+            }
+        t_stage[12] = (double)live;
+    }
+    if (sw.on && std::getenv("IMPGPU_JPEG_TRACE"))
         std::fprintf(stderr, "jpeg x%d (%zu live): headers %.0f %s %.0f jobs %.0f enqueue %.0f wait %.0f us\n", count, live, sw.marks[0],
                      on_device ? "unstuff" : "host-entropy", sw.marks[1], sw.marks[2], sw.marks[3], sw.marks[4]);
 done:
+    for (int i = 0; i < 8; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
     dev_free(d_words);
     dev_free(d_coef);
     dev_free(d_side);
@@ -340,6 +365,7 @@ done:
     }
     return IMP_OK;
 fail:
+    for (int i = 0; i < 8; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
     if (token) (void)stage_upload(token, nullptr, 0);
     (void)lane_wait();                                              // nothing of this call may still be running when its buffers go back
     dev_free(d_words);
@@ -388,6 +414,16 @@ int impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* si
             return rc;
         }
     }
+    return IMP_OK;
+}
+
+int impgpu_jpeg_profile(int on) {
+    return g_profile.exchange(on ? 1 : 0);
+}
+
+int impgpu_jpeg_stage_times(double* microseconds, int n) {
+    if (!microseconds || n < 0) return IMP_ERROR_INVALID_ARGS;
+    for (int i = 0; i < n; i++) microseconds[i] = i < 16 ? t_stage[i] : 0.0;
     return IMP_OK;
 }
 
