@@ -159,6 +159,11 @@ int   impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* 
  * [11] verdict copy + k_jpeg_pixels (events on the stream; the call then also waits for the pixels); [12] files decoded.
  * Returns the previous setting / IMP_OK. */
 int   impgpu_jpeg_profile(int on);
+/* Process-wide counts since the library was loaded: [0] files whose entropy stage ran on the device, [1] of those, refused
+ * by its verdict (the caller's cvDecodeImage fallback took them), [2] of those, because a wait between workgroups ran out --
+ * must stay 0 on a healthy box, however many processes share the device -- [3] files kept on the calling thread because
+ * their blocks are too long for the device scheme (more than 200 bits each). */
+int   impgpu_jpeg_counters(unsigned long long* counters, int n);
 int   impgpu_jpeg_stage_times(double* microseconds, int n);
 /* The other end of the request: CvMat* encoded = cvEncodeImage(".jpg", image, basicCoderopt)          bridge.c:704
  * with basicCoderopt = {CV_IMWRITE_JPEG_QUALITY, quality} (bridge.c:474-486; OpenCV clamps the value to 0..100), for the

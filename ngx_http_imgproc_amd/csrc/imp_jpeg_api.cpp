@@ -30,6 +30,10 @@ bool entropy_on_device(size_t launch_bytes) {
 // impgpu_jpeg_profile(1): every decode call leaves its stages' durations with the calling thread (impgpu_jpeg_stage_times) --
 // the host's from its clock, the device's from events recorded between the kernels
 std::atomic<int> g_profile{0};
+// process-wide: files whose entropy stage ran on the device, of those refused by its verdict, of those with a chain wait
+// that ran out (JPEG_ST_CHAIN_TIMEOUT: the file is then decoded by the caller's fallback -- a box that does this silently
+// looks healthy and is not), files kept on the calling thread because their blocks are too long
+std::atomic<unsigned long long> g_count[4];
 thread_local double t_stage[16];
 
 // IMPGPU_JPEG_TRACE=1: one line per call on stderr with the host's share of it, in microseconds
@@ -107,7 +111,10 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
     if (on_device && !std::getenv("IMPGPU_JPEG_HUFF"))
         for (int i = 0; i < count; i++) {
             Prep& p = P[(size_t)i];
-            if (!p.code && (sizes[i] - p.H.scan_begin) * 8 > DENSE_BITS_PER_BLOCK * ((size_t)p.F.total_slots / 64)) p.code = CODE_DEFERRED;
+            if (!p.code && (sizes[i] - p.H.scan_begin) * 8 > DENSE_BITS_PER_BLOCK * ((size_t)p.F.total_slots / 64)) {
+                p.code = CODE_DEFERRED;
+                g_count[3].fetch_add(1, std::memory_order_relaxed);
+            }
         }
     sw.mark();                                                      // [0] headers
     // ---- the compressed bytes: FF00 unstuffing while they are copied into pinned memory -- the only pass the host makes
@@ -327,6 +334,9 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
             if (p.code) continue;
             const uint32_t status = mailbox[4 * j + 1];
             if (sw.on && std::getenv("IMPGPU_JPEG_TRACE")) std::fprintf(stderr, "jpeg %dx%d: %u chunks of %u bits (overlap %u), %u repair walks, %u chunks chased, %u walks in k_jpeg_select, status %u\n", p.H.width, p.H.height, p.F.nchunks, p.F.chunk_bits, p.F.overlap_bits, mailbox[4 * j + 2], mailbox[4 * j + 3], mailbox[4 * j + 0], status);
+            g_count[0].fetch_add(1, std::memory_order_relaxed);
+            if (status) g_count[1].fetch_add(1, std::memory_order_relaxed);
+            if (status & JPEG_ST_CHAIN_TIMEOUT) g_count[2].fetch_add(1, std::memory_order_relaxed);
             if (status) {
                 char text[96];
                 std::snprintf(text, sizeof text, "jpeg entropy stage refused the scan (status 0x%x)", status);
@@ -414,6 +424,12 @@ int impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* si
             return rc;
         }
     }
+    return IMP_OK;
+}
+
+int impgpu_jpeg_counters(unsigned long long* counters, int n) {
+    if (!counters || n < 0) return IMP_ERROR_INVALID_ARGS;
+    for (int i = 0; i < n; i++) counters[i] = i < 4 ? g_count[i].load(std::memory_order_relaxed) : 0ull;
     return IMP_OK;
 }
 
