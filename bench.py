@@ -411,9 +411,11 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
         for _ in range(n_threads):
             pending.put(None)
 
+    bound_ok = []
+
     def worker():
         if NUMA_BIND:
-            lib.impgpu_env_bind_thread()
+            bound_ok.append(lib.impgpu_env_bind_thread() == 0)
         hdst = lib.impgpu_host_alloc(out_bytes * max(1, batch))
         if decoder == "host":
             from PIL import Image
@@ -543,7 +545,7 @@ def jpeg_stream(imp, n_requests, n_threads, queue_depth, decoder, files, rank=0,
         raise SystemExit("jpeg_stream failed: %r" % errors[:3])
     return {"requests": len(mine), "seconds": dt, "source_bytes": sum(w * h * 3 for w, h, _ in mine),
             "file_bytes": sum(len(b) for _, _, b in mine), "answer_bytes": answer_bytes[0], "numa_node": lib.impgpu_env_numa_node(),
-            "threads_bound": bool(NUMA_BIND and lib.impgpu_env_numa_node() >= 0)}
+            "threads_bound": bool(NUMA_BIND and bound_ok and all(bound_ok))}
 
 
 def jpeg_stream_native(n_requests, n_threads, files, batch, out_quality, device):
@@ -577,7 +579,7 @@ def jpeg_stream_native(n_requests, n_threads, files, batch, out_quality, device)
         w, h, _ = files[i % len(files)]
         src += w * h * 3
     return {"requests": r["requests"], "seconds": r["seconds"], "source_bytes": src, "file_bytes": r["file_bytes"], "answer_bytes": r["answer_bytes"],
-            "numa_node": r["numa_node"], "threads_bound": r["numa_node"] >= 0}
+            "numa_node": r["numa_node"], "threads_bound": bool(r.get("threads_bound"))}
 
 
 def jpeg_stage_profile(imp, files, batch, out_quality, reps=6):

@@ -17,6 +17,7 @@ check() {  # file sha256
 check bridge.c   f0bf6dfca6739f396636dd961677306d6b75481076328ca36e79a826f6290b24
 check required.h 27c2f9c0a283e9cfeb740d8a7edb1392639da0f9986dd92759db8d2f28155b05
 check config     c05ab98b00581607a549d347b8fb5a3927f349cec2a000959b8bc77dd2c54ae7
+check advancedio.c a33b9fe31ad7f0f6a888c6c182fc8ee9959ddfcf82455776c44ea66f74af78be
 
 mkdir -p "$T/glue"
 cp "$HERE/imp_gpu_bridge.c" "$HERE/imp_gpu_bridge.h" "$T/glue/"
@@ -33,8 +34,15 @@ sed -i '702a\
 			goto finalize;\
 		}' "$B"
 # every other encoder (bridge.c:683-710) reads IplImages: bring the results back right after Step = ENCODE / Code = OK (bridge.c:681)
+# -- except FreeImage's single-frame encoders: SaveSingle fetches the frame straight into the bitmap it encodes (advancedio.c:428)
 sed -i '681a\
-	if (encodeAdvancedIO || answer->MIME != IMP_MIME_JPG) {\
+	album.Device = NULL;\
+	#ifdef IMP_FEATURE_ADVANCED_IO\
+		if (encodeAdvancedIO \&\& encodeAdvancedIO != FIF_GIF \&\& album.Count == 1) {\
+			album.Device = gpu.Handle;\
+		}\
+	#endif\
+	if (!album.Device \&\& (encodeAdvancedIO || answer->MIME != IMP_MIME_JPG)) {\
 		answer->Code = ImpGpuDownload(\&gpu, \&album, req->pool);\
 		if (answer->Code) {\
 			goto finalize;\
@@ -68,10 +76,18 @@ sed -i '574,656c\
 		}\
 	}\
 ' "$B"
-# Step 2 (bridge.c:545): a JPEG is decoded on the device; whatever ImpGpuDecode does not take goes to cvDecodeImage as before
+# FreeImage's decoders (bridge.c:565) leave their frames in HBM (advancedio.c edits below): RunJob takes the handle over
+sed -i '565a\
+			gpu.Handle = album.Device;' "$B"
+# Step 2 (bridge.c:545): a JPEG is decoded on the device; whatever ImpGpuDecode does not take goes to cvDecodeImage as before;
+# a DEVICE failure fails the request at its DECODE step (bridge.c:568-571 returns album.Error)
 sed -i '545c\
 	ImpGpuAlbum gpu = { NULL };\
-	if (decodeBasicIo \&\& ImpGpuDecode(blob, size, \&album, \&gpu, req->pool)) {\
+	album.Device = NULL;\
+	int gpuDecoded = decodeBasicIo ? ImpGpuDecode(blob, size, \&album, \&gpu, req->pool) : 0;\
+	if (gpuDecoded < 0) {\
+		album.Error = -gpuDecoded;\
+	} else if (gpuDecoded) {\
 		// the frame is in HBM already\
 	} else if (decodeBasicIo) {' "$B"
 # worker lifecycle (bridge.c:10-16): the two "No op" bodies
@@ -86,5 +102,52 @@ sed -i '5a\
 # module.c:118; filled by the first request that needs it, glue/imp_gpu_bridge.c FillConfig)
 sed -i '117a\
     void*        WatermarkDevice;' "$T/required.h"
+
+# Album (required.h:136-140) gains the device handle FiLoadFrames returns its frames in / SaveSingle fetches its frame from
+sed -i '139a\
+    void*  Device;' "$T/required.h"
+
+# ---- advancedio.c: the FreeImage side hands frames to / takes them from the device without an IplImage in between
+A="$T/advancedio.c"
+# SaveSingle (advancedio.c:428-429): IplToFI32 / IplToFI24 on the device, into the bitmap FreeImage encodes
+sed -i '428,429c\
+    FIBITMAP* frame;\
+    if (source->Device) {\
+        int bpp = FiSupports32bit(format) ? 32 : 24;\
+        frame = FreeImage_Allocate(ImpGpuFrameWidth(source->Device), ImpGpuFrameHeight(source->Device), bpp, 0, 0, 0);\
+        if (!frame || ImpGpuFetchFi(source->Device, bpp, FreeImage_GetBits(frame), FreeImage_GetPitch(frame))) {\
+            result->Error = IMP_ERROR_ENCODE_FAILED;\
+            if (frame) {\
+                FreeImage_Unload(frame);\
+            }\
+            return;\
+        }\
+    } else {\
+        IplImage* image = source->Frames[0].Image;\
+        frame = FiSupports32bit(format) ? IplToFI32(image) : IplToFI24(image);\
+    }' "$A"
+# FiLoadFrames (advancedio.c:325-326): no device frames yet
+sed -i '326a\
+    result.Device = NULL;' "$A"
+# LoadSingle (advancedio.c:295-318): the bottom-up 32-bit bitmap goes to the device as it is; the flip happens there
+sed -i '295,318c\
+    result->Error = ImpGpuLoadSingle(result, pool, FreeImage_GetBits(fullcolor), w, h, FreeImage_GetPitch(fullcolor));' "$A"
+# LoadGIF (advancedio.c:260-262, the release of `master`): all pages collected -> composited on the device in one call
+sed -i '260,262c\
+    if (!result->Error) {\
+        result->Error = ImpGpuGifCompose(\&gif, isdestructive, page, result);\
+    }' "$A"
+# LoadGIF (advancedio.c:187-248): the per-page IplImage, the `master` canvas and the per-pixel compositing loop
+sed -i '187,248c\
+        result->Frames[frameid].Image = NULL;\
+        if (!result->Error) {\
+            result->Error = ImpGpuGifPage(\&gif, pool, frameid, framecount, FreeImage_GetBits(frame), w, h, FreeImage_GetPitch(frame), left, top,\
+                                          result->Frames[frameid].Dispose, result->Frames[frameid].TransparencyKey, palette, canvasW, canvasH);\
+        }' "$A"
+# LoadGIF (advancedio.c:122): the index canvas lives on the device now; the pages are collected here
+sed -i '122c\
+    ImpGpuGif gif = { NULL, 0 };' "$A"
+sed -i '6a\
+#include "glue/imp_gpu_bridge.h"' "$A"
 
 echo "glue applied to $T: build nginx with --add-module=$T and IMPGPU_HOME=<this repository>"

@@ -4,6 +4,7 @@
 #include "required.h"
 #include "helpers.h"
 #include "imp_gpu_bridge.h"
+#include <string.h>
 
 void ImpGpuEnvStart(int worker) {
     /* HIP is initialised here, in the worker, never in the master before fork.  A failure is not fatal for nginx:
@@ -59,8 +60,14 @@ int ImpGpuDecode(u_char* blob, size_t size, Album* album, ImpGpuAlbum* gpu, ngx_
     if (size < 3 || blob[0] != 0xFF || blob[1] != 0xD8 || blob[2] != 0xFF) {
         return 0;
     }
-    if (impgpu_image_decode_jpeg(blob, size, &frame) != IMP_OK) {
-        return 0;
+    {
+        int rc = impgpu_image_decode_jpeg(blob, size, &frame);
+        if (rc == IMP_ERROR_UNSUPPORTED || rc == IMP_ERROR_DECODE_FAILED) {
+            return 0;               /* not this decoder's file: cvDecodeImage, as before */
+        }
+        if (rc != IMP_OK) {
+            return -rc;             /* the device (or its memory) failed: the request fails here */
+        }
     }
     album->Frames = ngx_palloc(pool, sizeof(Frame));
     if (!album->Frames) {
@@ -198,13 +205,25 @@ int ImpGpuEncodeJpeg(ImpGpuAlbum* gpu, int quality, ngx_pool_t* pool, u_char** b
     /* cvEncodeImage(".jpg", album.Frames[0].Image, basicCoderopt) at bridge.c:703-709 for the frame in HBM: the same file,
      * and the compressed bytes are all that crosses the link.  The buffer is sized for the worst case and lives in the
      * request pool like the reference's own copy of the encoder's output. */
-    size_t capacity = impgpu_jpeg_encode_bound(impgpu_image_width(gpu->Handle), impgpu_image_height(gpu->Handle),
-                                               impgpu_image_channels(gpu->Handle));
-    u_char* output = capacity ? ngx_palloc(pool, capacity) : NULL;
+    /* a realistic first size (half a byte per sample and some headroom; the worst case is 432 bytes per 8x8 block: 21 MB
+     * for a 1080p answer, held until the request ends, where the reference allocates the encoded length, bridge.c:705-706);
+     * when the file is larger the call says by how much in *length, and one retry has exactly that */
+    size_t capacity = (size_t)impgpu_image_width(gpu->Handle) * impgpu_image_height(gpu->Handle) / 2 + 65536;
+    u_char* output = ngx_palloc(pool, capacity);
+    int rc;
     if (!output) {
         return IMP_ERROR_MALLOC_FAILED;
     }
-    int rc = impgpu_image_encode_jpeg(gpu->Handle, quality, output, capacity, length);
+    rc = impgpu_image_encode_jpeg(gpu->Handle, quality, output, capacity, length);
+    if (rc == IMP_ERROR_MALLOC_FAILED && *length > capacity) {
+        ngx_pfree(pool, output);
+        capacity = *length;
+        output = ngx_palloc(pool, capacity);
+        if (!output) {
+            return IMP_ERROR_MALLOC_FAILED;
+        }
+        rc = impgpu_image_encode_jpeg(gpu->Handle, quality, output, capacity, length);
+    }
     if (rc) {
         return rc;
     }
@@ -215,3 +234,82 @@ int ImpGpuEncodeJpeg(ImpGpuAlbum* gpu, int quality, ngx_pool_t* pool, u_char** b
 void ImpGpuRelease(ImpGpuAlbum* gpu) {
     impgpu_image_release(&gpu->Handle);
 }
+
+#ifdef IMP_FEATURE_ADVANCED_IO
+/* ---- the FreeImage side.  LoadGIF (advancedio.c:103-274) keeps its walk over the pages -- metadata, the 8-bit conversion,
+ * the lock / unlock -- and hands every page's indices and palette to ImpGpuGifPage instead of compositing it pixel by
+ * pixel (advancedio.c:187-248); ImpGpuGifCompose then runs that loop for all pages on the device. */
+int ImpGpuGifPage(ImpGpuGif* gif, ngx_pool_t* pool, int frameid, int framecount, const unsigned char* bits, int w, int h, int pitch,
+                  int left, int top, int dispose, int key, const void* palette, int canvasW, int canvasH) {
+    impgpu_gif_page* p;
+    unsigned char* copy;
+    (void)canvasW; (void)canvasH;                   /* (the canvas is the first page's size: impgpu_gif_compose takes it from there) */
+    if (!gif->Pages) {
+        gif->Pages = ngx_pcalloc(pool, framecount * sizeof(impgpu_gif_page));
+        gif->Count = 0;
+        if (!gif->Pages) {
+            return IMP_ERROR_MALLOC_FAILED;
+        }
+    }
+    if (frameid != gif->Count || frameid >= framecount) {
+        return IMP_ERROR_INVALID_ARGS;
+    }
+    /* the page is unlocked (or unloaded) before the next one is read: keep what the compositing needs */
+    copy = ngx_palloc(pool, (size_t)h * pitch + 1024);
+    if (!copy) {
+        return IMP_ERROR_MALLOC_FAILED;
+    }
+    memcpy(copy, bits, (size_t)h * pitch);
+    memcpy(copy + (size_t)h * pitch, palette, 1024);                /* 256 RGBQUADs */
+    p = &gif->Pages[gif->Count++];
+    p->indices = copy;
+    p->width = w; p->height = h; p->pitch = pitch;
+    p->left = left; p->top = top;
+    p->dispose = dispose;
+    p->transparency_key = key;
+    p->palette = copy + (size_t)h * pitch;
+    return IMP_OK;
+}
+
+int ImpGpuGifCompose(ImpGpuGif* gif, int isdestructive, int page, Album* result) {
+    impgpu_image* frames = NULL;
+    int rc;
+    if (!gif->Pages || gif->Count < 1) {
+        return IMP_ERROR_DECODE_FAILED;
+    }
+    rc = impgpu_gif_compose_album(gif->Pages, gif->Count, isdestructive, page, &frames);
+    if (rc == IMP_OK) {
+        result->Device = frames;                    /* RunJob takes it over (gpu.Handle) right after FiLoadFrames */
+    }
+    return rc;
+}
+
+/* LoadSingle (advancedio.c:276-321): the 32-bit bitmap goes to the device as it is, bottom-up; the flip into a top-down
+ * 4-channel frame (advancedio.c:310-318) happens there */
+int ImpGpuLoadSingle(Album* result, ngx_pool_t* pool, const unsigned char* bits, int w, int h, int pitch) {
+    impgpu_image* frame = NULL;
+    int rc = impgpu_image_upload_fi32(bits, w, h, pitch, &frame);
+    if (rc) {
+        return rc;
+    }
+    result->Frames = ngx_palloc(pool, sizeof(Frame));
+    if (!result->Frames) {
+        impgpu_image_release(&frame);
+        return IMP_ERROR_MALLOC_FAILED;
+    }
+    result->Count = 1;
+    result->Frames[0].Image = NULL;
+    result->Frames[0].Time = result->Frames[0].TransparencyKey = result->Frames[0].Dispose = 0;
+    result->Device = frame;
+    return IMP_OK;
+}
+
+int ImpGpuFrameWidth(void* device)  { return impgpu_image_width((impgpu_image*)device); }
+int ImpGpuFrameHeight(void* device) { return impgpu_image_height((impgpu_image*)device); }
+
+/* SaveSingle (advancedio.c:427-446): IplToFI32 / IplToFI24 (advancedio.c:65-101) -- the flip and the 32 / 24-bit repack -- run
+ * on the device and land in the bitmap FreeImage is about to encode */
+int ImpGpuFetchFi(void* device, int bpp, unsigned char* bits, int pitch) {
+    return impgpu_image_download_fi((impgpu_image*)device, bpp, bits, pitch);
+}
+#endif

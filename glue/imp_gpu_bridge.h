@@ -12,6 +12,11 @@
  *   bridge.c:703-709  cvEncodeImage(".jpg")                 -> ImpGpuEncodeJpeg (the file is written on the device)
  *   bridge.c:714      finalize:                             -> ImpGpuRelease
  *   required.h:117    Config gains `void* WatermarkDevice`  (per-worker handle of the uploaded overlay)
+ *   required.h:139    Album gains `void* Device`            (the frames FiLoadFrames put into HBM / SaveSingle fetches from it)
+ * and in advancedio.c (round 4: the FreeImage side hands frames over without an IplImage in between):
+ *   advancedio.c:187-248  LoadGIF's per-pixel compositing loop  -> ImpGpuGifPage (collect) + ImpGpuGifCompose at :260
+ *   advancedio.c:295-318  LoadSingle's flip-and-copy loop       -> ImpGpuLoadSingle
+ *   advancedio.c:428-429  SaveSingle's IplToFI32 / IplToFI24    -> ImpGpuFetchFi into the bitmap FreeImage encodes
  * Needs nginx, OpenCV 2.4 and FreeImage headers exactly like the files around it, so it is not BUILT in this repository;
  * tests/test_glue.py compiles it (and the patched bridge.c) with -fsyntax-only against declaration-only stand-ins for
  * those headers (tests/c/decls/, a compile check of this glue and nothing else), and the C ABI underneath it is exercised
@@ -41,7 +46,8 @@ void   ImpGpuEnvDestroy(void);
 
 /* bridge.c:545-552 for a JPEG blob: returns 1 when the file was decoded on the device (album gets its one frame with
  * Image = NULL, gpu holds the device frame), 0 when the caller must decode on the host as before (not a JPEG, a JPEG the
- * device decoder does not take, or a damaged one). */
+ * device decoder does not take, or a damaged one), and -IMP_ERROR_* when the DEVICE failed: the request then fails at
+ * its DECODE step (HTTP 500) instead of paying for a host decode whose upload would fail the same way. */
 int    ImpGpuDecode(u_char* blob, size_t size, Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool);
 
 /* Steps 3-7 of RunJob for all frames of the album at once: upload (unless ImpGpuDecode put the frame there), then crop ->
@@ -55,5 +61,19 @@ int    ImpGpuDownload(ImpGpuAlbum* gpu, Album* album, ngx_pool_t* pool);        
 /* bridge.c:703-709 when the answer is a JPEG from the basic encoder: the file is written on the device, nothing is downloaded */
 int    ImpGpuEncodeJpeg(ImpGpuAlbum* gpu, int quality, ngx_pool_t* pool, u_char** bytes, size_t* length);
 void   ImpGpuRelease(ImpGpuAlbum* gpu);
+
+/* ---- the FreeImage side (advancedio.c, IMP_FEATURE_ADVANCED_IO) ---- */
+/* the pages of a GIF as LoadGIF walks them (advancedio.c:128-259): indices and palette are copied out of the locked page */
+typedef struct {
+    impgpu_gif_page* Pages;
+    int Count;
+} ImpGpuGif;
+int    ImpGpuGifPage(ImpGpuGif* gif, ngx_pool_t* pool, int frameid, int framecount, const unsigned char* bits, int w, int h, int pitch,
+                     int left, int top, int dispose, int key, const void* palette, int canvasW, int canvasH);
+int    ImpGpuGifCompose(ImpGpuGif* gif, int isdestructive, int page, Album* result);     /* advancedio.c:204-247 on the device */
+int    ImpGpuLoadSingle(Album* result, ngx_pool_t* pool, const unsigned char* bits, int w, int h, int pitch);   /* advancedio.c:295-318 */
+int    ImpGpuFrameWidth(void* device);
+int    ImpGpuFrameHeight(void* device);
+int    ImpGpuFetchFi(void* device, int bpp, unsigned char* bits, int pitch);              /* advancedio.c:65-101 */
 
 #endif

@@ -29,7 +29,7 @@ SOURCES = [
     "imp_jpeg.cpp",
     "imp_jpeg_api.cpp",
 ]
-HEADERS = ["imp_internal.h", "imp_jpeg.h", "imp_jpeg_core.h", os.path.join("..", "..", "include", "impgpu.h")]
+HEADERS = ["imp_internal.h", "imp_jpeg.h", "imp_jpeg_core.h", "imp_jpeg_std.h", os.path.join("..", "..", "include", "impgpu.h")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

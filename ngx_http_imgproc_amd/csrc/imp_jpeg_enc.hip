@@ -402,9 +402,10 @@ __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__
 // Workgroups take a ticket when they start (never blockIdx): the ones a workgroup waits for are then always running.
 struct EncSeg { int job, local; };
 
-__device__ __forceinline__ uint32_t enc_sum_before(const uint32_t* __restrict__ rec, int upto, int* s_part) {
+__device__ __forceinline__ uint32_t enc_sum_before(const uint32_t* __restrict__ rec, int upto, int* s_part, uint32_t* verdict) {
     // sum of rec[2 * p] over p < upto, each read once its flag rec[2 * p + 1] is up (the same bounded, relaxed poll as the
-    // decoder's chain); all threads of the block get the sum
+    // decoder's chain); all threads of the block get the sum.  A wait that runs out says so in the image's verdict word
+    // (bit 1): what is written from a wrong offset is not a file, and the host must not hand it on as one.
     uint32_t acc = 0;
     for (int p = threadIdx.x; p < upto; p += 256) {
         bool up = false;
@@ -412,6 +413,7 @@ __device__ __forceinline__ uint32_t enc_sum_before(const uint32_t* __restrict__ 
             up = __hip_atomic_load(&rec[2 * p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (!up) __builtin_amdgcn_s_sleep(8);
         }
+        if (!up) atomicOr(verdict, 2u);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         acc += __hip_atomic_load(&rec[2 * p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -421,7 +423,7 @@ __device__ __forceinline__ uint32_t enc_sum_before(const uint32_t* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_jpeg_enc_pack(const EncJob* __restrict__ jobs, const EncSeg* __restrict__ map, const EncTables* __restrict__ tabs,
-                                                       uint32_t* __restrict__ ticket) {
+                                                       uint32_t* __restrict__ result, uint32_t* __restrict__ ticket) {
     __shared__ uint32_t s_win[ENC_WIN_WORDS];
     __shared__ int s_part[4];
     __shared__ uint32_t s_ticket;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_pack(const EncJob* __restrict_
         __hip_atomic_store(&J.seg_rec[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                                                // (s_part is free again)
-    const uint32_t base = enc_sum_before(J.seg_rec, sg, s_part);    // bits of the image in front of this segment
+    const uint32_t base = enc_sum_before(J.seg_rec, sg, s_part, &result[4 * me.job + 1]);    // bits of the image in front of this segment
     const int lead = (int)(base & 31u);
     if (live) {
         EncPut P;
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_stuff(const EncJob* __restrict
     }
     __syncthreads();
     if (c0 >= nbytes) return;                                       // (uniform)
-    const uint32_t before = enc_sum_before(J.chunk_rec, ck, s_part);
+    const uint32_t before = enc_sum_before(J.chunk_rec, ck, s_part, &result[4 * me.job + 1]);
     long long at = (long long)s + before + (incl - ff);
     for (uint32_t i = s; i < e; i++) {
         const uint32_t v = (U[i >> 2] >> (24 - (i & 3) * 8)) & 0xff;
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_stuff(const EncJob* __restrict
         if (fits) { J.out[at] = 0xff; J.out[at + 1] = 0xd9; }
         const int r = me.job;
         result[4 * r] = (uint32_t)len;
-        result[4 * r + 1] = fits ? 0u : 1u;
+        if (!fits) atomicOr(&result[4 * r + 1], 1u);
         result[4 * r + 2] = 0xffffffffu;                            // fetched from its own region, not from the compact area
     }
 }
@@ -707,7 +709,7 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     const uint8_t* sd = (const uint8_t*)side;
     const EncJob* djobs = (const EncJob*)(sd + o_jobs);
     uint32_t* cursor = (uint32_t*)res + (size_t)nj * 4;
-    hipError_t e = hipMemsetAsync(cursor, 0, 4, s);             // the compact area's cursor
+    hipError_t e = hipMemsetAsync(res, 0, res_bytes, s);        // the verdict words (the large frames' workgroups OR into them) and the compact area's cursor
     if (e == hipSuccess && aux) e = hipMemsetAsync(aux, 0, aux_bytes, s);
     hipLaunchKernelGGL(k_jpeg_enc_blocks, dim3((unsigned)map.size()), dim3(256), 0, s, djobs, (const EncMap*)(sd + o_map), (const EncTables*)sd);
     if (nsmall) {
@@ -719,7 +721,7 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
                                 (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
     }
     if (nsmall < nj) {
-        hipLaunchKernelGGL(k_jpeg_enc_pack, dim3((unsigned)pack_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_pack), (const EncTables*)sd, (uint32_t*)aux);
+        hipLaunchKernelGGL(k_jpeg_enc_pack, dim3((unsigned)pack_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_pack), (const EncTables*)sd, (uint32_t*)res, (uint32_t*)aux);
         hipLaunchKernelGGL(k_jpeg_enc_stuff, dim3((unsigned)stuff_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_stuff), (uint32_t*)res, (uint32_t*)aux + 1);
     }
     if (e == hipSuccess) e = hipGetLastError();
@@ -735,7 +737,11 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     for (int k = 0; k < nj; k++) {
         const int i = owner[k];
         lens[i] = heads[k].size() + seg[4 * k];
-        if (seg[4 * k + 1]) { codes[i] = IMP_ERROR_DEVICE; set_error_text("jpeg encode: a segment outgrew its bound"); continue; }
+        if (seg[4 * k + 1]) {
+            codes[i] = IMP_ERROR_DEVICE;
+            set_error_text((seg[4 * k + 1] & 2u) ? "jpeg encode: a wait between workgroups ran out" : "jpeg encode: a segment outgrew its bound");
+            continue;
+        }
         if (lens[i] > caps[i]) { codes[i] = IMP_ERROR_MALLOC_FAILED; continue; }       // lens[i] says what it takes
         if (seg[4 * k + 2] == 0xffffffffu) { at2[k] = more; more += (seg[4 * k] + 63) & ~size_t(63); }
     }

@@ -333,7 +333,7 @@ static bool lane_take_back(Lane* L, void* p) {
 }
 
 // Bytes a lane may keep on its free list.  Without a bound a worker that once saw a burst of large frames holds their
-// buckets for ever, and N workers x lanes share one GPU.  IMPGPU_POOL_CAP_MB (default 2048 -- 288 GB of HBM and a
+// buckets for ever, and N workers x lanes share one GPU.  IMPGPU_POOL_CAP_MB (default 8192 -- 288 GB of HBM and a
 // hipFree / hipMalloc pair that costs more than a 1080p request: the default only catches a pool that has run away,
 // a 256-file JPEG batch legitimately recycles 1.2 GB of coefficient planes per call; 0 = never trim).
 static size_t pool_cap() {
@@ -504,7 +504,16 @@ static int stage_reserve(Lane* L, size_t bytes, Staging** out) {
         IMP_HIP(hipEventSynchronize(S->done));
         S->busy = false;
     }
-    if (S->cap < bytes) {
+    // A buffer that one outsized request made larger than IMPGPU_STAGE_CAP_MB (default 512: a 256-file JPEG batch stages
+    // 112 MB) goes back when it is next taken for something a quarter of that cap would hold: a worker does not keep an
+    // unswappable gigabyte for life because of one request.  (Here and not after a wait: the caller still reads a download
+    // out of the buffer then.)
+    static const size_t trim_cap = [] {
+        const char* s = std::getenv("IMPGPU_STAGE_CAP_MB");
+        return (size_t)(s ? std::atoll(s) : 512) << 20;
+    }();
+    const bool outsized = trim_cap && S->cap > trim_cap && bytes <= trim_cap / 4;
+    if (S->cap < bytes || outsized) {
         if (S->p) IMP_HIP(hipHostFree(S->p));
         S->p = nullptr;
         S->cap = 0;

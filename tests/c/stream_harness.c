@@ -25,7 +25,7 @@ typedef struct {
     unsigned char** blobs;
     size_t* sizes;
     int nfiles;
-    int rc;
+    int rc, bound;
     long done;
     double file_bytes, answer_bytes;
 } worker_t;
@@ -54,7 +54,7 @@ static void* worker(void* arg) {
     long at = 0;
     memset(&cfg, 0, sizeof cfg);
     cfg.max_target_w = 2000; cfg.max_target_h = 2000; cfg.max_filters_count = 5;
-    impgpu_env_bind_thread();
+    w->bound = impgpu_env_bind_thread() == IMP_OK;
     if (!host) { w->rc = IMP_ERROR_MALLOC_FAILED; return NULL; }
     while (at < w->count && w->rc == IMP_OK) {
         int n = 0, k, rc;
@@ -97,6 +97,8 @@ static void* worker(void* arg) {
     return NULL;
 }
 
+static int g_all_bound = 1;
+
 static int run(worker_t* proto, long requests, int nthreads, double* seconds, double* file_bytes, double* answer_bytes) {
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
     worker_t* ws = (worker_t*)malloc(sizeof(worker_t) * (size_t)nthreads);
@@ -114,6 +116,7 @@ static int run(worker_t* proto, long requests, int nthreads, double* seconds, do
     *file_bytes = *answer_bytes = 0;
     for (i = 0; i < nthreads; i++) {
         if (ws[i].rc != IMP_OK) rc = ws[i].rc;
+        if (!ws[i].bound) g_all_bound = 0;
         *file_bytes += ws[i].file_bytes;
         *answer_bytes += ws[i].answer_bytes;
     }
@@ -157,8 +160,8 @@ int main(int argc, char** argv) {
     rc = run(&proto, requests, proto.nthreads, &s, &fb, &ab);
     if (rc != IMP_OK) { fprintf(stderr, "stream failed: %d %s\n", rc, impgpu_last_error()); return 4; }
     printf("{\"requests\": %ld, \"seconds\": %.6f, \"requests_per_s\": %.1f, \"threads\": %d, \"batch\": %d, \"quality\": %d, "
-           "\"file_bytes\": %.0f, \"answer_bytes\": %.0f, \"numa_node\": %d}\n",
-           requests, s, (double)requests / s, proto.nthreads, proto.batch, proto.quality, fb, ab, impgpu_env_numa_node());
+           "\"file_bytes\": %.0f, \"answer_bytes\": %.0f, \"numa_node\": %d, \"threads_bound\": %s}\n",
+           requests, s, (double)requests / s, proto.nthreads, proto.batch, proto.quality, fb, ab, impgpu_env_numa_node(), g_all_bound ? "true" : "false");
     impgpu_env_destroy();
     return 0;
 }

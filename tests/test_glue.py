@@ -1,7 +1,8 @@
 """glue/ (SURVEY 8f N3): the nginx-side binding as source.  It cannot be BUILT here (nginx / OpenCV / FreeImage headers and
 libraries are absent); what is checked is that glue/apply_glue.sh applies to the reference revision it names, leaves RunJob
-calling the glue instead of the five CPU loops, and that the result COMPILES: `gcc -fsyntax-only -std=gnu99` over the
-patched bridge.c and glue/imp_gpu_bridge.c against tests/c/decls/ -- declaration-only stand-ins for those headers, test
+calling the glue instead of the five CPU loops (and advancedio.c's LoadGIF / LoadSingle / SaveSingle handing frames to and
+from the device), and that the result COMPILES: `gcc -fsyntax-only -std=gnu99` over the patched bridge.c, advancedio.c and
+glue/imp_gpu_bridge.c against tests/c/decls/ -- declaration-only stand-ins for those headers, test
 scaffolding for this one compile check (no oracle, no _ref, nothing is linked or run).  The reference only exists in the
 build container: skipped elsewhere."""
 import os
@@ -35,13 +36,27 @@ def test_apply_glue_rewrites_the_operator_segment(tmp_path):
     assert run_job.index("ImpGpuEncodeJpeg(") < run_job.index("cvEncodeImage(")                       # the host encoder stays for PNG
     assert run_job.count("{") == run_job.count("}")                      # the edit kept the function balanced
     assert "WatermarkDevice;" in (work / "required.h").read_text()
+    assert "void*  Device;" in (work / "required.h").read_text()
+    assert run_job.index("album.Error = -gpuDecoded;") < run_job.index("cvDecodeImage(&rawencoded, -1)")      # a lost device fails the request, it is not decoded on the host
+    assert run_job.count("gpu.Handle = album.Device;") == 1 and run_job.count("album.Device = gpu.Handle;") == 1
+    # the FreeImage side (advancedio.c): its three pixel loops are gone, the frames never become IplImages on the way
+    adv = (work / "advancedio.c").read_text()
+    load_gif = adv[adv.index("static void LoadGIF("):adv.index("static void LoadSingle(")]
+    load_single = adv[adv.index("static void LoadSingle("):adv.index("Album FiLoadFrames(")]
+    save_single = adv[adv.index("static void SaveSingle("):adv.index("Memory FiSaveFrames(")]
+    assert load_gif.count("ImpGpuGifPage(&gif") == 1 and load_gif.count("ImpGpuGifCompose(&gif, isdestructive, page, result)") == 1
+    assert "cvSetComponent" not in load_gif and "cvCreateImage" not in load_gif and "master" not in load_gif
+    assert "ImpGpuLoadSingle(result, pool, FreeImage_GetBits(fullcolor)" in load_single and "cvSetComponent" not in load_single
+    assert "ImpGpuFetchFi(source->Device" in save_single and "IplToFI32(image)" in save_single       # (the host path stays for frames that were downloaded)
+    for part in (load_gif, load_single, save_single):
+        assert part.count("{") == part.count("}")
     assert "glue/imp_gpu_bridge.c" in (work / "config").read_text() and "-limpgpu" in (work / "config").read_text()
     assert (work / "glue" / "imp_gpu_bridge.c").exists()
     # the patched module compiles: every call matches its prototype, nothing of impgpu.h clashes with required.h, and both
     # spellings of the worker index exist (ngx_worker came with nginx 1.9.1)
     decls = os.path.join(ROOT, "tests", "c", "decls")
     for extra in ([], ["-Dnginx_version=1009005"], ["-Dnginx_version=1004006"]):
-        for src in ("bridge.c", os.path.join("glue", "imp_gpu_bridge.c")):
+        for src in ("bridge.c", "advancedio.c", os.path.join("glue", "imp_gpu_bridge.c")):
             p = subprocess.run(["gcc", "-fsyntax-only", "-std=gnu99", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
                                 "-Werror=int-conversion", "-I", decls, "-I", os.path.join(ROOT, "include"), "-I", str(work)] + extra + [src],
                                cwd=str(work), capture_output=True, text=True)
