@@ -8,6 +8,7 @@
 //
 // Two streaming kernels with an int32 intermediate in HBM.  Taps are wave-uniform (scalar
 // loads); BGRA pixels move as dwords / 16-byte int4 rows so both passes are coalesced.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <type_traits>
@@ -474,6 +475,341 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
         if (out_y[o] >= 0 && live) emit(out_y[o], out_px[o]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The separable convolution on the matrix unit (round 4).  north_star says "no MFMA (there is no dense contraction here)",
+// which is true of 2-8-tap resampling; a 49-151-tap 8-bit Gaussian IS a banded contraction, and the VALU forms above spend
+// ~350 instructions per output row and wave on it (0.04 / 0.02 of the HBM roofline at sigma 8 / 16).  Both passes are
+// C = A x B with v_mfma_i32_16x16x64_i8: one operand is a 16 x 64 window of bytes, the other a Toeplitz band of the taps.
+//   * everything is integer and EXACT.  OpenCV's column pass is float, but (taps <= 127, tap sum <= 257, which the host
+//     checks) every product (a + b) * ky[k] is below 2^24 and so is every partial sum below 256.0 in units of 2^-16: the float
+//     accumulation never rounds until the final cvRound (a sum past 256.0 can, and saturates to 255 either way), so
+//     dst = saturate(round_half_even(sum / 65536)) -- or (sum + 2^15) >> 16 for the last (w * cn) & 3 elements of a row, which
+//     OpenCV's SSE2 loop leaves to the scalar template -- reproduces it bit for bit.
+//   * u8 operands: pixels enter as p - 128 (one XOR), 128 * (tap sum) is added back; the 16-bit row sums are split into
+//     two bytes for the column pass (two MFMAs, 256 * hi + lo).
+//   * interleaved channels are NOT separated: the row pass convolves along the BYTES of a row with the taps cn bytes apart
+//     (three of four band entries are zero -- the matrix unit has the time: 144 MFMAs per 64 x 64-byte tile are 2 us per
+//     1080p frame), so operands are plain 16-byte runs of a row.
+//   * k_blur_mfma_rows leaves the row sums TRANSPOSED ([byte column][row], two byte planes): the accumulator layout of the
+//     MFMA (a lane holds four consecutive ROWS of one byte column) writes that as dwords, and k_blur_mfma_cols reads its
+//     operands -- sixteen consecutive rows of one byte column -- as one 16-byte run again.
+// Operand maps checked on hardware with one-hot data (tools/mfma_i8_probe.hip): lane l, byte b of A is A[l & 15][16 (l >> 4) + b],
+// of B is B[16 (l >> 4) + b][l & 15]; C[4 (l >> 4) + reg][l & 15].
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+constexpr int BM_W = 64, BM_H = 64;                 // bytes across / rows down per workgroup tile
+constexpr int BM_MAXC = 8;                          // 64-byte chunks of a row window: 16 + 2 * cn * r <= 512
+
+// the Toeplitz operand of chunk c as the lanes hold it (built on the host, once per call: 64 lanes x 16 bytes): byte b of lane l =
+// tap[(64 c + 16 (l >> 4) + b - (l & 15)) / dil] where that is a whole number in 0 .. 2r, else 0
+static void bm_band_host(const std::vector<int>& ik, int r, int dil, int nchunk, std::vector<int>* blob) {
+    for (int c = 0; c < nchunk; c++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int q = 0; q < 4; q++) {
+                uint32_t word = 0;
+                for (int b = 0; b < 4; b++) {
+                    const int d = 64 * c + 16 * (lane >> 4) + 4 * q + b - (lane & 15);
+                    const int m = d >= 0 ? d / dil : -1;
+                    const int v = (d >= 0 && m * dil == d && m <= 2 * r) ? ik[(size_t)m] : 0;
+                    word |= (uint32_t)(v & 0xff) << (8 * b);
+                }
+                blob->push_back((int)word);
+            }
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_blur_mfma_rows(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
+                                                        uint8_t* __restrict__ planes, long long pstride, int hp, int roww_pad,
+                                                        const bm_v4i* __restrict__ bands, int r, int nchunk, int pitch_s, int bias) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t bm_smem[];
+    uint8_t* s_src = bm_smem;                                       // [BM_H][pitch_s]: source bytes - 128, window column 0 = byte x0b - CN r
+    uint8_t* s_pl = bm_smem + (size_t)BM_H * pitch_s;               // [2][BM_W][BM_H + 16]: the row sums' low / high bytes - 128, transposed
+    constexpr int PT = BM_H + 16;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int x0b = blockIdx.x * BM_W, y0 = blockIdx.y * BM_H, roww = w * CN;
+    const uint8_t* frame = src + (long long)blockIdx.z * sstride;
+    // stage the rows: replicated borders; sixteen bytes at a time where they are inside the row (a byte-aligned address is fine)
+    const int wbytes = BM_W + 2 * CN * r, wq = (wbytes + 15) >> 4;
+    for (int idx = t; idx < BM_H * wq; idx += 256) {
+        const int ry = idx / wq, bc = (idx - ry * wq) * 16;
+        const uint8_t* row = frame + (size_t)min(y0 + ry, h - 1) * sstep;
+        const int gb = x0b - CN * r + bc;
+        uint32_t v[4];
+        if (gb >= 0 && gb + 15 < roww) {
+            __builtin_memcpy(v, row + gb, 16);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int g = gb + b;
+                int px = g >= 0 ? g / CN : -((-g + CN - 1) / CN);    // floor division
+                const int ch = g - px * CN;
+                px = min(max(px, 0), w - 1);
+                v[b >> 2] |= (uint32_t)row[px * CN + ch] << (8 * (b & 3));
+            }
+        }
+        *(uint4*)(s_src + (size_t)ry * pitch_s + bc) = make_uint4(v[0] ^ 0x80808080u, v[1] ^ 0x80808080u, v[2] ^ 0x80808080u, v[3] ^ 0x80808080u);
+    }
+    bm_v4i band[BM_MAXC];
+#pragma unroll
+    for (int c = 0; c < BM_MAXC; c++) band[c] = c < nchunk ? bands[c * 64 + lane] : bm_v4i{0, 0, 0, 0};
+    __syncthreads();
+    // C[row][byte] for 16 x 16 tiles: A = the rows' windows, B = the band
+    for (int tile = wv; tile < (BM_W / 16) * (BM_H / 16); tile += 4) {
+        const int xg = tile & 3, rg = tile >> 2;
+        bm_v4i acc = {0, 0, 0, 0};
+        const uint8_t* arow = s_src + (size_t)(rg * 16 + (lane & 15)) * pitch_s + xg * 16 + 16 * (lane >> 4);
+#pragma unroll
+        for (int c = 0; c < BM_MAXC; c++)
+            if (c < nchunk) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(arow + 64 * c), band[c], acc, 0, 0, 0);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t S = (uint32_t)(acc[i] + bias);            // 0 .. 65535: the row sum of OpenCV's int32 row pass
+            lo |= (S & 255u) << (8 * i);
+            hi |= (S >> 8) << (8 * i);
+        }
+        uint8_t* col = s_pl + (size_t)(xg * 16 + (lane & 15)) * PT + rg * 16 + 4 * (lane >> 4);
+        *(uint32_t*)col = lo ^ 0x80808080u;
+        *(uint32_t*)(col + (size_t)BM_W * PT) = hi ^ 0x80808080u;
+    }
+    __syncthreads();
+    // the tile's two planes out, 64 contiguous bytes (64 rows) per byte column
+    uint8_t* pl = planes + (long long)blockIdx.z * pstride;
+    for (int idx = t; idx < 2 * BM_W * 4; idx += 256) {
+        const int q = idx & 3, xb = (idx >> 2) & (BM_W - 1), p = idx >> 8;
+        const uint4 v = *(const uint4*)(s_pl + (size_t)(p * BM_W + xb) * PT + q * 16);
+        *(uint4*)(pl + ((size_t)p * roww_pad + x0b + xb) * hp + y0 + q * 16) = v;
+    }
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_blur_mfma_cols(const uint8_t* __restrict__ planes, long long pstride, int hp, int roww_pad,
+                                                        uint8_t* __restrict__ dst, long long dstride, int dstep, int w, int h,
+                                                        const bm_v4i* __restrict__ bands, int r, int nchunk, int pitch_p, int bias) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t bm_smem[];
+    uint8_t* s_pl = bm_smem;                                        // [2][BM_W][pitch_p]: row 0 = image row y0 - r
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int x0b = blockIdx.x * BM_W, y0 = blockIdx.y * BM_H, roww = w * CN;
+    const uint8_t* pl = planes + (long long)blockIdx.z * pstride;
+    const int nrows = BM_H + 2 * r, n16 = (nrows + 15) >> 4;
+    for (int idx = t; idx < 2 * BM_W * n16; idx += 256) {
+        const int piece = idx % n16, xb = (idx / n16) & (BM_W - 1), p = idx / (n16 * BM_W);
+        const uint8_t* colp = pl + ((size_t)p * roww_pad + x0b + xb) * hp;
+        const int ya = y0 - r + piece * 16;
+        uint4 v;
+        if (ya >= 0 && ya + 15 < h) {
+            __builtin_memcpy(&v, colp + ya, 16);                    // (a byte-aligned address is fine)
+        } else {
+            uint32_t a[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[i >> 2] |= (uint32_t)colp[min(max(ya + i, 0), h - 1)] << (8 * (i & 3));
+            v = make_uint4(a[0], a[1], a[2], a[3]);
+        }
+        *(uint4*)(s_pl + (size_t)(p * BM_W + xb) * pitch_p + piece * 16) = v;
+    }
+    bm_v4i band[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) band[c] = c < nchunk ? bands[c * 64 + lane] : bm_v4i{0, 0, 0, 0};
+    __syncthreads();
+    uint8_t* out = dst + (long long)blockIdx.z * dstride;
+    const int vec_end = roww & ~3;                                  // OpenCV's SSE2 column loop; behind it the scalar template
+    for (int tile = wv; tile < (BM_W / 16) * (BM_H / 16); tile += 4) {
+        const int xg = tile & 3, og = tile >> 2;
+        bm_v4i al = {0, 0, 0, 0}, ah = {0, 0, 0, 0};
+        const uint8_t* acol = s_pl + (size_t)(xg * 16 + (lane & 15)) * pitch_p + og * 16 + 16 * (lane >> 4);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            if (c < nchunk) {
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + 64 * c), band[c], al, 0, 0, 0);
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + (size_t)BM_W * pitch_p + 64 * c), band[c], ah, 0, 0, 0);
+            }
+        const int y = y0 + og * 16 + (lane & 15), xb = x0b + xg * 16 + 4 * (lane >> 4);
+        if (y >= h || xb >= roww) continue;
+        uint32_t px = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t T = (uint32_t)(al[i] + 256 * ah[i] + bias);        // the column sum in units of 2^-16
+            uint32_t q = T >> 16;
+            const uint32_t rem = T & 0xffffu;
+            if (xb + i < vec_end) q += (rem > 0x8000u || (rem == 0x8000u && (q & 1u))) ? 1u : 0u;   // cvRound: half to even
+            else q += rem >= 0x8000u ? 1u : 0u;                                                          // (sum + 2^15) >> 16
+            px |= min(q, 255u) << (8 * i);
+        }
+        uint8_t* o = out + (size_t)y * dstep + xb;
+        if (xb + 3 < roww) *(uint32_t*)o = px;
+        else for (int i = 0; xb + i < roww; i++) o[i] = (uint8_t)(px >> (8 * i));
+    }
+}
+
+// Both passes in ONE launch for the radii whose tile fits LDS twice per compute unit: the rows of the tile AND its 2r halo rows
+// are reduced into the transposed planes in LDS (never in memory), then the columns.  The halo rows are reduced once per tile
+// row they border (x (64 + 2r) / 64 of the row pass: the matrix unit has the time), the row sums never leave the chip.
+template <int CN>
+__global__ __launch_bounds__(256) void k_blur_mfma_fused(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
+                                                         uint8_t* __restrict__ dst, long long dstride, int dstep,
+                                                         const bm_v4i* __restrict__ bands_r, const bm_v4i* __restrict__ bands_c, int r, int nrc, int ncc,
+                                                         int pitch_s, int pitch_p, int bias_r, int bias_c) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t bm_smem[];
+    const int nr16 = (BM_H + 2 * r + 15) & ~15;                     // staged rows: image rows y0 - r .. (replicated past the borders)
+    uint8_t* s_src = bm_smem;                                       // [nr16][pitch_s]
+    uint8_t* s_pl = bm_smem + (size_t)nr16 * pitch_s;               // [2][BM_W][pitch_p], row 0 = image row y0 - r
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int x0b = blockIdx.x * BM_W, y0 = blockIdx.y * BM_H, roww = w * CN;
+    const uint8_t* frame = src + (long long)blockIdx.z * sstride;
+    const int wbytes = BM_W + 2 * CN * r, wq = (wbytes + 15) >> 4;
+    for (int idx = t; idx < nr16 * wq; idx += 256) {
+        const int ry = idx / wq, bc = (idx - ry * wq) * 16;
+        const uint8_t* row = frame + (size_t)min(max(y0 - r + ry, 0), h - 1) * sstep;
+        const int gb = x0b - CN * r + bc;
+        uint32_t v[4];
+        if (gb >= 0 && gb + 15 < roww) {
+            __builtin_memcpy(v, row + gb, 16);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int g = gb + b;
+                int px = g >= 0 ? g / CN : -((-g + CN - 1) / CN);    // floor division
+                const int ch = g - px * CN;
+                px = min(max(px, 0), w - 1);
+                v[b >> 2] |= (uint32_t)row[px * CN + ch] << (8 * (b & 3));
+            }
+        }
+        *(uint4*)(s_src + (size_t)ry * pitch_s + bc) = make_uint4(v[0] ^ 0x80808080u, v[1] ^ 0x80808080u, v[2] ^ 0x80808080u, v[3] ^ 0x80808080u);
+    }
+    bm_v4i band[BM_MAXC];
+#pragma unroll
+    for (int c = 0; c < BM_MAXC; c++) band[c] = c < nrc ? bands_r[c * 64 + lane] : bm_v4i{0, 0, 0, 0};
+    __syncthreads();
+    for (int tile = wv; tile < (BM_W / 16) * (nr16 / 16); tile += 4) {
+        const int xg = tile & 3, rg = tile >> 2;
+        bm_v4i acc = {0, 0, 0, 0};
+        const uint8_t* arow = s_src + (size_t)(rg * 16 + (lane & 15)) * pitch_s + xg * 16 + 16 * (lane >> 4);
+#pragma unroll
+        for (int c = 0; c < BM_MAXC; c++)
+            if (c < nrc) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(arow + 64 * c), band[c], acc, 0, 0, 0);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t S = (uint32_t)(acc[i] + bias_r);
+            lo |= (S & 255u) << (8 * i);
+            hi |= (S >> 8) << (8 * i);
+        }
+        uint8_t* col = s_pl + (size_t)(xg * 16 + (lane & 15)) * pitch_p + rg * 16 + 4 * (lane >> 4);
+        *(uint32_t*)col = lo ^ 0x80808080u;
+        *(uint32_t*)(col + (size_t)BM_W * pitch_p) = hi ^ 0x80808080u;
+    }
+    bm_v4i bandc[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) bandc[c] = c < ncc ? bands_c[c * 64 + lane] : bm_v4i{0, 0, 0, 0};
+    __syncthreads();
+    uint8_t* out = dst + (long long)blockIdx.z * dstride;
+    const int vec_end = roww & ~3;
+    for (int tile = wv; tile < (BM_W / 16) * (BM_H / 16); tile += 4) {
+        const int xg = tile & 3, og = tile >> 2;
+        bm_v4i al = {0, 0, 0, 0}, ah = {0, 0, 0, 0};
+        const uint8_t* acol = s_pl + (size_t)(xg * 16 + (lane & 15)) * pitch_p + og * 16 + 16 * (lane >> 4);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            if (c < ncc) {
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + 64 * c), bandc[c], al, 0, 0, 0);
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + (size_t)BM_W * pitch_p + 64 * c), bandc[c], ah, 0, 0, 0);
+            }
+        const int y = y0 + og * 16 + (lane & 15), xb = x0b + xg * 16 + 4 * (lane >> 4);
+        if (y >= h || xb >= roww) continue;
+        uint32_t px = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t T = (uint32_t)(al[i] + 256 * ah[i] + bias_c);
+            uint32_t q = T >> 16;
+            const uint32_t rem = T & 0xffffu;
+            if (xb + i < vec_end) q += (rem > 0x8000u || (rem == 0x8000u && (q & 1u))) ? 1u : 0u;
+            else q += rem >= 0x8000u ? 1u : 0u;
+            px |= min(q, 255u) << (8 * i);
+        }
+        uint8_t* o = out + (size_t)y * dstep + xb;
+        if (xb + 3 < roww) *(uint32_t*)o = px;
+        else for (int i = 0; xb + i < roww; i++) o[i] = (uint8_t)(px >> (8 * i));
+    }
+}
+
+// The two launches above.  IMP_ERROR_UNSUPPORTED when the exactness conditions (taps <= 127, sum <= 257) or the size limits
+// do not hold: the caller goes on to the VALU kernels.
+static int launch_gaussian_mfma(const Frames& f, const std::vector<int>& ik, int r, hipStream_t s) {
+    const View& v = f.v;
+    long long sum = 0;
+    int top = 0;
+    for (int k : ik) { sum += k; top = std::max(top, k); }
+    if (top > 127 || sum > 257 || r < 1 || 2 * r + 1 > 250) return IMP_ERROR_UNSUPPORTED;
+    const int cn = v.c, roww = v.w * cn;
+    const int nrc = (16 + 2 * cn * r + 63) / 64, ncc = (16 + 2 * r + 63) / 64;
+    if (nrc > BM_MAXC || ncc > 3) return IMP_ERROR_UNSUPPORTED;
+    if ((f.dstep & 3) || ((uintptr_t)f.dst & 3) || (f.dst_stride & 3)) return IMP_ERROR_UNSUPPORTED;
+    const int roww_pad = (roww + BM_W - 1) / BM_W * BM_W, hp = (v.h + BM_H - 1) / BM_H * BM_H;
+    const int pitch_s = 64 * nrc + 64 + 16, pitch_p = 64 * ncc + 64 + 16;   // (+16: sixteen rows / byte columns start in sixteen different 16-byte slots of the banks)
+    const size_t lds_r = (size_t)BM_H * pitch_s + 2 * (size_t)BM_W * (BM_H + 16), lds_c = 2 * (size_t)BM_W * pitch_p;
+    const long long pstride = 2LL * roww_pad * hp;
+    void *dev_k = nullptr, *planes = nullptr;
+    std::vector<int> blob;                                   // the two passes' band operands, lane by lane
+    bm_band_host(ik, r, cn, nrc, &blob);
+    const size_t off_c = blob.size();
+    bm_band_host(ik, r, 1, ncc, &blob);
+    if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
+    // one launch for the small radii (the halo rows are cheap there and four tiles fit a compute unit); IMPGPU_BLUR_MFMA2=1: always two (A/B)
+    const int nr16 = (BM_H + 2 * r + 15) & ~15;
+    const size_t lds_f = (size_t)nr16 * pitch_s + 2 * (size_t)BM_W * pitch_p;
+    static const bool two = std::getenv("IMPGPU_BLUR_MFMA2") != nullptr;
+    if (lds_f <= 40 * 1024 && !two && f.count <= 65535) {        // (measured at 1080p BGRA: sigma 2 19 us against 24 in two launches, sigma 8 32 against 30, sigma 12 48 against 35)
+        hipError_t e = hipSuccess;
+        const dim3 grid((unsigned)(roww_pad / BM_W), (unsigned)(hp / BM_H), (unsigned)f.count);
+        const bm_v4i* br = (const bm_v4i*)dev_k;
+        const bm_v4i* bc = (const bm_v4i*)((const int*)dev_k + off_c);
+#define IMP_BLUR_FUSED(CN_)                                                                                                          \
+    do {                                                                                                                             \
+        e = hipFuncSetAttribute((const void*)k_blur_mfma_fused<CN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);        \
+        if (e == hipSuccess)                                                                                                         \
+            hipLaunchKernelGGL((k_blur_mfma_fused<CN_>), grid, dim3(256), lds_f, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, \
+                               f.dstep, br, bc, r, nrc, ncc, pitch_s, pitch_p, (int)(128 * sum), (int)(128 * sum * 257));             \
+    } while (0)
+        if (cn == 4) IMP_BLUR_FUSED(4); else if (cn == 3) IMP_BLUR_FUSED(3); else IMP_BLUR_FUSED(1);
+#undef IMP_BLUR_FUSED
+        if (e == hipSuccess) e = hipGetLastError();
+        dev_free_on(dev_k, s);
+        if (e != hipSuccess) { set_error("k_blur_mfma_fused", e); return IMP_ERROR_DEVICE; }
+        return IMP_OK;
+    }
+    int chunk = (int)std::min<long long>(f.count, std::max<long long>(1, (1LL << 30) / pstride));
+    if (int rc = dev_alloc_on((size_t)pstride * chunk, &planes, s)) { dev_free_on(dev_k, s); return rc; }
+    hipError_t e = hipSuccess;
+    const int bias_r = (int)(128 * sum), bias_c = (int)(128 * sum * 257);
+    for (int f0 = 0; f0 < f.count && e == hipSuccess; f0 += chunk) {
+        const int n = std::min(chunk, f.count - f0);
+        const dim3 grid((unsigned)(roww_pad / BM_W), (unsigned)(hp / BM_H), (unsigned)n);
+        const uint8_t* src = f.src + (long long)f0 * f.src_stride;
+        uint8_t* dst = f.dst + (long long)f0 * f.dst_stride;
+#define IMP_BLUR_MFMA(CN_)                                                                                                                  \
+    do {                                                                                                                                    \
+        e = hipFuncSetAttribute((const void*)k_blur_mfma_rows<CN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);                \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_blur_mfma_cols<CN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c); \
+        if (e == hipSuccess) {                                                                                                              \
+            hipLaunchKernelGGL((k_blur_mfma_rows<CN_>), grid, dim3(256), lds_r, s, src, f.src_stride, v.step, v.w, v.h, (uint8_t*)planes, pstride, hp, \
+                               roww_pad, (const bm_v4i*)dev_k, r, nrc, pitch_s, bias_r);                                                       \
+            hipLaunchKernelGGL((k_blur_mfma_cols<CN_>), grid, dim3(256), lds_c, s, (const uint8_t*)planes, pstride, hp, roww_pad, dst, f.dst_stride, \
+                               f.dstep, v.w, v.h, (const bm_v4i*)((const int*)dev_k + off_c), r, ncc, pitch_p, bias_c);                                              \
+        }                                                                                                                                   \
+    } while (0)
+        if (cn == 4) IMP_BLUR_MFMA(4); else if (cn == 3) IMP_BLUR_MFMA(3); else IMP_BLUR_MFMA(1);
+#undef IMP_BLUR_MFMA
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    dev_free_on(planes, s);
+    dev_free_on(dev_k, s);
+    if (e != hipSuccess) { set_error("k_blur_mfma", e); return IMP_ERROR_DEVICE; }
+    return IMP_OK;
+}
+
 // src view -> dst (same size, BGRA, separate buffers).  IMP_ERROR_UNSUPPORTED when the fused form does not apply
 // (other channel counts, radius > 16, fixed-point taps summing above 257, 1-pixel axes): callers fall back to
 // launch_gaussian.  sigma must give ksize > 1.
@@ -501,6 +837,10 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
         ik = std::vector<int>(ik.begin() + (r0 - r), ik.begin() + (r0 + r + 1));
     }
     const int ks = 2 * r + 1;
+    if (r >= 3) {                                           // the matrix-unit form (exact when its conditions hold; else the VALU kernels below)
+        const int rc = launch_gaussian_mfma(f, ik, r, s);
+        if (rc != IMP_ERROR_UNSUPPORTED) return rc;
+    }
     if (r > 60) return IMP_ERROR_UNSUPPORTED;
     std::vector<int> blob;
     for (int j = 0; j <= r; j++) {                           // pairs (k[2j], k[2j+1]); the pair past the end is (k[2r], 0)
