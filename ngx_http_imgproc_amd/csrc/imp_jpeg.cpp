@@ -513,7 +513,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     F.chunk_bits = (unsigned)scan.chunk_bytes * 8;
     F.overlap_bits = jpeg_overlap_bits_for(F.chunk_bits, size - H.scan_begin, (size_t)F.total_slots / 64);
     const uint8_t* bytes = buf.data();
-    auto word = [bytes](uint32_t i) -> uint32_t {
+    auto word1 = [bytes](uint32_t i) -> uint32_t {
         const uint8_t* q = bytes + (size_t)i * 4;
         return ((uint32_t)q[3] << 24) | ((uint32_t)q[2] << 16) | ((uint32_t)q[1] << 8) | q[0];      // as a little-endian load
     };
@@ -544,7 +544,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
         c.exact = p0 == seg_start;                                   // the walk starts where the interval does: no guess
         for (uint32_t k = 0; k < 6; k++) { c.in[k] = c.out[k] = c.rep_out[k] = JPEG_STATE_NONE; c.n[k] = c.rep_n[k] = 0; }
         for (uint32_t k = 0; k < (c.exact ? 1u : B); k++) {
-            const JpegSpan sp = jpeg_span_walk(L, word, jpeg_pack_state(p0, k, 0, 0), start, limit[g], seg_end[g], F);
+            const JpegSpan sp = jpeg_span_walk(L, word1, jpeg_pack_state(p0, k, 0, 0), start, limit[g], seg_end[g], F);
             c.in[k] = sp.in; c.out[k] = sp.out; c.n[k] = sp.n;
         }
     }
@@ -570,7 +570,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
             } else {
                 for (uint32_t k1 = 0; k1 < B && v == JPEG_MAP_FAIL; k1++) if (c.in[k1] == E) v = k1;
                 if (v == JPEG_MAP_FAIL) {
-                    const JpegSpan sp = jpeg_span_walk(L, word, E, (uint32_t)g * CB, limit[g], seg_end[g], F);
+                    const JpegSpan sp = jpeg_span_walk(L, word1, E, (uint32_t)g * CB, limit[g], seg_end[g], F);
                     c.rep_out[k] = sp.out; c.rep_n[k] = sp.n;
                     via = 1;
                     repairs++;
@@ -595,7 +595,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
                 uint32_t k1 = 6;
                 for (uint32_t k = 0; k < B && k1 == 6; k++) if (c.in[k] == S) k1 = k;
                 if (k1 < 6) { entry[g] = S; slots[g] = c.n[k1]; idx = k1; explicit_state = false; continue; }
-                const JpegSpan sp = jpeg_span_walk(L, word, S, (uint32_t)g * CB, limit[g], seg_end[g], F);
+                const JpegSpan sp = jpeg_span_walk(L, word1, S, (uint32_t)g * CB, limit[g], seg_end[g], F);
                 entry[g] = S; slots[g] = sp.n;
                 for (uint32_t k = 0; k < B && k1 == 6; k++) if (c.out[k] == sp.out) k1 = k;
                 if (k1 < 6) { idx = k1; explicit_state = false; } else S = sp.out;
@@ -638,7 +638,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
         if (!closes && run_n > want) { *status |= JPEG_ST_OVERRUN; continue; }
         // the last chunk of an interval walks with the interval's remaining slots as a budget and gives the verdict
         const uint32_t budget = closes ? (want >= base_n ? want - base_n : 0u) : 0xffffffffu;
-        dec[g] = jpeg_write_chunk(L, K, word, entry[g], limit[g], seg_end[g], F, &W, budget);
+        dec[g] = jpeg_write_chunk(L, K, word1, entry[g], limit[g], seg_end[g], F, &W, budget);
         if (closes) {
             const uint32_t pe = (uint32_t)dec[g].exit, fle = (uint32_t)(dec[g].exit >> 48);
             if ((fle & JPEG_FL_INVALID) || pe > seg_end[g] || seg_end[g] - pe >= 8) *status |= JPEG_ST_BAD_CODE;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(SB) void k_jpeg_walks(const JpegJob* __restrict__ j
     // wait for a table read would then wait for the stream word as well.
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
     const GlobalWords gwords = (GlobalWords)(uintptr_t)J.words;
-    auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
+    auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };      // (a plain load: the lane comes back to the line for its next word, which a non-temporal load does not keep -- 313 against 465 us per 64 files in k_jpeg_walks)
     __syncthreads();
     // (the tables as the lanes read them, for k_jpeg_mend)
     if (b == 0) for (int i = t; i < (int)(sizeof(JpegHuffTabs) / 4); i += SB) ((uint32_t*)J.tabs)[i] = ((const uint32_t*)&L)[i];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(SB) void k_jpeg_mend(const JpegJob* __restrict__ jo
     const uint32_t g = g0 + j;
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
     const GlobalWords gwords = (GlobalWords)(uintptr_t)J.words;
-    auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
+    auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };      // (a plain load: the lane comes back to the line for its next word, which a non-temporal load does not keep -- 313 against 465 us per 64 files in k_jpeg_walks)
     __syncthreads();
     if (k >= B || j >= nlive) return;
     const uint32_t seg = J.chunk_seg[g], first = J.seg_first_chunk[seg];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(SB) void k_jpeg_select(const JpegJob* __restrict__ 
     stamp(0);
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
     const GlobalWords gwords = (GlobalWords)(uintptr_t)A.words;
-    auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
+    auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };      // (a plain load: the lane comes back to the line for its next word, which a non-temporal load does not keep -- 313 against 465 us per 64 files in k_jpeg_walks)
     if (t == 0) { s_ext = 0xffffffffu; s_ei = 0; s_from = 0; s_jf = 0xffffffffu; s_mode = 0; s_idx0 = 0; s_fin = 0; s_chases = 0; s_S = 0; }
 
     // ---- A. what the walks found (k_jpeg_walks) and where each of the predecessor's candidates leads (k_jpeg_mend), this
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_write(const JpegJob* __restrict__ j
     }
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
     const GlobalWords gwords = (GlobalWords)(uintptr_t)A.words;
-    auto word = [&](uint32_t i) -> uint32_t { return __builtin_nontemporal_load(gwords + i); };
+    auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };
     // ---- the slot of every chunk's first symbol: running totals inside each interval (a segmented scan), plus what the
     // interval had passed before this workgroup's first chunk (k_jpeg_sync left its workgroups' totals in their records)
     s_n[t] = own_n;

@@ -181,8 +181,40 @@ IMP_HD inline void jpeg_zero_block(int16_t* base, uint32_t at) {
 #endif
 }
 
+// The stream as a decoder lane reads it: one word per load (`word(i)` = the i-th word as loaded), the next one requested a
+// refill ahead.  Measured against sixteen bytes per load with a four-word queue in registers (same box, 64 files): k_jpeg_write
+// 427 against 517 us, k_jpeg_walks 460 against 512 -- the walks are bound by the instructions they issue, and the queue costs
+// more of those than the wider loads save.  What matters is that the loads are PLAIN ones: a lane comes back to its 128-byte
+// line for the next word, and a non-temporal load (round 3's) does not keep the line -- k_jpeg_walks 318 against 465 us.
+template <class WordFn>
+struct JpegBitReader1 {
+    WordFn word;
+    uint32_t w0, w1, ahead, nxt;
+    int sh;
+    IMP_HD explicit JpegBitReader1(WordFn f) : word(f) {}
+    IMP_HD void start(uint32_t p) {
+        const uint32_t widx = p >> 5, bit = p & 31;
+        w0 = bit ? jpeg_be(word(widx)) : 0u;
+        w1 = jpeg_be(word(widx + (bit ? 1u : 0u)));
+        nxt = widx + (bit ? 2u : 1u);
+        sh = bit ? 32 - (int)bit : 0;
+        ahead = word(nxt);
+    }
+    IMP_HD uint32_t window() const { return jpeg_window(w0, w1, sh); }
+    IMP_HD void take(uint32_t bits) {
+        sh -= (int)bits;
+        if (sh < 0) {
+            w0 = w1;
+            w1 = jpeg_be(ahead);
+            sh += 32;
+            nxt++;
+            ahead = word(nxt);
+        }
+    }
+};
+
 // One chunk, decoded for good: every symbol that STARTS before `limit`, from the packed state `entry` (its true one, found
-// by k_jpeg_sync).  `word(i)` returns the i-th 32-bit word of the unstuffed stream AS LOADED (little-endian: jpeg_be turns it
+// by k_jpeg_select).  `word(i)` returns the i-th 32-bit word of the unstuffed stream AS LOADED (little-endian: jpeg_be turns it
 // round where it is used, not where it is loaded, so that the load has a whole refill's worth of symbols to arrive).
 // `max_slots` ends the walk once that many coefficient slots have been passed: the last chunk of an interval stops after the
 // interval's last MCU like a sequential decoder does, whatever the (up to seven) padding bits behind it look like.
@@ -221,11 +253,8 @@ IMP_HD inline JpegDecoded jpeg_write_chunk(const Tabs& L, const JpegBlockTabs& K
         dc_sel |= (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]) << k;
         ac_sel |= (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]) << k;
     }
-    // the bit window (jpeg_window); `ahead` = the word after it, as loaded
-    const uint32_t widx = p >> 5, bit = p & 31;
-    uint32_t w0 = bit ? jpeg_be(word(widx)) : 0u, w1 = jpeg_be(word(widx + (bit ? 1u : 0u))), nxt = widx + (bit ? 2u : 1u);
-    int sh = bit ? 32 - (int)bit : 0;
-    uint32_t ahead = word(nxt);
+    JpegBitReader1<WordFn> bits(word);
+    bits.start(p);
     uint32_t fl = 0, n = 0, damaged = 0, ndc = 0;
     int dcs0 = 0, dcs1 = 0, dcs2 = 0;
     // where the coefficients go: MCU coordinates are carried along, a block's address is base + mx*dx + my*dy
@@ -258,7 +287,7 @@ IMP_HD inline JpegDecoded jpeg_write_chunk(const Tabs& L, const JpegBlockTabs& K
         const uint32_t ci = (comp_of >> (2 * c)) & 3;
         const bool isdc = z == 0;
         const uint32_t tab = isdc ? ((dc_sel >> c) & 1) : 2 + ((ac_sel >> c) & 1);
-        const uint32_t win = jpeg_window(w0, w1, sh), peek = win >> 16;
+        const uint32_t win = bits.window(), peek = win >> 16;
         // (only the entry as the host built it is read here -- length, value bits, run, end-of-block: its low 16 bits)
         uint32_t e = jpeg_tab_first_raw(L, tab, peek >> (16 - JPEG_LOOKBITS));
         if ((e & 31) == 0) {                                        // a code longer than the table's index
@@ -285,14 +314,7 @@ IMP_HD inline JpegDecoded jpeg_write_chunk(const Tabs& L, const JpegBlockTabs& K
             const int v = (int)((vb >> 1) >> (31 - size)) + ((int)(~vb) >> 31 & (1 - (1 << size)));
             const bool counted = p < limit;                         // (not so for the symbols that finish a block behind the chunk's end)
             p += total;
-            sh -= (int)total;
-            if (sh < 0) {
-                w0 = w1;
-                w1 = jpeg_be(ahead);                                // the byte swap HERE: a swap at the load would wait for it there
-                sh += 32;
-                nxt++;
-                ahead = word(nxt);
-            }
+            bits.take(total);
             uint32_t adv = eob ? 64 - z : run + 1;
             const bool over = z + adv > 64;                         // a run that leaves the block: damaged
             adv = over ? 64 - z : adv;
@@ -406,10 +428,8 @@ IMP_HD inline JpegSpan jpeg_span_walk(const Tabs& L, WordFn word, uint64_t entry
         tabsel |= (dct | (act << 2)) << (4 * k);
         nextc |= (k + 1 == bpm ? 0u : k + 1) << (4 * k);
     }
-    const uint32_t widx = p >> 5, bit = p & 31;
-    uint32_t w0 = bit ? jpeg_be(word(widx)) : 0u, w1 = jpeg_be(word(widx + (bit ? 1u : 0u))), nxt = widx + (bit ? 2u : 1u);
-    int sh = bit ? 32 - (int)bit : 0;
-    uint32_t ahead = word(nxt);                                     // (as loaded: the byte swap where it is used, so that the load has a refill's time to arrive)
+    JpegBitReader1<WordFn> bits(word);
+    bits.start(p);
     uint32_t fl = 0, blocks = 0, z0 = z;
     // No look at the interval's end here (the write walk does that): only an interval's LAST chunk could meet the padding,
     // and its exit state and slot count are never used -- the chunk behind it starts a new interval.
@@ -421,7 +441,7 @@ IMP_HD inline JpegSpan jpeg_span_walk(const Tabs& L, WordFn word, uint64_t entry
         blocks = 0;
         z0 = z;
         while (p < target) {                                        // (an ending pulls `target` down to zero: one way out)
-            const uint32_t win = jpeg_window(w0, w1, sh);
+            const uint32_t win = bits.window();
             const uint32_t tab = (tabsel >> (4 * c + (z == 0 ? 0u : 2u))) & 3;
             uint32_t e = jpeg_tab_first(L, tab, win >> (32 - JPEG_LOOKBITS));
             if ((e >> 16) == 0) {                                   // a code longer than the table's index
@@ -443,14 +463,7 @@ IMP_HD inline JpegSpan jpeg_span_walk(const Tabs& L, WordFn word, uint64_t entry
             }
             const uint32_t total = (e >> 16) & 31, adv = e >> 21;
             p += total;
-            sh -= (int)total;
-            if (sh < 0) {
-                w0 = w1;
-                w1 = jpeg_be(ahead);
-                sh += 32;
-                nxt++;
-                ahead = word(nxt);
-            }
+            bits.take(total);
             z += adv;
             const bool ended = z >= 64;
             const uint32_t cn = (nextc >> (4 * c)) & 15;

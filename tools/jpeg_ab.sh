@@ -11,7 +11,9 @@ import csv, sys
 for row in csv.DictReader(open(sys.argv[1])):
     n = row["Name"]
     if "jpeg" in n:
-        short = n.split("::")[-1].split("(")[0]
+        import re
+        m = re.search(r"(k_jpeg_\w+(?:<[^>]*>)?)", n)
+        short = m.group(1) if m else n[:28]
         print("   %-28s calls %3s avg %8.1f us  min %8.1f" % (short, row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3))
 PY
   grep -E "^batch" $R/gpurun_out/ab_jpeg_batch64.log | tail -1

@@ -63,6 +63,24 @@ with torch.cuda.stream(stream):
     for _ in range(reps):
         imp.batch_cv_resize(src.data_ptr(), 1080 * 1920 * 4, 1920, 1080, 1920 * 4, dsta.data_ptr(), 540 * 960 * 4,
                             960, 540, 960 * 4, 4, na, imp.INTER_AREA, stream=stream.cuda_stream)
+    # round 3 / 4: the rolling-strip kernel's four bench modes (bench.py WORKLOADS), batch / 4 (batch / 16 for the 2880-wide one)
+    for name, (sw, sh, dw, dh, interp, div) in {"upscale_x": (1080, 1920, 1920, 1080, imp.INTER_CUBIC, 4), "lanczos_up": (960, 540, 1920, 1080, imp.INTER_LANCZOS4, 4),
+                                                "linear_up": (960, 540, 1920, 1080, imp.INTER_LINEAR, 4), "lanczos_15": (2880, 1620, 1920, 1080, imp.INTER_LANCZOS4, 16)}.items():
+        ns = max(1, batch // div)
+        ss = src.view(-1)[: ns * sw * sh * 4]
+        dd = torch.zeros((ns, dh, dw, 4), dtype=torch.uint8, device="cuda")
+        for _ in range(reps):
+            imp.batch_cv_resize(ss.data_ptr(), sw * sh * 4, sw, sh, sw * 4, dd.data_ptr(), dw * dh * 4, dw, dh, dw * 4, 4, ns, interp, stream=stream.cuda_stream)
+        del dd
 torch.cuda.synchronize()
+# round 4: filter-blur on the matrix unit, one 1080p BGRA frame per call (sigma 2: one launch; 8 and 16: rows + columns)
+frames = [imp.Image(src[i].cpu().numpy()) for i in range(4)]
+for sigma in ("2", "8", "16"):
+    for im in frames:
+        for _ in range(reps):
+            assert im.filter("blur=" + sigma, 1) == 0
+imp.sync()
+for im in frames:
+    im.release()
 print("probe done: batch", batch, "reps", reps)
 imp.env_destroy()

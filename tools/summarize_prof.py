@@ -24,17 +24,25 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_rows<4, 10>": "area", "k_resize_nn<4>": "nn",
          "k_resize_taps<2, 4, 0>": "linear", "k_resize_2x_dma<8, 2": "lanczos", "k_area2x2_turn": "chain",
-         "k_resize_up_cubic4": "upscale", "k_area2x2_c4": "area2x"}
+         "k_resize_up_cubic4": "upscale", "k_area2x2_c4": "area2x",
+         "k_resize_strip<4, 1, 4>": "upscale_x", "[lanczos_up]": "lanczos_up", "[lanczos_15]": "lanczos_15", "k_resize_strip<2, 0, 4>": "linear_up"}
+# (lanczos_up and lanczos_15 run the same k_resize_strip<8, 2, 4>: the per-launch counters of both are in <round>_pmc.json,
+# and traffic_lanczos_15.json is written from the dispatches with the larger FETCH_SIZE -- see strip_split below)
 # frames per launch in tools/pmc_probe.py, as a divisor of PROBE_BATCH
-BATCH_DIV = {"lanczos": 16, "upscale": 2, "area2x": 4}
+BATCH_DIV = {"lanczos": 16, "upscale": 2, "area2x": 4, "upscale_x": 4, "lanczos_up": 4, "linear_up": 4, "lanczos_15": 16}
 
 
 def counter_means(kind):
     files = glob.glob(os.path.join(OUT, "prof_%s" % kind, "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(list)
     for f in files:
-        for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0)))
+        for r in rows:
+            name = r["Kernel_Name"]
+            if "k_resize_strip<8, 2, 4>" in name:                    # two workloads share it: lanczos_up comes first in tools/pmc_probe.py
+                reps = int(os.environ.get("PROBE_REPS", "3"))
+                name += " [lanczos_up]" if len(agg[name + " [lanczos_up]"]) < reps else " [lanczos_15]"
+            agg[name].append(float(r["Counter_Value"]))
     return agg
 
 
