@@ -55,13 +55,17 @@ static int FillConfig(Config* config, impgpu_config* g) {
 
 int ImpGpuDecode(u_char* blob, size_t size, Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool) {
     impgpu_image* frame = NULL;
-    /* SIG_JPG (bridge.c:8).  Anything the device decoder does not take -- progressive, CMYK, damaged files: a non-zero
-     * code -- goes to cvDecodeImage exactly as before, so no request changes its answer */
-    if (size < 3 || blob[0] != 0xFF || blob[1] != 0xD8 || blob[2] != 0xFF) {
+    /* SIG_JPG / SIG_PNG (bridge.c:8).  Anything the device decoders do not take -- progressive or CMYK JPEGs, 16-bit,
+     * palette or interlaced PNGs, damaged files: a non-zero code -- goes to cvDecodeImage exactly as before, so no request
+     * changes its answer */
+    static const u_char png[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    int isJpeg = size >= 3 && blob[0] == 0xFF && blob[1] == 0xD8 && blob[2] == 0xFF;
+    int isPng  = size >= 8 && memcmp(blob, png, 8) == 0;
+    if (!isJpeg && !isPng) {
         return 0;
     }
     {
-        int rc = impgpu_image_decode_jpeg(blob, size, &frame);
+        int rc = isJpeg ? impgpu_image_decode_jpeg(blob, size, &frame) : impgpu_image_decode_png(blob, size, &frame);
         if (rc == IMP_ERROR_UNSUPPORTED || rc == IMP_ERROR_DECODE_FAILED) {
             return 0;               /* not this decoder's file: cvDecodeImage, as before */
         }

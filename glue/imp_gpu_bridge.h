@@ -4,7 +4,7 @@
  * Compiled INTO the reference module (it uses the reference's own types: Album, Frame, Config, Memory from required.h),
  * next to bridge.c; glue/apply_glue.sh makes the edits in the reference's files that call these functions:
  *   bridge.c:10-16    OnEnvStart / OnEnvDestroy bodies      -> ImpGpuEnvStart / ImpGpuEnvDestroy
- *   bridge.c:545      before cvDecodeImage                  -> ImpGpuDecode     (a JPEG is decoded on the device; else as before)
+ *   bridge.c:545      before cvDecodeImage                  -> ImpGpuDecode     (a JPEG / PNG is decoded on the device; else as before)
  *   bridge.c:574-656  crop / resize / filter / watermark / flatten loops over the album -> ImpGpuOperators
  *   bridge.c:661      Info()                                -> ImpGpuInfo      (brightness reduced on the device)
  *   bridge.c:669-670  ASCII()                               -> ImpGpuASCII
@@ -44,9 +44,9 @@ typedef struct {
 void   ImpGpuEnvStart(int worker);
 void   ImpGpuEnvDestroy(void);
 
-/* bridge.c:545-552 for a JPEG blob: returns 1 when the file was decoded on the device (album gets its one frame with
- * Image = NULL, gpu holds the device frame), 0 when the caller must decode on the host as before (not a JPEG, a JPEG the
- * device decoder does not take, or a damaged one), and -IMP_ERROR_* when the DEVICE failed: the request then fails at
+/* bridge.c:545-552 for a JPEG or PNG blob: returns 1 when the file was decoded on the device (album gets its one frame with
+ * Image = NULL, gpu holds the device frame), 0 when the caller must decode on the host as before (neither format, a file the
+ * device decoders do not take, or a damaged one), and -IMP_ERROR_* when the DEVICE failed: the request then fails at
  * its DECODE step (HTTP 500) instead of paying for a host decode whose upload would fail the same way. */
 int    ImpGpuDecode(u_char* blob, size_t size, Album* album, ImpGpuAlbum* gpu, ngx_pool_t* pool);
 

@@ -22,6 +22,7 @@ SOURCES = [
     "imp_blur.hip",
     "imp_jpeg.hip",
     "imp_jpeg_enc.hip",
+    "imp_png.hip",
     "imp_api.cpp",
     "imp_args.cpp",
     "imp_request.cpp",
@@ -107,7 +108,7 @@ def build_library(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as pool:
         list(pool.map(run, jobs))
-    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, f + ".o") for f in SOURCES] + ["-o", LIB]
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, f + ".o") for f in SOURCES] + ["-lz", "-o", LIB]   # zlib: the host inflate of imp_png.hip
     run(link)
     return LIB
 

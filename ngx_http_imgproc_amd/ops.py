@@ -118,6 +118,14 @@ class Image:
         return rc, (cls(handle=h.value) if rc == 0 else None)
 
     @classmethod
+    def decode_png(cls, blob):
+        """cvDecodeImage(&rawencoded, -1) for a PNG blob (bridge.c:545-552): host inflate, filters undone on the device
+        -> (code, Image or None)."""
+        h = C.c_void_p()
+        rc = lib.impgpu_image_decode_png(bytes(blob), len(blob), C.byref(h))
+        return rc, (cls(handle=h.value) if rc == 0 else None)
+
+    @classmethod
     def album(cls, frames):
         """The frames of one animation (same geometry) as ONE handle: every operator then runs once for all of them
         (impgpu_album_upload; Album, required.h:56-66)."""
@@ -299,6 +307,19 @@ def jpeg_info(blob):
     w, h, c = C.c_int(), C.c_int(), C.c_int()
     rc = lib.impgpu_jpeg_info(bytes(blob), len(blob), w, h, c)
     return rc, (w.value, h.value, c.value)
+
+
+def png_info(blob):
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.impgpu_png_info(bytes(blob), len(blob), w, h, c)
+    return rc, (w.value, h.value, c.value)
+
+
+def png_stage_times():
+    """the calling thread's last decode_png: host microseconds (header, chunks + CRC + inflate, check + enqueue), scanline bytes"""
+    t = (C.c_double * 4)()
+    lib.impgpu_png_stage_times(t, 4)
+    return list(t)
 
 
 def crop_geometry(width, height, args, gravity=None):

@@ -272,6 +272,19 @@ def jpeg_decode(blob):
     return rc, Img(handle=h.value).numpy()
 
 
+# ---- PNG decode (oracle/orc_png.c; cvDecodeImage for a PNG blob, pinned against Pillow's libpng)
+lib.orc_png_decode.argtypes = [C.c_char_p, C.c_long, C.POINTER(C.c_void_p)]
+
+
+def png_decode(blob):
+    """-> (rc, H x W x {1,3,4} uint8 in gray / B,G,R / B,G,R,A order or None)"""
+    h = C.c_void_p()
+    rc = lib.orc_png_decode(blob, len(blob), C.byref(h))
+    if rc:
+        return rc, None
+    return rc, Img(handle=h.value).numpy()
+
+
 def jpeg_info(blob):
     info = (C.c_int * 8)()
     rc = lib.orc_jpeg_info(blob, len(blob), info)
