@@ -760,7 +760,7 @@ static int launch_gaussian_mfma(const Frames& f, const std::vector<int>& ik, int
     // one launch for the small radii (the halo rows are cheap there and four tiles fit a compute unit); IMPGPU_BLUR_MFMA2=1: always two (A/B)
     const int nr16 = (BM_H + 2 * r + 15) & ~15;
     const size_t lds_f = (size_t)nr16 * pitch_s + 2 * (size_t)BM_W * pitch_p;
-    static const bool two = std::getenv("IMPGPU_BLUR_MFMA2") != nullptr;
+    static const bool two = ab_env("IMPGPU_BLUR_MFMA2") != nullptr;
     if (lds_f <= 40 * 1024 && !two && f.count <= 65535) {        // (measured at 1080p BGRA: sigma 2 19 us against 24 in two launches, sigma 8 32 against 30, sigma 12 48 against 35)
         hipError_t e = hipSuccess;
         const dim3 grid((unsigned)(roww_pad / BM_W), (unsigned)(hp / BM_H), (unsigned)f.count);
@@ -861,12 +861,13 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
     if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
     if (r > 16 || !fits16) {   // column strips with an LDS ring (k_blur_strip4); also any radius whose rounded taps sum above 257
         const int RH0 = 2 * r + 8 <= 64 ? 64 : 128;          // (sigma = 4: 258 -- those kernels used to take the two-pass fallback: 89 us)
-        static const bool one_row = std::getenv("IMPGPU_BLUR_NO1") != nullptr;     // A/B: one output row per wave and step
+        static const bool one_row = ab_env("IMPGPU_BLUR_NO1") != nullptr;     // A/B: one output row per wave and step
         // Four output rows per wave and step (a 128-row ring of u16 sums: radius <= 48, taps summing to at most 257) is built,
         // bit-exact and OFF: two ring reads per tap then serve four outputs -- a quarter of the one-row form's LDS bytes -- but
         // the eight u16 -> float conversions per tap and 162 VGPRs cost more than the reads saved (sigma = 8: 70 us against 57,
-        // sigma = 16: 124 against 114).  The column pass is bound by its packed-FP32 issue, not by LDS.  IMPGPU_BLUR_FOUR=1 to A/B.
-        static const bool want_four = std::getenv("IMPGPU_BLUR_FOUR") != nullptr;
+        // sigma = 16: 124 against 114).  The column pass is bound by its packed-FP32 issue, not by LDS.  In the binary only with
+        // -DIMPGPU_AB_SWITCHES (then IMPGPU_BLUR_FOUR=1 selects it).
+        static const bool want_four = ab_env("IMPGPU_BLUR_FOUR") != nullptr;
         const bool four = want_four && !one_row && fits16 && 2 * r + 32 <= 128;
         const int RH = four ? 128 : RH0;
         const bool r16 = RH == 128 && fits16;
@@ -886,9 +887,11 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
                                f.dst, f.dst_stride, f.dstep, (const int*)dev_k, (const float*)((const int*)dev_k + off_f),          \
                                (const int*)dev_k + off_i, r, rpb);                                                                  \
     } while (0)
+#ifdef IMPGPU_AB_SWITCHES
         if (NO == 4) {
             if (v.c == 4) IMP_BLUR_STRIP(128, 4, 4, true); else IMP_BLUR_STRIP(128, 3, 4, true);
         } else
+#endif
         switch ((RH == 64 ? 0 : 4) + (v.c == 4 ? 0 : 2) + (NO == 2 ? 0 : 1) + (r16 ? 8 : 0)) {
             case 0: IMP_BLUR_STRIP(64, 4, 2, false); break;
             case 1: IMP_BLUR_STRIP(64, 4, 1, false); break;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../include/impgpu.h"
@@ -47,6 +48,17 @@ inline bool view_fits(long long w, long long h, int c, long long step) {
     return w > 0 && h > 0 && w <= 0x7fffffffLL && h <= 0x7fffffffLL && step >= w * c && step <= 0x7fffffffLL &&
            w * h <= (1LL << 30) && step * h <= 0xffffffffLL;
 }
+
+// ---------------------------------------------------------------- A/B switches
+// The environment switches of the measurement sessions (tools/switch_matrix.sh; DESIGN.md lists them with what each one
+// measured) select kernel variants that LOST their comparison or tuning values other than the chosen ones.  They are compiled
+// in only with -DIMPGPU_AB_SWITCHES (IMPGPU_EXTRA_FLAGS=-DIMPGPU_AB_SWITCHES python ngx_http_imgproc_amd/build.py): the
+// shipped library reads none of them, and the variants only they reach are not in its binary.
+#ifdef IMPGPU_AB_SWITCHES
+inline const char* ab_env(const char* name) { return std::getenv(name); }
+#else
+constexpr const char* ab_env(const char*) { return nullptr; }
+#endif
 
 // ---------------------------------------------------------------- runtime (imp_runtime.hip)
 void set_error(const char* what, hipError_t e);

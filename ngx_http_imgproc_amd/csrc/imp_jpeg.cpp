@@ -245,7 +245,7 @@ size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs) {
 // rest of its chunk is filled with 1-bits, exactly what the encoder pads the last byte with) and the next one starts on a
 // chunk boundary.  Stops at EOI, at any other marker, or at the end of the file.
 size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
-    if (const char* s = std::getenv("IMPGPU_JPEG_CHUNK_WORDS")) {
+    if (const char* s = ab_env("IMPGPU_JPEG_CHUNK_WORDS")) {
         const int w = std::atoi(s);
         if (w == 8 || w == 16 || w == 32 || w == 64) return (size_t)w * 4;
     }
@@ -257,7 +257,7 @@ size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
 }
 
 unsigned jpeg_overlap_bits_for(unsigned chunk_bits, size_t scan_bytes, size_t total_blocks) {
-    if (const char* s = std::getenv("IMPGPU_JPEG_OVERLAP")) {
+    if (const char* s = ab_env("IMPGPU_JPEG_OVERLAP")) {
         const int v = std::atoi(s);
         if (v >= 0 && v <= 1 << 20) return (unsigned)v;
     }

@@ -616,7 +616,7 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     hipStream_t s = env_stream();
     EncTables T;
     enc_static_tables(&T, quality);
-    static const bool one_wg = std::getenv("IMPGPU_JPEG_ENC_ONE_WG") != nullptr;       // A/B: every frame through k_jpeg_enc_huff
+    static const bool one_wg = ab_env("IMPGPU_JPEG_ENC_ONE_WG") != nullptr;       // A/B: every frame through k_jpeg_enc_huff
     std::vector<EncJob> jobs;                                   // small frames first, then the large ones
     std::vector<int> owner;                                     // job -> index into images
     std::vector<std::vector<uint8_t>> heads;

@@ -2412,7 +2412,7 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
             }
             yr[dh] = yr[dh - 1];
             yr[dh].adv = 0;
-            static const bool no_period = std::getenv("IMPGPU_UP_NO_PERIOD") != nullptr;
+            static const bool no_period = ab_env("IMPGPU_UP_NO_PERIOD") != nullptr;
             for (int per = 2; per <= 4 && !ts.up_period && !no_period; per++) {   // rows p, p + per, p + 2 per ... advance by one, the others not at all
                 int p0 = 1;
                 while (p0 < dh && yr[p0].adv == 0) p0++;
@@ -2475,7 +2475,7 @@ static bool area_rows_plan(int sw, int sh, int dw, int dh, double scale_x, long 
     if (even) ww += ww & 1;                                // the mixed-geometry kernel carries the even windows only
     while (ww <= 4 * MIX_NV && 63 * scale_x + ww + 8 > 256 * ((ww + 3) / 4)) ww += even ? 2 : 1;
     if (ww < 1 || ww > 4 * MIX_NV || sw < ww || sw < 4) return false;
-    static const int bh_env = std::getenv("IMPGPU_AREA_BH") ? std::atoi(std::getenv("IMPGPU_AREA_BH")) : 0;
+    static const int bh_env = ab_env("IMPGPU_AREA_BH") ? std::atoi(ab_env("IMPGPU_AREA_BH")) : 0;
     int b = 16;
     const long long nstrips = (dw + 63) / 64;
     while (b > 4 && frames * nstrips * ((dh + b - 1) / b) < 4096) b /= 2;
@@ -2537,7 +2537,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                 const dim3 qgrid((unsigned)(((long long)qpr * a.dh + 255) / 256), (unsigned)count);
                 const int gpr2 = a.sw / 4;
                 const dim3 cgrid2((unsigned)(((long long)gpr2 * a.dh + 511) / 512), (unsigned)count);
-                static const bool no_c4 = std::getenv("IMPGPU_NO_C4") != nullptr;
+                static const bool no_c4 = ab_env("IMPGPU_NO_C4") != nullptr;
                 if (CN == 4 && !(a.dw & 1) && !no_c4) hipLaunchKernelGGL(k_area2x2_c4, cgrid2, block, 0, s, a, gpr2);
                 else if (CN == 4) hipLaunchKernelGGL(k_area2x2_v4, qgrid, block, 0, s, a, qpr);
                 else hipLaunchKernelGGL(k_area2x2_v3, qgrid, block, 0, s, a, qpr);
@@ -2545,7 +2545,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
                 const float scale = 1.f / (float)(isx * isy);
                 const int cpr = a.sw / 4;                         // 16-byte granules per source row (k_area_boxc)
                 const dim3 cgrid((unsigned)(((long long)cpr * a.dh + 1023) / 1024), (unsigned)count);
-                static const bool all_lds = std::getenv("IMPGPU_BOXL") != nullptr;        // A/B: 4 and 8 through their other form
+                static const bool all_lds = ab_env("IMPGPU_BOXL") != nullptr;        // A/B: 4 and 8 through their other form
                 const int P = (4096 / (4 * isx)) & ~3, lcpr = (a.dw + P - 1) / P;
                 const dim3 lgrid((unsigned)(((long long)lcpr * a.dh + 3) / 4), (unsigned)count);
                 switch (isx + (all_lds ? 100 : 0)) {
@@ -2582,7 +2582,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             if (CN == 4 || (CN == 3 && rows4b && a.sw >= 6)) {
                 int w = 0, bh = 0;
                 if (area_rows_plan(a.sw, a.sh, a.dw, a.dh, scale_x, count, false, &w, &bh)) {
-                    static const bool no_rows4 = std::getenv("IMPGPU_NO_ROWS4") != nullptr;
+                    static const bool no_rows4 = ab_env("IMPGPU_NO_ROWS4") != nullptr;
                     // four columns per lane while the windows are small and there are enough columns and waves for it
                     const long long waves4 = (long long)count * ((a.dw + 255) / 256) * ((a.dh + bh - 1) / bh);
                     if (!no_rows4 && w >= 2 && w <= 5 && a.dw >= 160 && waves4 >= 2048 && 255 * scale_x + w + 8 <= (CN == 4 ? 1024 : 1340)) {
@@ -2640,12 +2640,12 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
         TableSet ts;
         if (int rc = get_tables(interp, a.sw, a.sh, a.dw, a.dh, scale_x, scale_y, s, &ts)) return rc;
         // both scales <= 2: neighbouring outputs share taps -> LDS-tiled separable kernel (BGRA)
-        static const bool no_roll = std::getenv("IMPGPU_NO_ROLL") != nullptr;
+        static const bool no_roll = ab_env("IMPGPU_NO_ROLL") != nullptr;
         if (CN == 3 && ts.step2 && a.sw >= 8 && !no_roll && interp != IMP_INTER_LINEAR) {
             // exact 2x decimation of a 3-channel frame: register-rolling strips
             const int nstrips = (a.dh + ROLL_STRIP - 1) / ROLL_STRIP;
             const dim3 rgrid((a.dw + 255) / 256, nstrips, (unsigned)count);
-            static const bool no_dma3 = std::getenv("IMPGPU_NO_DMA3") != nullptr;
+            static const bool no_dma3 = ab_env("IMPGPU_NO_DMA3") != nullptr;
             const bool dma3 = !no_dma3 && (a.sw & 15) == 0 && (long long)a.sh * a.sstep < (1LL << 32) && (long long)a.dh * a.dstep < (1LL << 32) &&
                               !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 15);
             const int nbx = (a.dw + 255) / 256, bpf = nbx * nstrips;
@@ -2667,13 +2667,13 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             const int nstrips = (a.dh + ROLL_STRIP - 1) / ROLL_STRIP;
             // LDS-DMA row ring when the 16-byte DMA granules line up with the rows; IMPGPU_DMA_DEPTH = iterations
             // prefetched (0 = off: the register-rolling kernel, which has no alignment demands)
-            static const int dma_depth = std::getenv("IMPGPU_DMA_DEPTH") ? std::atoi(std::getenv("IMPGPU_DMA_DEPTH")) : 3;
+            static const int dma_depth = ab_env("IMPGPU_DMA_DEPTH") ? std::atoi(ab_env("IMPGPU_DMA_DEPTH")) : 3;
             const bool dma_ok = dma_depth > 0 && interp != IMP_INTER_LINEAR && (a.sw & 3) == 0 &&
                                 (long long)a.sh * a.sstep < (1LL << 32) && (long long)a.dh * a.dstep < (1LL << 32) &&
                                 !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 15);
             const dim3 rgrid((a.dw + 255) / 256, nstrips, (unsigned)count);
             // waves of a block are independent (no barriers, private LDS rings): small blocks only shorten the tail
-            static const int wpb = std::getenv("IMPGPU_DMA_WPB") ? std::atoi(std::getenv("IMPGPU_DMA_WPB")) : 4;
+            static const int wpb = ab_env("IMPGPU_DMA_WPB") ? std::atoi(ab_env("IMPGPU_DMA_WPB")) : 4;
             const int nbx = (a.dw + 64 * wpb - 1) / (64 * wpb), bpf = nbx * nstrips;
             const dim3 dgrid((unsigned)(bpf * 8), (unsigned)((count + 7) / 8));
 #define IMP_DMA_W(KS_, MODE_, VEC_, VS_, D_)                                                                             \
@@ -2700,7 +2700,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             else
                 hipLaunchKernelGGL((k_resize_2x_roll<8, M_LANCZOS>), rgrid, block, 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0);
         } else if (CN == 3 && interp == IMP_INTER_CUBIC && scale_y <= 1.0 && scale_x <= 2.0 && a.sw >= 4 &&
-                   (long long)a.dh * a.dstep < (1LL << 32) && !std::getenv("IMPGPU_NO_UP")) {
+                   (long long)a.dh * a.dstep < (1LL << 32) && !ab_env("IMPGPU_NO_UP")) {
             // enlargement of a 3-channel frame (every JPEG): the BGRA kernel's structure on bytes
             const int nbx = (a.dw + 255) / 256;
             const int wbmax = ((((int)std::floor(63 * scale_x) + 6) * 3 + 3) & ~3) + 4;
@@ -2718,11 +2718,11 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
               else hipLaunchKernelGGL(k_resize_up_cubic3<0>, dim3((unsigned)(nbx * ncy), (unsigned)count), block, 0, s, a,
                                ts.xofs, ts.xco, ts.yco, (const UpRow*)ts.yrows, (a.dw * 3) & ~7, nbx, rpw); }
         } else if (CN == 4 && interp == IMP_INTER_CUBIC && scale_y <= 1.0 && scale_x <= 2.0 && a.sw >= 4 &&
-                   (long long)a.dh * a.dstep < (1LL << 32) && !std::getenv("IMPGPU_NO_UP")) {
+                   (long long)a.dh * a.dstep < (1LL << 32) && !ab_env("IMPGPU_NO_UP")) {
             // enlargement (bridge.c:190's CUBIC case): wave-private strips, float H sums in a register ring
             const int nbx = (a.dw + 255) / 256;                 // four 64-column strips per block, one per wave
             // few frames: shorter row chunks so that every CU still gets waves
-            static const int up_rows = std::getenv("IMPGPU_UP_ROWS") ? std::atoi(std::getenv("IMPGPU_UP_ROWS")) : UP_ROWS;
+            static const int up_rows = ab_env("IMPGPU_UP_ROWS") ? std::atoi(ab_env("IMPGPU_UP_ROWS")) : UP_ROWS;
             // rows per wave chunk: as many as keep the chunk's source footprint (strip columns x footprint rows, from the
             // bound floor(n * scale) + 1 on how far n + 1 sample positions spread, + 3 taps + 1) inside the wave's LDS
             // patch, at most UP_ROWS; fewer when there are too few frames to fill the chip otherwise
@@ -2974,7 +2974,7 @@ __global__ __launch_bounds__(256) void k_area2x2_turn(RArgs a, int amount, int r
 // geometry is not the exact-2x BGRA case so the caller can fall back to resize + rotate.
 int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s) {
     const View& v = f.v;
-    static const int shape = std::getenv("IMPGPU_CHAIN_TILE") ? std::atoi(std::getenv("IMPGPU_CHAIN_TILE")) : 64;   // measured (profiles/r01_chain_tiles.txt): 64x64 with the column walk
+    static const int shape = ab_env("IMPGPU_CHAIN_TILE") ? std::atoi(ab_env("IMPGPU_CHAIN_TILE")) : 64;   // measured (profiles/r01_chain_tiles.txt): 64x64 with the column walk
     if (v.c != 4 || (amount != 90 && amount != 270) || (v.w & 1) || (v.h & 1)) return IMP_ERROR_UNSUPPORTED;
     const int rw = v.w / 2, rh = v.h / 2;
     if (rw < 2 || rh < 1) return IMP_ERROR_UNSUPPORTED;
@@ -2983,7 +2983,7 @@ int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overla
     if (((uintptr_t)f.dst | (uintptr_t)f.dstep | (uintptr_t)f.dst_stride) & 3) return IMP_ERROR_UNSUPPORTED;
     RArgs a{f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
     const dim3 block(256);
-    static const int stream_cfg = std::getenv("IMPGPU_CHAIN_STREAM") ? std::atoi(std::getenv("IMPGPU_CHAIN_STREAM")) : 128032;   // SW * 1000 + BH; 0 = the block-tile kernel
+    static const int stream_cfg = ab_env("IMPGPU_CHAIN_STREAM") ? std::atoi(ab_env("IMPGPU_CHAIN_STREAM")) : 128032;   // SW * 1000 + BH; 0 = the block-tile kernel
     if (stream_cfg && !(rw & 1)) {
         OverlayArgs wm0{};
         if (overlay) wm0 = *overlay;
@@ -2998,23 +2998,27 @@ int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overla
         if (e == hipSuccess)                                                                                                      \
             hipLaunchKernelGGL((k_area2x2_turn<SW_, BH_>), sgrid, block, lds, s, a, amount, rw, rh, nstrips, nbands, bpf, f.count, wm0); \
     } while (0)
+#ifdef IMPGPU_AB_SWITCHES      // the other strip shapes (IMPGPU_CHAIN_STREAM)
         if (sw == 64 && bh == 64) IMP_TURN(64, 64);
         else if (sw == 64 && bh == 32) IMP_TURN(64, 32);
         else if (sw == 128 && bh == 64) IMP_TURN(128, 64);
         else if (sw == 128 && bh == 16) IMP_TURN(128, 16);
-        else IMP_TURN(128, 32);
+        else
+#endif
+        IMP_TURN(128, 32);
 #undef IMP_TURN
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) { set_error("k_area2x2_turn", e); return IMP_ERROR_DEVICE; }
         return IMP_OK;
     }
-    static const int shape_y = std::getenv("IMPGPU_CHAIN_TILE_Y") ? std::atoi(std::getenv("IMPGPU_CHAIN_TILE_Y")) : 0;
+    static const int shape_y = ab_env("IMPGPU_CHAIN_TILE_Y") ? std::atoi(ab_env("IMPGPU_CHAIN_TILE_Y")) : 0;
     const int tx = shape, ty = shape_y ? shape_y : 4096 / shape;
     const int ntx = (rw + tx - 1) / tx, nty = (rh + ty - 1) / ty;
-    static const int order = std::getenv("IMPGPU_CHAIN_ORDER") ? std::atoi(std::getenv("IMPGPU_CHAIN_ORDER")) : 0;
+    static const int order = ab_env("IMPGPU_CHAIN_ORDER") ? std::atoi(ab_env("IMPGPU_CHAIN_ORDER")) : 0;
     const dim3 grid((unsigned)(ntx * nty), (unsigned)((f.count + 7) / 8 * 8));
     OverlayArgs wm{};
     if (overlay) wm = *overlay;
+#ifdef IMPGPU_AB_SWITCHES      // the other tile shapes of profiles/r01_chain_tiles.txt (IMPGPU_CHAIN_TILE / _TILE_Y)
     if (tx == 64 && ty == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
     else if (tx == 128 && ty == 64) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
     else if (tx == 64 && ty == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 256>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
@@ -3024,7 +3028,9 @@ int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overla
     else if (tx == 32) hipLaunchKernelGGL((k_area2x2_rotate_bgra<32, 128>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
     else if (tx == 128) hipLaunchKernelGGL((k_area2x2_rotate_bgra<128, 32>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
     else if (tx == 256) hipLaunchKernelGGL((k_area2x2_rotate_bgra<256, 16>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
-    else hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
+    else
+#endif
+    hipLaunchKernelGGL((k_area2x2_rotate_bgra<64, 64>), grid, block, 0, s, a, amount, rw, rh, ntx, nty, f.count, order, wm);
     IMP_HIP(hipGetLastError());
     return IMP_OK;
 }
@@ -3067,7 +3073,7 @@ static int launch_mix(std::vector<MixDesc>& v, int cn, hipStream_t s) {
     std::vector<int> order(v.size());
     for (size_t i = 0; i < v.size(); i++) order[i] = (int)i;
     auto cost = [&](int i) { return (long long)v[i].a.sw * v[i].a.sh; };
-    static const bool no_sort = std::getenv("IMPGPU_MIX_NOSORT") != nullptr;
+    static const bool no_sort = ab_env("IMPGPU_MIX_NOSORT") != nullptr;
     if (!no_sort) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost(x) > cost(y); });
     std::vector<int> list[8];
     long long load[8] = {0};
@@ -3129,7 +3135,7 @@ int launch_resize_mixed(const MixFrame* fr, int count, int cn, int simple, hipSt
             d.gm = AreaGeom{scale_x, scale_y};
             const bool aligned = !(((uintptr_t)f.src | (uintptr_t)f.sstep) & 3);
             int w4 = 0, bh4 = 0;
-            static const bool no_rows4 = std::getenv("IMPGPU_NO_ROWS4") != nullptr;
+            static const bool no_rows4 = ab_env("IMPGPU_NO_ROWS4") != nullptr;
             if (!no_rows4 && (cn == 4 || (aligned && f.sw >= 6)) && f.dw >= 160 && area_rows_plan(f.sw, f.sh, f.dw, f.dh, scale_x, count, false, &w4, &bh4) &&
                 w4 >= 2 && w4 <= 5 && 255 * scale_x + w4 + 8 <= (cn == 4 ? 1024 : 1340)) {
                 // windows of at most five pixels (factors below ~3.9): four destination columns per lane, like the uniform batches

@@ -368,7 +368,8 @@ def test_import_order_with_torch_does_not_matter():
     import sys
 
     code = (
-        "import sys, numpy as np\n"
+        "import faulthandler, sys, numpy as np\n"
+        "faulthandler.dump_traceback_later(200, exit=True)\n"          # a hang says where, in this test's failure text
         "sys.path.insert(0, %r)\n"
         "import ngx_http_imgproc_amd as gpu\n"
         "assert 'torch' not in sys.modules\n"
