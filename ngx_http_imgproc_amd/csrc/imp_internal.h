@@ -59,6 +59,10 @@ inline const char* ab_env(const char* name) { return std::getenv(name); }
 #else
 constexpr const char* ab_env(const char*) { return nullptr; }
 #endif
+inline int ab_env_int(const char* name, int otherwise) {
+    const char* s = ab_env(name);
+    return s ? std::atoi(s) : otherwise;
+}
 
 // ---------------------------------------------------------------- runtime (imp_runtime.hip)
 void set_error(const char* what, hipError_t e);

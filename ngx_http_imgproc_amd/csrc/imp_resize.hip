@@ -948,91 +948,104 @@ __global__ __launch_bounds__(256) void k_resize_2x_roll3(RArgs a, const int* __r
 // The exact-2x strips generalised: a lane owns one destination column, a wave walks a strip of rows down and keeps the
 // horizontal sums of the CURRENT footprint -- rows first .. first + KS - 1, in order -- in registers.  The footprint moves
 // by yofs[dy] - yofs[dy - 1] rows per destination row (0 or 1 when enlarging, 1 or 2 when shrinking by up to 2): every
-// step shifts the ring by one row and reduces one new source row (the windows come straight from memory: neighbouring
-// lanes overlap, so a wave's request is a few contiguous lines).  The row's weights are wave-uniform (scalar loads).
-// Nothing is shared between waves: no LDS, no barrier.
-template <int KS, int MODE>
-__device__ __forceinline__ uint32_t vpass_bgr(const int (*ring)[3], const int* by, int dx, int vec_end) {
-    int out[3];
+// step reduces one new source row into the ring slot of the row that leaves (the windows come straight from memory:
+// neighbouring lanes overlap, so a wave's request is a few contiguous lines).  The row's weights are wave-uniform
+// (scalar loads).  Nothing is shared between waves: no LDS, no barrier.
+constexpr int strip_row_ints(int ks) { return ks <= 2 ? 4 : 16; }   // per destination row: {first footprint row, KS weights, padding; CUBIC: the weights as floats at [8..11]}
+
+// The vertical pass of the strip kernels: footprint row k is ring[(k + P) & (KS - 1)] (P = 0 where the ring is shifted, the
+// footprint's position in the slots where it is not).
+//   LINEAR: the ring holds S >> 4, the only form VResizeLinear reads a horizontal sum in (shifted once per SOURCE row, not
+//     once per use); the result cannot exceed 255, so the bytes are packed without masks.
+//   CUBIC: VResizeCubicVec_32s8u's four float products, added in footprint order; the weights come as the floats b * 2^-22
+//     the host tabulated (one IEEE multiply each, the same one the kernel used to do per lane and row).
+template <int KS, int MODE, int CN, int P>
+__device__ __forceinline__ uint32_t strip_vpass(const int (*ring)[CN], const int* by, const float* bf, int dx, int vec_end) {
+    if constexpr (MODE == M_LINEAR) {
+        uint32_t px = 0;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        int hc[KS];
+        for (int c = 0; c < CN; c++) {                          // (T < 2^15, b <= 2^11: the 24-bit multiplier is exact)
+            const uint32_t o = ((((uint32_t)__mul24(by[0], ring[P & 1][c])) >> 16) + (((uint32_t)__mul24(by[1], ring[(P + 1) & 1][c])) >> 16) + 2u) >> 2;
+            px |= o << (8 * c);
+        }
+        return px;
+    } else if constexpr (MODE == M_LANCZOS) {
+        int v[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < KS; k++) hc[k] = ring[k][c];
-        if constexpr (MODE == M_LINEAR) {
-            out[c] = (uint8_t)(((__mul24(by[0], hc[0] >> 4) >> 16) + (__mul24(by[1], hc[1] >> 4) >> 16) + 2) >> 2);
-        } else if constexpr (MODE == M_CUBIC) {
-            if (dx * 3 + c < vec_end) {
-                const float sc = 1.f / (2048.f * 2048.f);
-                float v = __fmul_rn(__int2float_rn(hc[0]), __fmul_rn((float)by[0], sc));
-                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[1]), __fmul_rn((float)by[1], sc)));
-                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[2]), __fmul_rn((float)by[2], sc)));
-                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[3]), __fmul_rn((float)by[3], sc)));
-                out[c] = sat_u8(__float2int_rn(v));
+        for (int c = 0; c < CN; c++) {
+            v[c] = 1 << 21;                                     // |h| < 2^23: the 24-bit multiplier is exact
+#pragma unroll
+            for (int k = 0; k < KS; k++) v[c] = mad24s(ring[(k + P) & (KS - 1)][c], by[k], v[c]);
+        }
+        return shr_sat_pack4(v[0], v[1], v[2], v[3], 22) & (CN == 4 ? 0xffffffffu : 0xffffffu);
+    } else {
+        uint32_t px = 0;
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+            int hc[KS];
+#pragma unroll
+            for (int k = 0; k < KS; k++) hc[k] = ring[(k + P) & (KS - 1)][c];
+            int o;
+            if (dx * CN + c < vec_end) {
+                float v = __fmul_rn(__int2float_rn(hc[0]), bf[0]);
+                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[1]), bf[1]));
+                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[2]), bf[2]));
+                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[3]), bf[3]));
+                o = sat_u8(__float2int_rn(v));
             } else {
                 const int v = __mul24(hc[0], by[0]) + __mul24(hc[1], by[1]) + __mul24(hc[2], by[2]) + __mul24(hc[3], by[3]);
-                out[c] = shr_sat_u8(v + (1 << 21), 22);
+                o = shr_sat_u8(v + (1 << 21), 22);
             }
-        } else {
-            int v = 1 << 21;                                   // |hc| < 2^23: the 24-bit multiplier is exact
-#pragma unroll
-            for (int k = 0; k < KS; k++) v = mad24s(hc[k], by[k], v);
-            out[c] = shr_sat_u8(v, 22);
+            px |= (uint32_t)o << (8 * c);
         }
+        return px;
     }
-    return (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16);
 }
 
-constexpr int strip_row_ints(int ks) { return ks <= 2 ? 4 : ks <= 4 ? 8 : 16; }   // per destination row: {first footprint row, KS weights, padding}
-
+// What a lane of a strip kernel knows about its destination column: the horizontal weights, where its window starts, and
+// how to fetch and reduce one source row's window.
 template <int KS, int MODE, int CN>
-__global__ __launch_bounds__(256) void k_resize_strip(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
-                                                      const int* __restrict__ srows, int vec_end, int rows_per_strip) {
-    static_assert(CN == 3 || CN == 4, "interleaved BGR / BGRA");
-    constexpr int NDW = (KS * 3 + 3) / 4;                       // dwords holding a BGR window
-    constexpr int NW = CN == 4 ? KS : NDW + 1;                  // registers of one window in flight (BGR: before the byte alignment)
-    constexpr int SR = strip_row_ints(KS);
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int strip = blockIdx.x * 4 + wv;                      // the four waves of a block: neighbouring strips of the same rows
-    if (strip * 64 >= a.dw) return;
-    const int dx = strip * 64 + lane;
-    const int dy0 = blockIdx.y * rows_per_strip, dy1 = min(a.dh, dy0 + rows_per_strip);
-    const bool live = dx < a.dw;
-    const int dxc = live ? dx : a.dw - 1;                       // idle lanes shadow the last column (no stores)
-    const uint8_t* S = a.src + (long long)blockIdx.z * a.src_stride;
-    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dx * CN;
-
+struct StripLane {
+    static constexpr int NDW = (KS * 3 + 3) / 4;               // dwords holding a BGR window
+    static constexpr int NW = CN == 4 ? KS : NDW + 1;          // registers of one window in flight (BGR: before the byte alignment)
+    const uint8_t* S;
+    int sstep, sh;
     short2_t axp[KS / 2];
-#pragma unroll
-    for (int j = 0; j < KS / 2; j++) { axp[j].x = xco[dxc * KS + 2 * j]; axp[j].y = xco[dxc * KS + 2 * j + 1]; }
-    const int sx0 = xofs[dxc] - (KS / 2 - 1);
-    const bool interior = sx0 >= 0 && sx0 + KS <= a.sw;
-    const int sxv = clampi(sx0, 0, a.sw - KS) * CN;
-    const unsigned bsh = (unsigned)(uintptr_t)(S + sxv) & 3u;   // BGR: where the window starts inside its first aligned dword
+    bool interior;
+    int sxv;
+    unsigned bsh;                                              // BGR: where the window starts inside its first aligned dword
     int sxk[KS];
-#pragma unroll
-    for (int k = 0; k < KS; k++) sxk[k] = clampi(sx0 + k, 0, a.sw - 1) * CN;
 
+    __device__ __forceinline__ void init(const RArgs& a, const uint8_t* src, int dxc, const int* __restrict__ xofs, const short* __restrict__ xco) {
+        S = src; sstep = a.sstep; sh = a.sh;
+#pragma unroll
+        for (int j = 0; j < KS / 2; j++) { axp[j].x = xco[dxc * KS + 2 * j]; axp[j].y = xco[dxc * KS + 2 * j + 1]; }
+        const int sx0 = xofs[dxc] - (KS / 2 - 1);
+        interior = sx0 >= 0 && sx0 + KS <= a.sw;
+        sxv = clampi(sx0, 0, a.sw - KS) * CN;
+        bsh = (unsigned)(uintptr_t)(S + sxv) & 3u;
+#pragma unroll
+        for (int k = 0; k < KS; k++) sxk[k] = clampi(sx0 + k, 0, a.sw - 1) * CN;
+    }
     // A source row's window is REQUESTED two footprint steps before it is reduced (no wait at the request: loads and stores
     // share vmcnt, and a wave that waited for every window where it asks for it spent its time in that wait) ...
-    auto request = [&](int sy, uint32_t* w) {
-        const uint8_t* row = S + (size_t)clampi(sy, 0, a.sh - 1) * a.sstep;
+    __device__ __forceinline__ void request(int sy, uint32_t* w) const {
+        const uint8_t* row = S + (size_t)clampi(sy, 0, sh - 1) * sstep;
         if constexpr (CN == 4) __builtin_memcpy(w, __builtin_assume_aligned(row + sxv, 4), KS * 4);
         else {
             const uint32_t* q = (const uint32_t*)(row + sxv - bsh);
             __builtin_memcpy(w, __builtin_assume_aligned(q, 4), NDW * 4);
             w[NDW] = q[(bsh + 3 * KS - 1) >> 2];                // the word the window's last byte lives in: never past it
         }
-    };
+    }
     // ... and reduced here: horizontal sums of that row for this column.  Border columns (the strips at the frame's edges)
     // re-read their taps one by one at clamped positions.
-    auto reduce = [&](int sy, uint32_t* w, int* h) {
+    __device__ __forceinline__ void reduce(int sy, uint32_t* w, int* h) const {
 #pragma unroll
         for (int i = 0; i < NW; i++) asm volatile("" : "+v"(w[i]));   // opaque: keeps the wide load apart from the fallback below
         if constexpr (CN == 4) {
             if (!interior) {
-                const uint8_t* row = S + (size_t)clampi(sy, 0, a.sh - 1) * a.sstep;
+                const uint8_t* row = S + (size_t)clampi(sy, 0, sh - 1) * sstep;
 #pragma unroll
                 for (int k = 0; k < KS; k++) w[k] = *(const uint32_t*)(row + sxk[k]);
             }
@@ -1042,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_resize_strip(RArgs a, const int* __rest
 #pragma unroll
             for (int i = 0; i < NDW; i++) v[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], bsh);
             if (!interior) {
-                const uint8_t* row = S + (size_t)clampi(sy, 0, a.sh - 1) * a.sstep;
+                const uint8_t* row = S + (size_t)clampi(sy, 0, sh - 1) * sstep;
 #pragma unroll
                 for (int i = 0; i < NDW; i++) v[i] = 0;
 #pragma unroll
@@ -1055,18 +1068,49 @@ __global__ __launch_bounds__(256) void k_resize_strip(RArgs a, const int* __rest
             }
             hpass_bgr<KS>(v, axp, h);
         }
-    };
+        if constexpr (MODE == M_LINEAR) {
+#pragma unroll
+            for (int c = 0; c < CN; c++) h[c] = (h[c] >> 4) & 0xffff;   // VResizeLinear reads S >> 4 and nothing else of S (0 <= S < 2^20: one v_bfe_u32, and the multiplier's operand is known to fit)
+        }
+    }
+};
+
+template <int CN>
+__device__ __forceinline__ void strip_store(uint8_t* q, uint32_t px) {
+    if constexpr (CN == 4) *(uint32_t*)q = px;
+    else { q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16); }
+}
+
+// any advance pattern: the ring is shifted by one row per footprint step
+template <int KS, int MODE, int CN>
+__global__ __launch_bounds__(256) void k_resize_strip(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                      const int* __restrict__ srows, int vec_end, int rows_per_strip) {
+    static_assert(CN == 3 || CN == 4, "interleaved BGR / BGRA");
+    using Lane = StripLane<KS, MODE, CN>;
+    constexpr int NW = Lane::NW;
+    constexpr int SR = strip_row_ints(KS);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x * 4 + wv;                      // the four waves of a block: neighbouring strips of the same rows
+    if (strip * 64 >= a.dw) return;
+    const int dx = strip * 64 + lane;
+    const int dy0 = blockIdx.y * rows_per_strip, dy1 = min(a.dh, dy0 + rows_per_strip);
+    const bool live = dx < a.dw;
+    const int dxc = live ? dx : a.dw - 1;                       // idle lanes shadow the last column (no stores)
+    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dx * CN;
+    Lane L;
+    L.init(a, a.src + (long long)blockIdx.z * a.src_stride, dxc, xofs, xco);
 
     int ring[KS][CN];
     int first = srows[(size_t)dy0 * SR];
     {
         uint32_t w[NW];
 #pragma unroll
-        for (int k = 0; k < KS; k++) { request(first + k, w); reduce(first + k, w, ring[k]); }
+        for (int k = 0; k < KS; k++) { L.request(first + k, w); L.reduce(first + k, w, ring[k]); }
     }
     uint32_t p0[NW], p1[NW];                                    // windows of rows first + KS and first + KS + 1, in flight
-    request(first + KS, p0);
-    request(first + KS + 1, p1);
+    L.request(first + KS, p0);
+    L.request(first + KS + 1, p1);
     for (int dy = dy0; dy < dy1; dy++) {
         const int* __restrict__ rw = srows + (size_t)dy * SR;   // (wave-uniform: scalar loads)
         const int want = rw[0];
@@ -1075,25 +1119,83 @@ __global__ __launch_bounds__(256) void k_resize_strip(RArgs a, const int* __rest
             for (int k = 0; k + 1 < KS; k++)
 #pragma unroll
                 for (int c = 0; c < CN; c++) ring[k][c] = ring[k + 1][c];
-            reduce(first + KS, p0, ring[KS - 1]);
+            L.reduce(first + KS, p0, ring[KS - 1]);
             first++;
 #pragma unroll
             for (int i = 0; i < NW; i++) p0[i] = p1[i];
-            request(first + KS + 1, p1);
+            L.request(first + KS + 1, p1);
         }
         int by[KS];
+        float bf[KS];
 #pragma unroll
-        for (int k = 0; k < KS; k++) by[k] = rw[1 + k];
-        if constexpr (CN == 4) {
-            const uint32_t px = vpass_px<KS, MODE, 0>(ring, by, dx, vec_end);
-            if (live) *(uint32_t*)(D + (size_t)dy * a.dstep) = px;
-        } else {
-            const uint32_t px = vpass_bgr<KS, MODE>(ring, by, dx, vec_end);
-            if (live) {
-                uint8_t* q = D + (size_t)dy * a.dstep;
-                q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16);
-            }
-        }
+        for (int k = 0; k < KS; k++) { by[k] = rw[1 + k]; bf[k] = MODE == M_CUBIC ? __int_as_float(rw[(SR > 8 ? 8 : 0) + k]) : 0.f; }
+        const uint32_t px = strip_vpass<KS, MODE, CN, 0>(ring, by, bf, dx, vec_end);
+        if (live) strip_store<CN>(D + (size_t)dy * a.dstep, px);
+    }
+}
+
+// The same walk for the geometries whose footprint advance is periodic with period two -- A0 rows after every even
+// destination row, A1 after every odd one: (1, 0) / (0, 1) is the exact 2x enlargement, (1, 2) / (2, 1) the 1.5x
+// reduction -- which are the common ones (bridge.c:183-193 reaches LINEAR / LANCZOS4 only through a `resize` with explicit
+// interpolation, and callers ask for round factors).  The schedule is then static: a block of 2 * NP destination rows is
+// unrolled until the footprint is back in the ring slot it started from, so nothing is ever shifted -- source row j of the
+// block lives in ring[j & (KS - 1)], the vertical pass names its rows by its position P in the block -- and the window
+// registers alternate by the row's parity.  (The shifts were 28 of LANCZOS4's ~70 instructions per footprint step.  The
+// same walk with DYNAMIC slots -- scalar branches on first & (KS - 1) -- was built and is slower than shifting: the
+// branches cost what the moves did and hipcc's s_waitcnt placement at the joins waits for the windows in flight.)
+// Strips start on multiples of the block, so every strip sees the pattern at the same phase; the last block of a frame
+// computes past the last row (clamped table row, clamped source rows) and stores nothing there.
+template <int KS, int MODE, int CN, int A0, int A1>
+__global__ __launch_bounds__(256) void k_resize_strip2(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
+                                                       const int* __restrict__ srows, int vec_end, int rows_per_strip) {
+    static_assert(CN == 3 || CN == 4, "interleaved BGR / BGRA");
+    static_assert((A0 + A1) % 2 == 1, "an odd advance per pair of rows: the block is 2 * KS rows");
+    using Lane = StripLane<KS, MODE, CN>;
+    constexpr int NW = Lane::NW;
+    constexpr int SR = strip_row_ints(KS);
+    constexpr int A = A0 + A1, NP = KS;                         // KS pairs advance KS * A rows: a multiple of KS, and even
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x * 4 + wv;
+    if (strip * 64 >= a.dw) return;
+    const int dx = strip * 64 + lane;
+    const int dy0 = blockIdx.y * rows_per_strip, dy1 = min(a.dh, dy0 + rows_per_strip);
+    const bool live = dx < a.dw;
+    const int dxc = live ? dx : a.dw - 1;
+    uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dx * CN;
+    Lane L;
+    L.init(a, a.src + (long long)blockIdx.z * a.src_stride, dxc, xofs, xco);
+
+    int ring[KS][CN];
+    int first = __builtin_amdgcn_readfirstlane(srows[(size_t)dy0 * SR]);
+    {
+        uint32_t w[NW];
+#pragma unroll
+        for (int k = 0; k < KS; k++) { L.request(first + k, w); L.reduce(first + k, w, ring[k]); }
+    }
+    uint32_t pe[NW], po[NW];                                    // windows in flight: block rows KS, KS + 2, ... in pe, the odd ones in po
+    L.request(first + KS, pe);
+    L.request(first + KS + 1, po);
+    for (int dyb = dy0; dyb < dy1; dyb += 2 * NP) {
+        static_for<2 * NP>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int rel = (m / 2) * A + ((m & 1) ? A0 : 0);       // the footprint's first row, in block rows
+            const int dy = dyb + m;
+            const int* __restrict__ rw = srows + (size_t)min(dy, a.dh) * SR;   // (row dh is the table's sentinel)
+            int by[KS];
+            float bf[KS];
+#pragma unroll
+            for (int k = 0; k < KS; k++) { by[k] = rw[1 + k]; bf[k] = MODE == M_CUBIC ? __int_as_float(rw[(SR > 8 ? 8 : 0) + k]) : 0.f; }
+            const uint32_t px = strip_vpass<KS, MODE, CN, rel & (KS - 1)>(ring, by, bf, dx, vec_end);
+            if (live && dy < dy1) strip_store<CN>(D + (size_t)dy * a.dstep, px);
+            constexpr int adv = (m & 1) ? A1 : A0;
+            static_for<adv>([&](auto sc) {
+                constexpr int j = rel + decltype(sc)::value + KS;       // the block row that enters
+                if constexpr (j & 1) { L.reduce(first + j, po, ring[j & (KS - 1)]); L.request(first + j + 2, po); }
+                else                 { L.reduce(first + j, pe, ring[j & (KS - 1)]); L.request(first + j + 2, pe); }
+            });
+        });
+        first += NP * A;
     }
 }
 
@@ -2323,6 +2425,7 @@ struct TableSet {
     const int* srows = nullptr;   // per destination row {first footprint row, ksize weights, padding}: strip_row_ints(ksize) ints (k_resize_strip)
     const void* yrows = nullptr;  // CUBIC: per destination row {footprint advance, yco * 2^-22 as floats, first footprint row} (UpRow)
     int up_period = 0;        // CUBIC enlargement: P when exactly every P-th destination row advances the footprint (integer factor), else 0
+    int strip_a0 = -1, strip_a1 = -1;   // the footprint advances by a0 rows after even destination rows and a1 after odd ones (k_resize_strip2), or -1
     bool ysym = false;        // step2 and the one set of row weights is mirror-symmetric (vpass_px's VSYM form)
     bool step2 = false;       // xofs[d] = xofs[0] + 2d and yofs[d] = yofs[0] + 2d: k_resize_2x_roll applies
     AreaDev area{};
@@ -2424,12 +2527,29 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
             o[4] = put(blob, yr);
         }
         {
-            const int sr = strip_row_ints(ty.ksize);
+            // the strip kernels' row constants: the footprint's first row, then the KS weights; for CUBIC again at [8..11] as
+            // the floats b * 2^-22 of VResizeCubicVec_32s8u's multiplies.  And the advance pattern, when it has period two
+            // (k_resize_strip2): A0 rows after every even destination row, A1 after every odd one.
+            const int sr = strip_row_ints(ty.ksize), ks = ty.ksize;
             std::vector<int> rows((size_t)(dh + 1) * sr, 0);     // + a sentinel row
             for (int d = 0; d <= dh; d++) {
                 const int dd = d < dh ? d : dh - 1;
-                rows[(size_t)d * sr] = ty.ofs[dd] - (ty.ksize / 2 - 1);
-                for (int k = 0; k < ty.ksize; k++) rows[(size_t)d * sr + 1 + k] = ty.coef[(size_t)dd * ty.ksize + k];
+                rows[(size_t)d * sr] = ty.ofs[dd] - (ks / 2 - 1);
+                for (int k = 0; k < ks; k++) {
+                    const int coef = ty.coef[(size_t)dd * ks + k];
+                    rows[(size_t)d * sr + 1 + k] = coef;
+                    if (interp == IMP_INTER_CUBIC) {
+                        const float bf = (float)coef * (1.f / (2048.f * 2048.f));
+                        __builtin_memcpy(&rows[(size_t)d * sr + 8 + k], &bf, 4);
+                    }
+                }
+            }
+            ts.strip_a0 = ts.strip_a1 = -1;
+            if (dh >= 3) {
+                const int a0 = ty.ofs[1] - ty.ofs[0], a1 = ty.ofs[2] - ty.ofs[1];
+                bool ok = a0 >= 0 && a1 >= 0 && a0 <= 2 && a1 <= 2 && ((a0 + a1) & 1);
+                for (int d = 1; d < dh && ok; d++) ok = ty.ofs[d] - ty.ofs[d - 1] == ((d & 1) ? a0 : a1);
+                if (ok) { ts.strip_a0 = a0; ts.strip_a1 = a1; }
             }
             while (blob.size() % 64) blob.push_back(0);
             o[5] = put(blob, rows);
@@ -2475,7 +2595,7 @@ static bool area_rows_plan(int sw, int sh, int dw, int dh, double scale_x, long 
     if (even) ww += ww & 1;                                // the mixed-geometry kernel carries the even windows only
     while (ww <= 4 * MIX_NV && 63 * scale_x + ww + 8 > 256 * ((ww + 3) / 4)) ww += even ? 2 : 1;
     if (ww < 1 || ww > 4 * MIX_NV || sw < ww || sw < 4) return false;
-    static const int bh_env = ab_env("IMPGPU_AREA_BH") ? std::atoi(ab_env("IMPGPU_AREA_BH")) : 0;
+    static const int bh_env = ab_env_int("IMPGPU_AREA_BH", 0);
     int b = 16;
     const long long nstrips = (dw + 63) / 64;
     while (b > 4 && frames * nstrips * ((dh + b - 1) / b) < 4096) b /= 2;
@@ -2667,13 +2787,13 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             const int nstrips = (a.dh + ROLL_STRIP - 1) / ROLL_STRIP;
             // LDS-DMA row ring when the 16-byte DMA granules line up with the rows; IMPGPU_DMA_DEPTH = iterations
             // prefetched (0 = off: the register-rolling kernel, which has no alignment demands)
-            static const int dma_depth = ab_env("IMPGPU_DMA_DEPTH") ? std::atoi(ab_env("IMPGPU_DMA_DEPTH")) : 3;
+            static const int dma_depth = ab_env_int("IMPGPU_DMA_DEPTH", 3);
             const bool dma_ok = dma_depth > 0 && interp != IMP_INTER_LINEAR && (a.sw & 3) == 0 &&
                                 (long long)a.sh * a.sstep < (1LL << 32) && (long long)a.dh * a.dstep < (1LL << 32) &&
                                 !(((uintptr_t)a.src | (uintptr_t)a.sstep | (uintptr_t)a.src_stride) & 15);
             const dim3 rgrid((a.dw + 255) / 256, nstrips, (unsigned)count);
             // waves of a block are independent (no barriers, private LDS rings): small blocks only shorten the tail
-            static const int wpb = ab_env("IMPGPU_DMA_WPB") ? std::atoi(ab_env("IMPGPU_DMA_WPB")) : 4;
+            static const int wpb = ab_env_int("IMPGPU_DMA_WPB", 4);
             const int nbx = (a.dw + 64 * wpb - 1) / (64 * wpb), bpf = nbx * nstrips;
             const dim3 dgrid((unsigned)(bpf * 8), (unsigned)((count + 7) / 8));
 #define IMP_DMA_W(KS_, MODE_, VEC_, VS_, D_)                                                                             \
@@ -2722,7 +2842,7 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             // enlargement (bridge.c:190's CUBIC case): wave-private strips, float H sums in a register ring
             const int nbx = (a.dw + 255) / 256;                 // four 64-column strips per block, one per wave
             // few frames: shorter row chunks so that every CU still gets waves
-            static const int up_rows = ab_env("IMPGPU_UP_ROWS") ? std::atoi(ab_env("IMPGPU_UP_ROWS")) : UP_ROWS;
+            static const int up_rows = ab_env_int("IMPGPU_UP_ROWS", UP_ROWS);
             // rows per wave chunk: as many as keep the chunk's source footprint (strip columns x footprint rows, from the
             // bound floor(n * scale) + 1 on how far n + 1 sample positions spread, + 3 taps + 1) inside the wave's LDS
             // patch, at most UP_ROWS; fewer when there are too few frames to fill the chip otherwise
@@ -2746,10 +2866,27 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             int rps = 64;
             while (rps > 8 && (long long)count * nsx * 4 * ((a.dh + rps - 1) / rps) < 8192) rps /= 2;
             const dim3 sgrid((unsigned)nsx, (unsigned)((a.dh + rps - 1) / rps), (unsigned)count);
-            if (interp == IMP_INTER_LINEAR)
+            const int ks = interp == IMP_INTER_LINEAR ? 2 : interp == IMP_INTER_CUBIC ? 4 : 8;
+            const int pat = ts.strip_a0 * 4 + ts.strip_a1;          // (1,0) 4, (0,1) 1, (1,2) 6, (2,1) 9; rps is a multiple of the 2 * ks row block
+            static const bool no_static = ab_env("IMPGPU_STRIP_DYNAMIC") != nullptr;
+            const bool periodic = !no_static && ts.strip_a0 >= 0 && rps % (2 * ks) == 0;
+            const int ve = interp == IMP_INTER_CUBIC ? (a.dw * CN) & ~7 : 0;
+#define IMP_STRIP2(KS_, MODE_, A0_, A1_) hipLaunchKernelGGL((k_resize_strip2<KS_, MODE_, C34, A0_, A1_>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, ve, rps)
+            if (periodic && interp == IMP_INTER_LINEAR && pat == 4) IMP_STRIP2(2, M_LINEAR, 1, 0);
+            else if (periodic && interp == IMP_INTER_LINEAR && pat == 1) IMP_STRIP2(2, M_LINEAR, 0, 1);
+            else if (periodic && interp == IMP_INTER_LINEAR && pat == 6) IMP_STRIP2(2, M_LINEAR, 1, 2);
+            else if (periodic && interp == IMP_INTER_LINEAR && pat == 9) IMP_STRIP2(2, M_LINEAR, 2, 1);
+            else if (periodic && interp == IMP_INTER_LANCZOS4 && pat == 4) IMP_STRIP2(8, M_LANCZOS, 1, 0);
+            else if (periodic && interp == IMP_INTER_LANCZOS4 && pat == 1) IMP_STRIP2(8, M_LANCZOS, 0, 1);
+            else if (periodic && interp == IMP_INTER_LANCZOS4 && pat == 6) IMP_STRIP2(8, M_LANCZOS, 1, 2);
+            else if (periodic && interp == IMP_INTER_LANCZOS4 && pat == 9) IMP_STRIP2(8, M_LANCZOS, 2, 1);
+            else if (periodic && interp == IMP_INTER_CUBIC && pat == 6) IMP_STRIP2(4, M_CUBIC, 1, 2);      // (CUBIC comes here only when y shrinks)
+            else if (periodic && interp == IMP_INTER_CUBIC && pat == 9) IMP_STRIP2(4, M_CUBIC, 2, 1);
+#undef IMP_STRIP2
+            else if (interp == IMP_INTER_LINEAR)
                 hipLaunchKernelGGL((k_resize_strip<2, M_LINEAR, C34>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, 0, rps);
             else if (interp == IMP_INTER_CUBIC)
-                hipLaunchKernelGGL((k_resize_strip<4, M_CUBIC, C34>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, (a.dw * CN) & ~7, rps);
+                hipLaunchKernelGGL((k_resize_strip<4, M_CUBIC, C34>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, ve, rps);
             else
                 hipLaunchKernelGGL((k_resize_strip<8, M_LANCZOS, C34>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, 0, rps);
         } else if (interp == IMP_INTER_LINEAR)
@@ -2974,7 +3111,7 @@ __global__ __launch_bounds__(256) void k_area2x2_turn(RArgs a, int amount, int r
 // geometry is not the exact-2x BGRA case so the caller can fall back to resize + rotate.
 int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overlay, hipStream_t s) {
     const View& v = f.v;
-    static const int shape = ab_env("IMPGPU_CHAIN_TILE") ? std::atoi(ab_env("IMPGPU_CHAIN_TILE")) : 64;   // measured (profiles/r01_chain_tiles.txt): 64x64 with the column walk
+    static const int shape = ab_env_int("IMPGPU_CHAIN_TILE", 64);   // measured (profiles/r01_chain_tiles.txt): 64x64 with the column walk
     if (v.c != 4 || (amount != 90 && amount != 270) || (v.w & 1) || (v.h & 1)) return IMP_ERROR_UNSUPPORTED;
     const int rw = v.w / 2, rh = v.h / 2;
     if (rw < 2 || rh < 1) return IMP_ERROR_UNSUPPORTED;
@@ -2983,7 +3120,7 @@ int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overla
     if (((uintptr_t)f.dst | (uintptr_t)f.dstep | (uintptr_t)f.dst_stride) & 3) return IMP_ERROR_UNSUPPORTED;
     RArgs a{f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, f.dstep, f.dw, f.dh};
     const dim3 block(256);
-    static const int stream_cfg = ab_env("IMPGPU_CHAIN_STREAM") ? std::atoi(ab_env("IMPGPU_CHAIN_STREAM")) : 128032;   // SW * 1000 + BH; 0 = the block-tile kernel
+    static const int stream_cfg = ab_env_int("IMPGPU_CHAIN_STREAM", 128032);   // SW * 1000 + BH; 0 = the block-tile kernel
     if (stream_cfg && !(rw & 1)) {
         OverlayArgs wm0{};
         if (overlay) wm0 = *overlay;
@@ -3011,10 +3148,10 @@ int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overla
         if (e != hipSuccess) { set_error("k_area2x2_turn", e); return IMP_ERROR_DEVICE; }
         return IMP_OK;
     }
-    static const int shape_y = ab_env("IMPGPU_CHAIN_TILE_Y") ? std::atoi(ab_env("IMPGPU_CHAIN_TILE_Y")) : 0;
+    static const int shape_y = ab_env_int("IMPGPU_CHAIN_TILE_Y", 0);
     const int tx = shape, ty = shape_y ? shape_y : 4096 / shape;
     const int ntx = (rw + tx - 1) / tx, nty = (rh + ty - 1) / ty;
-    static const int order = ab_env("IMPGPU_CHAIN_ORDER") ? std::atoi(ab_env("IMPGPU_CHAIN_ORDER")) : 0;
+    static const int order = ab_env_int("IMPGPU_CHAIN_ORDER", 0);
     const dim3 grid((unsigned)(ntx * nty), (unsigned)((f.count + 7) / 8 * 8));
     OverlayArgs wm{};
     if (overlay) wm = *overlay;

@@ -292,3 +292,31 @@ def test_area_small_factors_four_columns_per_lane(gpu, c, geom):
     for i in range(0, n, 5):
         assert np.array_equal(out[i], orc.cv_resize(frames[i], dw, dh, orc.INTER_AREA)), (geom, c, i)
     src.release(); dst.release()
+
+
+# ---- k_resize_strip2: the static schedule for footprint advances of period two (exact 2x enlargement, 1.5x reduction)
+@pytest.mark.parametrize("c", [3, 4])
+@pytest.mark.parametrize("interp", [orc.INTER_LINEAR, orc.INTER_LANCZOS4], ids=lambda m: NAMES[m])
+@pytest.mark.parametrize("src,dst", [((96, 54), (192, 108)),        # 2x up: rows advance 1, 0, 1, 0
+                                     ((333, 77), (666, 154)),       # 2x up, strips that end inside a 16-row block
+                                     ((300, 150), (200, 100)),      # 1.5x down: 1, 2 / 2, 1
+                                     ((999, 303), (666, 202)),      # 1.5x down, odd sizes
+                                     ((64, 9), (128, 18)),          # shorter than one block
+                                     ((150, 90), (300, 60))])       # x grows 2x, y shrinks 1.5x
+def test_strip_static_schedule(gpu, interp, c, src, dst):
+    (sw, sh), (dw, dh) = src, dst
+    rng = np.random.default_rng(sw * 7 + dh + c)
+    for count in (1, 3):
+        frames = [rng.integers(0, 256, size=(sh, sw, c), dtype=np.uint8) for _ in range(count)]
+        for f in frames:
+            assert np.array_equal(gpu_resize(gpu, f, dw, dh, interp), orc.cv_resize(f, dw, dh, interp))
+
+
+@pytest.mark.parametrize("c", [3, 4])
+@pytest.mark.parametrize("src,dst", [((150, 90), (300, 60)), ((101, 303), (180, 202)), ((64, 1500), (100, 1000))])
+def test_strip_static_schedule_cubic(gpu, c, src, dst):
+    """CUBIC reaches the strips when x grows while y shrinks (bridge.c:190); y by 1.5 is the period-two pattern"""
+    (sw, sh), (dw, dh) = src, dst
+    rng = np.random.default_rng(sw + dh * 3 + c)
+    f = rng.integers(0, 256, size=(sh, sw, c), dtype=np.uint8)
+    assert np.array_equal(gpu_resize(gpu, f, dw, dh, orc.INTER_CUBIC), orc.cv_resize(f, dw, dh, orc.INTER_CUBIC))
