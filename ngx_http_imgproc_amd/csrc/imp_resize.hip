@@ -957,8 +957,9 @@ constexpr int strip_row_ints(int ks) { return ks <= 2 ? 4 : 16; }   // per desti
 // footprint's position in the slots where it is not).
 //   LINEAR: the ring holds S >> 4, the only form VResizeLinear reads a horizontal sum in (shifted once per SOURCE row, not
 //     once per use); the result cannot exceed 255, so the bytes are packed without masks.
-//   CUBIC: VResizeCubicVec_32s8u's four float products, added in footprint order; the weights come as the floats b * 2^-22
-//     the host tabulated (one IEEE multiply each, the same one the kernel used to do per lane and row).
+//   CUBIC: VResizeCubicVec_32s8u's four float products, added in footprint order, two channels per packed instruction, from
+//     a ring of floats; the weights come as the floats b * 2^-22 the host tabulated (one IEEE multiply each, the same one
+//     the kernel used to do per lane and row).
 template <int KS, int MODE, int CN, int P>
 __device__ __forceinline__ uint32_t strip_vpass(const int (*ring)[CN], const int* by, const float* bf, int dx, int vec_end) {
     if constexpr (MODE == M_LINEAR) {
@@ -979,24 +980,40 @@ __device__ __forceinline__ uint32_t strip_vpass(const int (*ring)[CN], const int
         }
         return shr_sat_pack4(v[0], v[1], v[2], v[3], 22) & (CN == 4 ? 0xffffffffu : 0xffffffu);
     } else {
-        uint32_t px = 0;
+        // the ring holds the sums as floats (exact: |sum| < 2^24; converted once per source row); channels ride in pairs
+        // (v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar operations, contraction is off), v_cvt_pk_u8_f32 is
+        // saturate_cast<uchar>(cvRound(x)) -- k_resize_up_cubic4's vertical pass
+        float f[KS][4];
 #pragma unroll
-        for (int c = 0; c < CN; c++) {
-            int hc[KS];
+        for (int k = 0; k < KS; k++)
 #pragma unroll
-            for (int k = 0; k < KS; k++) hc[k] = ring[(k + P) & (KS - 1)][c];
-            int o;
-            if (dx * CN + c < vec_end) {
-                float v = __fmul_rn(__int2float_rn(hc[0]), bf[0]);
-                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[1]), bf[1]));
-                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[2]), bf[2]));
-                v = __fadd_rn(v, __fmul_rn(__int2float_rn(hc[3]), bf[3]));
-                o = sat_u8(__float2int_rn(v));
-            } else {
-                const int v = __mul24(hc[0], by[0]) + __mul24(hc[1], by[1]) + __mul24(hc[2], by[2]) + __mul24(hc[3], by[3]);
-                o = shr_sat_u8(v + (1 << 21), 22);
-            }
-            px |= (uint32_t)o << (8 * c);
+            for (int c = 0; c < 4; c++) f[k][c] = c < CN ? __int_as_float(ring[(k + P) & (KS - 1)][c < CN ? c : 0]) : 0.f;
+        float2v_t sxy = float2v_t{f[0][0], f[0][1]} * bf[0];
+#pragma unroll
+        for (int k = 1; k < KS; k++) sxy = sxy + float2v_t{f[k][0], f[k][1]} * bf[k];
+        uint32_t px = cvt_pk_u8(sxy.x, 0u, 0);
+        px = cvt_pk_u8(sxy.y, px, 1);
+        if constexpr (CN == 4) {
+            float2v_t szw = float2v_t{f[0][2], f[0][3]} * bf[0];
+#pragma unroll
+            for (int k = 1; k < KS; k++) szw = szw + float2v_t{f[k][2], f[k][3]} * bf[k];
+            px = cvt_pk_u8(szw.x, px, 2);
+            px = cvt_pk_u8(szw.y, px, 3);
+        } else {
+            float sz = __fmul_rn(f[0][2], bf[0]);
+#pragma unroll
+            for (int k = 1; k < KS; k++) sz = __fadd_rn(sz, __fmul_rn(f[k][2], bf[k]));
+            px = cvt_pk_u8(sz, px, 2);
+        }
+        if (dx * CN + CN > vec_end) {                           // the row's scalar tail (its last 0..7 bytes): the integer form
+#pragma unroll
+            for (int c = 0; c < CN; c++)
+                if (dx * CN + c >= vec_end) {
+                    int v = 1 << 21;
+#pragma unroll
+                    for (int k = 0; k < KS; k++) v += __mul24(__float2int_rn(f[k][c]), by[k]);
+                    px = (px & ~(0xffu << (8 * c))) | ((uint32_t)shr_sat_u8(v, 22) << (8 * c));
+                }
         }
         return px;
     }
@@ -1067,6 +1084,10 @@ struct StripLane {
                     }
             }
             hpass_bgr<KS>(v, axp, h);
+        }
+        if constexpr (MODE == M_CUBIC) {
+#pragma unroll
+            for (int c = 0; c < CN; c++) h[c] = __float_as_int(__int2float_rn(h[c]));   // the vertical pass is float (strip_vpass)
         }
         if constexpr (MODE == M_LINEAR) {
 #pragma unroll
@@ -1147,9 +1168,10 @@ __global__ __launch_bounds__(256) void k_resize_strip(RArgs a, const int* __rest
 // computes past the last row (clamped table row, clamped source rows) and stores nothing there.
 template <int KS, int MODE, int CN, int A0, int A1>
 __global__ __launch_bounds__(256) void k_resize_strip2(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
-                                                       const int* __restrict__ srows, int vec_end, int rows_per_strip) {
+                                                       const int* __restrict__ srows, int vec_end, int rows_per_strip, int wide_stores) {
     static_assert(CN == 3 || CN == 4, "interleaved BGR / BGRA");
     static_assert((A0 + A1) % 2 == 1, "an odd advance per pair of rows: the block is 2 * KS rows");
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][4][64];   // per wave: four finished rows of its 64 columns
     using Lane = StripLane<KS, MODE, CN>;
     constexpr int NW = Lane::NW;
     constexpr int SR = strip_row_ints(KS);
@@ -1163,6 +1185,8 @@ __global__ __launch_bounds__(256) void k_resize_strip2(RArgs a, const int* __res
     const bool live = dx < a.dw;
     const int dxc = live ? dx : a.dw - 1;
     uint8_t* D = a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)dx * CN;
+    uint8_t* Dw = a.dst + (long long)blockIdx.z * a.dst_stride + (size_t)strip * 64 * CN;     // the strip's first byte of row 0
+    const bool patch = wide_stores && strip * 64 + 64 <= a.dw;  // (wave-uniform; the frame's last, partial strip stores pixel by pixel)
     Lane L;
     L.init(a, a.src + (long long)blockIdx.z * a.src_stride, dxc, xofs, xco);
 
@@ -1187,7 +1211,31 @@ __global__ __launch_bounds__(256) void k_resize_strip2(RArgs a, const int* __res
 #pragma unroll
             for (int k = 0; k < KS; k++) { by[k] = rw[1 + k]; bf[k] = MODE == M_CUBIC ? __int_as_float(rw[(SR > 8 ? 8 : 0) + k]) : 0.f; }
             const uint32_t px = strip_vpass<KS, MODE, CN, rel & (KS - 1)>(ring, by, bf, dx, vec_end);
-            if (live && dy < dy1) strip_store<CN>(D + (size_t)dy * a.dstep, px);
+            if (patch) {
+                // four finished rows of the wave's 64 columns leave as 16-byte (BGR: 4-byte) stores: a pixel per lane and
+                // row is a 256-byte (192-byte, in byte stores) write per instruction, and the store stream is what bounds
+                // the enlargements once the arithmetic is down
+                if constexpr (CN == 4) s_patch[wv][m & 3][lane] = px;
+                else {
+                    uint8_t* pb = (uint8_t*)s_patch[wv][m & 3] + lane * 3;
+                    pb[0] = (uint8_t)px; pb[1] = (uint8_t)(px >> 8); pb[2] = (uint8_t)(px >> 16);
+                }
+                if constexpr ((m & 3) == 3) {
+                    const int dyg = dyb + m - 3;
+                    if constexpr (CN == 4) {
+                        const int r = lane >> 4, g = lane & 15;
+                        const uint4 v = *(const uint4*)&s_patch[wv][r][g * 4];
+                        if (dyg + r < dy1) *(uint4*)(Dw + (size_t)(dyg + r) * a.dstep + g * 16) = v;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 3; t++) {
+                            const int i = lane + 64 * t, r = i / 48, wd = i % 48;
+                            const uint32_t v = s_patch[wv][r][wd];
+                            if (dyg + r < dy1) *(uint32_t*)(Dw + (size_t)(dyg + r) * a.dstep + wd * 4) = v;
+                        }
+                    }
+                }
+            } else if (live && dy < dy1) strip_store<CN>(D + (size_t)dy * a.dstep, px);
             constexpr int adv = (m & 1) ? A1 : A0;
             static_for<adv>([&](auto sc) {
                 constexpr int j = rel + decltype(sc)::value + KS;       // the block row that enters
@@ -2871,7 +2919,9 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
             static const bool no_static = ab_env("IMPGPU_STRIP_DYNAMIC") != nullptr;
             const bool periodic = !no_static && ts.strip_a0 >= 0 && rps % (2 * ks) == 0;
             const int ve = interp == IMP_INTER_CUBIC ? (a.dw * CN) & ~7 : 0;
-#define IMP_STRIP2(KS_, MODE_, A0_, A1_) hipLaunchKernelGGL((k_resize_strip2<KS_, MODE_, C34, A0_, A1_>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, ve, rps)
+            // the patch stores are 16 bytes (BGR: 4) at row start + a multiple of 256 (192): rows and frames aligned to that
+            const int wide = !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & (CN == 4 ? 15 : 3)) && !ab_env("IMPGPU_STRIP_NARROW");
+#define IMP_STRIP2(KS_, MODE_, A0_, A1_) hipLaunchKernelGGL((k_resize_strip2<KS_, MODE_, C34, A0_, A1_>), sgrid, block, 0, s, a, ts.xofs, ts.xco, ts.srows, ve, rps, wide)
             if (periodic && interp == IMP_INTER_LINEAR && pat == 4) IMP_STRIP2(2, M_LINEAR, 1, 0);
             else if (periodic && interp == IMP_INTER_LINEAR && pat == 1) IMP_STRIP2(2, M_LINEAR, 0, 1);
             else if (periodic && interp == IMP_INTER_LINEAR && pat == 6) IMP_STRIP2(2, M_LINEAR, 1, 2);
