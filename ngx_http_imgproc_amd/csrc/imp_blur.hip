@@ -497,6 +497,25 @@ __global__ __launch_bounds__(256) void k_blur_strip4(const uint8_t* __restrict__
 // of B is B[16 (l >> 4) + b][l & 15]; C[4 (l >> 4) + reg][l & 15].
 typedef int bm_v4i __attribute__((ext_vector_type(4)));
 constexpr int BM_W = 64, BM_H = 64;                 // bytes across / rows down per workgroup tile
+// Which tile a workgroup takes.  Workgroups go to the eight XCDs round-robin in launch order, so tiles that are neighbours in
+// x -- whose windows overlap by the 2 * CN * r halo bytes (four of every five staged bytes at sigma = 8) -- would each pull
+// that halo into a different L2: FETCH_SIZE showed the row pass reading 57 MB for an 8.3 MB frame.  Launch slot g is therefore
+// mapped to tile (slots of XCD k) = one contiguous range of the launch's tiles -- in row-major order for the passes whose
+// windows overlap along x (rows, fused), in column-major order for the column pass, whose windows overlap along y.
+template <bool COLUMN_MAJOR>
+__device__ __forceinline__ void bm_xcd_tile(int* bx, int* by, int* bz) {
+    const unsigned nx = gridDim.x, T = gridDim.x * gridDim.y, N = T * gridDim.z;
+    const unsigned g = blockIdx.x + blockIdx.y * nx + blockIdx.z * T;
+    const unsigned k = g & 7, i = g >> 3, q = N >> 3, rem = N & 7;
+    const unsigned n = k * q + (k < rem ? k : rem) + i;
+    const unsigned t = n % T;
+    *bz = (int)(n / T);
+    if (COLUMN_MAJOR && !(nx & 7)) {                           // launch order already keeps a column of tiles on one XCD (slot + nx = same XCD) and walks rows of the frame
+        *bx = (int)blockIdx.x; *by = (int)blockIdx.y; *bz = (int)blockIdx.z;
+    } else if (COLUMN_MAJOR) { *bx = (int)(t / gridDim.y); *by = (int)(t % gridDim.y); }
+    else { *by = (int)(t / nx); *bx = (int)(t % nx); }
+}
+
 constexpr int BM_MAXC = 8;                          // 64-byte chunks of a row window: 16 + 2 * cn * r <= 512
 
 // the Toeplitz operand of chunk c as the lanes hold it (built on the host, once per call: 64 lanes x 16 bytes): byte b of lane l =
@@ -525,8 +544,10 @@ __global__ __launch_bounds__(256) void k_blur_mfma_rows(const uint8_t* __restric
     uint8_t* s_pl = bm_smem + (size_t)BM_H * pitch_s;               // [2][BM_W][BM_H + 16]: the row sums' low / high bytes - 128, transposed
     constexpr int PT = BM_H + 16;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int x0b = blockIdx.x * BM_W, y0 = blockIdx.y * BM_H, roww = w * CN;
-    const uint8_t* frame = src + (long long)blockIdx.z * sstride;
+    int tbx, tby, tbz;
+    bm_xcd_tile<false>(&tbx, &tby, &tbz);
+    const int x0b = tbx * BM_W, y0 = tby * BM_H, roww = w * CN;
+    const uint8_t* frame = src + (long long)tbz * sstride;
     // stage the rows: replicated borders; sixteen bytes at a time where they are inside the row (a byte-aligned address is fine)
     const int wbytes = BM_W + 2 * CN * r, wq = (wbytes + 15) >> 4;
     for (int idx = t; idx < BM_H * wq; idx += 256) {
@@ -575,7 +596,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma_rows(const uint8_t* __restric
     }
     __syncthreads();
     // the tile's two planes out, 64 contiguous bytes (64 rows) per byte column
-    uint8_t* pl = planes + (long long)blockIdx.z * pstride;
+    uint8_t* pl = planes + (long long)tbz * pstride;
     for (int idx = t; idx < 2 * BM_W * 4; idx += 256) {
         const int q = idx & 3, xb = (idx >> 2) & (BM_W - 1), p = idx >> 8;
         const uint4 v = *(const uint4*)(s_pl + (size_t)(p * BM_W + xb) * PT + q * 16);
@@ -590,8 +611,10 @@ __global__ __launch_bounds__(256) void k_blur_mfma_cols(const uint8_t* __restric
     extern __shared__ __attribute__((aligned(16))) uint8_t bm_smem[];
     uint8_t* s_pl = bm_smem;                                        // [2][BM_W][pitch_p]: row 0 = image row y0 - r
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int x0b = blockIdx.x * BM_W, y0 = blockIdx.y * BM_H, roww = w * CN;
-    const uint8_t* pl = planes + (long long)blockIdx.z * pstride;
+    int tbx, tby, tbz;
+    bm_xcd_tile<true>(&tbx, &tby, &tbz);
+    const int x0b = tbx * BM_W, y0 = tby * BM_H, roww = w * CN;
+    const uint8_t* pl = planes + (long long)tbz * pstride;
     const int nrows = BM_H + 2 * r, n16 = (nrows + 15) >> 4;
     for (int idx = t; idx < 2 * BM_W * n16; idx += 256) {
         const int piece = idx % n16, xb = (idx / n16) & (BM_W - 1), p = idx / (n16 * BM_W);
@@ -612,7 +635,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma_cols(const uint8_t* __restric
 #pragma unroll
     for (int c = 0; c < 3; c++) band[c] = c < nchunk ? bands[c * 64 + lane] : bm_v4i{0, 0, 0, 0};
     __syncthreads();
-    uint8_t* out = dst + (long long)blockIdx.z * dstride;
+    uint8_t* out = dst + (long long)tbz * dstride;
     const int vec_end = roww & ~3;                                  // OpenCV's SSE2 column loop; behind it the scalar template
     for (int tile = wv; tile < (BM_W / 16) * (BM_H / 16); tile += 4) {
         const int xg = tile & 3, og = tile >> 2;
@@ -655,8 +678,10 @@ __global__ __launch_bounds__(256) void k_blur_mfma_fused(const uint8_t* __restri
     uint8_t* s_src = bm_smem;                                       // [nr16][pitch_s]
     uint8_t* s_pl = bm_smem + (size_t)nr16 * pitch_s;               // [2][BM_W][pitch_p], row 0 = image row y0 - r
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int x0b = blockIdx.x * BM_W, y0 = blockIdx.y * BM_H, roww = w * CN;
-    const uint8_t* frame = src + (long long)blockIdx.z * sstride;
+    int tbx, tby, tbz;
+    bm_xcd_tile<false>(&tbx, &tby, &tbz);
+    const int x0b = tbx * BM_W, y0 = tby * BM_H, roww = w * CN;
+    const uint8_t* frame = src + (long long)tbz * sstride;
     const int wbytes = BM_W + 2 * CN * r, wq = (wbytes + 15) >> 4;
     for (int idx = t; idx < nr16 * wq; idx += 256) {
         const int ry = idx / wq, bc = (idx - ry * wq) * 16;
@@ -705,7 +730,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma_fused(const uint8_t* __restri
 #pragma unroll
     for (int c = 0; c < 3; c++) bandc[c] = c < ncc ? bands_c[c * 64 + lane] : bm_v4i{0, 0, 0, 0};
     __syncthreads();
-    uint8_t* out = dst + (long long)blockIdx.z * dstride;
+    uint8_t* out = dst + (long long)tbz * dstride;
     const int vec_end = roww & ~3;
     for (int tile = wv; tile < (BM_W / 16) * (BM_H / 16); tile += 4) {
         const int xg = tile & 3, og = tile >> 2;

@@ -25,11 +25,15 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_rows<4, 10>": "area", "k_resize_nn<4>": "nn",
          "k_resize_taps<2, 4, 0>": "linear", "k_resize_2x_dma<8, 2": "lanczos", "k_area2x2_turn": "chain",
          "k_resize_up_cubic4": "upscale", "k_area2x2_c4": "area2x",
-         "k_resize_strip<4, 1, 4>": "upscale_x", "[lanczos_up]": "lanczos_up", "[lanczos_15]": "lanczos_15", "k_resize_strip<2, 0, 4>": "linear_up"}
-# (lanczos_up and lanczos_15 run the same k_resize_strip<8, 2, 4>: the per-launch counters of both are in <round>_pmc.json,
-# and traffic_lanczos_15.json is written from the dispatches with the larger FETCH_SIZE -- see strip_split below)
+         "k_resize_strip<4, 1, 4>": "upscale_x", "k_resize_strip2<2, 0, 4,": "linear_up",
+         "k_resize_strip2<8, 2, 4, 1, 0>": "lanczos_up", "k_resize_strip2<8, 2, 4, 0, 1>": "lanczos_up",
+         "k_resize_strip2<8, 2, 4, 1, 2>": "lanczos_15", "k_resize_strip2<8, 2, 4, 2, 1>": "lanczos_15",
+         "k_blur_mfma_fused<4>": "blur_sigma2", "k_blur_mfma_rows<4>": "blur_rows", "k_blur_mfma_cols<4>": "blur_cols"}
+# (round 4: the 2x enlargements and the 1.5x reduction run k_resize_strip2 with different advance patterns, so their
+# dispatches no longer share a kernel name; the blur kernels' entries are per launch of ONE 1080p frame, batch 1)
 # frames per launch in tools/pmc_probe.py, as a divisor of PROBE_BATCH
-BATCH_DIV = {"lanczos": 16, "upscale": 2, "area2x": 4, "upscale_x": 4, "lanczos_up": 4, "linear_up": 4, "lanczos_15": 16}
+BATCH_DIV = {"lanczos": 16, "upscale": 2, "area2x": 4, "upscale_x": 4, "lanczos_up": 4, "linear_up": 4, "lanczos_15": 16,
+             "blur_sigma2": 1024, "blur_rows": 1024, "blur_cols": 1024}
 
 
 def counter_means(kind):
@@ -39,9 +43,6 @@ def counter_means(kind):
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0)))
         for r in rows:
             name = r["Kernel_Name"]
-            if "k_resize_strip<8, 2, 4>" in name:                    # two workloads share it: lanczos_up comes first in tools/pmc_probe.py
-                reps = int(os.environ.get("PROBE_REPS", "3"))
-                name += " [lanczos_up]" if len(agg[name + " [lanczos_up]"]) < reps else " [lanczos_15]"
             agg[name].append(float(r["Counter_Value"]))
     return agg
 
