@@ -200,3 +200,42 @@ def test_jpeg_in_jpeg_out_from_c(tmp_path, name, uri, ext):
     assert rc_o == rc_d == rc_w == rc_e == 0 and f["code"] == 0 and f["step"] == 8
     assert (f["h"], f["w"], f["c"]) == want.shape
     assert out.read_bytes() == file_want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quality", [0, 86])
+def test_request_stream_from_c_threads(tmp_path, quality):
+    """tests/c/stream_harness.c (what bench.py --stream --jpeg device --native starts): three C threads take JPEG files eight at
+    a time through impgpu_batch_decode_jpeg -> impgpu_batch_resize_mixed -> impgpu_batch_encode_jpeg / impgpu_batch_download.
+    The byte counts it reports are exact functions of the answers: they must be the oracle's."""
+    import json
+    import struct
+
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+    names = ["c420_q50_640x480", "c420_q90_67x45", "c444_q90_48x40", "c422_q85_49x37", "c420_q92_opt_120x90", "c420_q90_dri4_95x51", "c440_q80_dri2_patched_40x48"]
+    blobs = [open(os.path.join(ROOT, "tests", "golden", "jpeg", n + ".jpg"), "rb").read() for n in names]
+    pool = tmp_path / "pool.bin"
+    with open(pool, "wb") as f:
+        f.write(struct.pack("<I", len(blobs)))
+        for b in blobs:
+            f.write(struct.pack("<I", len(b)) + b)
+    requests = 61
+    per_file = []
+    for b in blobs:
+        rc, frame = orc.jpeg_decode(b)
+        assert rc == 0
+        rc, small = orc.resize(frame, "224,0")
+        assert rc == 0
+        if quality:
+            rc, answer = orc.jpeg_encode(small, quality)
+            assert rc == 0
+            per_file.append(len(answer))
+        else:
+            per_file.append(((small.shape[1] * 3 + 3) & ~3) * small.shape[0])          # the rows as the device holds them (cvCreateImage's widthStep)
+    p = subprocess.run([os.path.join(ROOT, "tests", "c", "_build", "stream_harness"), str(pool), str(requests), "3", "8", str(quality), "16"],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, IMPGPU_JPEG_HUFF="device"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["requests"] == requests and r["threads"] == 3 and r["batch"] == 8 and r["quality"] == quality
+    assert r["file_bytes"] == sum(len(blobs[i % len(blobs)]) for i in range(requests))
+    assert r["answer_bytes"] == sum(per_file[i % len(blobs)] for i in range(requests))
