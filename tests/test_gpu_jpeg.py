@@ -282,6 +282,40 @@ def test_batch_download_one_wait_for_an_album(gpu):
         im.release()
 
 
+def test_batch_download_into_pinned_memory_is_written_by_the_kernel(gpu):
+    """destinations inside impgpu_host_alloc memory get their rows straight from the gather kernel (no staging pass): same
+    bytes, the caller's pitch and padding respected, odd row lengths and unaligned pitches included"""
+    import ctypes as C
+
+    frames = [noise_image(37, 53, 4, 1), noise_image(20, 31, 3, 2), noise_image(5, 7, 1, 3), noise_image(224, 224, 3, 4), noise_image(9, 33, 3, 5)]
+    pads = [8, 5, 3, 0, 1]                                   # pitch = row bytes + pad: 4-aligned and not
+    ims = [gpu.Image(f) for f in frames]
+    n = len(ims)
+    sizes = [f.shape[0] * (f.shape[1] * f.shape[2] + p) for f, p in zip(frames, pads)]
+    offs = np.concatenate([[0], np.cumsum([(sz + 64 + 3) & ~3 for sz in sizes])])[:-1] + np.array([0, 1, 0, 2, 0])     # some destinations start on odd bytes
+    total = int(offs[-1] + sizes[-1] + 64)
+    gpu.lib.impgpu_host_alloc.restype = C.c_void_p
+    base = gpu.lib.impgpu_host_alloc(total)
+    assert base
+    buf = np.ctypeslib.as_array((C.c_ubyte * total).from_address(base))
+    buf[:] = 0xEE
+    handles = (C.c_void_p * n)(*[im.h for im in ims])
+    datas = (C.c_void_p * n)(*[base + int(o) for o in offs])
+    steps = (C.c_int * n)(*[f.shape[1] * f.shape[2] + p for f, p in zip(frames, pads)])
+    assert gpu.lib.impgpu_batch_download(handles, n, datas, steps) == 0
+    touched = np.zeros(total, dtype=bool)
+    for f, p, o in zip(frames, pads, offs):
+        rb = f.shape[1] * f.shape[2]
+        view = buf[int(o): int(o) + f.shape[0] * (rb + p)].reshape(f.shape[0], rb + p)
+        assert np.array_equal(view[:, :rb].reshape(f.shape), f)
+        for y in range(f.shape[0]):
+            touched[int(o) + y * (rb + p): int(o) + y * (rb + p) + rb] = True
+    assert np.all(buf[~touched] == 0xEE)                     # nothing outside the rows was written
+    gpu.lib.impgpu_host_free(C.c_void_p(base))
+    for im in ims:
+        im.release()
+
+
 def test_jpeg_request_batch_end_to_end(gpu):
     """What bench.py --stream --jpeg device --jpeg-batch N does per batch: decode all files with one call, resize all
     decoded frames with one descriptor launch (resize=224,0 -> the reference's per-frame Resize(), bridge.c:588-604),
