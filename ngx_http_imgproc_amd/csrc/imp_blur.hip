@@ -786,7 +786,7 @@ static int launch_gaussian_mfma(const Frames& f, const std::vector<int>& ik, int
     const int nr16 = (BM_H + 2 * r + 15) & ~15;
     const size_t lds_f = (size_t)nr16 * pitch_s + 2 * (size_t)BM_W * pitch_p;
     static const bool two = ab_env("IMPGPU_BLUR_MFMA2") != nullptr;
-    if (lds_f <= 40 * 1024 && !two && f.count <= 65535) {        // (measured at 1080p BGRA: sigma 2 19 us against 24 in two launches, sigma 8 32 against 30, sigma 12 48 against 35)
+    if (lds_f <= (size_t)ab_env_int("IMPGPU_BLUR_FUSE_KB", 40) * 1024 && !two && f.count <= 65535) {        // (measured at 1080p BGRA: sigma 2 19 us against 24 in two launches, sigma 8 32 against 30, sigma 12 48 against 35)
         hipError_t e = hipSuccess;
         const dim3 grid((unsigned)(roww_pad / BM_W), (unsigned)(hp / BM_H), (unsigned)f.count);
         const bm_v4i* br = (const bm_v4i*)dev_k;
