@@ -205,6 +205,10 @@ void  impgpu_jpeg_sync_stats(int stats[8]);
 int   impgpu_image_decode_png(const unsigned char* blob, size_t size, impgpu_image** out);
 int   impgpu_png_info(const unsigned char* blob, size_t size, int* width, int* height, int* channels);
 int   impgpu_png_stage_times(double* microseconds, int n);
+/* Diagnostics (host, no device): the filtered scanlines of the file -- height rows of (1 filter byte + width * channels bytes),
+ * as the device receives them -- after the chunk walk, the CRC checks and the inflate.  *length = the bytes the image needs
+ * (set whenever the header was readable); IMP_ERROR_MALLOC_FAILED when capacity is smaller. */
+int   impgpu_png_scanlines(const unsigned char* blob, size_t size, unsigned char* out, size_t capacity, size_t* length);
 int   impgpu_image_wrap(void* device_ptr, int width, int height, int channels, int step,
                         impgpu_image** out);               /* borrow memory already in HBM */
 int   impgpu_image_clone(const impgpu_image* src, impgpu_image** out);

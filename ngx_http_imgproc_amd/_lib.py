@@ -117,6 +117,7 @@ SIGNATURES = {
     "impgpu_image_decode_png": (C.c_int, [C.c_char_p, C.c_size_t, PP]),
     "impgpu_png_info": (C.c_int, [C.c_char_p, C.c_size_t, IP, IP, IP]),
     "impgpu_png_stage_times": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
+    "impgpu_png_scanlines": (C.c_int, [C.c_char_p, C.c_size_t, P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "impgpu_jpeg_coefficients": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, P, C.c_size_t, IP]),
     "impgpu_jpeg_sync_stats": (None, [IP]),
     "impgpu_jpeg_profile": (C.c_int, [C.c_int]),

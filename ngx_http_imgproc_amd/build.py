@@ -29,8 +29,9 @@ SOURCES = [
     "imp_tables.cpp",
     "imp_jpeg.cpp",
     "imp_jpeg_api.cpp",
+    "imp_png.cpp",
 ]
-HEADERS = ["imp_internal.h", "imp_jpeg.h", "imp_jpeg_core.h", "imp_jpeg_std.h", os.path.join("..", "..", "include", "impgpu.h")]
+HEADERS = ["imp_internal.h", "imp_jpeg.h", "imp_jpeg_core.h", "imp_jpeg_std.h", "imp_png.h", os.path.join("..", "..", "include", "impgpu.h")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

@@ -1,0 +1,105 @@
+// imp_png.cpp -- the host side of the PNG front: the file format (PNG specification, 2nd edition, section 5: signature,
+// chunk layout, CRC; 11.2.2 IHDR; 10.1 the zlib stream across IDAT chunks; 9.2 filter types).  Host code only -- no HIP
+// call -- so that tests/c/fuzz_host.cpp can run it under AddressSanitizer / UBSan on damaged files
+// (tests/test_host_sanitizers.py); impgpu_image_decode_png (imp_png.hip) calls png_scanlines with the pinned staging buffer
+// as its destination.  zlib does the inflate: there is no device inflate in this library.
+#include <zlib.h>
+#include <cstring>
+#include "../../include/impgpu.h"
+#include "imp_png.h"
+
+namespace imp {
+
+static unsigned be32(const unsigned char* p) { return ((unsigned)p[0] << 24) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 8) | p[3]; }
+
+int png_header(const unsigned char* blob, size_t size, PngHeader* H) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (!blob || size < 8 || std::memcmp(blob, sig, 8) != 0) return IMP_ERROR_UNSUPPORTED;
+    if (size < 8 + 25 || be32(blob + 8) != 13 || std::memcmp(blob + 12, "IHDR", 4) != 0) return IMP_ERROR_DECODE_FAILED;
+    if ((unsigned)crc32(0, blob + 12, 17) != be32(blob + 29)) return IMP_ERROR_DECODE_FAILED;
+    const unsigned w = be32(blob + 16), h = be32(blob + 20);
+    const int depth = blob[24], colour = blob[25], compression = blob[26], filter = blob[27], interlace = blob[28];
+    if (w == 0 || h == 0 || w > 0x7fffffffu || h > 0x7fffffffu || compression != 0 || filter != 0 || interlace > 1)
+        return IMP_ERROR_DECODE_FAILED;
+    H->w = (int)w; H->h = (int)h;
+    H->bpp = colour == 0 ? 1 : colour == 2 ? 3 : colour == 6 ? 4 : 0;
+    H->taken = depth == 8 && H->bpp != 0 && interlace == 0 && w <= (unsigned)PNG_MAX_W && h <= (unsigned)PNG_MAX_H;
+    return IMP_OK;
+}
+
+int png_scanlines(const unsigned char* blob, size_t size, const PngHeader& H, unsigned char* dst) {
+    const size_t rstride = (size_t)H.w * H.bpp + 1, raw_bytes = rstride * H.h;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit(&zs) != Z_OK) return IMP_ERROR_MALLOC_FAILED;
+    size_t produced = 0;
+    bool bad = false, ended = false, seen_idat = false, seen_iend = false;
+    for (size_t at = 8 + 25; !bad && !seen_iend;) {
+        if (size - at < 12) { bad = true; break; }
+        const unsigned len = be32(blob + at);
+        const unsigned char* kind = blob + at + 4;
+        if (len > 0x7fffffffu || size - at - 12 < len) { bad = true; break; }
+        const bool critical = !(kind[0] & 0x20);
+        // (libpng's default only warns about a damaged ANCILLARY chunk and skips it; such a file is left to the host decoder)
+        if ((unsigned)crc32(0, kind, 4 + len) != be32(blob + at + 8 + len)) { bad = true; break; }
+        if (!std::memcmp(kind, "IDAT", 4)) {
+            seen_idat = true;
+            zs.next_in = (Bytef*)(blob + at + 8);
+            zs.avail_in = (uInt)len;
+            while (zs.avail_in && !ended && !bad) {
+                if (zs.avail_out == 0) {
+                    if (produced == raw_bytes) break;                        // more data than the image holds: ignored, as libpng does
+                    const size_t room = raw_bytes - produced, piece = room > (size_t)1 << 30 ? (size_t)1 << 30 : room;
+                    zs.next_out = (Bytef*)dst + produced;
+                    zs.avail_out = (uInt)piece;
+                }
+                const uInt before = zs.avail_out;
+                const int z = inflate(&zs, Z_NO_FLUSH);
+                produced += before - zs.avail_out;
+                if (z == Z_STREAM_END) ended = true;
+                else if (z != Z_OK && !(z == Z_BUF_ERROR && zs.avail_in == 0)) bad = true;
+            }
+        } else if (!std::memcmp(kind, "IEND", 4)) {
+            seen_iend = true;
+        } else if (critical && std::memcmp(kind, "PLTE", 4) != 0) {
+            bad = true;                                                      // an unknown critical chunk (5.4)
+        }
+        at += 12 + (size_t)len;
+    }
+    inflateEnd(&zs);
+    if (bad || !seen_idat || produced != raw_bytes) return IMP_ERROR_DECODE_FAILED;
+    for (int y = 0; y < H.h; y++)
+        if (dst[(size_t)y * rstride] > 4) return IMP_ERROR_DECODE_FAILED;   // 9.2: types 0..4
+    return IMP_OK;
+}
+
+}  // namespace imp
+
+using namespace imp;
+
+extern "C" {
+
+int impgpu_png_info(const unsigned char* blob, size_t size, int* width, int* height, int* channels) {
+    PngHeader H;
+    const int rc = png_header(blob, size, &H);
+    if (rc) return rc;
+    if (!H.taken) return IMP_ERROR_UNSUPPORTED;
+    if (width) *width = H.w;
+    if (height) *height = H.h;
+    if (channels) *channels = H.bpp;
+    return IMP_OK;
+}
+
+int impgpu_png_scanlines(const unsigned char* blob, size_t size, unsigned char* out, size_t capacity, size_t* length) {
+    PngHeader H;
+    int rc = png_header(blob, size, &H);
+    if (rc) return rc;
+    if (!H.taken) return IMP_ERROR_UNSUPPORTED;
+    const size_t raw_bytes = ((size_t)H.w * H.bpp + 1) * H.h;
+    if (length) *length = raw_bytes;
+    if (raw_bytes / 1032 > size) return IMP_ERROR_DECODE_FAILED;             // (zlib's best ratio: the file cannot hold that much)
+    if (!out || capacity < raw_bytes) return IMP_ERROR_MALLOC_FAILED;
+    return png_scanlines(blob, size, H, out);
+}
+
+}  // extern "C"

@@ -14,16 +14,16 @@
 //
 // Takes: bit depth 8, colour types 0 / 2 / 6, not interlaced, width <= 4096, height <= 16384.  Everything else is
 // IMP_ERROR_UNSUPPORTED (decode with cvDecodeImage as before); a damaged file is IMP_ERROR_DECODE_FAILED.
-#include <zlib.h>
 #include <chrono>
 #include <cstring>
 #include "imp_internal.h"
+#include "imp_png.h"
 
 namespace imp {
 
 constexpr int PNG_WAVES = 8;             // waves of the workgroup = bands in flight = edge rows held in LDS
-constexpr int PNG_MAX_W = 4096;          // 8 edge rows x ceil(w / 4) groups x 16 bytes = 128 KB of the CU's 160 KB
-constexpr int PNG_MAX_H = 16384;         // one progress word per band of 64 rows
+// (PNG_MAX_W = 4096: 8 edge rows x ceil(w / 4) groups x 16 bytes = 128 KB of the CU's 160 KB; PNG_MAX_H = 16384: one progress
+// word per band of 64 rows -- imp_png.h)
 constexpr int PNG_RAW_SLACK = 64;        // the word stream of the last row reads a few bytes past its end
 
 struct PngJob {
@@ -200,31 +200,6 @@ static int launch_png_unfilter(const PngJob* dev_jobs, int count, int bpp, int m
     return IMP_OK;
 }
 
-// ---------------------------------------------------------------- the file (PNG specification 5: signature, chunks)
-struct PngHeader {
-    int w = 0, h = 0, bpp = 0;
-    bool taken = false;                  // within what k_png_unfilter does
-};
-
-static uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-
-// IMP_OK with H filled; IMP_ERROR_UNSUPPORTED = not a PNG at all, or one the device path does not take;
-// IMP_ERROR_DECODE_FAILED = a PNG whose IHDR is damaged
-static int png_header(const unsigned char* blob, size_t size, PngHeader* H) {
-    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (!blob || size < 8 || std::memcmp(blob, sig, 8) != 0) return IMP_ERROR_UNSUPPORTED;
-    if (size < 8 + 25 || be32(blob + 8) != 13 || std::memcmp(blob + 12, "IHDR", 4) != 0) return IMP_ERROR_DECODE_FAILED;
-    if ((uint32_t)crc32(0, blob + 12, 17) != be32(blob + 29)) return IMP_ERROR_DECODE_FAILED;
-    const uint32_t w = be32(blob + 16), h = be32(blob + 20);
-    const int depth = blob[24], colour = blob[25], compression = blob[26], filter = blob[27], interlace = blob[28];
-    if (w == 0 || h == 0 || w > 0x7fffffffu || h > 0x7fffffffu || compression != 0 || filter != 0 || interlace > 1)
-        return IMP_ERROR_DECODE_FAILED;
-    H->w = (int)w; H->h = (int)h;
-    H->bpp = colour == 0 ? 1 : colour == 2 ? 3 : colour == 6 ? 4 : 0;
-    H->taken = depth == 8 && H->bpp != 0 && interlace == 0 && w <= (uint32_t)PNG_MAX_W && h <= (uint32_t)PNG_MAX_H;
-    return IMP_OK;
-}
-
 static thread_local double t_png_us[4] = {0, 0, 0, 0};
 
 static double png_now_us() {
@@ -236,17 +211,6 @@ static double png_now_us() {
 using namespace imp;
 
 extern "C" {
-
-int impgpu_png_info(const unsigned char* blob, size_t size, int* width, int* height, int* channels) {
-    PngHeader H;
-    const int rc = png_header(blob, size, &H);
-    if (rc) return rc;
-    if (!H.taken) return IMP_ERROR_UNSUPPORTED;
-    if (width) *width = H.w;
-    if (height) *height = H.h;
-    if (channels) *channels = H.bpp;
-    return IMP_OK;
-}
 
 int impgpu_png_stage_times(double* microseconds, int n) {
     if (!microseconds || n < 0) return IMP_ERROR_INVALID_ARGS;
@@ -272,53 +236,11 @@ int impgpu_image_decode_png(const unsigned char* blob, size_t size, impgpu_image
     void *host = nullptr, *token = nullptr;
     rc = stage_begin(raw_bytes + PNG_RAW_SLACK + 16 + sizeof(PngJob), &host, &token);
     if (rc) return rc;
-    // ---- the chunks: IDAT data is one zlib stream cut into pieces (10.1); every chunk carries a checked CRC (5.4)
-    z_stream zs;
-    std::memset(&zs, 0, sizeof zs);
-    if (inflateInit(&zs) != Z_OK) { (void)stage_upload(token, nullptr, 0); return IMP_ERROR_MALLOC_FAILED; }
-    zs.next_out = (Bytef*)host;
-    zs.avail_out = (uInt)0;
-    size_t produced = 0;
-    bool bad = false, ended = false, seen_idat = false, seen_iend = false;
+    // ---- the chunks, the zlib stream, the filter bytes (imp_png.cpp: host code, also run under the sanitizers)
     const double t1 = png_now_us();
-    for (size_t at = 8 + 25; !bad && !seen_iend;) {
-        if (size - at < 12) { bad = true; break; }
-        const uint32_t len = be32(blob + at);
-        const unsigned char* kind = blob + at + 4;
-        if (len > 0x7fffffffu || size - at - 12 < len) { bad = true; break; }
-        const bool critical = !(kind[0] & 0x20);
-        // (libpng's default only warns about a damaged ANCILLARY chunk and skips it; such a file is left to the host decoder)
-        if ((uint32_t)crc32(0, kind, 4 + len) != be32(blob + at + 8 + len)) { bad = true; break; }
-        if (!std::memcmp(kind, "IDAT", 4)) {
-            seen_idat = true;
-            zs.next_in = (Bytef*)(blob + at + 8);
-            zs.avail_in = (uInt)len;
-            while (zs.avail_in && !ended && !bad) {
-                if (zs.avail_out == 0) {
-                    if (produced == raw_bytes) break;                        // more data than the image holds: ignored, as libpng does
-                    const size_t room = raw_bytes - produced, piece = room > (size_t)1 << 30 ? (size_t)1 << 30 : room;
-                    zs.next_out = (Bytef*)host + produced;
-                    zs.avail_out = (uInt)piece;
-                }
-                const uInt before = zs.avail_out;
-                const int z = inflate(&zs, Z_NO_FLUSH);
-                produced += before - zs.avail_out;
-                if (z == Z_STREAM_END) ended = true;
-                else if (z != Z_OK && !(z == Z_BUF_ERROR && zs.avail_in == 0)) bad = true;
-            }
-        } else if (!std::memcmp(kind, "IEND", 4)) {
-            seen_iend = true;
-        } else if (critical && std::memcmp(kind, "PLTE", 4) != 0) {
-            bad = true;                                                      // an unknown critical chunk (5.4)
-        }
-        at += 12 + (size_t)len;
-    }
-    inflateEnd(&zs);
+    rc = png_scanlines(blob, size, H, (unsigned char*)host);
     const double t2 = png_now_us();
-    if (bad || !seen_idat || produced != raw_bytes) { (void)stage_upload(token, nullptr, 0); return IMP_ERROR_DECODE_FAILED; }
-    const unsigned char* rows = (const unsigned char*)host;
-    for (int y = 0; y < H.h; y++)
-        if (rows[(size_t)y * rstride] > 4) { (void)stage_upload(token, nullptr, 0); return IMP_ERROR_DECODE_FAILED; }   // 9.2: types 0..4
+    if (rc) { (void)stage_upload(token, nullptr, 0); return rc; }
     // ---- to the device: the scanlines as they are, then one workgroup undoes the filters
     impgpu_image* im = nullptr;
     rc = image_new(H.w, H.h, H.bpp, &im);

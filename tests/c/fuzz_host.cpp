@@ -12,6 +12,7 @@
 //   taps <ssize> <dsize> <interp> <is_x> -> checksum of the table
 //   area <ssize> <dsize>                 -> checksum of the table
 //   gauss <sigma as text>                -> ksize checksum
+//   png <file bytes>                     -> rc of the header, rc of the chunk walk + inflate, bytes of scanlines, their checksum (imp_png.cpp)
 //   jpeg <file bytes>                    -> rc of the sequential decoder, rc + status + sweeps of the chunk-parallel scheme
 //                                           run lane by lane, checksum of the coefficients (imp_jpeg.cpp: marker parser,
 //                                           table builder, scan preparation and both entropy decoders see the bytes of a
@@ -137,6 +138,22 @@ int main() {
                 if (!rc1) for (int i = 0; i < info[0]; i++) sum1 = sum1 * 31u + (unsigned short)out[(size_t)i];
             }
             std::printf("%d %d %d %llu %llu\n", rci, rc0, rc1, sum0, sum1);
+        } else if (kind == "png") {
+            std::string h, blob;
+            in >> h;
+            unhex(h, &blob);
+            std::vector<unsigned char> file(blob.begin(), blob.end());         // exact size: an over-read of the file is a report
+            int w = 0, hh = 0, c = 0;
+            const int rci = impgpu_png_info(file.data(), file.size(), &w, &hh, &c);
+            size_t need = 0;
+            int rcs = impgpu_png_scanlines(file.data(), file.size(), nullptr, 0, &need);
+            unsigned long long sum = 0;
+            if (!rci && need <= (size_t)64 << 20) {
+                std::vector<unsigned char> out(need);                           // exact size: one scanline byte too many is a report
+                rcs = impgpu_png_scanlines(file.data(), file.size(), out.data(), out.size(), &need);
+                if (!rcs) for (size_t i = 0; i < need; i++) sum = sum * 31u + out[i];
+            }
+            std::printf("%d %d %zu %llu\n", rci, rcs, need, sum);
         } else {
             std::printf("?\n");
         }
