@@ -107,3 +107,33 @@ def test_decoded_png_enters_the_chain(gpu):
     rc = im.resize("200,0", imp.Config())
     orc, want = O.resize(np.ascontiguousarray(bgr), "200,0")
     assert rc == 0 and orc == 0 and np.array_equal(im.numpy(), want)
+
+
+def test_random_files_every_filter_any_geometry(gpu):
+    """files written by tests/png_writer.py with a RANDOM filter type per row, random geometry (bands of 64 rows cut anywhere,
+    groups of four pixels cut anywhere), colour type, deflate level (0 = stored blocks) and IDAT cuts; Pillow decodes them,
+    the device must agree.  IMP_FUZZ_SCALE multiplies the number of files."""
+    from png_writer import write_png
+
+    imp = gpu
+    n = 40 * int(os.environ.get("IMP_FUZZ_SCALE", "1"))
+    rng = np.random.default_rng(int.from_bytes(os.urandom(4), "little") if os.environ.get("IMP_FUZZ_RANDOM") else 20261005)
+    for k in range(n):
+        c = int(rng.choice([1, 3, 4]))
+        w = int(rng.choice([int(rng.integers(1, 12)), int(rng.integers(1, 300)), int(rng.integers(1, 1500))]))
+        h = int(rng.choice([int(rng.integers(1, 8)), int(rng.integers(1, 200)), int(rng.integers(60, 700))])) if w < 400 else int(rng.integers(1, 140))
+        style = int(rng.integers(0, 3))
+        if style == 0:
+            arr = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+        elif style == 1:
+            yy, xx = np.mgrid[0:h, 0:w]
+            arr = np.stack([(xx * (k % 7 + 1) + yy * (ch + 2) + rng.integers(0, 5, size=(h, w))) % 256 for ch in range(c)], axis=2).astype(np.uint8)
+        else:
+            arr = np.full((h, w, c), int(rng.integers(0, 256)), dtype=np.uint8)
+        kinds = [int(v) for v in (rng.integers(0, 5, size=h) if rng.integers(0, 3) else np.full(h, int(rng.integers(0, 5))))]
+        blob = write_png(arr[:, :, 0] if c == 1 else arr, kinds, {1: 0, 3: 2, 4: 6}[c], pieces=int(rng.integers(1, 5)), level=int(rng.choice([0, 1, 6, 9])))
+        want = reference_order(np.asarray(Image.open(io.BytesIO(blob))))
+        assert np.array_equal(want, reference_order(arr if c > 1 else arr[:, :, 0])), "the test's own encoder wrote a file Pillow reads differently"
+        rc, got = decode(imp, blob)
+        assert rc == 0, (k, w, h, c)
+        assert np.array_equal(got, want), (k, w, h, c, kinds[:8])
