@@ -152,6 +152,18 @@ int   impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_im
  * error), in which case no image is returned. */
 int   impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* sizes, int count,
                                impgpu_image** images, int* codes);
+/* The same in two halves, for a caller that has more to do than wait (round 4): _begin parses, copies the scans into pinned
+ * memory and enqueues the whole decode -- it does NOT wait; _finish sleeps until THAT batch is done (not whatever the thread
+ * enqueued after it), reads the verdicts and fills images[] / codes[] as impgpu_batch_decode_jpeg would.  Between the two the
+ * thread may begin the next batch (up to four in flight per thread) or enqueue anything else; the blobs must stay readable
+ * until _finish (a file the device defers is read again), and both halves belong to one thread.  count <= 256.
+ * (impgpu_batch_decode_jpeg itself already prepares the second half of a large batch while the device works on the first.
+ * Measured in the request loop of tests/c/stream_harness.c: beginning batch n + 1 before batch n's answers are enqueued puts
+ * those answers BEHIND the new decode on the thread's in-order stream and gains nothing; the split is for callers whose
+ * other work is on the host.) */
+typedef struct impgpu_jpeg_batch impgpu_jpeg_batch;
+int   impgpu_batch_decode_jpeg_begin(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_jpeg_batch** batch);
+int   impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** images, int* codes);
 /* Where a decode call's time goes (per-stage timing): impgpu_jpeg_profile(1) makes every later decode call leave
  * its stages with the calling thread, impgpu_jpeg_stage_times reads the last call's, in microseconds:
  * [0] marker segments, [1] FF00 unstuffing into pinned memory, [2] tables + job table, [3] enqueue, [4] wait for the verdicts

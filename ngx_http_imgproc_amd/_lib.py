@@ -114,6 +114,8 @@ SIGNATURES = {
     "impgpu_image_decode_jpeg": (C.c_int, [C.c_char_p, C.c_size_t, PP]),
     "impgpu_batch_decode_jpeg": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, PP, IP]),
     "impgpu_jpeg_info": (C.c_int, [C.c_char_p, C.c_size_t, IP, IP, IP]),
+    "impgpu_batch_decode_jpeg_begin": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, PP]),
+    "impgpu_batch_decode_jpeg_finish": (C.c_int, [PP, PP, IP]),
     "impgpu_image_decode_png": (C.c_int, [C.c_char_p, C.c_size_t, PP]),
     "impgpu_png_info": (C.c_int, [C.c_char_p, C.c_size_t, IP, IP, IP]),
     "impgpu_png_stage_times": (C.c_int, [C.POINTER(C.c_double), C.c_int]),

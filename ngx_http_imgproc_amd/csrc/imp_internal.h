@@ -87,7 +87,9 @@ int  dev_alloc_on(size_t bytes, void** out, hipStream_t s); // dev_alloc + make 
 int  stream_join(hipStream_t s);                           // `s` waits for everything the lane stream holds now
 int  stream_join_back(hipStream_t s);                      // the lane stream waits for everything `s` holds now
 bool lane_stream_idle();
-uint32_t* lane_mailbox();                                  // 64 pinned words of the calling thread's lane
+uint32_t* lane_mailbox();                                  // pinned words of the calling thread's lane: [0, 1024) for any caller, then 1024 per JPEG group in flight
+int  lane_mark(void** mark);                               // a point of the lane's stream ...
+int  lane_wait_mark(void* mark);                           // ... to sleep until (nullptr: the whole stream)
 int  lane_wait();                                          // wait for the lane's stream (sleeping, unless IMPGPU_SYNC=spin)
 bool on_lane_stream(hipStream_t s);
 // Per-lane caches (resize tables): owned by the lane, dropped with it (impgpu_env_destroy), no lock.

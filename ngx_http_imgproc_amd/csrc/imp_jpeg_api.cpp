@@ -76,16 +76,54 @@ struct Prep {                                       // one file on its way to th
 constexpr size_t DENSE_BITS_PER_BLOCK = 200;
 constexpr int CODE_DEFERRED = -0x7fff;              // internal: "decode this one in the host-entropy group"
 
-int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes, int force_host) {
+// A group of files between the call that enqueued its decode and the call that reads its verdicts.  Everything the device
+// works on (stream words, planes, tables, work areas) and the pinned words its verdicts arrive in belong to the group until
+// group_finish; the caller's blobs must stay readable until then (a file deferred to the host-entropy group is read again).
+constexpr int GROUP_SLOTS = 4;                      // groups in flight per calling thread: one slot of the lane's mailbox each
+struct Group {
+    std::vector<Prep> P;
+    const unsigned char* const* blobs = nullptr;
+    const size_t* sizes = nullptr;
+    int count = 0;
+    bool on_device = false, profile = false;
+    void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr, *d_work = nullptr;
+    void* mark = nullptr;                           // the point of the lane's stream where this group's last kernel was enqueued
+    uint32_t* mailbox = nullptr;
+    int slot = -1;
+    size_t live = 0, ctl_total = 0;
+    hipEvent_t ev[8] = {};
     Stopwatch sw;
+};
+thread_local unsigned t_slots_busy = 0;             // bit k: mailbox slot k holds a group that has not been finished
+std::atomic<int> g_groups_in_flight{0};             // over all threads: groups begun and not finished
+
+void group_release(Group& G) {
+    for (int i = 0; i < 8; i++) if (G.ev[i]) { (void)hipEventDestroy(G.ev[i]); G.ev[i] = nullptr; }
+    dev_free(G.d_words); dev_free(G.d_coef); dev_free(G.d_side); dev_free(G.d_ctl); dev_free(G.d_work);
+    G.d_words = G.d_coef = G.d_side = G.d_ctl = G.d_work = nullptr;
+    if (G.slot >= 0) { t_slots_busy &= ~(1u << G.slot); g_groups_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+    G.slot = -1;
+}
+
+// Everything up to the last enqueue: headers, the unstuffing copy (or the host's entropy decoding), job tables, uploads,
+// the entropy and pixel kernels, the verdicts' copy.  Does NOT wait.  A non-zero return means nothing is in flight and
+// nothing is held (codes[] of the caller are then filled by the caller from G.P where they are set, else with the return).
+int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes, int count, int force_host) {
+    Stopwatch& sw = G.sw;
     hipStream_t s = env_stream();
     if (!s) return IMP_ERROR_DEVICE;
-    std::vector<Prep> P((size_t)count);
+    G.blobs = blobs; G.sizes = sizes; G.count = count;
+    G.P.assign((size_t)count, Prep());
+    std::vector<Prep>& P = G.P;
+    for (int k = 0; k < GROUP_SLOTS && G.slot < 0; k++)
+        if (!(t_slots_busy & (1u << k))) G.slot = k;
+    if (G.slot < 0) { set_error_text("too many JPEG batches begun and not finished on this thread"); return IMP_ERROR_INVALID_ARGS; }
+    t_slots_busy |= 1u << G.slot;
+    g_groups_in_flight.fetch_add(1, std::memory_order_relaxed);
     // ---- headers, geometry, the sizes of everything
     size_t words_total = 0, coef_total = 0;
     for (int i = 0; i < count; i++) {
         Prep& p = P[(size_t)i];
-        images[i] = nullptr;
         if (!blobs[i]) { p.code = IMP_ERROR_INVALID_ARGS; continue; }
         p.code = jpeg_parse(blobs[i], sizes[i], &p.H);
         if (!p.code && !frame_fits(p.H.width, p.H.height, p.H.ncomp)) p.code = IMP_ERROR_UNSUPPORTED;
@@ -107,7 +145,7 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
     size_t launch_bytes = 0;
     for (int i = 0; i < count; i++)
         if (!P[(size_t)i].code) launch_bytes += sizes[i] - P[(size_t)i].H.scan_begin;
-    const bool on_device = !force_host && entropy_on_device(launch_bytes);
+    const bool on_device = G.on_device = !force_host && entropy_on_device(launch_bytes);
     if (on_device && !std::getenv("IMPGPU_JPEG_HUFF"))
         for (int i = 0; i < count; i++) {
             Prep& p = P[(size_t)i];
@@ -122,8 +160,8 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
     void* host = nullptr;
     void* token = nullptr;
     int rc = stage_begin(on_device ? words_total : coef_total, &host, &token);
-    if (rc) return rc;
-    size_t live = 0;
+    if (rc) { group_release(G); return rc; }
+    size_t& live = G.live;
     for (int i = 0; i < count; i++) {
         Prep& p = P[(size_t)i];
         if (p.code) continue;
@@ -145,12 +183,14 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
         if (!p.code) live++;
     }
     sw.mark();                                                      // [1] unstuffing copy / host entropy decoding
-    void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr, *d_work = nullptr;
-    bool profile = g_profile.load(std::memory_order_relaxed) != 0;
-    hipEvent_t ev[8] = {};
-    size_t njobs = 0, ctl_total = 0;
-    uint32_t* mailbox = lane_mailbox();
-    if (live == 0) { (void)stage_upload(token, nullptr, 0); goto done; }
+    void *&d_words = G.d_words, *&d_coef = G.d_coef, *&d_side = G.d_side, *&d_ctl = G.d_ctl, *&d_work = G.d_work;
+    bool& profile = G.profile;
+    profile = g_profile.load(std::memory_order_relaxed) != 0;
+    hipEvent_t* ev = G.ev;
+    size_t njobs = 0;
+    size_t& ctl_total = G.ctl_total;
+    uint32_t* mailbox = G.mailbox = lane_mailbox() ? lane_mailbox() + 1024 * (1 + G.slot) : nullptr;      // (slot 0 of the mailbox is the other callers': brightness, the encoder)
+    if (live == 0) { (void)stage_upload(token, nullptr, 0); return IMP_OK; }
     if (!mailbox) { rc = IMP_ERROR_DEVICE; goto fail; }
     {
         // ---- the side blob: per job its tables, quantisers and interval arrays, then the job table and the workgroup maps
@@ -292,9 +332,35 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
         if (profile && on_device) (void)hipEventRecord(ev[7], s);
     }
     sw.mark();                                                      // [3] enqueue
+    rc = lane_mark(&G.mark);
+    if (rc) goto fail;
+    return IMP_OK;
+fail:
+    if (token) (void)stage_upload(token, nullptr, 0);
+    (void)lane_wait();                                              // nothing of this call may still be running when its buffers go back
+    for (Prep& p : P) if (p.im) { image_delete(p.im); p.im = nullptr; }
+    group_release(G);
+    return rc;
+}
+
+// The other half: waits for the group's last kernel (not for whatever the thread enqueued after it), reads the verdicts,
+// hands the frames out, gives the device memory back.
+int group_finish(Group& G, impgpu_image** images, int* codes) {
+    std::vector<Prep>& P = G.P;
+    Stopwatch& sw = G.sw;
+    const bool on_device = G.on_device;
+    const int count = G.count;
+    const size_t live = G.live, ctl_total = G.ctl_total;
+    void *d_ctl = G.d_ctl, *d_work = G.d_work;
+    uint32_t* mailbox = G.mailbox;
+    hipEvent_t* ev = G.ev;
+    const bool profile = G.profile;
+    int rc = IMP_OK;
+    if (live == 0) goto done;
+    rc = lane_wait_mark(G.mark);
+    G.mark = nullptr;
+    if (rc) goto fail;
     if (on_device) {
-        rc = lane_wait();
-        if (rc) goto fail;
         if (const char* tr = std::getenv("IMPGPU_JPEG_TRACE"); tr && !std::strcmp(tr, "2")) {
             // the workgroups' clocks at their phase boundaries (k_jpeg_sync's stamp()), microseconds since the launch's
             // first workgroup started: wg: start | walks | candidates exchanged | maps | scan + look-back | done
@@ -361,38 +427,27 @@ int decode_group_as(const unsigned char* const* blobs, const size_t* sizes, int 
         std::fprintf(stderr, "jpeg x%d (%zu live): headers %.0f %s %.0f jobs %.0f enqueue %.0f wait %.0f us\n", count, live, sw.marks[0],
                      on_device ? "unstuff" : "host-entropy", sw.marks[1], sw.marks[2], sw.marks[3], sw.marks[4]);
 done:
-    for (int i = 0; i < 8; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
-    dev_free(d_words);
-    dev_free(d_coef);
-    dev_free(d_side);
-    dev_free(d_ctl);
-    dev_free(d_work);
     for (int i = 0; i < count; i++) {
         Prep& p = P[(size_t)i];
         if (p.code && p.im) { image_delete(p.im); p.im = nullptr; }
         images[i] = p.im;
         codes[i] = p.code;
     }
+    group_release(G);
     return IMP_OK;
 fail:
-    for (int i = 0; i < 8; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
-    if (token) (void)stage_upload(token, nullptr, 0);
-    (void)lane_wait();                                              // nothing of this call may still be running when its buffers go back
-    dev_free(d_words);
-    dev_free(d_coef);
-    dev_free(d_side);
-    dev_free(d_ctl);
-    dev_free(d_work);
+    (void)lane_wait();                                              // nothing of this group may still be running when its buffers go back
     for (int i = 0; i < count; i++) {
         if (P[(size_t)i].im) image_delete(P[(size_t)i].im);
         images[i] = nullptr;
         codes[i] = P[(size_t)i].code ? P[(size_t)i].code : rc;
     }
+    group_release(G);
     return rc;
 }
 
-int decode_group(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
-    if (int rc = decode_group_as(blobs, sizes, count, images, codes, 0)) return rc;
+// files a device group deferred (dense blocks: CODE_DEFERRED) are decoded in a host-entropy group of their own
+int group_deferred(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
     std::vector<int> late;
     for (int i = 0; i < count; i++) if (codes[i] == CODE_DEFERRED) late.push_back(i);
     if (late.empty()) return IMP_OK;
@@ -401,13 +456,45 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
     std::vector<impgpu_image*> i2(late.size(), nullptr);
     std::vector<int> c2(late.size(), IMP_OK);
     for (size_t k = 0; k < late.size(); k++) { b2[k] = blobs[late[k]]; s2[k] = sizes[late[k]]; }
-    const int rc = decode_group_as(b2.data(), s2.data(), (int)late.size(), i2.data(), c2.data(), 1);
+    Group H;
+    int rc = group_begin(H, b2.data(), s2.data(), (int)late.size(), 1);
+    if (!rc) rc = group_finish(H, i2.data(), c2.data());
+    else for (size_t k = 0; k < late.size(); k++) c2[k] = H.P[k].code ? H.P[k].code : rc;
     for (size_t k = 0; k < late.size(); k++) { images[late[k]] = rc ? nullptr : i2[k]; codes[late[k]] = rc ? rc : c2[k]; }
     if (rc) for (int i = 0; i < count; i++) if (images[i]) { impgpu_image_release(&images[i]); codes[i] = rc; }
     return rc;
 }
 
+// One group, begun and finished in one go -- except that a large group is cut in two and the second half is PREPARED (headers,
+// unstuffing copy, job table: 2.3 of a 64-file call's 5.8 ms) while the device already works on the first: one calling thread
+// went 11 -> 15 k requests/s with that.  When other threads keep the device busy anyway (four or more groups in flight) the
+// group stays whole: two launches of half the size are the less efficient way to fill a device that is already full.
+int decode_group(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
+    const int first = count >= 32 && g_groups_in_flight.load(std::memory_order_relaxed) < 4 ? count / 2 : count;
+    Group A, B;
+    int rc = group_begin(A, blobs, sizes, first, 0);
+    if (rc) {
+        for (int i = 0; i < count; i++) { images[i] = nullptr; codes[i] = i < first && A.P.size() > (size_t)i && A.P[(size_t)i].code ? A.P[(size_t)i].code : rc; }
+        return rc;
+    }
+    int rcb = IMP_OK;
+    if (first < count) rcb = group_begin(B, blobs + first, sizes + first, count - first, 0);
+    rc = group_finish(A, images, codes);
+    if (first < count) {
+        if (!rcb) rcb = group_finish(B, images + first, codes + first);
+        else for (int i = first; i < count; i++) { images[i] = nullptr; codes[i] = rcb; }
+        if (!rc) rc = rcb;
+    }
+    if (rc) {
+        for (int i = 0; i < count; i++) if (images[i]) { impgpu_image_release(&images[i]); codes[i] = rc; }
+        return rc;
+    }
+    return group_deferred(blobs, sizes, count, images, codes);
+}
+
 }  // namespace
+
+struct impgpu_jpeg_batch { Group G; };
 
 extern "C" {
 
@@ -425,6 +512,33 @@ int impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* si
         }
     }
     return IMP_OK;
+}
+
+int impgpu_batch_decode_jpeg_begin(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_jpeg_batch** batch) {
+    if (!batch) return IMP_ERROR_INVALID_ARGS;
+    *batch = nullptr;
+    if (count <= 0 || count > MAX_BATCH || !blobs || !sizes) return IMP_ERROR_INVALID_ARGS;
+    if (!env_ready()) { set_error_text("impgpu_env_start has not been called"); return IMP_ERROR_DEVICE; }
+    TraceRange tr("IMP_STEP_DECODE");
+    IMP_FAULT_POINT(IMP_STEP_DECODE);
+    impgpu_jpeg_batch* b = new impgpu_jpeg_batch();
+    const int rc = group_begin(b->G, blobs, sizes, count, 0);
+    if (rc) { delete b; return rc; }
+    *batch = b;
+    return IMP_OK;
+}
+
+int impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** images, int* codes) {
+    if (!batch || !*batch || !images || !codes) return IMP_ERROR_INVALID_ARGS;
+    impgpu_jpeg_batch* b = *batch;
+    *batch = nullptr;
+    const unsigned char* const* blobs = b->G.blobs;
+    const size_t* sizes = b->G.sizes;
+    const int count = b->G.count;
+    int rc = group_finish(b->G, images, codes);
+    delete b;
+    if (!rc) rc = group_deferred(blobs, sizes, count, images, codes);
+    return rc;
 }
 
 int impgpu_jpeg_counters(unsigned long long* counters, int n) {

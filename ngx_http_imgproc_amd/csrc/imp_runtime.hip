@@ -33,7 +33,7 @@ namespace imp {
 constexpr int    RING_SEGS = 8;
 constexpr size_t RING_SEG_BYTES = size_t(128) << 10;   // blobs above this take a one-off pinned buffer
 constexpr int    N_STAGE = 2;
-constexpr size_t MAILBOX_BYTES = 4096;                  // pinned words a kernel's verdict is copied into (behind the ring)
+constexpr size_t MAILBOX_BYTES = 5 * 4096;              // pinned words a kernel's verdict is copied into (behind the ring): 1024 for everyone, then 1024 per JPEG group in flight (imp_jpeg_api.cpp)
 
 struct Staging {
     uint8_t* p = nullptr;
@@ -63,6 +63,7 @@ struct Lane {
     hipEvent_t join_ev = nullptr;               // lane stream -> foreign stream ordering
     hipEvent_t sync_ev = nullptr;               // blocking wait for the lane stream (lane_wait)
     std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> mark_pool;          // blocking-sync events for lane_mark / lane_wait_mark
     std::deque<Parked> parked;
     LaneCache* caches[LANE_CACHE_SLOTS] = {};
 };
@@ -459,6 +460,34 @@ int lane_wait() {
     return IMP_OK;
 }
 
+// A point of the lane's stream to come back to: lane_wait_mark sleeps until everything enqueued BEFORE the mark is done --
+// not what the thread enqueued after it (a JPEG group's verdicts are read while the next group is already on the device).
+int lane_mark(void** mark) {
+    Lane* L = lane();
+    if (!L) return no_env();
+    hipEvent_t ev = nullptr;
+    if (!L->mark_pool.empty()) { ev = L->mark_pool.back(); L->mark_pool.pop_back(); }
+    else IMP_HIP(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
+    const hipError_t e = hipEventRecord(ev, L->stream);
+    if (e != hipSuccess) { L->mark_pool.push_back(ev); set_error("hipEventRecord(mark)", e); return IMP_ERROR_DEVICE; }
+    *mark = (void*)ev;
+    return IMP_OK;
+}
+
+int lane_wait_mark(void* mark) {
+    Lane* L = lane();
+    if (!L) return no_env();
+    if (!mark) return lane_wait();
+    hipEvent_t ev = (hipEvent_t)mark;
+    static const bool spin = [] { const char* s = std::getenv("IMPGPU_SYNC"); return s && !std::strcmp(s, "spin"); }();
+    hipError_t e = hipSuccess;
+    if (spin) { while ((e = hipEventQuery(ev)) == hipErrorNotReady) {} }
+    else e = hipEventSynchronize(ev);
+    L->mark_pool.push_back(ev);
+    if (e != hipSuccess) { set_error("hipEventSynchronize(mark)", e); return IMP_ERROR_DEVICE; }
+    return IMP_OK;
+}
+
 LaneCache** lane_cache_slot(int which) {
     Lane* L = lane();
     return (L && which >= 0 && which < LANE_CACHE_SLOTS) ? &L->caches[which] : nullptr;
@@ -615,6 +644,7 @@ static void lane_destroy(Lane* L) {
     if (L->ring) (void)hipHostFree(L->ring);
     for (hipEvent_t ev : L->seg_done) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : L->ev_pool) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : L->mark_pool) (void)hipEventDestroy(ev);
     if (L->join_ev) (void)hipEventDestroy(L->join_ev);
     if (L->sync_ev) (void)hipEventDestroy(L->sync_ev);
     if (L->stream) (void)hipStreamDestroy(L->stream);

@@ -8,7 +8,9 @@
  *  or impgpu_batch_download               the raw thumbnails                          (quality = 0)
  * bench.py --stream --jpeg --native starts it: a Python thread pool measures the interpreter's lock as much as the device.
  *
- *   stream_harness <pool.bin> <requests> <threads> <batch> <quality> [warmup_requests]
+ *   stream_harness <pool.bin> <requests> <threads> <batch> <quality> [warmup_requests] [ahead]
+ * ahead = 1: a thread begins the decode of its next batch (impgpu_batch_decode_jpeg_begin) before it finishes the current one
+ * (_finish), so its own unstuffing copy overlaps the device's work on the batch before.
  * pool.bin: u32 count, then per file u32 size + bytes.  Prints one JSON line.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -20,7 +22,7 @@
 #include <time.h>
 
 typedef struct {
-    int id, nthreads, batch, quality;
+    int id, nthreads, batch, quality, ahead;
     long first, count;                   /* this thread's requests: first, first + nthreads, ... */
     unsigned char** blobs;
     size_t* sizes;
@@ -56,8 +58,40 @@ static void* worker(void* arg) {
     cfg.max_target_w = 2000; cfg.max_target_h = 2000; cfg.max_filters_count = 5;
     w->bound = impgpu_env_bind_thread() == IMP_OK;
     if (!host) { w->rc = IMP_ERROR_MALLOC_FAILED; return NULL; }
-    while (at < w->count && w->rc == IMP_OK) {
-        int n = 0, k, rc;
+    impgpu_jpeg_batch* pending = NULL;                           /* ahead: the batch begun one round early, and its files */
+    const unsigned char** blobs2 = (const unsigned char**)malloc(sizeof(*blobs2) * (size_t)B);
+    size_t* sizes2 = (size_t*)malloc(sizeof(size_t) * (size_t)B);
+    int npending = 0;
+    while ((at < w->count || pending) && w->rc == IMP_OK) {
+        int n = 0, k, rc = IMP_OK;
+        if (w->ahead) {
+            /* this round's batch was begun last round (or is begun now, the first time); the next one is begun before the wait */
+            const unsigned char** tb; size_t* ts;
+            if (!pending) {
+                for (; npending < B && at < w->count; npending++, at++) {
+                    const long req = w->first + at * w->nthreads;
+                    blobs2[npending] = w->blobs[req % w->nfiles]; sizes2[npending] = w->sizes[req % w->nfiles];
+                    w->file_bytes += (double)sizes2[npending];
+                }
+                rc = impgpu_batch_decode_jpeg_begin(blobs2, sizes2, npending, &pending);
+            }
+            tb = blobs; blobs = blobs2; blobs2 = tb;                /* `blobs` / `sizes` now name the batch in `pending` */
+            ts = sizes; sizes = sizes2; sizes2 = ts;
+            n = npending; npending = 0;
+            {
+                impgpu_jpeg_batch* mine = pending;
+                pending = NULL;
+                if (rc == IMP_OK && at < w->count) {
+                    for (; npending < B && at < w->count; npending++, at++) {
+                        const long req = w->first + at * w->nthreads;
+                        blobs2[npending] = w->blobs[req % w->nfiles]; sizes2[npending] = w->sizes[req % w->nfiles];
+                        w->file_bytes += (double)sizes2[npending];
+                    }
+                    rc = impgpu_batch_decode_jpeg_begin(blobs2, sizes2, npending, &pending);
+                }
+                if (mine) { const int rf = impgpu_batch_decode_jpeg_finish(&mine, imgs, codes); if (rc == IMP_OK) rc = rf; }
+            }
+        } else {
         for (; n < B && at < w->count; n++, at++) {
             const long req = w->first + at * w->nthreads;
             blobs[n] = w->blobs[req % w->nfiles];
@@ -65,6 +99,7 @@ static void* worker(void* arg) {
             w->file_bytes += (double)sizes[n];
         }
         rc = impgpu_batch_decode_jpeg(blobs, sizes, n, imgs, codes);
+        }
         for (k = 0; k < n && rc == IMP_OK; k++) rc = codes[k];
         for (k = 0; k < n && rc == IMP_OK; k++) {
             int ow = 0, oh = 0, ip = 0;
@@ -93,6 +128,8 @@ static void* worker(void* arg) {
         w->done += n;
     }
     impgpu_host_free(host);
+    if (pending) { impgpu_batch_decode_jpeg_finish(&pending, imgs, codes); for (int k2 = 0; k2 < B; k2++) impgpu_image_release(&imgs[k2]); }
+    free(blobs2); free(sizes2);
     free(blobs); free(sizes); free(imgs); free(outs); free(codes); free(items); free(datas); free(caps); free(lens); free(steps);
     return NULL;
 }
@@ -138,6 +175,7 @@ int main(int argc, char** argv) {
     proto.batch = (int)strtol(argv[4], NULL, 10);
     proto.quality = (int)strtol(argv[5], NULL, 10);
     warm = argc > 6 ? strtol(argv[6], NULL, 10) : 0;
+    proto.ahead = argc > 7 ? (int)strtol(argv[7], NULL, 10) : 0;
     if (requests < 1 || proto.nthreads < 1 || proto.batch < 1 || proto.batch > 256) return 2;
     f = fopen(argv[1], "rb");
     if (!f || fread(&count, 4, 1, f) != 1 || count == 0) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
@@ -160,8 +198,8 @@ int main(int argc, char** argv) {
     rc = run(&proto, requests, proto.nthreads, &s, &fb, &ab);
     if (rc != IMP_OK) { fprintf(stderr, "stream failed: %d %s\n", rc, impgpu_last_error()); return 4; }
     printf("{\"requests\": %ld, \"seconds\": %.6f, \"requests_per_s\": %.1f, \"threads\": %d, \"batch\": %d, \"quality\": %d, "
-           "\"file_bytes\": %.0f, \"answer_bytes\": %.0f, \"numa_node\": %d, \"threads_bound\": %s}\n",
-           requests, s, (double)requests / s, proto.nthreads, proto.batch, proto.quality, fb, ab, impgpu_env_numa_node(), g_all_bound ? "true" : "false");
+           "\"file_bytes\": %.0f, \"answer_bytes\": %.0f, \"ahead\": %d, \"numa_node\": %d, \"threads_bound\": %s}\n",
+           requests, s, (double)requests / s, proto.nthreads, proto.batch, proto.quality, fb, ab, proto.ahead, impgpu_env_numa_node(), g_all_bound ? "true" : "false");
     impgpu_env_destroy();
     return 0;
 }

@@ -203,11 +203,13 @@ def test_jpeg_in_jpeg_out_from_c(tmp_path, name, uri, ext):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ahead", [0, 1])
 @pytest.mark.parametrize("quality", [0, 86])
-def test_request_stream_from_c_threads(tmp_path, quality):
+def test_request_stream_from_c_threads(tmp_path, quality, ahead):
     """tests/c/stream_harness.c (what bench.py --stream --jpeg device --native starts): three C threads take JPEG files eight at
     a time through impgpu_batch_decode_jpeg -> impgpu_batch_resize_mixed -> impgpu_batch_encode_jpeg / impgpu_batch_download.
-    The byte counts it reports are exact functions of the answers: they must be the oracle's."""
+    The byte counts it reports are exact functions of the answers: they must be the oracle's.  ahead = 1: every thread begins
+    its next batch (impgpu_batch_decode_jpeg_begin) before it finishes the current one (_finish)."""
     import json
     import struct
 
@@ -232,10 +234,10 @@ def test_request_stream_from_c_threads(tmp_path, quality):
             per_file.append(len(answer))
         else:
             per_file.append(((small.shape[1] * 3 + 3) & ~3) * small.shape[0])          # the rows as the device holds them (cvCreateImage's widthStep)
-    p = subprocess.run([os.path.join(ROOT, "tests", "c", "_build", "stream_harness"), str(pool), str(requests), "3", "8", str(quality), "16"],
+    p = subprocess.run([os.path.join(ROOT, "tests", "c", "_build", "stream_harness"), str(pool), str(requests), "3", "8", str(quality), "16", str(ahead)],
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, IMPGPU_JPEG_HUFF="device"))
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
-    assert r["requests"] == requests and r["threads"] == 3 and r["batch"] == 8 and r["quality"] == quality
+    assert r["requests"] == requests and r["threads"] == 3 and r["batch"] == 8 and r["quality"] == quality and r["ahead"] == ahead
     assert r["file_bytes"] == sum(len(blobs[i % len(blobs)]) for i in range(requests))
     assert r["answer_bytes"] == sum(per_file[i % len(blobs)] for i in range(requests))
