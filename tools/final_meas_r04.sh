@@ -38,7 +38,7 @@ c)
   make -C tests/c > /dev/null
   for q in 0 86; do
     echo "# tests/c/stream_harness: 65536 requests, 64 files per call, answers: $([ $q = 0 ] && echo raw thumbnails || echo JPEG quality $q); one box, one session"
-    JPEG_BATCH=64 JPEG_OUT=$q bash tools/jpeg_stream_native.sh 65536 4 8 16
+    JPEG_BATCH=64 JPEG_OUT=$q bash tools/jpeg_stream_native.sh 65536 1 2 4 8 16
   done > $O/r04_jpeg_stream_native.txt 2>&1
   cat $O/r04_jpeg_stream_native.txt
   python bench.py --stream 16384 --jpeg device --native --threads 8 --jpeg-batch 64 > $O/r04_jpeg_stream_line.json 2>/dev/null || true
