@@ -594,6 +594,8 @@ def jpeg_stage_profile(imp, files, batch, out_quality, reps=6):
     lib = imp.lib
     n = min(batch, len(files)) if batch > 1 else 1
     cfg = imp.Config()
+    whole_before = os.environ.get("IMPGPU_JPEG_WHOLE")
+    os.environ["IMPGPU_JPEG_WHOLE"] = "1"          # the stages of ONE launch per kernel (the decode call otherwise cuts a batch in two)
     items = [files[i % len(files)] for i in range(n)]
     blobs = (C.c_char_p * n)(*[b for _, _, b in items])
     sizes = (C.c_size_t * n)(*[len(b) for _, _, b in items])
@@ -648,6 +650,10 @@ def jpeg_stage_profile(imp, files, batch, out_quality, reps=6):
     out["resize"] = round(float(med[12]), 1)
     out["encode" if out_quality else "download"] = round(float(med[13]), 1)
     out["files_per_call"] = n
+    if whole_before is None:
+        os.environ.pop("IMPGPU_JPEG_WHOLE", None)
+    else:
+        os.environ["IMPGPU_JPEG_WHOLE"] = whole_before
     return out
 
 

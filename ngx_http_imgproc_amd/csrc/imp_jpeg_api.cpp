@@ -470,7 +470,8 @@ int group_deferred(const unsigned char* const* blobs, const size_t* sizes, int c
 // went 11 -> 15 k requests/s with that.  When other threads keep the device busy anyway (four or more groups in flight) the
 // group stays whole: two launches of half the size are the less efficient way to fill a device that is already full.
 int decode_group(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
-    const int first = count >= 32 && g_groups_in_flight.load(std::memory_order_relaxed) < 4 ? count / 2 : count;
+    const bool whole = std::getenv("IMPGPU_JPEG_WHOLE") != nullptr;      // measurements of ONE launch per batch (tools/jpeg_prof_r04.sh, bench.py's stage profile); read per call
+    const int first = !whole && count >= 32 && g_groups_in_flight.load(std::memory_order_relaxed) < 4 ? count / 2 : count;
     Group A, B;
     int rc = group_begin(A, blobs, sizes, first, 0);
     if (rc) {

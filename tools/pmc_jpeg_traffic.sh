@@ -6,6 +6,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_jfetch $R/gpurun_out/prof_jwrite
+export IMPGPU_JPEG_WHOLE=1          # one launch per kernel and batch
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_jfetch -- python3 $R/tools/jpeg_pmc_probe.py > $R/gpurun_out/prof_jfetch.log 2>&1 || { tail -5 $R/gpurun_out/prof_jfetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_jwrite -- python3 $R/tools/jpeg_pmc_probe.py > $R/gpurun_out/prof_jwrite.log 2>&1 || { tail -5 $R/gpurun_out/prof_jwrite.log; exit 1; }
 rm -f $R/gpurun_out/prof_jfetch/*/*kernel_trace.csv $R/gpurun_out/prof_jwrite/*/*kernel_trace.csv
