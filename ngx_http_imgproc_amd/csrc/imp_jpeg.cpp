@@ -473,8 +473,8 @@ void jpeg_scan_meta(const JpegScan& scan, std::vector<uint32_t>* meta) {
 }
 
 // ---- the device's entropy stage, lane by lane on the host (diagnostics and CPU tests only; see imp_jpeg_core.h).
-// The same three steps as the kernels (imp_jpeg.hip), with the very same walks:
-//   k_jpeg_sync   one jpeg_span_walk per (chunk, block of the MCU) from `overlap` bits in front of the chunk; a chunk's true
+// The same steps as the kernels (imp_jpeg.hip), with the very same walks:
+//   k_jpeg_walks / k_jpeg_mend / k_jpeg_select   one jpeg_span_walk per (chunk, block of the MCU) from `overlap` bits in front of the chunk; a chunk's true
 //                 entry state is SELECTED among its walks' `in` states by comparing them with its predecessor's true exit --
 //                 on the device a scan over per-chunk maps, here the plain recurrence -- and only a chunk none of whose
 //                 walks had fallen into step by its first bit ("miss") is walked again from the true state
@@ -521,7 +521,7 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     const size_t n = scan.nchunks;
     std::vector<uint32_t> meta;
     jpeg_scan_meta(scan, &meta);
-    // ---- k_jpeg_sync
+    // ---- k_jpeg_walks, k_jpeg_mend, k_jpeg_select
     std::vector<uint64_t> entry(n);
     std::vector<uint32_t> slots(n), seg_end(n), limit(n);
     std::vector<char> origin(n);

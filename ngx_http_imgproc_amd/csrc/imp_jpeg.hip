@@ -1,18 +1,20 @@
 // imp_jpeg.hip -- device side of the JPEG front (imp_jpeg.h): what libjpeg does under cvDecodeImage at bridge.c:545-552.
 //
-// Huffman decoding of any number of scans in three launches.  The unstuffed stream of a file is cut into chunks of 256 ...
-// 1024 bits.  A Huffman stream has no random access, but a decoder started at a wrong bit falls into step with the true one
-// after a few symbols; what does NOT fall into step by itself is the block within the MCU (luma or chroma tables?), which a
-// guessing decoder only learns by derailing at the next luma/chroma boundary.  So:
-//   k_jpeg_sync    a lane per (chunk, block of the MCU): it starts `overlap` bits in FRONT of its chunk as if block k of an MCU
-//                  began there, and notes the state it is in at the chunk's first bit and at its last.  The true entry state
-//                  of a chunk is then SELECTED, not decoded: it is the walk whose state at the first bit equals the
-//                  predecessor's true exit state -- per chunk a map from the predecessor's six exit candidates to its own
-//                  six, composed along the chain by a scan inside the workgroup and a look-back between workgroups (which
-//                  take tickets, so the one waited for is always running already).  The few predecessor states no walk
-//                  arrived in are decoded on from ("repair": they almost always join a walk before the chunk ends); what
-//                  even that leaves open is carried forward as an explicit state by one lane ("chase").  Round 3 re-decoded
-//                  in rounds instead, one chunk of progress per round: 9-14 + 2-6 rounds for a 4:2:0 file.
+// Huffman decoding of any number of scans in five launches, none of them a round that is repeated.  The unstuffed stream of a
+// file is cut into chunks of 256 ... 2048 bits.  A Huffman stream has no random access, but a decoder started at a wrong bit
+// falls into step with the true one after a few symbols; what does NOT fall into step by itself is the block within the MCU
+// (luma or chroma tables?), which a guessing decoder only learns by derailing at the next luma/chroma boundary.  So:
+//   k_jpeg_walks   a lane per (chunk, block of the MCU): it starts `overlap` bits in FRONT of its chunk as if block k of an MCU
+//                  began there, and notes the state it is in at the chunk's first bit ("in") and at its last ("out")
+//   k_jpeg_mend    a lane per (chunk, predecessor candidate): the predecessor's exit either equals one of the chunk's `in`
+//                  states (then the chunk's MAP sends that candidate there) or no walk arrived in it; those few are decoded on
+//                  from ("repair": they almost always join a walk before the chunk ends), and what even that leaves open is
+//                  carried forward speculatively for a few chunks as explicit states ("ext records")
+//   k_jpeg_select  the true entry state of a chunk is SELECTED, not decoded: the maps compose, so a scan inside the workgroup
+//                  and a look-back between workgroups (which take tickets, so the one waited for is always running already)
+//                  turn "my predecessor's candidate" into "my candidate"; where a composition is open one lane follows the
+//                  explicit state ("chase") until it joins a candidate again.  Round 3 re-decoded in rounds instead, one chunk
+//                  of progress per round: 9-14 + 2-6 rounds for a 4:2:0 file.
 //   k_jpeg_write   a lane per chunk decodes it once from its true entry state; a block belongs to the chunk it begins in, whose
 //                  lane writes all 64 of its coefficients (zeros, then the others), so nothing has to be cleared
 //                  beforehand; DC terms are summed up inside the chunk only
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_write(const JpegJob* __restrict__ j
     const GlobalWords gwords = (GlobalWords)(uintptr_t)A.words;
     auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };
     // ---- the slot of every chunk's first symbol: running totals inside each interval (a segmented scan), plus what the
-    // interval had passed before this workgroup's first chunk (k_jpeg_sync left its workgroups' totals in their records)
+    // interval had passed before this workgroup's first chunk (k_jpeg_select left its workgroups' totals in their records)
     s_n[t] = own_n;
     s_head[t] = origin ? 1 : 0;
     __syncthreads();

@@ -310,7 +310,7 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         token = nullptr;
         if (rc) goto fail;
         if (on_device) {
-            // (the coefficient planes are zeroed by k_jpeg_sync itself, on the side)
+            // (the coefficient planes are not cleared: k_jpeg_write stores whole blocks)
             if (hipMemsetAsync(d_ctl, 0, ctl_words * sizeof(uint32_t), s) != hipSuccess) {
                 set_error("hipMemsetAsync(jpeg)", hipGetLastError());
                 rc = IMP_ERROR_DEVICE;
@@ -362,7 +362,7 @@ int group_finish(Group& G, impgpu_image** images, int* codes) {
     if (rc) goto fail;
     if (on_device) {
         if (const char* tr = std::getenv("IMPGPU_JPEG_TRACE"); tr && !std::strcmp(tr, "2")) {
-            // the workgroups' clocks at their phase boundaries (k_jpeg_sync's stamp()), microseconds since the launch's
+            // the workgroups' clocks at their phase boundaries (the kernels' stamp()), microseconds since the launch's
             // first workgroup started: wg: start | walks | candidates exchanged | maps | scan + look-back | done
             std::vector<uint32_t> ctl(ctl_total);
             if (hipMemcpy(ctl.data(), d_ctl, ctl_total * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {

@@ -1,5 +1,5 @@
-// imp_jpeg_core.h -- the chunk decoder of the device's entropy stage, written once for both sides: k_jpeg_entropy
-// (imp_jpeg.hip) runs it per lane, and the host runs the very same function lane by lane in jpeg_emulate_entropy
+// imp_jpeg_core.h -- the chunk decoder of the device's entropy stage, written once for both sides: the kernels of
+// imp_jpeg.hip run it per lane, and the host runs the very same function lane by lane in jpeg_emulate_entropy
 // (imp_jpeg.cpp) so that the self-synchronising scheme can be checked on a machine without a GPU
 // (tests/test_jpeg_host.py) and under AddressSanitizer.  The product path never decodes on the host.
 #pragma once
@@ -396,7 +396,7 @@ IMP_HD inline void jpeg_dc_fixup(const JpegBlockTabs& K, const JpegFrame& F, int
     }
 }
 
-// Round 4: the walk of the phase-parallel scheme (k_jpeg_sync).  It starts `overlap` bits BEFORE the chunk it belongs to, in
+// Round 4: the walk of the phase-parallel scheme (k_jpeg_walks, and the repair / chase walks of k_jpeg_mend / k_jpeg_select).  It starts `overlap` bits BEFORE the chunk it belongs to, in
 // a guessed state (that bit, start of block k of the MCU), and reports two states: `in`, the first state it reaches at or
 // behind bit `cross` (the chunk's first bit), and `out`, the first at or behind `limit` -- plus the coefficient slots passed
 // by the symbols that start in [cross, limit).  A state is everything the decoder's future depends on, so whenever a
