@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as orc
-from conftest import noise_image, smooth_image
+from conftest import ROOT, noise_image, smooth_image
 
 pytestmark = pytest.mark.gpu
 
@@ -314,6 +314,67 @@ def test_batch_download_into_pinned_memory_is_written_by_the_kernel(gpu):
     gpu.lib.impgpu_host_free(C.c_void_p(base))
     for im in ims:
         im.release()
+
+
+def test_batches_begun_and_finished_apart(gpu):
+    """impgpu_batch_decode_jpeg_begin / _finish: four batches in flight on one thread, a fifth refused, finished in another
+    order than begun, other work enqueued in between -- every frame is what the one-call form gives"""
+    import ctypes as C
+
+    gold = os.path.join(ROOT, "tests", "golden", "jpeg")
+    names = sorted(n for n in os.listdir(gold) if n.endswith(".jpg"))
+    blobs = [open(os.path.join(gold, n), "rb").read() for n in names]
+    groups = [blobs[0:5], blobs[5:9], blobs[9:16], blobs[16:19] + [b"\xff\xd8\xff\xe0 not a jpeg"]]
+    os.environ["IMPGPU_JPEG_HUFF"] = "device"
+    try:
+        want = []
+        for g in groups:
+            res = gpu.batch_decode_jpeg(g)
+            want.append([(code, None if im is None else im.numpy()) for code, im in res])
+            for _, im in res:
+                if im is not None:
+                    im.release()
+        held, handles = [], []
+        for g in groups:
+            n = len(g)
+            arr = (C.c_char_p * n)(*g)
+            sizes = (C.c_size_t * n)(*[len(b) for b in g])
+            h = C.c_void_p()
+            assert gpu.lib.impgpu_batch_decode_jpeg_begin(arr, sizes, n, C.byref(h)) == 0 and h.value
+            held.append((arr, sizes, n))
+            handles.append(h)
+        extra = C.c_void_p()
+        arr, sizes, n = held[0]
+        assert gpu.lib.impgpu_batch_decode_jpeg_begin(arr, sizes, n, C.byref(extra)) == gpu.IMP_ERROR_INVALID_ARGS and not extra.value
+        busy = gpu.Image(noise_image(64, 64, 4, 9))                # other work on the thread's stream between the halves
+        assert busy.cv_resize(32, 32, gpu.INTER_AREA) == 0
+        for k in (2, 0, 3, 1):
+            arr, sizes, n = held[k]
+            imgs = (C.c_void_p * n)()
+            codes = (C.c_int * n)()
+            assert gpu.lib.impgpu_batch_decode_jpeg_finish(C.byref(handles[k]), imgs, codes) == 0 and not handles[k].value
+            for i in range(n):
+                code, pixels = want[k][i]
+                assert codes[i] == code
+                if code == 0:
+                    im = gpu.Image(handle=imgs[i])
+                    assert np.array_equal(im.numpy(), pixels)
+                    im.release()
+                else:
+                    assert not imgs[i]
+        # all slots are free again
+        h = C.c_void_p()
+        arr, sizes, n = held[1]
+        assert gpu.lib.impgpu_batch_decode_jpeg_begin(arr, sizes, n, C.byref(h)) == 0
+        imgs = (C.c_void_p * n)()
+        codes = (C.c_int * n)()
+        assert gpu.lib.impgpu_batch_decode_jpeg_finish(C.byref(h), imgs, codes) == 0
+        for i in range(n):
+            if imgs[i]:
+                gpu.Image(handle=imgs[i]).release()
+        busy.release()
+    finally:
+        os.environ.pop("IMPGPU_JPEG_HUFF", None)
 
 
 def test_jpeg_request_batch_end_to_end(gpu):
