@@ -207,11 +207,11 @@ void  impgpu_jpeg_sync_stats(int stats[8]);
 /* ---- PNG in (round 4, a bounded experiment: DESIGN.md "PNG decode") ----
  * cvDecodeImage(&rawencoded, -1) (bridge.c:545-552) for a PNG blob (SIG_PNG, bridge.c:376-378), i.e. OpenCV 2.4's PngDecoder
  * over libpng with the "unchanged" flag: 8-bit gray -> 1 channel, RGB -> BGR, RGBA -> BGRA, tRNS not expanded.  The zlib
- * stream is inflated on the HOST (zlib) straight into pinned memory; the filtered scanlines cross the link and the five
+ * stream is inflated on the HOST (csrc/imp_inflate.cpp) straight into pinned memory; the filtered scanlines cross the link and the five
  * scanline filters (PNG specification 9.2) are undone on the device.  Takes bit depth 8, colour types 0 / 2 / 6, not
  * interlaced, width <= 4096, height <= 16384; IMP_ERROR_UNSUPPORTED = any other PNG (or not a PNG): decode it with
- * cvDecodeImage as before.  IMP_ERROR_DECODE_FAILED = damaged (a CRC of a critical chunk, the zlib stream, too little
- * data, a filter type above 4).  Does not wait for the device.
+ * cvDecodeImage as before.  IMP_ERROR_DECODE_FAILED = damaged (a chunk's CRC, the deflate stream, too little data, a
+ * filter type above 4; the stream's Adler-32 trailer is not checked).  Does not wait for the device.
  * impgpu_png_stage_times: the calling thread's last decode, host clock, microseconds: [0] header, [1] chunk walk + CRC +
  * inflate, [2] filter-type check + enqueue (upload, kernel); [3] = bytes of filtered scanlines. */
 int   impgpu_image_decode_png(const unsigned char* blob, size_t size, impgpu_image** out);

@@ -30,8 +30,9 @@ SOURCES = [
     "imp_jpeg.cpp",
     "imp_jpeg_api.cpp",
     "imp_png.cpp",
+    "imp_inflate.cpp",
 ]
-HEADERS = ["imp_internal.h", "imp_jpeg.h", "imp_jpeg_core.h", "imp_jpeg_std.h", "imp_png.h", os.path.join("..", "..", "include", "impgpu.h")]
+HEADERS = ["imp_internal.h", "imp_jpeg.h", "imp_jpeg_core.h", "imp_jpeg_std.h", "imp_png.h", "imp_inflate.h", os.path.join("..", "..", "include", "impgpu.h")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

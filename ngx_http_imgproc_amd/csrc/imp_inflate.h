@@ -1,0 +1,15 @@
+// imp_inflate.h -- a one-shot inflate for the PNG front (imp_png.cpp): RFC 1950 container, RFC 1951 blocks.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace imp {
+
+// Inflates the zlib stream in[0, in_size) into out[0, out_size): exactly out_size bytes are wanted (a PNG's scanlines).
+// Returns 0 when out is full (whatever follows in the stream is not read: libpng's rule for data past the image) or the stream
+// ended having produced exactly out_size bytes; 1 when the stream is damaged, ends early, or refers to data before its start.
+// Never reads outside in[], never writes outside out[].  The Adler-32 trailer is not checked (the chunks' CRCs cover the
+// compressed bytes; tests/test_inflate.py checks the decoder itself against zlib and the oracle's inflate).
+int inflate_exact(const uint8_t* in, size_t in_size, uint8_t* out, size_t out_size);
+
+}  // namespace imp
