@@ -109,7 +109,7 @@ bool build_table(const uint8_t* lens, int nsym, int bits, bool is_dist, uint32_t
 
 }  // namespace
 
-int inflate_exact(const uint8_t* in, size_t in_size, uint8_t* out, size_t out_size) {
+int inflate_exact(const uint8_t* in, size_t in_size, uint8_t* out, size_t out_size, inflate_progress_fn progress, void* ctx) {
     if (in_size < 2) return 1;
     const unsigned cmf = in[0], flg = in[1];
     if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) return 1;
@@ -163,6 +163,7 @@ int inflate_exact(const uint8_t* in, size_t in_size, uint8_t* out, size_t out_si
             }
             if (op == oend) return 0;
             if (last) break;
+            if (progress && !progress(ctx, (size_t)(op - out))) return 1;
             continue;
         } else if (type == 1) {
             if (!fixed_built) {
@@ -355,6 +356,7 @@ int inflate_exact(const uint8_t* in, size_t in_size, uint8_t* out, size_t out_si
     block_done:
         if (op == oend) return 0;
         if (last) break;
+        if (progress && !progress(ctx, (size_t)(op - out))) return 1;
     }
     return op == oend ? 0 : 1;
 }

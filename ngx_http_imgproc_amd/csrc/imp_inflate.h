@@ -10,6 +10,9 @@ namespace imp {
 // ended having produced exactly out_size bytes; 1 when the stream is damaged, ends early, or refers to data before its start.
 // Never reads outside in[], never writes outside out[].  The Adler-32 trailer is not checked (the chunks' CRCs cover the
 // compressed bytes; tests/test_inflate.py checks the decoder itself against zlib and the oracle's inflate).
-int inflate_exact(const uint8_t* in, size_t in_size, uint8_t* out, size_t out_size);
+// progress (optional) is called at the end of every deflate block with the bytes produced so far (they are final); returning
+// false stops the inflate with 1.
+typedef bool (*inflate_progress_fn)(void* ctx, size_t produced);
+int inflate_exact(const uint8_t* in, size_t in_size, uint8_t* out, size_t out_size, inflate_progress_fn progress = nullptr, void* ctx = nullptr);
 
 }  // namespace imp

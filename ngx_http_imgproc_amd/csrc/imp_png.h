@@ -16,6 +16,9 @@ struct PngHeader {
 int png_header(const unsigned char* blob, size_t size, PngHeader* H);
 // the chunk walk (every CRC checked), the zlib stream of the IDAT chunks inflated into dst[h * (w * bpp + 1)], the filter
 // bytes checked: IMP_OK or IMP_ERROR_DECODE_FAILED
-int png_scanlines(const unsigned char* blob, size_t size, const PngHeader& H, unsigned char* dst);
+// rows (optional) is called while the inflate goes, at the ends of deflate blocks: rows [0, complete) of dst are final and their
+// filter bytes checked; a non-zero return stops the decode with that code.
+typedef int (*png_rows_fn)(void* ctx, int complete);
+int png_scanlines(const unsigned char* blob, size_t size, const PngHeader& H, unsigned char* dst, png_rows_fn rows = nullptr, void* ctx = nullptr);
 
 }  // namespace imp

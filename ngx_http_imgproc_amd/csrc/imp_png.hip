@@ -29,6 +29,7 @@ constexpr int PNG_RAW_SLACK = 64;        // the word stream of the last row read
 struct PngJob {
     const uint8_t* raw;                  // h rows of (1 filter byte + w * bpp bytes), as inflate delivered them
     uint8_t* dst;
+    const uint8_t* prev;                 // the finished row above row 0 (a slice of an image: the slice before wrote it), or null
     int w, h, step;
 };
 
@@ -57,10 +58,23 @@ __device__ __forceinline__ uint32_t png_from_above(uint32_t edge, uint32_t v) {
 
 __device__ __forceinline__ int png_progress(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// four finished pixels (B,G,R order already) of the row above a slice, as the lanes hand them on: one per word
 template <int BPP>
-__global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(const PngJob* jobs) {
+__device__ __forceinline__ uint4 png_prev_group(const uint8_t* prev, int g) {
+    const uint32_t* q = (const uint32_t*)(prev + (size_t)g * 4 * BPP);      // (rows are 4-byte aligned; 12 / 16 / 4 bytes per group)
+    if constexpr (BPP == 4) return make_uint4(q[0], q[1], q[2], q[3]);
+    else if constexpr (BPP == 3) {
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        return make_uint4(d0 & 0xffffffu, __builtin_amdgcn_alignbit(d1, d0, 24) & 0xffffffu, __builtin_amdgcn_alignbit(d2, d1, 16) & 0xffffffu, d2 >> 8);
+    } else {
+        const uint32_t d0 = q[0];
+        return make_uint4(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, d0 >> 24);
+    }
+}
+
+template <int BPP>
+__global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(const PngJob J) {
     extern __shared__ uint4 s_png[];
-    const PngJob J = jobs[blockIdx.x];
     const int G = (J.w + 3) >> 2;                                    // groups of 4 pixels per row
     const int nbands = (J.h + 63) >> 6;
     uint4* s_edge = s_png;                                           // [PNG_WAVES][G]: the last row of a band, unpacked
@@ -94,6 +108,8 @@ __global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(const PngJob* j
 #pragma unroll
             for (int i = 0; i <= NW; i++) nxt[i] = wp[g0 * NW + i];
         }
+        uint4 pe = make_uint4(0, 0, 0, 0);                           // band 0 of a slice: lane 0's next group of the row above
+        if (band == 0 && J.prev != nullptr && lane == 0) pe = png_prev_group<BPP>(J.prev, 0);
         const int steps = G + 63;
         for (int S = 0; S < steps; S++) {
             const int g = S - lane;
@@ -126,8 +142,13 @@ __global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(const PngJob* j
 #pragma unroll
                 for (int i = 0; i < 4; i++) px[i] = (d[0] >> (8 * i)) & 255u;
             }
-            // the row above: the previous band's last row for lane 0 (LDS), the lane above for everyone else
+            // the row above: the previous band's last row for lane 0 (LDS; for the first band of a slice the row the slice before
+            // left in the image, fetched one step ahead), the lane above for everyone else
             uint4 e = make_uint4(0, 0, 0, 0);
+            if (band == 0 && J.prev != nullptr) {
+                e = pe;
+                if (lane == 0) pe = png_prev_group<BPP>(J.prev, S + 1 < G ? S + 1 : G - 1);
+            }
             if (band > 0 && S < G) {
                 while (known <= S) {
                     known = png_progress(&s_prog[band - 1]);
@@ -176,8 +197,8 @@ __global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(const PngJob* j
 
 static size_t png_lds_bytes(int w, int h) { return (size_t)PNG_WAVES * ((w + 3) / 4) * 16 + (size_t)((h + 63) / 64) * 4; }
 
-static int launch_png_unfilter(const PngJob* dev_jobs, int count, int bpp, int max_w, int max_h, hipStream_t s) {
-    const size_t lds = png_lds_bytes(max_w, max_h);
+static int launch_png_unfilter(const PngJob& job, int bpp, hipStream_t s) {
+    const size_t lds = png_lds_bytes(job.w, job.h);
     hipError_t e = hipSuccess;
 #define PNG_LAUNCH(BPP_)                                                                                                      \
     do {                                                                                                                      \
@@ -188,7 +209,7 @@ static int launch_png_unfilter(const PngJob* dev_jobs, int count, int bpp, int m
             raised = e == hipSuccess;                                                                                         \
         }                                                                                                                     \
         if (e == hipSuccess) {                                                                                                \
-            hipLaunchKernelGGL(k_png_unfilter<BPP_>, dim3(count), dim3(PNG_WAVES * 64), lds, s, dev_jobs);                    \
+            hipLaunchKernelGGL(k_png_unfilter<BPP_>, dim3(1), dim3(PNG_WAVES * 64), lds, s, job);                             \
             e = hipGetLastError();                                                                                            \
         }                                                                                                                     \
     } while (0)
@@ -233,28 +254,44 @@ int impgpu_image_decode_png(const unsigned char* blob, size_t size, impgpu_image
     // the scanlines can be no larger than zlib's best ratio lets the file hold (1032 : 1, zlib technical details):
     // a header that promises more is refused before anything is staged for it
     if (raw_bytes / 1032 > size) return IMP_ERROR_DECODE_FAILED;
+    // Pinned memory for the scanlines, device memory for them and for the frame -- all before the inflate starts, because the
+    // rows leave for the device WHILE it runs: every time another SLICE_ROWS rows are final (the inflate reports at the ends
+    // of deflate blocks) they are uploaded and a k_png_unfilter launch takes them, its first row reading the row above from the
+    // frame the slice before wrote.  The device's share of a decode (a quarter of it) then hides behind the host's.
     void *host = nullptr, *token = nullptr;
-    rc = stage_begin(raw_bytes + PNG_RAW_SLACK + 16 + sizeof(PngJob), &host, &token);
+    rc = stage_begin(raw_bytes + PNG_RAW_SLACK, &host, &token);
     if (rc) return rc;
-    // ---- the chunks, the zlib stream, the filter bytes (imp_png.cpp: host code, also run under the sanitizers)
-    const double t1 = png_now_us();
-    rc = png_scanlines(blob, size, H, (unsigned char*)host);
-    const double t2 = png_now_us();
-    if (rc) { (void)stage_upload(token, nullptr, 0); return rc; }
-    // ---- to the device: the scanlines as they are, then one workgroup undoes the filters
     impgpu_image* im = nullptr;
     rc = image_new(H.w, H.h, H.bpp, &im);
     if (rc) { (void)stage_upload(token, nullptr, 0); return rc; }
-    const size_t job_at = (raw_bytes + PNG_RAW_SLACK + 15) & ~size_t(15);
     void* dev = nullptr;
-    rc = dev_alloc(job_at + sizeof(PngJob), &dev);
+    rc = dev_alloc(raw_bytes + PNG_RAW_SLACK, &dev);
     if (rc) { (void)stage_upload(token, nullptr, 0); image_delete(im); return rc; }
-    std::memset((unsigned char*)host + raw_bytes, 0, job_at - raw_bytes);
-    PngJob job{(const uint8_t*)dev, im->d, H.w, H.h, im->step};
-    std::memcpy((unsigned char*)host + job_at, &job, sizeof job);
-    rc = stage_upload(token, dev, job_at + sizeof(PngJob));
-    if (!rc) rc = launch_png_unfilter((const PngJob*)((const uint8_t*)dev + job_at), 1, H.bpp, H.w, H.h, env_stream());
-    dev_free(dev);                                                           // (handed out again in lane-stream order)
+    struct Feed {
+        void* token; uint8_t* dev; impgpu_image* im; PngHeader H; size_t rstride; int sent; hipStream_t s;
+        int upto(int rows, bool last) {                              // rows [sent, rows) -> device, unfiltered there
+            if (rows <= sent) return last ? stage_upload_part(token, 0, nullptr, 0, true) : IMP_OK;
+            const size_t off = (size_t)sent * rstride, bytes = (size_t)(rows - sent) * rstride + (last ? PNG_RAW_SLACK : 0);
+            if (int rc = stage_upload_part(token, off, dev + off, bytes, last)) return rc;
+            PngJob job{dev + off, im->d + (size_t)sent * im->step, sent ? im->d + (size_t)(sent - 1) * im->step : nullptr, H.w, rows - sent, im->step};
+            if (int rc = launch_png_unfilter(job, H.bpp, s)) return rc;
+            sent = rows;
+            return IMP_OK;
+        }
+    } feed{token, (uint8_t*)dev, im, H, rstride, 0, env_stream()};
+    constexpr int SLICE_ROWS = 128;                                  // two bands of the kernel; a launch costs ~10 us of the host's time
+    std::memset((unsigned char*)host + raw_bytes, 0, PNG_RAW_SLACK);
+    const double t1 = png_now_us();
+    rc = png_scanlines(blob, size, H, (unsigned char*)host,
+                       [](void* p, int complete) -> int {
+                           Feed* f = (Feed*)p;
+                           const int ready = complete & ~63;         // whole bands only: a slice starts on a band's first row
+                           return ready - f->sent >= SLICE_ROWS ? f->upto(ready, false) : IMP_OK;
+                       }, &feed);
+    const double t2 = png_now_us();
+    if (!rc) rc = feed.upto(H.h, true);
+    else (void)stage_upload_part(token, 0, nullptr, 0, true);        // (pieces may be on their way: fence the buffer all the same)
+    dev_free(dev);                                                   // (handed out again in lane-stream order)
     if (rc) { image_delete(im); return rc; }
     const double t3 = png_now_us();
     t_png_us[0] = t1 - t0; t_png_us[1] = t2 - t1; t_png_us[2] = t3 - t2; t_png_us[3] = (double)raw_bytes;

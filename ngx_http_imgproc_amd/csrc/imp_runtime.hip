@@ -631,6 +631,20 @@ int stage_upload(void* token, void* dev, size_t bytes) {
     return IMP_OK;
 }
 
+// The same in pieces: part of the pinned buffer (from `offset`) to `dev`, on the lane stream; the buffer is fenced when `last`
+// (bytes may be 0 then: a decode that gives up after some pieces still has to fence them).
+int stage_upload_part(void* token, size_t offset, void* dev, size_t bytes, bool last) {
+    Lane* L = lane();
+    if (!L) return no_env();
+    Staging* S = (Staging*)token;
+    if (!S) return IMP_OK;
+    hipError_t e = hipSuccess;
+    if (bytes) e = hipMemcpyAsync(dev, S->p + offset, bytes, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess && last) { e = hipEventRecord(S->done, L->stream); if (e == hipSuccess) S->busy = true; }
+    if (e != hipSuccess) { set_error("hipMemcpyAsync(stage_upload_part)", e); (void)hipStreamSynchronize(L->stream); return IMP_ERROR_DEVICE; }
+    return IMP_OK;
+}
+
 static void lane_destroy(Lane* L) {
     if (L->stream) (void)hipStreamSynchronize(L->stream);
     reap(L, true);
