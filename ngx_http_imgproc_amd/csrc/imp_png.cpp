@@ -4,7 +4,6 @@
 // (tests/test_host_sanitizers.py); impgpu_image_decode_png (imp_png.hip) calls png_scanlines with the pinned staging buffer
 // as its destination.  The inflate is imp_inflate.cpp's (1.6-1.9 x zlib 1.2.11 on scanlines); there is no device inflate in this
 // library.
-#include <zlib.h>                 // crc32 only
 #include <cstring>
 #include <vector>
 #include "../../include/impgpu.h"
@@ -19,7 +18,7 @@ int png_header(const unsigned char* blob, size_t size, PngHeader* H) {
     static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (!blob || size < 8 || std::memcmp(blob, sig, 8) != 0) return IMP_ERROR_UNSUPPORTED;
     if (size < 8 + 25 || be32(blob + 8) != 13 || std::memcmp(blob + 12, "IHDR", 4) != 0) return IMP_ERROR_DECODE_FAILED;
-    if ((unsigned)crc32(0, blob + 12, 17) != be32(blob + 29)) return IMP_ERROR_DECODE_FAILED;
+    if (crc32_ieee(blob + 12, 17) != be32(blob + 29)) return IMP_ERROR_DECODE_FAILED;
     const unsigned w = be32(blob + 16), h = be32(blob + 20);
     const int depth = blob[24], colour = blob[25], compression = blob[26], filter = blob[27], interlace = blob[28];
     if (w == 0 || h == 0 || w > 0x7fffffffu || h > 0x7fffffffu || compression != 0 || filter != 0 || interlace > 1)
@@ -69,7 +68,7 @@ int png_scanlines(const unsigned char* blob, size_t size, const PngHeader& H, un
         if (len > 0x7fffffffu || size - at - 12 < len) { bad = true; break; }
         const bool critical = !(kind[0] & 0x20);
         // (libpng's default only warns about a damaged ANCILLARY chunk and skips it; such a file is left to the host decoder)
-        if ((unsigned)crc32(0, kind, 4 + len) != be32(blob + at + 8 + len)) { bad = true; break; }
+        if (crc32_ieee(kind, 4 + (size_t)len) != be32(blob + at + 8 + len)) { bad = true; break; }
         if (!std::memcmp(kind, "IDAT", 4)) {
             seen_idat = true;
             stream.insert(stream.end(), blob + at + 8, blob + at + 8 + len);

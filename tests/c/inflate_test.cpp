@@ -99,6 +99,15 @@ int main(int argc, char** argv) {
             (void)zfull;
         }
     }
+    // the chunk CRC against zlib's: every length around the 16- and 64-byte steps of the folding loop, unaligned starts
+    for (int it = 0; it < 6000; it++) {
+        size_t n = it < 400 ? (size_t)it : rnd() % 70000;
+        std::vector<uint8_t> b(n + 3);
+        for (auto& v : b) v = (uint8_t)rnd();
+        const uint8_t* p = b.data() + (it % 3);
+        cases++;
+        if (crc32_ieee(p, n) != (uint32_t)crc32(0, p, (uInt)n)) { bad++; printf("FAIL crc n %zu\n", n); }
+    }
     printf("%ld cases, %ld bad\n", cases, bad);
     // speed
     {
