@@ -4,13 +4,14 @@
 // filtering section 9, zlib stream section 10) and what OpenCV asks libpng for with the "unchanged" flag: 8-bit gray stays
 // one channel, RGB becomes BGR, RGBA becomes BGRA, a tRNS chunk is not expanded.
 //
-// ROUND 4, A BOUNDED EXPERIMENT (DESIGN.md "PNG decode"): the zlib stream is inflated ON THE HOST (zlib, one pass into the
-// pinned staging buffer: there is no device inflate here), the filtered scanlines cross the link as they are, and
-// k_png_unfilter undoes the five scanline filters and swaps R/B on the device.  Unfiltering is a recurrence along x (Sub,
-// Average, Paeth read the pixel to the left) and along y (Up, Average, Paeth read the row above), so one image is ONE
-// workgroup that walks it as a wavefront: lane l of a wave owns row 64 * band + l and works on group (S - l) of 4 pixels at
-// macro step S, one group behind the lane above it, whose finished group arrives by a wave_shr DPP move.  The rows between
-// bands (lane 63 of one wave -> lane 0 of the next) travel through LDS with a progress counter per band.
+// ROUND 4, A BOUNDED EXPERIMENT: the zlib stream is inflated ON THE HOST (imp_png.cpp / imp_inflate.cpp:
+// there is no device inflate here) into the pinned staging buffer, the filtered scanlines cross the link as they are -- in
+// slices of 128 rows, WHILE the inflate is still running -- and k_png_unfilter undoes the five scanline filters and swaps R/B on
+// the device.  Unfiltering is a recurrence along x (Sub, Average, Paeth read the pixel to the left) and along y (Up, Average,
+// Paeth read the row above), so a slice is ONE workgroup that walks it as a wavefront: lane l of a wave owns row 64 * band + l
+// and works on group (S - l) of 4 pixels at macro step S, one group behind the lane above it, whose finished group arrives by a
+// wave_shr DPP move.  The rows between bands (lane 63 of one wave -> lane 0 of the next) travel through LDS with a progress
+// counter per band; the row above a slice's first row is read from the frame, where the slice before left it.
 //
 // Takes: bit depth 8, colour types 0 / 2 / 6, not interlaced, width <= 4096, height <= 16384.  Everything else is
 // IMP_ERROR_UNSUPPORTED (decode with cvDecodeImage as before); a damaged file is IMP_ERROR_DECODE_FAILED.
