@@ -141,7 +141,7 @@ int   impgpu_image_download_fi(const impgpu_image* image, int bpp, unsigned char
  * intervals.  IMP_ERROR_UNSUPPORTED = a JPEG outside that set (progressive, CMYK, ...): decode it with cvDecodeImage as
  * before and impgpu_image_upload the pixels.  IMP_ERROR_DECODE_FAILED = damaged data; libjpeg would warn and deliver
  * what it could, so the same fallback applies.  Waits for the device's verdict on the entropy-coded data before it
- * returns (the only wait on the request path besides the download).  A launch with less than 100 KB of entropy-coded
+ * returns (the only wait on the request path besides the download).  A launch with less than 40 KB of entropy-coded
  * data keeps its Huffman decoding on the calling thread (6 ns per byte against a fixed few hundred microseconds of
  * device rounds); IMPGPU_JPEG_HUFF=device|host forces one.  The pixels do not depend on it. */
 int   impgpu_image_decode_jpeg(const unsigned char* blob, size_t size, impgpu_image** out);

@@ -13,18 +13,19 @@ using namespace imp;
 
 namespace {
 
-// Where the entropy stage of a launch runs.  The device's takes a chain of rounds that costs a few hundred microseconds
-// however small the file is; the calling thread's takes 6 ns per byte.  One request at a time (tools/jpeg_tiny_probe.py,
-// frame complete, ms: device / calling thread / libjpeg-turbo on one core) -- 64x64 0.24 / 0.05 / 0.04, 320x240 0.48 / 0.15 /
-// 0.20, 640x480 0.73 / 0.54 / 0.85, 800x600 0.65 / 0.85 / 1.29, 1080p 0.76 / 3.5 / 5.4 -- they cross near 100 KB of
-// entropy-coded data, so a launch smaller than that keeps its Huffman decoding on the thread that is about to sleep in the
+// Where the entropy stage of a launch runs.  The device's five launches cost about a quarter of a millisecond however small
+// the file is; the calling thread's decoder takes 6 ns per byte.  One request at a time (tools/jpeg_tiny_probe.py,
+// profiles/r04_jpeg_small_files.txt, frame complete, ms: device / calling thread / libjpeg-turbo on one core) -- 64x64 0.17 /
+// 0.06 / 0.04, 160x120 0.21 / 0.09 / 0.09, 320x240 (22 KB) 0.24 / 0.17 / 0.23, 480x360 (50 KB) 0.26 / 0.31 / 0.45, 640x480
+// (88 KB) 0.26 / 0.54 / 0.82, 1080p 0.37 / 3.4 / 5.4 -- they cross near 40 KB of entropy-coded data (round 3's stage, with its
+// rounds: near 100 KB), so a launch smaller than that keeps its Huffman decoding on the thread that is about to sleep in the
 // wait anyway (dequantisation, IDCT, upsampling and colour stay on the device either way), and everything larger -- every
 // batch -- is the device's.  IMPGPU_JPEG_HUFF = device | host forces one (read per call: a getenv is nothing next to a decode).
 bool entropy_on_device(size_t launch_bytes) {
     const char* s = std::getenv("IMPGPU_JPEG_HUFF");
     if (s && !std::strcmp(s, "host")) return false;
     if (s && !std::strcmp(s, "device")) return true;
-    return launch_bytes >= (size_t(100) << 10);
+    return launch_bytes >= (size_t(40) << 10);
 }
 
 // impgpu_jpeg_profile(1): every decode call leaves its stages' durations with the calling thread (impgpu_jpeg_stage_times) --
