@@ -253,7 +253,10 @@ size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
     // 720p 0.83 / 0.84 / 0.94, 1080p 0.90 / 0.84 / 0.95, 4K 1.45 / 1.24 / 1.24; a queue's worth of files (28 MB) is a little
     // faster on 1024
     if (launch_bytes > (size_t(4) << 20)) return JPEG_CHUNK_BYTES_MAX;    // (a walk's overlap weighs half as much on 2048 bits as on 1024)
-    return file_bytes <= (size_t(96) << 10) ? 32 : 64;
+    // round 4, the stage without rounds, one file at a time (profiles/r04_jpeg_chunk_ab.txt, ms at 256 / 512 / 1024 / 2048 bits):
+    // 640x480 0.25 / 0.30 / 0.41 / 0.62, 1080p 4:2:0 0.32 / 0.36 / 0.46 / 0.67, 4:4:4 0.28 / 0.33 / 0.45 / 0.67, 4K 0.58 / 0.52 / 0.61 / 0.81
+    // -- every kernel's time is the length of a chunk's walk until the chunks no longer fit the device at once
+    return file_bytes <= (size_t(1200) << 10) ? 32 : 64;
 }
 
 unsigned jpeg_overlap_bits_for(unsigned chunk_bits, size_t scan_bytes, size_t total_blocks) {
