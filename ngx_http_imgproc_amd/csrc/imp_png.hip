@@ -50,6 +50,39 @@ __device__ __forceinline__ uint32_t png_recon(int type, uint32_t f, uint32_t a, 
     return out;
 }
 
+// The same for a pixel of three or four channels, two channels per instruction: the bytes are spread to 16-bit lanes
+// (c0 | c1 << 16, c2 | c3 << 16) and every step of the predictors is a packed 16-bit operation (v_pk_sub_i16, v_pk_max_i16,
+// v_pk_min_u16, v_pk_mad_u16 ...).  Paeth without compares: with m = min(pa, pb, pc), nea = min(pa - m, 1) is 0 exactly where
+// a is the choice, neb = min(pb - m, 1) likewise for b, and pred = a + nea * ((b + neb * (c - b)) - a) -- ties go to a, then b,
+// as 9.4 asks.  The filter type is a lane's constant for a whole row: four masks pick the predictor.
+typedef short png_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short png_u2 __attribute__((ext_vector_type(2)));
+struct PngTypeMasks { uint32_t sub, up, avg, paeth; };
+__device__ __forceinline__ PngTypeMasks png_type_masks(int type) {
+    return PngTypeMasks{type == 1 ? ~0u : 0u, type == 2 ? ~0u : 0u, type == 3 ? ~0u : 0u, type == 4 ? ~0u : 0u};
+}
+__device__ __forceinline__ uint32_t png_recon_pair(const PngTypeMasks& M, uint32_t f, uint32_t a, uint32_t b, uint32_t c) {
+    const png_s2 A = __builtin_bit_cast(png_s2, a), B = __builtin_bit_cast(png_s2, b), C = __builtin_bit_cast(png_s2, c);
+    const png_s2 d1 = B - C, d2 = A - C, d3 = d1 + d2;
+    const png_s2 zero = {0, 0};
+    const png_u2 pa = __builtin_bit_cast(png_u2, __builtin_elementwise_max(d1, zero - d1));
+    const png_u2 pb = __builtin_bit_cast(png_u2, __builtin_elementwise_max(d2, zero - d2));
+    const png_u2 pc = __builtin_bit_cast(png_u2, __builtin_elementwise_max(d3, zero - d3));
+    const png_u2 m = __builtin_elementwise_min(pa, __builtin_elementwise_min(pb, pc));
+    const png_u2 one = {1, 1};
+    const png_u2 nea = __builtin_elementwise_min((png_u2)(pa - m), one), neb = __builtin_elementwise_min((png_u2)(pb - m), one);
+    const png_u2 Au = __builtin_bit_cast(png_u2, a), Bu = __builtin_bit_cast(png_u2, b), Cu = __builtin_bit_cast(png_u2, c);
+    const png_u2 u = Bu + neb * (png_u2)(Cu - Bu);
+    const png_u2 paeth = Au + nea * (png_u2)(u - Au);
+    const png_u2 avg = (png_u2)(Au + Bu) >> 1;
+    const uint32_t pred = (a & M.sub) | (b & M.up) | (__builtin_bit_cast(uint32_t, avg) & M.avg) | (__builtin_bit_cast(uint32_t, paeth) & M.paeth);
+    const png_u2 r = __builtin_bit_cast(png_u2, f) + __builtin_bit_cast(png_u2, pred);
+    return __builtin_bit_cast(uint32_t, r) & 0x00ff00ffu;
+}
+__device__ __forceinline__ uint32_t png_spread_lo(uint32_t p) { return __builtin_amdgcn_perm(p, p, 0x0c010c00u); }   // c0 | c1 << 16
+__device__ __forceinline__ uint32_t png_spread_hi(uint32_t p) { return __builtin_amdgcn_perm(p, p, 0x0c030c02u); }   // c2 | c3 << 16
+__device__ __forceinline__ uint32_t png_gather(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
+
 __device__ __forceinline__ uint32_t png_swap_rb(uint32_t p) { return __builtin_amdgcn_perm(p, p, 0x03000102u); }
 
 // the lane above (wave_shr:1); lane 0 keeps `edge`
@@ -91,6 +124,7 @@ __global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(const PngJob J)
         const bool rowok = row < J.h;
         const uint8_t* rp = J.raw + (size_t)(rowok ? row : J.h - 1) * rstride;
         const int type = rowok ? (int)rp[0] : 0;
+        const PngTypeMasks tm = png_type_masks(type);
         const uintptr_t a0 = (uintptr_t)(rp + 1);
         const uint32_t sh = (uint32_t)(a0 & 3) * 8;
         const uint32_t* wp = (const uint32_t*)(a0 & ~(uintptr_t)3);
@@ -163,10 +197,24 @@ __global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(const PngJob J)
             up[2] = png_from_above(e.z, cur[2]);
             up[3] = png_from_above(e.w, cur[3]);
             if (g == 0) { left = 0; upleft = 0; }
-            cur[0] = png_recon<BPP>(type, px[0], left, up[0], upleft);
-            cur[1] = png_recon<BPP>(type, px[1], cur[0], up[1], up[0]);
-            cur[2] = png_recon<BPP>(type, px[2], cur[1], up[2], up[1]);
-            cur[3] = png_recon<BPP>(type, px[3], cur[2], up[3], up[2]);
+            if constexpr (BPP >= 3) {
+                // channels in pairs: the pixel to the left stays in its spread form from one pixel to the next
+                uint32_t a_lo = png_spread_lo(left), a_hi = png_spread_hi(left);
+                uint32_t c_lo = png_spread_lo(upleft), c_hi = png_spread_hi(upleft);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t b_lo = png_spread_lo(up[i]), b_hi = png_spread_hi(up[i]);
+                    a_lo = png_recon_pair(tm, png_spread_lo(px[i]), a_lo, b_lo, c_lo);
+                    a_hi = png_recon_pair(tm, png_spread_hi(px[i]), a_hi, b_hi, c_hi);
+                    cur[i] = png_gather(a_lo, a_hi);
+                    c_lo = b_lo; c_hi = b_hi;
+                }
+            } else {
+                cur[0] = png_recon<BPP>(type, px[0], left, up[0], upleft);
+                cur[1] = png_recon<BPP>(type, px[1], cur[0], up[1], up[0]);
+                cur[2] = png_recon<BPP>(type, px[2], cur[1], up[2], up[1]);
+                cur[3] = png_recon<BPP>(type, px[3], cur[2], up[3], up[2]);
+            }
             left = cur[3];
             upleft = up[3];
             if (act) {
