@@ -90,6 +90,8 @@ int  stream_join_back(hipStream_t s);                      // the lane stream wa
 bool lane_stream_idle();
 uint32_t* lane_mailbox();                                  // pinned words of the calling thread's lane: [0, 1024) for any caller, then 1024 per JPEG group in flight
 int  lane_mark(void** mark);                               // a point of the lane's stream ...
+int  lane_mark_on(hipStream_t s, void** mark);             // ... or of another stream of the thread (nullptr: the lane's)
+hipStream_t lane_side_stream();                            // the lane's second stream (made on first use; nullptr if it cannot be)
 int  lane_wait_mark(void* mark);                           // ... to sleep until (nullptr: the whole stream)
 int  lane_wait();                                          // wait for the lane's stream (sleeping, unless IMPGPU_SYNC=spin)
 bool on_lane_stream(hipStream_t s);

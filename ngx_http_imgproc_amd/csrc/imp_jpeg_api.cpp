@@ -88,7 +88,8 @@ struct Group {
     int count = 0;
     bool on_device = false, profile = false;
     void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr, *d_work = nullptr;
-    void* mark = nullptr;                           // the point of the lane's stream where this group's last kernel was enqueued
+    void* mark = nullptr;                           // the point of the group's stream where its last kernel was enqueued
+    hipStream_t stream = nullptr;                   // the lane's stream, or its side stream (a batch begun ahead: its decode overlaps what the thread enqueues next)
     uint32_t* mailbox = nullptr;
     int slot = -1;
     size_t live = 0, ctl_total = 0;
@@ -100,7 +101,9 @@ std::atomic<int> g_groups_in_flight{0};             // over all threads: groups 
 
 void group_release(Group& G) {
     for (int i = 0; i < 8; i++) if (G.ev[i]) { (void)hipEventDestroy(G.ev[i]); G.ev[i] = nullptr; }
-    dev_free(G.d_words); dev_free(G.d_coef); dev_free(G.d_side); dev_free(G.d_ctl); dev_free(G.d_work);
+    void* blocks[5] = {G.d_words, G.d_coef, G.d_side, G.d_ctl, G.d_work};
+    for (void* b : blocks)
+        if (b) { if (G.stream && !on_lane_stream(G.stream)) dev_free_on(b, G.stream); else dev_free(b); }
     G.d_words = G.d_coef = G.d_side = G.d_ctl = G.d_work = nullptr;
     if (G.slot >= 0) { t_slots_busy &= ~(1u << G.slot); g_groups_in_flight.fetch_sub(1, std::memory_order_relaxed); }
     G.slot = -1;
@@ -109,10 +112,12 @@ void group_release(Group& G) {
 // Everything up to the last enqueue: headers, the unstuffing copy (or the host's entropy decoding), job tables, uploads,
 // the entropy and pixel kernels, the verdicts' copy.  Does NOT wait.  A non-zero return means nothing is in flight and
 // nothing is held (codes[] of the caller are then filled by the caller from G.P where they are set, else with the return).
-int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes, int count, int force_host) {
+int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes, int count, int force_host, bool side = false) {
     Stopwatch& sw = G.sw;
-    hipStream_t s = env_stream();
+    hipStream_t s = side ? lane_side_stream() : nullptr;
+    if (!s) s = env_stream();
     if (!s) return IMP_ERROR_DEVICE;
+    G.stream = s;
     G.blobs = blobs; G.sizes = sizes; G.count = count;
     G.P.assign((size_t)count, Prep());
     std::vector<Prep>& P = G.P;
@@ -242,6 +247,7 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         if (!rc && on_device) rc = dev_alloc(work, &d_work);
         ctl_total = ctl_words;
         if (!rc && on_device) rc = dev_alloc(ctl_words * sizeof(uint32_t), &d_ctl);
+        if (!rc) rc = stream_join(s);                               // (side stream: the pool recycles in lane-stream order; the frames were allocated there too)
         if (rc) goto fail;
         std::vector<uint8_t> blob(side);
         JpegJob* jobs = (JpegJob*)(blob.data() + side_jobs);
@@ -306,9 +312,9 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
             for (int i = 0; i < 8; i++) if (hipEventCreate(&ev[i]) != hipSuccess) { ev[i] = nullptr; profile = false; }
             if (profile) (void)hipEventRecord(ev[0], s);
         }
-        rc = upload_to(d_side, blob.data(), side, s);
-        if (!rc) rc = stage_upload(token, on_device ? d_words : d_coef, on_device ? words_total : coef_total);
+        rc = stage_upload(token, on_device ? d_words : d_coef, on_device ? words_total : coef_total);
         token = nullptr;
+        if (!rc) rc = upload_to(d_side, blob.data(), side, s);      // (both copies ride the lane's stream; `s` is made to wait for them here)
         if (rc) goto fail;
         if (on_device) {
             // (the coefficient planes are not cleared: k_jpeg_write stores whole blocks)
@@ -333,11 +339,12 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         if (profile && on_device) (void)hipEventRecord(ev[7], s);
     }
     sw.mark();                                                      // [3] enqueue
-    rc = lane_mark(&G.mark);
+    rc = lane_mark_on(s, &G.mark);
     if (rc) goto fail;
     return IMP_OK;
 fail:
     if (token) (void)stage_upload(token, nullptr, 0);
+    (void)hipStreamSynchronize(s);
     (void)lane_wait();                                              // nothing of this call may still be running when its buffers go back
     for (Prep& p : P) if (p.im) { image_delete(p.im); p.im = nullptr; }
     group_release(G);
@@ -437,6 +444,7 @@ done:
     group_release(G);
     return IMP_OK;
 fail:
+    if (G.stream) (void)hipStreamSynchronize(G.stream);
     (void)lane_wait();                                              // nothing of this group may still be running when its buffers go back
     for (int i = 0; i < count; i++) {
         if (P[(size_t)i].im) image_delete(P[(size_t)i].im);
@@ -524,7 +532,7 @@ int impgpu_batch_decode_jpeg_begin(const unsigned char* const* blobs, const size
     TraceRange tr("IMP_STEP_DECODE");
     IMP_FAULT_POINT(IMP_STEP_DECODE);
     impgpu_jpeg_batch* b = new impgpu_jpeg_batch();
-    const int rc = group_begin(b->G, blobs, sizes, count, 0);
+    const int rc = group_begin(b->G, blobs, sizes, count, 0, true);      // on the lane's side stream: what the thread enqueues before _finish overlaps it
     if (rc) { delete b; return rc; }
     *batch = b;
     return IMP_OK;

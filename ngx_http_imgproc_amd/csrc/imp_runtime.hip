@@ -49,6 +49,7 @@ struct Parked {             // a pool block waiting for an event of a foreign st
 
 struct Lane {
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;                 // a second stream of the lane, made on first use (lane_side_stream)
     std::mutex mu;                              // guards the pool: frees may come from other threads
     std::multimap<size_t, void*> free_list;     // bucket size -> buffer
     size_t free_bytes = 0;                      // sum of the free list (trimmed above pool_cap() when the lane is idle)
@@ -462,13 +463,26 @@ int lane_wait() {
 
 // A point of the lane's stream to come back to: lane_wait_mark sleeps until everything enqueued BEFORE the mark is done --
 // not what the thread enqueued after it (a JPEG group's verdicts are read while the next group is already on the device).
-int lane_mark(void** mark) {
+// A second stream for work that should overlap what the thread enqueues next on its lane stream (a JPEG batch begun ahead of
+// the answers of the batch before).  Pool memory used on it follows the foreign-stream rules: stream_join before the first
+// use, dev_free_on afterwards.
+hipStream_t lane_side_stream() {
+    Lane* L = lane();
+    if (!L) return nullptr;
+    if (!L->side && hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) != hipSuccess) { L->side = nullptr; (void)hipGetLastError(); }
+    return L->side;
+}
+
+int lane_mark(void** mark) { return lane_mark_on(nullptr, mark); }
+
+int lane_mark_on(hipStream_t s, void** mark) {
     Lane* L = lane();
     if (!L) return no_env();
+    if (!s) s = L->stream;
     hipEvent_t ev = nullptr;
     if (!L->mark_pool.empty()) { ev = L->mark_pool.back(); L->mark_pool.pop_back(); }
     else IMP_HIP(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
-    const hipError_t e = hipEventRecord(ev, L->stream);
+    const hipError_t e = hipEventRecord(ev, s);
     if (e != hipSuccess) { L->mark_pool.push_back(ev); set_error("hipEventRecord(mark)", e); return IMP_ERROR_DEVICE; }
     *mark = (void*)ev;
     return IMP_OK;
@@ -661,6 +675,7 @@ static void lane_destroy(Lane* L) {
     for (hipEvent_t ev : L->mark_pool) (void)hipEventDestroy(ev);
     if (L->join_ev) (void)hipEventDestroy(L->join_ev);
     if (L->sync_ev) (void)hipEventDestroy(L->sync_ev);
+    if (L->side) { (void)hipStreamSynchronize(L->side); (void)hipStreamDestroy(L->side); }
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
 }
