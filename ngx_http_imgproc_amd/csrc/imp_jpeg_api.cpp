@@ -488,7 +488,9 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         return rc;
     }
     int rcb = IMP_OK;
-    if (first < count) rcb = group_begin(B, blobs + first, sizes + first, count - first, 0);
+    // (both halves on the lane's stream: the second on the side stream was measured on one box, two repetitions -- the same at 1, 2
+    // and 8 threads, 7 % slower at 4)
+    if (first < count) rcb = group_begin(B, blobs + first, sizes + first, count - first, 0);    // on the side stream: its kernels overlap the first half's (a launch of 32 files does not fill the device)
     rc = group_finish(A, images, codes);
     if (first < count) {
         if (!rcb) rcb = group_finish(B, images + first, codes + first);
