@@ -89,7 +89,12 @@ typedef struct {
 
 /* ---- lifecycle: OnEnvStart / OnEnvDestroy (bridge.h:1-2, bridge.c:10-16; called from
  *      module.c:100-107 once per worker process, after fork) ---- */
-/* device < 0: take $IMPGPU_DEVICE, else $LOCAL_RANK, else 0. */
+/* device < 0: take $IMPGPU_DEVICE, else $LOCAL_RANK, else 0.
+ * impgpu_env_start also registers impgpu_env_destroy with atexit() (once per process): a worker that leaves through
+ * exit() with a live env gives its streams, events, pinned buffers and pool blocks back BEFORE the HIP runtime's own exit
+ * handlers run, not during them.  That exit-time teardown waits at most $IMPGPU_EXIT_WAIT_MS (default 2000) for the
+ * device to go idle and otherwise leaves everything to the driver; a fork()ed copy of a process that started the env
+ * does nothing at exit.  impgpu_env_destroy is idempotent. */
 int         impgpu_env_start(int device);
 void        impgpu_env_destroy(void);
 int         impgpu_env_device(void);            /* -1 when no env */

@@ -115,6 +115,31 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+BROKER = os.path.join(HERE, "impgpu_broker")
+CLIENT_LIB = os.path.join(HERE, "libimpgpu_client.so")
+INCLUDE = os.path.join(HERE, "..", "include")
+CLIENT_SRC = os.path.join(HERE, "..", "glue", "imp_gpu_client.c")
+
+
+def build_broker(force=False, verbose=False):
+    """The one-process-per-GPU broker (host C++ over the C ABI, links libimpgpu.so next to it) and the workers' side of its
+    protocol (plain C, no HIP) as a shared object for the tests -- in an nginx build the same file is compiled into the module."""
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    hdrs = [os.path.join(INCLUDE, "impgpu_broker.h"), os.path.join(INCLUDE, "impgpu.h")]
+    if force or _stale(CLIENT_LIB, [CLIENT_SRC] + hdrs):
+        run(["gcc", "-std=gnu99", "-O2", "-Wall", "-Wextra", "-fPIC", "-shared", "-I", INCLUDE, CLIENT_SRC, "-o", CLIENT_LIB, "-lrt"])
+    src = os.path.join(CSRC, "imp_broker.cpp")
+    if force or _stale(BROKER, [src, LIB] + hdrs):
+        run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", INCLUDE, src, "-o", BROKER, "-L", HERE, "-limpgpu", "-pthread", "-lrt",
+             "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"])
+    return BROKER
+
+
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv, verbose=True)
+    build_broker(force="--force" in sys.argv, verbose=True)
     print(LIB)

@@ -18,6 +18,8 @@
 // the host copy of request N+1 overlaps the H2D DMA of request N.
 #include <dlfcn.h>
 #include <sched.h>
+#include <time.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <atomic>
 #include <cctype>
@@ -720,6 +722,53 @@ using namespace imp;
 
 extern "C" {
 
+// A process that ends with a live env (a worker told to quit between requests, a script that never calls
+// impgpu_env_destroy) used to leave the lanes' streams, blocking-sync events, pinned rings and pool blocks alive into the
+// HIP runtime's own exit handlers -- and, when another library shares the runtime (torch), into theirs.  impgpu_env_start
+// registers this once: handlers run in reverse order of registration, so it runs BEFORE the handlers of everything that
+// was initialised before it (the HIP runtime: hipGetDeviceCount below comes first) and after those of whatever came later.
+// The wait is bounded: a device that no longer answers must not keep a worker from exiting -- then nothing is touched and
+// the env is left to the kernel (IMPGPU_EXIT_WAIT_MS, default 2000).  A forked child of a process that started the env
+// (same memory, another pid) must not talk to the parent's device context at all.
+static pid_t g_env_pid = 0;
+
+static void env_atexit() {
+    if (g_env_pid != getpid()) return;
+    {
+        std::lock_guard<std::mutex> lk(g_env_mu);
+        Env* E = g_env.load();
+        if (!E) return;
+        const char* s = std::getenv("IMPGPU_EXIT_WAIT_MS");
+        const long budget_ms = s ? std::atol(s) : 2000;
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        bool idle = false;
+        for (;;) {
+            idle = true;
+            {
+                std::lock_guard<std::mutex> lk2(E->mu);
+                for (Lane* L : E->lanes) {
+                    if (L->stream && hipStreamQuery(L->stream) == hipErrorNotReady) idle = false;
+                    if (L->side && hipStreamQuery(L->side) == hipErrorNotReady) idle = false;
+                }
+            }
+            (void)hipGetLastError();
+            if (idle) break;
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_nsec - t0.tv_nsec) / 1000000 > budget_ms) break;
+            timespec nap{0, 200000};
+            nanosleep(&nap, nullptr);
+        }
+        if (!idle) {                            // leak on purpose: no further HIP call from this library
+            g_env.store(nullptr);
+            std::fprintf(stderr, "impgpu: device still busy at exit after %ld ms; env left to the driver\n", budget_ms);
+            return;
+        }
+    }
+    impgpu_env_destroy();
+}
+
 int impgpu_env_start(int device) {
     std::lock_guard<std::mutex> lk(g_env_mu);
     if (g_env.load()) return IMP_OK;
@@ -743,6 +792,9 @@ int impgpu_env_start(int device) {
     E->generation = ++g_generation;
     numa_probe(E);
     g_env = E;
+    g_env_pid = getpid();
+    static std::once_flag exit_hook;
+    std::call_once(exit_hook, [] { (void)std::atexit(env_atexit); });
     if (!lane()) {  // the calling thread's lane: fails loudly here rather than at the first operator
         g_env = nullptr;
         delete E;

@@ -241,3 +241,18 @@ def test_request_stream_from_c_threads(tmp_path, quality, ahead):
     assert r["requests"] == requests and r["threads"] == 3 and r["batch"] == 8 and r["quality"] == quality and r["ahead"] == ahead
     assert r["file_bytes"] == sum(len(blobs[i % len(blobs)]) for i in range(requests))
     assert r["answer_bytes"] == sum(per_file[i % len(blobs)] for i in range(requests))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["return", "exit", "busy"])
+def test_a_worker_may_exit_with_its_env_alive(how):
+    """A C worker that leaves without impgpu_env_destroy -- lanes of two threads, a frame never released, in `busy` even
+    work still running on the device: impgpu_env_start's atexit hook returns everything before the HIP runtime's own exit
+    handlers run.  The process must end by itself with status 0 (round 4: a child with a live env at exit once never came
+    back; the library issued no HIP call at exit then)."""
+    build()
+    exe = os.path.join(ROOT, "tests", "c", "_build", "exit_harness")
+    p = subprocess.run([exe, how], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr[-800:])
+    assert p.stdout.strip().splitlines()[-1] == "leaving"
+    assert "still busy at exit" not in p.stderr
