@@ -119,84 +119,108 @@ __global__ __launch_bounds__(SB) void k_jpeg_walks(const JpegJob* __restrict__ j
 // that walk are latency-bound and alone in their waves, so the kernel is as long as one walk however many there are.
 __global__ __launch_bounds__(SB) void k_jpeg_mend(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
     __shared__ JpegHuffTabs L;
+    __shared__ uint32_t s_count;
+    __shared__ uint16_t s_items[SB];                                // the lanes (k * CPW + j) whose candidate needs a repair walk
     const int t = threadIdx.x;
     const JpegMapEntry me = block_map[blockIdx.x];
     const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
     const JpegFrame& F = J.F;
     for (int i = t; i < (int)(sizeof(JpegHuffTabs) / 4); i += SB) ((uint32_t*)&L)[i] = ((const uint32_t*)J.tabs)[i];
+    if (t == 0) s_count = 0;
     const uint32_t CHUNK_BITS = F.chunk_bits, OVERLAP = F.overlap_bits;
     const uint32_t B = (uint32_t)F.bpm, CPW = (uint32_t)SB / B;
     const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
     const uint32_t g0 = b * CPW;
     const uint32_t nlive = min(CPW, F.nchunks - g0);
-    const uint32_t k = (uint32_t)t / CPW, j = (uint32_t)t - k * CPW;
-    const uint32_t g = g0 + j;
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
     const GlobalWords gwords = (GlobalWords)(uintptr_t)J.words;
     auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };      // (a plain load: the lane comes back to the line for its next word, which a non-temporal load does not keep -- 313 against 465 us per 64 files in k_jpeg_walks)
+    const size_t N = F.nchunks;
     __syncthreads();
-    if (k >= B || j >= nlive) return;
-    const uint32_t seg = J.chunk_seg[g], first = J.seg_first_chunk[seg];
-    const uint32_t seg_start = first * CHUNK_BITS, seg_end = seg_start + J.seg_bits[seg];
-    const uint32_t start = g * CHUNK_BITS, limit = min(start + CHUNK_BITS, seg_end);
-    const size_t N = F.nchunks, at = (size_t)k * N + g;
-    uint32_t nib = JPEG_MAP_FAIL | 64u;                             // bit 6: the chunk's one walk started with its interval -- nothing to select
-    if (start - seg_start > OVERLAP) {
-        nib = JPEG_MAP_FAIL;
-        const uint64_t E = J.cand_out[at - 1];
-        int twin = -1;
-        for (uint32_t k2 = 0; k2 < k && twin < 0; k2++) if (J.cand_out[(size_t)k2 * N + g - 1] == E) twin = (int)k2;
-        if (E == JPEG_STATE_NONE) {
-        } else if (twin >= 0) nib = 32u | (uint32_t)twin;           // bit 5: the answer is candidate `twin`'s
-        else {
-            for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_in[(size_t)k1 * N + g] == E) nib = k1;
-            if (nib == JPEG_MAP_FAIL) {
-                const JpegSpan sp = jpeg_span_walk(L, word, E, start, limit, seg_end, F);
-                for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_out[(size_t)k1 * N + g] == sp.out) nib = k1;
-                J.rep_out[at] = sp.out;
-                J.rep_n[at] = sp.n;
-                atomicAdd(&J.header[2], 1u);
-                if (nib == JPEG_MAP_FAIL) {
-                    // It has joined none of the chunk's walks: they are all out of step here, and those of the next chunk tend
-                    // to be too.  Decode on, chunk by chunk, until the state IS one of a chunk's candidates, and leave what was
-                    // found on the way -- every chunk's entry state and slot count -- in a record k_jpeg_select can follow
-                    // without decoding anything (it used to: one lane, a chunk at a time, its successors waiting).
-                    const uint32_t r = atomicAdd(J.ext_count, 1u);
-                    uint32_t* R = r < J.ext_cap ? J.ext + (size_t)r * JPEG_EXT_WORDS : nullptr;
-                    J.ext_idx[at] = R ? r : 0xffffffffu;
-                    if (R) {
-                        uint64_t S = sp.out;
-                        uint32_t count = 0, joined = 15;
-                        for (uint32_t m = 0; m < (uint32_t)JPEG_EXT_STEPS; m++) {
-                            const uint32_t gc = g + 1 + m;
-                            if (gc >= F.nchunks) { joined = 14; break; }
-                            const uint32_t seg2 = J.chunk_seg[gc], first2 = J.seg_first_chunk[seg2];
-                            const uint32_t sstart2 = first2 * CHUNK_BITS, send2 = sstart2 + J.seg_bits[seg2];
-                            const uint32_t start2 = gc * CHUNK_BITS, limit2 = min(start2 + CHUNK_BITS, send2);
-                            if (start2 - sstart2 <= OVERLAP) { joined = 14; break; }          // a chunk that selects nothing: the chain ends here
-                            uint32_t k1 = JPEG_MAP_FAIL, nn = 0;
-                            for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && J.cand_in[(size_t)i * N + gc] == S) { k1 = i; nn = J.cand_n[(size_t)i * N + gc]; }
-                            uint64_t out = S;
-                            if (k1 == JPEG_MAP_FAIL) {
-                                const JpegSpan s2 = jpeg_span_walk(L, word, S, start2, limit2, send2, F);
-                                nn = s2.n;
-                                out = s2.out;
-                                for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && J.cand_out[(size_t)i * N + gc] == out) k1 = i;
-                            }
-                            R[4 + 3 * count] = (uint32_t)S; R[5 + 3 * count] = (uint32_t)(S >> 32); R[6 + 3 * count] = nn;
-                            count++;
-                            if (k1 != JPEG_MAP_FAIL) { joined = k1; break; }
-                            S = out;
-                        }
-                        R[0] = g; R[1] = k; R[2] = count; R[3] = joined;
-                        R[4 + 3 * JPEG_EXT_STEPS] = (uint32_t)S; R[5 + 3 * JPEG_EXT_STEPS] = (uint32_t)(S >> 32);   // (not joined: where it stands)
-                    }
+    // ---- A. every (chunk, predecessor candidate): answered by a compare, or put on the workgroup's list of walks.  (Round 4
+    // walked right here: one candidate in ten needs a walk, so every wave ran the whole walk loop with 6 of its 64 lanes
+    // active -- profiles/r04_jpeg_sq_counters.txt -- and the kernel was bound by the instructions all those waves issued.)
+    {
+        const uint32_t k = (uint32_t)t / CPW, j = (uint32_t)t - k * CPW;
+        if (k < B && j < nlive) {
+            const uint32_t g = g0 + j;
+            const uint32_t seg = J.chunk_seg[g], first = J.seg_first_chunk[seg];
+            const uint32_t seg_start = first * CHUNK_BITS, start = g * CHUNK_BITS;
+            const size_t at = (size_t)k * N + g;
+            uint32_t nib = JPEG_MAP_FAIL | 64u;                     // bit 6: the chunk's one walk started with its interval -- nothing to select
+            bool walk = false;
+            if (start - seg_start > OVERLAP) {
+                nib = JPEG_MAP_FAIL;
+                const uint64_t E = J.cand_out[at - 1];
+                int twin = -1;
+                for (uint32_t k2 = 0; k2 < k && twin < 0; k2++) if (J.cand_out[(size_t)k2 * N + g - 1] == E) twin = (int)k2;
+                if (E == JPEG_STATE_NONE) {
+                } else if (twin >= 0) nib = 32u | (uint32_t)twin;   // bit 5: the answer is candidate `twin`'s
+                else {
+                    for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_in[(size_t)k1 * N + g] == E) nib = k1;
+                    walk = nib == JPEG_MAP_FAIL;
                 }
-                nib |= 16u;                                         // bit 4: this answer comes from a repair walk
             }
+            if (walk) s_items[atomicAdd(&s_count, 1u)] = (uint16_t)t;
+            else J.cand_nib[at] = (uint8_t)nib;
         }
     }
-    J.cand_nib[at] = (uint8_t)nib;
+    __syncthreads();
+    // ---- B. the walks, packed: lane i takes the i-th item, so the lanes that walk sit side by side in as few waves as it takes
+    const uint32_t count = s_count;
+    for (uint32_t it = (uint32_t)t; it < count; it += SB) {
+        const uint32_t t2 = s_items[it];
+        const uint32_t k = t2 / CPW, j = t2 - k * CPW;
+        const uint32_t g = g0 + j;
+        const uint32_t seg = J.chunk_seg[g], first = J.seg_first_chunk[seg];
+        const uint32_t seg_start = first * CHUNK_BITS, seg_end = seg_start + J.seg_bits[seg];
+        const uint32_t start = g * CHUNK_BITS, limit = min(start + CHUNK_BITS, seg_end);
+        const size_t at = (size_t)k * N + g;
+        const uint64_t E = J.cand_out[at - 1];
+        uint32_t nib = JPEG_MAP_FAIL;
+        const JpegSpan sp = jpeg_span_walk(L, word, E, start, limit, seg_end, F);
+        for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_out[(size_t)k1 * N + g] == sp.out) nib = k1;
+        J.rep_out[at] = sp.out;
+        J.rep_n[at] = sp.n;
+        atomicAdd(&J.header[2], 1u);
+        if (nib == JPEG_MAP_FAIL) {
+            // It has joined none of the chunk's walks: they are all out of step here, and those of the next chunk tend
+            // to be too.  Decode on, chunk by chunk, until the state IS one of a chunk's candidates, and leave what was
+            // found on the way -- every chunk's entry state and slot count -- in a record k_jpeg_select can follow
+            // without decoding anything (it used to: one lane, a chunk at a time, its successors waiting).
+            const uint32_t r = atomicAdd(J.ext_count, 1u);
+            uint32_t* R = r < J.ext_cap ? J.ext + (size_t)r * JPEG_EXT_WORDS : nullptr;
+            J.ext_idx[at] = R ? r : 0xffffffffu;
+            if (R) {
+                uint64_t S = sp.out;
+                uint32_t cnt = 0, joined = 15;
+                for (uint32_t m = 0; m < (uint32_t)JPEG_EXT_STEPS; m++) {
+                    const uint32_t gc = g + 1 + m;
+                    if (gc >= F.nchunks) { joined = 14; break; }
+                    const uint32_t seg2 = J.chunk_seg[gc], first2 = J.seg_first_chunk[seg2];
+                    const uint32_t sstart2 = first2 * CHUNK_BITS, send2 = sstart2 + J.seg_bits[seg2];
+                    const uint32_t start2 = gc * CHUNK_BITS, limit2 = min(start2 + CHUNK_BITS, send2);
+                    if (start2 - sstart2 <= OVERLAP) { joined = 14; break; }          // a chunk that selects nothing: the chain ends here
+                    uint32_t k1 = JPEG_MAP_FAIL, nn = 0;
+                    for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && J.cand_in[(size_t)i * N + gc] == S) { k1 = i; nn = J.cand_n[(size_t)i * N + gc]; }
+                    uint64_t out = S;
+                    if (k1 == JPEG_MAP_FAIL) {
+                        const JpegSpan s2 = jpeg_span_walk(L, word, S, start2, limit2, send2, F);
+                        nn = s2.n;
+                        out = s2.out;
+                        for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && J.cand_out[(size_t)i * N + gc] == out) k1 = i;
+                    }
+                    R[4 + 3 * cnt] = (uint32_t)S; R[5 + 3 * cnt] = (uint32_t)(S >> 32); R[6 + 3 * cnt] = nn;
+                    cnt++;
+                    if (k1 != JPEG_MAP_FAIL) { joined = k1; break; }
+                    S = out;
+                }
+                R[0] = g; R[1] = k; R[2] = cnt; R[3] = joined;
+                R[4 + 3 * JPEG_EXT_STEPS] = (uint32_t)S; R[5 + 3 * JPEG_EXT_STEPS] = (uint32_t)(S >> 32);   // (not joined: where it stands)
+            }
+        }
+        J.cand_nib[at] = (uint8_t)(nib | 16u);                      // bit 4: this answer comes from a repair walk
+    }
 }
 
 __global__ __launch_bounds__(SB) void k_jpeg_select(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map, uint32_t* __restrict__ launch_ticket) {
@@ -494,11 +518,14 @@ __global__ __launch_bounds__(HB) void k_jpeg_write(const JpegJob* __restrict__ j
     __shared__ uint8_t s_head[HB];                                  // 1 = an interval starts in or before this chunk (inside the workgroup)
     __shared__ uint32_t s_carry;
     __shared__ int s_tot[4];
-    __shared__ __attribute__((aligned(16))) int16_t s_stage[HB][64];      // per lane: the block it is decoding
+    // per lane: the block it is decoding.  144 bytes apart, not 128: with a power-of-two pitch every lane's coefficient k sits
+    // in one of two banks and a wave's scattered 2-byte stores queue up behind each other (31 % of the LDS-active cycles were
+    // bank conflicts, profiles/r04_jpeg_sq_counters.txt); 36 words apart the same k of sixteen lanes falls into sixteen banks
+    __shared__ __attribute__((aligned(16))) int16_t s_stage[HB][72];
     __shared__ uint32_t s_list[HB / 64][128];                       // per wave: its complete blocks {where in LDS, where in the planes}
     const int t = threadIdx.x;
     const uint32_t clock0 = (uint32_t)wall_clock64();
-    for (int i = t; i < HB * 64 / 8; i += HB) ((uint4*)&s_stage[0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = t; i < HB * 72 / 8; i += HB) ((uint4*)&s_stage[0][0])[i] = make_uint4(0, 0, 0, 0);
     const JpegMapEntry me = block_map[blockIdx.x];
     const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
     const JpegFrame& F = J.F;
@@ -569,7 +596,11 @@ __global__ __launch_bounds__(HB) void k_jpeg_write(const JpegJob* __restrict__ j
         if (overrun) atomicOr(&A.header[1], JPEG_ST_OVERRUN);
         const uint32_t budget = closes ? (slots_here >= base_n ? slots_here - base_n : 0u) : 0xffffffffu;
         // (every lane of the wave takes part: finished blocks are written out by the lanes together)
-        e = jpeg_write_chunk(L, K, word, entry, limit, seg_end, F, &W, budget, live && !overrun);
+#if defined(__HIP_DEVICE_COMPILE__)
+        e = jpeg_write_chunk_dev(L, K, word, entry, limit, seg_end, F, &W, budget, live && !overrun);
+#else
+        e = jpeg_write_chunk(L, K, word, entry, limit, seg_end, F, &W, budget, live && !overrun);    // (the host pass only parses the kernel)
+#endif
         if (live && !overrun) {
             if (closes) {
                 const uint32_t pe = (uint32_t)e.exit, fle = (uint32_t)(e.exit >> 48);

@@ -376,6 +376,148 @@ IMP_HD inline JpegDecoded jpeg_write_chunk(const Tabs& L, const JpegBlockTabs& K
     return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same walk as the kernel runs it (round 5).  jpeg_write_chunk above spent 273 instructions per symbol on the device
+// (profiles/r04_jpeg_sq_counters.txt: 101 k per wave of 2048-bit chunks) against 26 in jpeg_span_walk, because with 64
+// lanes in a wave SOME lane ends a block in nine iterations out of ten: the block bookkeeping (next block of the MCU, MCU
+// coordinates, the block's address: table reads and multiplies) and the cooperative flush (a ballot, a list in LDS, a
+// store loop) ran for one or two blocks at a time in almost every iteration.  Here a lane that ends a block STEPS ASIDE
+// (`pend`) and the symbol loop goes on with the others until an eighth of the wave's working lanes (at most eight: one
+// full store instruction) is waiting, or nobody is left to decode; then the waiting lanes do their bookkeeping together
+// and their blocks leave in one flush.  A waiting lane loses a couple of iterations per block of about 27; the wave's
+// instruction count per symbol falls to what the decode itself needs.  States, counts, flags and the bytes written are
+// those of jpeg_write_chunk (DC terms relative to the chunk's entry: W->dc0 is not read).
+template <class Tabs, class WordFn>
+__device__ inline JpegDecoded jpeg_write_chunk_dev(const Tabs& L, const JpegBlockTabs& K, WordFn word, uint64_t entry, uint32_t limit, uint32_t seg_end,
+                                                   const JpegFrame& F, const JpegWriteCtx* W, uint32_t max_slots, bool active) {
+    JpegDecoded r;
+    r.exit = entry;
+    uint32_t p = (uint32_t)entry;
+    uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
+    bool ok = active && (uint32_t)(entry >> 48) == 0 && p < limit;
+    p = ok ? p : 0u;
+    c = ok ? c : 0u;
+    const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2;
+    // per block of the MCU: its component (two bits each); four bits each: the table of its DC symbol (0 / 1) and, two bits
+    // up, of its AC symbols (2 / 3)
+    uint32_t comp_of = 0, tabsel = 0;
+    for (uint32_t k = 0; k < 6; k++) {
+        const uint32_t ci = k < nluma ? 0u : (k - nluma + 1 < 3 ? k - nluma + 1 : 2u);
+        const uint32_t dct = (uint32_t)(ci == 0 ? F.dctab[0] : ci == 1 ? F.dctab[1] : F.dctab[2]);
+        const uint32_t act = 2u + (uint32_t)(ci == 0 ? F.actab[0] : ci == 1 ? F.actab[1] : F.actab[2]);
+        comp_of |= ci << (2 * k);
+        tabsel |= (dct | (act << 2)) << (4 * k);
+    }
+    JpegBitReader1<WordFn> bits(word);
+    bits.start(p);
+    uint32_t fl = 0, n = 0, damaged = 0, ndc = 0;
+    int dcs0 = 0, dcs1 = 0, dcs2 = 0;
+    uint32_t mx = 0, my = 0, blk = 0;
+    bool blk_ok = false;
+    if (ok) {
+        const uint32_t gb = W->slot0 >> 6, mcu = gb / bpm;
+        my = mcu / (uint32_t)F.mcux;
+        mx = mcu - my * (uint32_t)F.mcux;
+        if (gb - mcu * bpm != c || (W->slot0 & 63) != z) { jpeg_flag(W->status, JPEG_ST_BAD_COUNT); ok = false; }
+        blk_ok = my < (uint32_t)F.mcuy;
+        blk = K.blk_base[c] + mx * K.blk_dx[c] + my * K.blk_dy[c];
+    }
+    JpegLdsShort stage = (JpegLdsShort)(uintptr_t)W->stage;
+    // The lane's flags in ONE register (as separate bools the compiler keeps each as a wave-wide mask in scalar registers and
+    // spends three scalar instructions on every update, a dozen per iteration just carrying them round the loop):
+    // GO = more symbols to decode; PEND = its block has ended, it waits for the next flush; OWN = the block being decoded
+    // began in this chunk; DIRTY = the block buffer holds coefficients not yet written out; BLKOK = the block lies inside the frame
+    constexpr uint32_t GO = 1, PEND = 2, OWN = 4, DIRTY = 8, BLKOK = 16;
+    uint32_t st = ((ok && n < max_slots) ? GO : 0u) | (blk_ok ? BLKOK : 0u);
+    for (;;) {
+        const uint64_t working = __ballot((st & (GO | PEND)) != 0);
+        if (working == 0) break;
+        const uint32_t eighth = (uint32_t)__popcll(working) >> 3;
+        const uint32_t enough = eighth < 1 ? 1u : eighth > 8 ? 8u : eighth;
+        for (;;) {
+            const bool act = (st & (GO | PEND)) == GO;
+            if (!__any(act) || (uint32_t)__popcll(__ballot((st & PEND) != 0)) >= enough) break;
+            if (act) {
+                const bool isdc = z == 0;
+                const uint32_t tab = (tabsel >> (4 * c + (isdc ? 0u : 2u))) & 3;
+                const uint32_t win = bits.window(), peek = win >> 16;
+                uint32_t e = jpeg_tab_first_raw(L, tab, peek >> (16 - JPEG_LOOKBITS));
+                if ((e & 31) == 0) {                                // a code longer than the table's index
+                    bool none;
+                    if (e & 0x8000u) {                              // ... in the second level, indexed by the bits that follow
+                        const uint32_t nb = (e >> 12) & 7, off = ((e >> 5) & 127) << 1;
+                        e = jpeg_tab_second_raw(L, tab, off + ((win >> (32 - JPEG_LOOKBITS - nb)) & ((1u << nb) - 1)));
+                        none = e == 0;
+                    } else {                                        // ... or (a table with too many of them) by the canonical limits
+                        uint32_t len = JPEG_LOOKBITS + 1;
+                        for (int l = JPEG_LOOKBITS + 1; l < 16; l++) len += peek >= jpeg_tab_limit(L, tab, l) ? 1u : 0u;
+                        none = peek >= jpeg_tab_limit(L, tab, 16);
+                        const uint32_t sym = jpeg_tab_val(L, tab, (uint32_t)(jpeg_tab_offs(L, tab, len) + (int)(peek >> (16 - len))) & 255);
+                        e = none ? 0u : jpeg_lut_entry(len, sym, isdc);
+                    }
+                    fl = none ? ((seg_end - p < 16) ? JPEG_FL_END : JPEG_FL_INVALID) : fl;
+                }
+                const uint32_t len = e & 31, size = (e >> 5) & 15, run = (e >> 9) & 15, eob = (e >> 13) & 1;
+                const uint32_t total = len + size;
+                if (fl == 0 && p + total > seg_end) fl = JPEG_FL_END;   // the interval's padding, not a symbol
+                if (fl == 0) {
+                    const uint32_t vb = win << len;
+                    const int v = (int)((vb >> 1) >> (31 - size)) + ((int)(~vb) >> 31 & (1 - (1 << size)));
+                    const bool counted = p < limit;
+                    p += total;
+                    bits.take(total);
+                    uint32_t adv = eob ? 64 - z : run + 1;
+                    const bool over = z + adv > 64;                 // a run that leaves the block: damaged
+                    adv = over ? 64 - z : adv;
+                    damaged |= over ? 1u : 0u;
+                    // DC and AC symbols take the same few instructions: a DC symbol has z = 0 and run = 0, so its place in the
+                    // block is natural[0] = 0 by itself; its value is the running sum of its component, and it makes the block
+                    // this lane's own
+                    const uint32_t ci = (comp_of >> (2 * c)) & 3;
+                    const int dsum = ci == 0 ? dcs0 : ci == 1 ? dcs1 : dcs2;
+                    st |= isdc ? (OWN | ((st & BLKOK) ? DIRTY : 0u)) : 0u;
+                    const bool store = (st & BLKOK) && (isdc || (size && !over && (st & OWN)));
+                    if (store) stage[K.natural[z + run]] = (int16_t)(v + (isdc ? dsum : 0));
+                    ndc += isdc ? 1u : 0u;
+                    dcs0 += (isdc && ci == 0) ? v : 0;
+                    dcs1 += (isdc && ci == 1) ? v : 0;
+                    dcs2 += (isdc && ci == 2) ? v : 0;
+                    z += adv;
+                    n += counted ? adv : 0u;
+                    st |= z >= 64 ? PEND : 0u;
+                }
+                // more to do?  (a block that began here is decoded to its end, past the chunk's)
+                const bool more = fl == 0 && n < max_slots && (p < limit || (st & (OWN | PEND)) == OWN);
+                st = more ? st : st & ~GO;
+            }
+        }
+        // the lanes whose block has ended: hand the block over, move on to the next block of the scan
+        bool ready = false;
+        uint32_t ready_at = 0;
+        if (st & PEND) {
+            ready = (st & DIRTY) != 0;
+            ready_at = blk;
+            z = 0;
+            c++;
+            if (c == bpm) { mx++; if (mx == (uint32_t)F.mcux) { mx = 0; my++; } }
+            c = c == bpm ? 0 : c;
+            st = (st & ~(PEND | DIRTY | BLKOK)) | (my < (uint32_t)F.mcuy ? BLKOK : 0u);
+            blk = K.blk_base[c] + mx * K.blk_dx[c] + my * K.blk_dy[c];
+        }
+        jpeg_flush_blocks(W, ready, ready_at);
+    }
+    jpeg_flush_blocks(W, (st & DIRTY) != 0, blk);                   // (a block cut short by an ending: what there is of it)
+    if (damaged || (fl & JPEG_FL_INVALID)) jpeg_flag(W->status, JPEG_ST_BAD_CODE);
+    if (ok) r.exit = jpeg_pack_state(p, c, z, fl);
+    r.n = n;
+    r.ndc = ndc;
+    r.dc[0] = dcs0;
+    r.dc[1] = dcs1;
+    r.dc[2] = dcs2;
+    return r;
+}
+#endif
+
 // The write walk (jpeg_write_chunk with dc0 = 0) leaves every DC term relative to its chunk's entry; this adds the
 // predictors at the entry (`base`, per component) to the `ndc` blocks that begin in the chunk.  Same block walk as the
 // decoder's: MCU coordinates carried along, a block's address is base + mx*dx + my*dy.

@@ -131,7 +131,8 @@ def main():
         finally:
             if broker:
                 err = stop_broker(broker)
-                print("# " + err.strip().splitlines()[-1] if err.strip() else "# broker gone", file=sys.stderr, flush=True)
+                for ln in err.strip().splitlines()[-2:]:
+                    print("# " + ln, flush=True)
 
 
 if __name__ == "__main__":
