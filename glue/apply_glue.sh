@@ -20,7 +20,7 @@ check config     c05ab98b00581607a549d347b8fb5a3927f349cec2a000959b8bc77dd2c54ae
 check advancedio.c a33b9fe31ad7f0f6a888c6c182fc8ee9959ddfcf82455776c44ea66f74af78be
 
 mkdir -p "$T/glue"
-cp "$HERE/imp_gpu_bridge.c" "$HERE/imp_gpu_bridge.h" "$T/glue/"
+cp "$HERE/imp_gpu_bridge.c" "$HERE/imp_gpu_bridge.h" "$HERE/imp_gpu_client.c" "$T/glue/"
 cp "$HERE/config" "$T/config"                                   # config:1-5 -> glue sources + -limpgpu
 
 B="$T/bridge.c"

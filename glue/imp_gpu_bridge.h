@@ -26,12 +26,30 @@
 #define IMP_GPU_BRIDGE_H
 
 #include <impgpu.h>
+#include <impgpu_broker.h>
 
 /* The device-resident counterpart of the request's Album: ONE handle for all of its frames (every frame of an album has
  * the canvas' geometry, advancedio.c:187, so they share a block and each operator is one launch for the whole animation;
- * impgpu_album_upload in impgpu.h). */
+ * impgpu_album_upload in impgpu.h).
+ *
+ * BROKER MODE (round 5; $IMPGPU_BROKER names the segment of an `impgpu_broker`, include/impgpu_broker.h): the worker never
+ * touches HIP.  ImpGpuDecode and ImpGpuOperators only NOTE the file and the job; the request's exit -- ImpGpuEncodeJpeg,
+ * ImpGpuDownload, ImpGpuInfo, ImpGpuASCII -- knows what kind of answer is wanted and makes the ONE round trip that
+ * carries {file, job, config} to the process that owns the GPU, where it rides a launch with whatever other workers
+ * have queued.  A failure comes back with the answer and names its own step (JobResult.Step through `Step`).  Requests
+ * whose frames come from FreeImage (IMP_FEATURE_ADVANCED_IO: GIF albums, LoadSingle) still need a device in the worker:
+ * their first occurrence starts an in-process env (ImpGpuEnvStart's other branch), everything else goes to the broker. */
 typedef struct {
     impgpu_image* Handle;
+    /* ---- broker mode only (zero otherwise) ---- */
+    const u_char* Blob;                 /* the file ImpGpuDecode was shown: sent as it is */
+    size_t        BlobSize;
+    int           Deferred;             /* the operators have been noted, nothing has run yet */
+    impgpu_job    Job;                  /* (its strings live in the request pool, like RunJob's own) */
+    impgpu_config Cfg;
+    int           WatermarkId;
+    int*          Step;                 /* &answer->Step */
+    Album*        Source;               /* the request's album (frames decoded on the host go as pixels) */
 } ImpGpuAlbum;
 
 /* once per worker process, after fork (module.c:100-107).  worker = ngx_worker (nginx >= 1.9.1) or ngx_process_slot:

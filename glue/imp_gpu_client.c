@@ -230,7 +230,7 @@ static int register_watermark(impgpu_client* c, impc_watermark* m) {
     memcpy(c->data, m->pixels, bytes);
     s->in_kind = IMPB_IN_WATERMARK; s->out_kind = IMPB_OUT_INFO;
     s->in_bytes = bytes; s->in_w = m->w; s->in_h = m->h; s->in_c = m->c; s->in_step = m->step;
-    s->filter_count = 0; s->crop_at = s->gravity_at = s->resize_at = -1; s->watermark_id = 0;
+    s->filter_count = 0; s->crop_at = s->gravity_at = s->resize_at = s->ascii_at = -1; s->watermark_id = 0;
     const unsigned epoch = c->hdr->f.epoch;
     int rc = roundtrip(c);
     if (rc != IMP_OK) return rc;
@@ -261,7 +261,7 @@ int impgpu_client_run(impgpu_client* c, const impgpu_client_request* r, impgpu_c
     memset(a, 0, sizeof *a);
     a->error = "";
     if (r->in_kind != IMPB_IN_FILE && r->in_kind != IMPB_IN_FRAME) return IMP_ERROR_INVALID_ARGS;
-    if (r->out_kind < IMPB_OUT_JPEG || r->out_kind > IMPB_OUT_INFO) return IMP_ERROR_INVALID_ARGS;
+    if (r->out_kind < IMPB_OUT_JPEG || r->out_kind > IMPB_OUT_ASCII) return IMP_ERROR_INVALID_ARGS;
     if (r->watermark_id < 0 || r->watermark_id > c->nmarks) return IMP_ERROR_INVALID_ARGS;
     int rc = ready(c);
     if (rc != IMP_OK) return rc;
@@ -282,8 +282,12 @@ int impgpu_client_run(impgpu_client* c, const impgpu_client_request* r, impgpu_c
     s->in_w = r->width; s->in_h = r->height; s->in_c = r->channels; s->in_step = r->step;
     s->quality = r->quality;
     size_t at = 0;
-    s->crop_at = s->gravity_at = s->resize_at = -1;
+    s->crop_at = s->gravity_at = s->resize_at = s->ascii_at = -1;
     s->simple = s->need_flatten = s->filter_count = 0;
+    if (r->out_kind == IMPB_OUT_ASCII && r->ascii_args) {
+        s->ascii_at = put_text(s, &at, r->ascii_args);
+        if (s->ascii_at == -2) { snprintf(t_err, sizeof t_err, "request text longer than %d bytes", IMPB_TEXT_BYTES); return IMP_ERROR_INVALID_ARGS; }
+    }
     if (r->job) {
         const impgpu_job* j = r->job;
         if (j->filter_count < 0) return IMP_ERROR_INVALID_ARGS;

@@ -160,12 +160,14 @@ int   impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* 
 /* The same in two halves, for a caller that has more to do than wait (round 4): _begin parses, copies the scans into pinned
  * memory and enqueues the whole decode -- it does NOT wait; _finish sleeps until THAT batch is done (not whatever the thread
  * enqueued after it), reads the verdicts and fills images[] / codes[] as impgpu_batch_decode_jpeg would.  Between the two the
- * thread may begin the next batch (up to four in flight per thread) or enqueue anything else; the blobs must stay readable
- * until _finish (a file the device defers is read again), and both halves belong to one thread.  count <= 256.
+ * thread may begin the next batch or enqueue anything else; the blobs must stay readable until _finish (a file the device
+ * defers is read again).  Both halves belong to ONE thread: _finish from another thread returns IMP_ERROR_INVALID_ARGS and
+ * leaves the batch with its owner.  A thread has FOUR slots for decodes in flight, shared by the batches it has begun and
+ * by its ordinary decode calls (one each; a one-call batch of 32 or more files takes two when two are free): with four
+ * batches begun and not finished, any further decode on that thread returns IMP_ERROR_INVALID_ARGS.  count <= 256.
  * The batch runs on a second stream of the calling thread, so work the thread enqueues between the two calls (the resize and
  * the answers of the batch before) overlaps it.  (impgpu_batch_decode_jpeg itself already prepares the second half of a large
- * batch while the device works on the first.  Measured in the request loop of tests/c/stream_harness.c, raw answers: two threads
- * 25.9 -> 30.3 k requests/s, four 34.3 -> 42.0 k; with JPEG answers or eight threads the one-call form is as fast or faster.) */
+ * batch while the device works on the first; profiles/r05_jpeg_stream_native.txt holds both forms side by side.) */
 typedef struct impgpu_jpeg_batch impgpu_jpeg_batch;
 int   impgpu_batch_decode_jpeg_begin(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_jpeg_batch** batch);
 int   impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** images, int* codes);
@@ -179,8 +181,15 @@ int   impgpu_jpeg_profile(int on);
 /* Process-wide counts since the library was loaded: [0] files whose entropy stage ran on the device, [1] of those, refused
  * by its verdict (the caller's cvDecodeImage fallback took them), [2] of those, because a wait between workgroups ran out --
  * must stay 0 on a healthy box, however many processes share the device -- [3] files kept on the calling thread because
- * their blocks are too long for the device scheme (more than 200 bits each). */
+ * their blocks are too long for the device scheme (more than 200 bits each).
+ * Round 5, what the cvDecodeImage fallback (bridge.c:545-552) is paid for -- files a decode call refused at their header, by
+ * reason: [5] progressive (SOF2), [6] arithmetic / lossless / hierarchical, [7] 12-bit samples, [8] CMYK / YCCK or another
+ * component count, [9] not one interleaved scan, [10] sampling factors outside 1x1 / 2x1 / 1x2 / 2x2 over 1x1, [11] anything
+ * else (a DNL height, not a JPEG at all), [12] headers damaged before the first scan.  ([4] is unused.)
+ * impgpu_jpeg_classify gives the same verdict for one file without decoding it (host, no device): 0 = the device takes it,
+ * 1..7 = the reasons in the order above, 8 = damaged; tools/corpus_probe.py adds them up over a directory. */
 int   impgpu_jpeg_counters(unsigned long long* counters, int n);
+int   impgpu_jpeg_classify(const unsigned char* blob, size_t size);
 int   impgpu_jpeg_stage_times(double* microseconds, int n);
 /* The other end of the request: CvMat* encoded = cvEncodeImage(".jpg", image, basicCoderopt)          bridge.c:704
  * with basicCoderopt = {CV_IMWRITE_JPEG_QUALITY, quality} (bridge.c:474-486; OpenCV clamps the value to 0..100), for the

@@ -51,7 +51,8 @@ enum { IMPB_FREE = 0, IMPB_CLAIMED = 1, IMPB_SUBMITTED = 2, IMPB_TAKEN = 3, IMPB
 enum { IMPB_IN_FILE = 0 /* a JPEG or PNG file */, IMPB_IN_FRAME = 1 /* decoded pixels (host fallback decoders) */,
        IMPB_IN_WATERMARK = 2 /* pixels of a location's overlay: registered, answer = its id */ };
 enum { IMPB_OUT_JPEG = 0 /* cvEncodeImage(".jpg"), bridge.c:704 */, IMPB_OUT_FRAME = 1 /* pixels for a host encoder */,
-       IMPB_OUT_INFO = 2 /* width, height, brightness (bridge.c:283-300) */ };
+       IMPB_OUT_INFO = 2 /* width, height, brightness (bridge.c:283-300) */,
+       IMPB_OUT_ASCII = 3 /* the text exit, ASCII() of filters.c:486-522 (bridge.c:669-670) */ };
 /* answer codes besides IMP_*: the broker did not take the file (not a JPEG/PNG the device decodes, or damaged) -- the
  * worker decodes on the host as before and comes back with IMPB_IN_FRAME */
 #define IMPB_NOT_TAKEN    (-1)
@@ -86,6 +87,7 @@ typedef struct {
     int32_t  quality;                   /* IMPB_OUT_JPEG */
     int32_t  simple, need_flatten, filter_count;
     int32_t  crop_at, gravity_at, resize_at;        /* offsets into text[], -1 = absent */
+    int32_t  ascii_at;                  /* IMPB_OUT_ASCII: the argument string of ASCII(), -1 = "" */
     int32_t  filter_at[IMPB_MAX_FILTERS];
     uint32_t max_target_w, max_target_h;
     int32_t  max_filters_count, allow_experiments;
@@ -120,6 +122,7 @@ typedef struct {
     int                  watermark_id;
     int                  out_kind;      /* IMPB_OUT_* */
     int                  quality;
+    const char*          ascii_args;    /* IMPB_OUT_ASCII (NULL = "") */
 } impgpu_client_request;
 
 typedef struct {

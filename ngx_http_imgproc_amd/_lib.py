@@ -124,6 +124,7 @@ SIGNATURES = {
     "impgpu_jpeg_sync_stats": (None, [IP]),
     "impgpu_jpeg_profile": (C.c_int, [C.c_int]),
     "impgpu_jpeg_counters": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
+    "impgpu_jpeg_classify": (C.c_int, [C.c_char_p, C.c_size_t]),
     "impgpu_jpeg_stage_times": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "impgpu_host_alloc": (P, [C.c_size_t]),
     "impgpu_host_free": (None, [P]),

@@ -10,7 +10,7 @@ CLIENT_LIB_PATH = os.path.join(HERE, "libimpgpu_client.so")
 BROKER_PATH = os.path.join(HERE, "impgpu_broker")
 
 IN_FILE, IN_FRAME = 0, 1
-OUT_JPEG, OUT_FRAME, OUT_INFO = 0, 1, 2
+OUT_JPEG, OUT_FRAME, OUT_INFO, OUT_ASCII = 0, 1, 2, 3
 NOT_TAKEN = -1
 
 
@@ -18,7 +18,7 @@ class CRequest(C.Structure):
     _fields_ = [("in_kind", C.c_int), ("input", C.c_void_p), ("input_bytes", C.c_size_t),
                 ("width", C.c_int), ("height", C.c_int), ("channels", C.c_int), ("step", C.c_int),
                 ("job", C.POINTER(CJob)), ("config", C.POINTER(CConfig)), ("watermark_id", C.c_int),
-                ("out_kind", C.c_int), ("quality", C.c_int)]
+                ("out_kind", C.c_int), ("quality", C.c_int), ("ascii_args", C.c_char_p)]
 
 
 class CAnswer(C.Structure):
@@ -67,7 +67,7 @@ class Client:
         return wid.value
 
     def run(self, blob=None, frame=None, crop=None, gravity=None, resize=None, filters=(), simple=0, need_flatten=0,
-            config=None, watermark_id=0, out=OUT_JPEG, quality=86):
+            config=None, watermark_id=0, out=OUT_JPEG, quality=86, ascii_args=None):
         """-> (transport rc, code, step, payload, answer).  payload: bytes (JPEG), ndarray (FRAME), or None."""
         import numpy as np
 
@@ -87,12 +87,13 @@ class Client:
         cfg = config if config is not None else CConfig(2000, 2000, 5, 0, 0, b"l", b"t", 0, 0, None)
         r.job, r.config = C.pointer(job), C.pointer(cfg)
         r.watermark_id, r.out_kind, r.quality = watermark_id, out, quality
+        r.ascii_args = ascii_args.encode() if ascii_args is not None else None
         a = CAnswer()
         rc = clib.impgpu_client_run(self.h, C.byref(r), C.byref(a))
         del buf
         if rc != 0 or a.code != 0:
             return rc, a.code, a.step, None, a
-        if out == OUT_JPEG:
+        if out in (OUT_JPEG, OUT_ASCII):
             return rc, 0, a.step, C.string_at(a.data, a.bytes), a
         if out == OUT_FRAME:
             rows = np.ctypeslib.as_array(C.cast(a.data, C.POINTER(C.c_ubyte)), shape=(a.height, a.row_step))

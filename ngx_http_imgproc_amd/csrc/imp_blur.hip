@@ -793,7 +793,7 @@ static int launch_gaussian_mfma(const Frames& f, const std::vector<int>& ik, int
         const bm_v4i* bc = (const bm_v4i*)((const int*)dev_k + off_c);
 #define IMP_BLUR_FUSED(CN_)                                                                                                          \
     do {                                                                                                                             \
-        e = hipFuncSetAttribute((const void*)k_blur_mfma_fused<CN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);        \
+        e = lds_limit_once<k_blur_mfma_fused<CN_>>();                                                                                \
         if (e == hipSuccess)                                                                                                         \
             hipLaunchKernelGGL((k_blur_mfma_fused<CN_>), grid, dim3(256), lds_f, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, \
                                f.dstep, br, bc, r, nrc, ncc, pitch_s, pitch_p, (int)(128 * sum), (int)(128 * sum * 257));             \
@@ -816,8 +816,8 @@ static int launch_gaussian_mfma(const Frames& f, const std::vector<int>& ik, int
         uint8_t* dst = f.dst + (long long)f0 * f.dst_stride;
 #define IMP_BLUR_MFMA(CN_)                                                                                                                  \
     do {                                                                                                                                    \
-        e = hipFuncSetAttribute((const void*)k_blur_mfma_rows<CN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);                \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_blur_mfma_cols<CN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c); \
+        e = lds_limit_once<k_blur_mfma_rows<CN_>>();                                                                                        \
+        if (e == hipSuccess) e = lds_limit_once<k_blur_mfma_cols<CN_>>();                                                                   \
         if (e == hipSuccess) {                                                                                                              \
             hipLaunchKernelGGL((k_blur_mfma_rows<CN_>), grid, dim3(256), lds_r, s, src, f.src_stride, v.step, v.w, v.h, (uint8_t*)planes, pstride, hp, \
                                roww_pad, (const bm_v4i*)dev_k, r, nrc, pitch_s, bias_r);                                                       \
@@ -906,7 +906,7 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s) {
         hipError_t e = hipSuccess;
 #define IMP_BLUR_STRIP(RH_, CN_, NO_, R16_)                                                                                        \
     do {                                                                                                                           \
-        e = hipFuncSetAttribute((const void*)k_blur_strip4<RH_, CN_, NO_, R16_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        e = lds_limit_once<k_blur_strip4<RH_, CN_, NO_, R16_>>();                                                                  \
         if (e == hipSuccess)                                                                                                       \
             hipLaunchKernelGGL((k_blur_strip4<RH_, CN_, NO_, R16_>), sgrid, dim3(256), lds, s, f.src, f.src_stride, v.step, v.w, v.h,     \
                                f.dst, f.dst_stride, f.dstep, (const int*)dev_k, (const float*)((const int*)dev_k + off_f),          \

@@ -180,8 +180,8 @@ void prepare(Req& r, const Segment& S) {
     impb_slot_fields& q = r.q;
     q.text[IMPB_TEXT_BYTES - 1] = 0;
     if (q.in_bytes > S.slot_bytes) return fail(r, IMP_ERROR_INVALID_ARGS, IMP_STEP_VALIDATE, "in_bytes past the slot");
-    if (q.in_kind > IMPB_IN_WATERMARK || q.out_kind > IMPB_OUT_INFO) return fail(r, IMP_ERROR_INVALID_ARGS, IMP_STEP_VALIDATE, "unknown kind");
-    if (q.filter_count < 0 || q.filter_count > IMPB_MAX_FILTERS || !text_ok(q, q.crop_at) || !text_ok(q, q.gravity_at) || !text_ok(q, q.resize_at))
+    if (q.in_kind > IMPB_IN_WATERMARK || q.out_kind > IMPB_OUT_ASCII) return fail(r, IMP_ERROR_INVALID_ARGS, IMP_STEP_VALIDATE, "unknown kind");
+    if (q.filter_count < 0 || q.filter_count > IMPB_MAX_FILTERS || !text_ok(q, q.crop_at) || !text_ok(q, q.gravity_at) || !text_ok(q, q.resize_at) || !text_ok(q, q.ascii_at))
         return fail(r, IMP_ERROR_INVALID_ARGS, IMP_STEP_VALIDATE, "bad text offsets");
     for (int i = 0; i < q.filter_count; i++) {
         if (q.filter_at[i] < 0 || q.filter_at[i] >= IMPB_TEXT_BYTES) return fail(r, IMP_ERROR_INVALID_ARGS, IMP_STEP_VALIDATE, "bad filter offset");
@@ -395,6 +395,15 @@ struct Worker {
                 const int rc = impgpu_calc_perceived_brightness(r.img, &b);
                 if (rc != IMP_OK) { fail(r, rc, IMP_STEP_INFO, impgpu_last_error()); continue; }
                 s->brightness = b;
+                r.code = IMP_OK; r.done = true;
+            } else if (r.q.out_kind == IMPB_OUT_ASCII) {            // the text exit (bridge.c:669-670): (width + 1) * height - 1 characters
+                r.step = IMP_STEP_INFO;
+                const long need = (long)(s->out_w + 1) * s->out_h - 1;
+                if (at >= S.slot_bytes || (uint64_t)(need > 0 ? need : 1) > S.slot_bytes - at) { fail(r, IMP_ERROR_MALLOC_FAILED, IMP_STEP_INFO, "answer does not fit the slot"); continue; }
+                long len = 0;
+                const int rc = impgpu_ascii(r.img, r.q.ascii_at >= 0 ? r.q.text + r.q.ascii_at : "", S.slot_data(r.slot) + at, need, &len);
+                if (rc != IMP_OK) { fail(r, rc, IMP_STEP_INFO, rc == IMP_ERROR_DEVICE ? impgpu_last_error() : ""); continue; }
+                s->out_bytes = (uint64_t)len;
                 r.code = IMP_OK; r.done = true;
             } else if (r.q.out_kind == IMPB_OUT_JPEG) {
                 r.step = IMP_STEP_ENCODE;

@@ -276,4 +276,25 @@ int launch_gaussian_fused(const Frames& f, double sigma, hipStream_t s);
 int watermark_rect(int basew, int baseh, int overw, int overh, const impgpu_config* cfg,
                    int* rx, int* ry, int* maxcol, int* maxrow);
 
+
+// The dynamic-LDS limit of a kernel is a per-function, process-wide attribute: raised ONCE per kernel instantiation (a
+// thread-safe static) to everything the device allows beside the kernel's static LDS -- not before every launch with that
+// launch's own size, where two request threads with different sizes could interleave set(small) between another thread's
+// set(large) and its launch, and every request paid a runtime call for a value that never changes (round 4's review).
+#if defined(__HIPCC__)
+template <auto Kernel>
+inline hipError_t lds_limit_once() {
+    static const hipError_t err = [] {
+        int dev = 0, cap = 0;
+        hipFuncAttributes fa;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+        if (e == hipSuccess) e = hipFuncGetAttributes(&fa, (const void*)Kernel);
+        if (e != hipSuccess) return e;
+        const int room = cap - (int)fa.sharedSizeBytes;
+        return hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room > 0 ? room : 0);
+    }();
+    return err;
+}
+#endif
 }  // namespace imp

@@ -31,12 +31,12 @@ struct Segment {            // one marker segment's payload
 
 int take_sof(const Segment& s, JpegHeader* H) {
     if (!s.has(0, 6)) return IMP_ERROR_DECODE_FAILED;
-    if (s.u8(0) != 8) return IMP_ERROR_UNSUPPORTED;                   // 12-bit samples
+    if (s.u8(0) != 8) { H->why = JPEG_WHY_12BIT; return IMP_ERROR_UNSUPPORTED; }   // 12-bit samples
     H->height = s.u16(1);
     H->width = s.u16(3);
     H->ncomp = s.u8(5);
-    if (H->height == 0 || H->width == 0) return IMP_ERROR_UNSUPPORTED;   // height deferred to a DNL marker
-    if (H->ncomp != 1 && H->ncomp != 3) return IMP_ERROR_UNSUPPORTED;    // CMYK / YCCK
+    if (H->height == 0 || H->width == 0) { H->why = JPEG_WHY_OTHER; return IMP_ERROR_UNSUPPORTED; }   // height deferred to a DNL marker
+    if (H->ncomp != 1 && H->ncomp != 3) { H->why = JPEG_WHY_COMPONENTS; return IMP_ERROR_UNSUPPORTED; }    // CMYK / YCCK
     if (s.n != size_t(6 + 3 * H->ncomp)) return IMP_ERROR_DECODE_FAILED;
     for (int i = 0; i < H->ncomp; i++) {
         JpegComp& c = H->comp[i];
@@ -89,7 +89,8 @@ int take_dqt(const Segment& s, JpegHeader* H) {
 }  // namespace
 
 int jpeg_parse(const uint8_t* blob, size_t size, JpegHeader* H) {
-    if (!blob || size < 4 || blob[0] != 0xFF || blob[1] != 0xD8) return IMP_ERROR_UNSUPPORTED;
+    H->why = JPEG_WHY_NONE;
+    if (!blob || size < 4 || blob[0] != 0xFF || blob[1] != 0xD8) { H->why = JPEG_WHY_OTHER; return IMP_ERROR_UNSUPPORTED; }
     size_t at = 2;
     bool have_frame = false, jfif = false, adobe = false;
     int adobe_transform = 1;
@@ -112,6 +113,7 @@ int jpeg_parse(const uint8_t* blob, size_t size, JpegHeader* H) {
             have_frame = true;
             break;
         case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            H->why = marker == 0xC2 ? JPEG_WHY_PROGRESSIVE : JPEG_WHY_PROCESS;
             return IMP_ERROR_UNSUPPORTED;                             // progressive, lossless, hierarchical, arithmetic
         case 0xC4: rc = take_dht(s, H); break;
         case 0xDB: rc = take_dqt(s, H); break;
@@ -127,14 +129,14 @@ int jpeg_parse(const uint8_t* blob, size_t size, JpegHeader* H) {
             if (!have_frame || s.n < 1) return IMP_ERROR_DECODE_FAILED;
             const int ns = s.u8(0);
             if (s.n != size_t(4 + 2 * ns)) return IMP_ERROR_DECODE_FAILED;
-            if (ns != H->ncomp) return IMP_ERROR_UNSUPPORTED;         // one scan per component
+            if (ns != H->ncomp) { H->why = JPEG_WHY_SCANS; return IMP_ERROR_UNSUPPORTED; }         // one scan per component
             for (int i = 0; i < ns; i++) {
-                if (s.u8(1 + 2 * i) != H->comp[i].id) return IMP_ERROR_UNSUPPORTED;
+                if (s.u8(1 + 2 * i) != H->comp[i].id) { H->why = JPEG_WHY_SCANS; return IMP_ERROR_UNSUPPORTED; }
                 H->comp[i].td = s.u8(2 + 2 * i) >> 4;
                 H->comp[i].ta = s.u8(2 + 2 * i) & 15;
                 if (H->comp[i].td > 3 || H->comp[i].ta > 3) return IMP_ERROR_DECODE_FAILED;
             }
-            if (s.u8(1 + 2 * ns) != 0 || s.u8(2 + 2 * ns) != 63 || s.u8(3 + 2 * ns) != 0) return IMP_ERROR_UNSUPPORTED;
+            if (s.u8(1 + 2 * ns) != 0 || s.u8(2 + 2 * ns) != 63 || s.u8(3 + 2 * ns) != 0) { H->why = JPEG_WHY_SCANS; return IMP_ERROR_UNSUPPORTED; }
             H->scan_begin = at + len;
             // which colour space three components mean (libjpeg's default_decompress_parms)
             H->ycc = true;
@@ -146,8 +148,8 @@ int jpeg_parse(const uint8_t* blob, size_t size, JpegHeader* H) {
             if (H->ncomp == 1) {
                 H->comp[0].h = H->comp[0].v = 1;                      // a one-component scan is never interleaved
             } else {
-                if (H->comp[1].h != 1 || H->comp[1].v != 1 || H->comp[2].h != 1 || H->comp[2].v != 1) return IMP_ERROR_UNSUPPORTED;
-                if (H->comp[0].h > 2 || H->comp[0].v > 2) return IMP_ERROR_UNSUPPORTED;
+                if (H->comp[1].h != 1 || H->comp[1].v != 1 || H->comp[2].h != 1 || H->comp[2].v != 1) { H->why = JPEG_WHY_SAMPLING; return IMP_ERROR_UNSUPPORTED; }
+                if (H->comp[0].h > 2 || H->comp[0].v > 2) { H->why = JPEG_WHY_SAMPLING; return IMP_ERROR_UNSUPPORTED; }
             }
             H->hs = H->comp[0].h;
             H->vs = H->comp[0].v;
@@ -671,6 +673,14 @@ int impgpu_jpeg_info(const unsigned char* blob, size_t size, int* width, int* he
     if (height) *height = H.height;
     if (channels) *channels = H.ncomp;
     return IMP_OK;
+}
+
+int impgpu_jpeg_classify(const unsigned char* blob, size_t size) {
+    JpegHeader H;
+    const int rc = jpeg_parse(blob, size, &H);
+    if (rc == IMP_OK) return 0;
+    if (rc == IMP_ERROR_UNSUPPORTED) return H.why > 0 && H.why < JPEG_WHY_COUNT ? H.why : JPEG_WHY_OTHER;
+    return JPEG_WHY_COUNT;                                           // damaged before the first scan
 }
 
 void impgpu_jpeg_sync_stats(int stats[8]) {

@@ -40,7 +40,13 @@ struct JpegHeader {
     int restart_interval = 0;
     bool ycc = true;                         // three components mean YCbCr (else R,G,B stored as such)
     size_t scan_begin = 0;                   // first entropy-coded byte
+    int why = 0;                             // JPEG_WHY_*: the reason for an IMP_ERROR_UNSUPPORTED (impgpu_jpeg_counters, impgpu_jpeg_classify)
 };
+// why the device does not take a file (round 5: what the cvDecodeImage fallback of bridge.c:545-552 is paid for)
+enum { JPEG_WHY_NONE = 0, JPEG_WHY_PROGRESSIVE = 1 /* SOF2 */, JPEG_WHY_PROCESS = 2 /* arithmetic, lossless, hierarchical */,
+       JPEG_WHY_12BIT = 3, JPEG_WHY_COMPONENTS = 4 /* CMYK / YCCK, two components */, JPEG_WHY_SCANS = 5 /* not one interleaved scan */,
+       JPEG_WHY_SAMPLING = 6 /* factors other than 1x1 / 2x1 / 1x2 / 2x2 luma over 1x1 chroma */, JPEG_WHY_OTHER = 7 /* DNL height, not a JPEG, ... */,
+       JPEG_WHY_COUNT = 8 };
 
 // Marker segments up to the first SOS.  IMP_OK, IMP_ERROR_UNSUPPORTED (a JPEG this path does not take: progressive,
 // arithmetic, 12-bit, CMYK, several scans, sampling other than 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 -- the caller decodes on the

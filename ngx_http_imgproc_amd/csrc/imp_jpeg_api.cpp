@@ -34,7 +34,7 @@ std::atomic<int> g_profile{0};
 // process-wide: files whose entropy stage ran on the device, of those refused by its verdict, of those with a chain wait
 // that ran out (JPEG_ST_CHAIN_TIMEOUT: the file is then decoded by the caller's fallback -- a box that does this silently
 // looks healthy and is not), files kept on the calling thread because their blocks are too long
-std::atomic<unsigned long long> g_count[4];
+std::atomic<unsigned long long> g_count[4 + JPEG_WHY_COUNT + 1];    // [4 + why]: files refused at their header, by reason; [4 + JPEG_WHY_COUNT]: damaged headers
 thread_local double t_stage[16];
 
 // IMPGPU_JPEG_TRACE=1: one line per call on stderr with the host's share of it, in microseconds
@@ -95,7 +95,9 @@ struct Group {
     size_t live = 0, ctl_total = 0;
     hipEvent_t ev[8] = {};
     Stopwatch sw;
+    const void* owner = nullptr;                    // the thread that began the group (its slot, its lane): only it may finish it
 };
+thread_local char t_thread_tag;                     // its address names the calling thread
 thread_local unsigned t_slots_busy = 0;             // bit k: mailbox slot k holds a group that has not been finished
 std::atomic<int> g_groups_in_flight{0};             // over all threads: groups begun and not finished
 
@@ -125,6 +127,7 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         if (!(t_slots_busy & (1u << k))) G.slot = k;
     if (G.slot < 0) { set_error_text("too many JPEG batches begun and not finished on this thread"); return IMP_ERROR_INVALID_ARGS; }
     t_slots_busy |= 1u << G.slot;
+    G.owner = &t_thread_tag;
     g_groups_in_flight.fetch_add(1, std::memory_order_relaxed);
     // ---- headers, geometry, the sizes of everything
     size_t words_total = 0, coef_total = 0;
@@ -132,7 +135,9 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         Prep& p = P[(size_t)i];
         if (!blobs[i]) { p.code = IMP_ERROR_INVALID_ARGS; continue; }
         p.code = jpeg_parse(blobs[i], sizes[i], &p.H);
-        if (!p.code && !frame_fits(p.H.width, p.H.height, p.H.ncomp)) p.code = IMP_ERROR_UNSUPPORTED;
+        if (!p.code && !frame_fits(p.H.width, p.H.height, p.H.ncomp)) { p.code = IMP_ERROR_UNSUPPORTED; p.H.why = JPEG_WHY_OTHER; }
+        if (p.code == IMP_ERROR_UNSUPPORTED) g_count[4 + (p.H.why > 0 && p.H.why < JPEG_WHY_COUNT ? p.H.why : JPEG_WHY_OTHER)].fetch_add(1, std::memory_order_relaxed);
+        else if (p.code == IMP_ERROR_DECODE_FAILED) g_count[4 + JPEG_WHY_COUNT].fetch_add(1, std::memory_order_relaxed);
         if (!p.code) p.code = jpeg_frame_setup(p.H, &p.F, p.dc_ids, p.ac_ids);
         if (p.code) continue;
         const size_t total_mcus = (size_t)p.H.mcux * p.H.mcuy;
@@ -480,7 +485,10 @@ int group_deferred(const unsigned char* const* blobs, const size_t* sizes, int c
 // group stays whole: two launches of half the size are the less efficient way to fill a device that is already full.
 int decode_group(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
     const bool whole = std::getenv("IMPGPU_JPEG_WHOLE") != nullptr;      // measurements of ONE launch per batch (tools/jpeg_prof_r04.sh, bench.py's stage profile); read per call
-    const int first = !whole && count >= 32 && g_groups_in_flight.load(std::memory_order_relaxed) < 4 ? count / 2 : count;
+    // (the two halves take a mailbox slot each: with batches begun and not finished on this thread -- impgpu_batch_decode_jpeg_begin --
+    // holding three of the four, the group stays whole instead of failing for want of a second slot)
+    const int free_slots = GROUP_SLOTS - __builtin_popcount(t_slots_busy & ((1u << GROUP_SLOTS) - 1));
+    const int first = !whole && count >= 32 && free_slots >= 2 && g_groups_in_flight.load(std::memory_order_relaxed) < 4 ? count / 2 : count;
     Group A, B;
     int rc = group_begin(A, blobs, sizes, first, 0);
     if (rc) {
@@ -488,9 +496,9 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
         return rc;
     }
     int rcb = IMP_OK;
-    // (both halves on the lane's stream: the second on the side stream was measured on one box, two repetitions -- the same at 1, 2
-    // and 8 threads, 7 % slower at 4)
-    if (first < count) rcb = group_begin(B, blobs + first, sizes + first, count - first, 0);    // on the side stream: its kernels overlap the first half's (a launch of 32 files does not fill the device)
+    // Both halves on the lane's stream (the second half on the lane's side stream was measured on one box, two repetitions: the
+    // same at 1, 2 and 8 threads, 7 % slower at 4 -- so it is not used here; impgpu_batch_decode_jpeg_begin does use it).
+    if (first < count) rcb = group_begin(B, blobs + first, sizes + first, count - first, 0);
     rc = group_finish(A, images, codes);
     if (first < count) {
         if (!rcb) rcb = group_finish(B, images + first, codes + first);
@@ -543,6 +551,9 @@ int impgpu_batch_decode_jpeg_begin(const unsigned char* const* blobs, const size
 int impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** images, int* codes) {
     if (!batch || !*batch || !images || !codes) return IMP_ERROR_INVALID_ARGS;
     impgpu_jpeg_batch* b = *batch;
+    // the slot, the mark event and the pool blocks belong to the beginning thread's lane: another thread would clear its own
+    // slot bits and hand the event to its own lane.  Refused; the batch stays valid for its owner.
+    if (b->G.owner != &t_thread_tag) { set_error_text("impgpu_batch_decode_jpeg_finish from another thread than _begin"); return IMP_ERROR_INVALID_ARGS; }
     *batch = nullptr;
     const unsigned char* const* blobs = b->G.blobs;
     const size_t* sizes = b->G.sizes;
@@ -555,7 +566,7 @@ int impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** im
 
 int impgpu_jpeg_counters(unsigned long long* counters, int n) {
     if (!counters || n < 0) return IMP_ERROR_INVALID_ARGS;
-    for (int i = 0; i < n; i++) counters[i] = i < 4 ? g_count[i].load(std::memory_order_relaxed) : 0ull;
+    for (int i = 0; i < n; i++) counters[i] = i < 4 + JPEG_WHY_COUNT + 1 ? g_count[i].load(std::memory_order_relaxed) : 0ull;
     return IMP_OK;
 }
 

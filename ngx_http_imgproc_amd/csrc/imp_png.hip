@@ -251,12 +251,7 @@ static int launch_png_unfilter(const PngJob& job, int bpp, hipStream_t s) {
     hipError_t e = hipSuccess;
 #define PNG_LAUNCH(BPP_)                                                                                                      \
     do {                                                                                                                      \
-        static bool raised = false; /* (per process; the attribute is per function) */                                       \
-        if (!raised) {                                                                                                        \
-            e = hipFuncSetAttribute((const void*)k_png_unfilter<BPP_>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                    (int)png_lds_bytes(PNG_MAX_W, PNG_MAX_H));                                                \
-            raised = e == hipSuccess;                                                                                         \
-        }                                                                                                                     \
+        e = lds_limit_once<k_png_unfilter<BPP_>>();  /* (once per process; the attribute is per function) */                 \
         if (e == hipSuccess) {                                                                                                \
             hipLaunchKernelGGL(k_png_unfilter<BPP_>, dim3(1), dim3(PNG_WAVES * 64), lds, s, job);                             \
             e = hipGetLastError();                                                                                            \

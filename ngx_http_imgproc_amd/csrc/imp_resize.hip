@@ -3181,7 +3181,7 @@ int launch_area2x2_rotate(const Frames& f, int amount, const OverlayArgs* overla
         hipError_t e = hipSuccess;
 #define IMP_TURN(SW_, BH_)                                                                                                        \
     do {                                                                                                                          \
-        e = hipFuncSetAttribute((const void*)k_area2x2_turn<SW_, BH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        e = lds_limit_once<k_area2x2_turn<SW_, BH_>>();                                                                           \
         if (e == hipSuccess)                                                                                                      \
             hipLaunchKernelGGL((k_area2x2_turn<SW_, BH_>), sgrid, block, lds, s, a, amount, rw, rh, nstrips, nbands, bpf, f.count, wm0); \
     } while (0)

@@ -42,6 +42,7 @@ struct Staging {
     size_t cap = 0;
     hipEvent_t done = nullptr;
     bool busy = false;
+    int small_streak = 0;               // reservations in a row that needed less than an eighth of the buffer
 };
 
 struct Parked {             // a pool block waiting for an event of a foreign stream
@@ -557,8 +558,14 @@ static int stage_reserve(Lane* L, size_t bytes, Staging** out) {
         const char* s = std::getenv("IMPGPU_STAGE_CAP_MB");
         return (size_t)(s ? std::atoll(s) : 512) << 20;
     }();
-    const bool outsized = trim_cap && S->cap > trim_cap && bytes <= trim_cap / 4;
+    bool outsized = trim_cap && S->cap > trim_cap && bytes <= trim_cap / 4;
+    // ... and below that cap: a buffer of more than 64 MB (one PNG of 4096 x 16384 stages 268 MB for a file that may weigh
+    // 260 KB) that the last sixteen requests each used less than an eighth of goes back too -- N workers x lanes x two
+    // buffers of unswappable memory is the worst case an operator has to budget for
+    S->small_streak = (S->cap > (size_t(64) << 20) && bytes <= S->cap / 8) ? S->small_streak + 1 : 0;
+    if (S->small_streak >= 16) outsized = true;
     if (S->cap < bytes || outsized) {
+        S->small_streak = 0;
         if (S->p) IMP_HIP(hipHostFree(S->p));
         S->p = nullptr;
         S->cap = 0;

@@ -56,7 +56,7 @@ def test_apply_glue_rewrites_the_operator_segment(tmp_path):
     # spellings of the worker index exist (ngx_worker came with nginx 1.9.1)
     decls = os.path.join(ROOT, "tests", "c", "decls")
     for extra in ([], ["-Dnginx_version=1009005"], ["-Dnginx_version=1004006"]):
-        for src in ("bridge.c", "advancedio.c", os.path.join("glue", "imp_gpu_bridge.c")):
+        for src in ("bridge.c", "advancedio.c", os.path.join("glue", "imp_gpu_bridge.c"), os.path.join("glue", "imp_gpu_client.c")):
             p = subprocess.run(["gcc", "-fsyntax-only", "-std=gnu99", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
                                 "-Werror=int-conversion", "-I", decls, "-I", os.path.join(ROOT, "include"), "-I", str(work)] + extra + [src],
                                cwd=str(work), capture_output=True, text=True)
@@ -71,6 +71,7 @@ def test_glue_uses_only_declared_abi_symbols():
 
     src = open(os.path.join(ROOT, "glue", "imp_gpu_bridge.c")).read()
     header = open(os.path.join(ROOT, "include", "impgpu.h")).read()
+    header += open(os.path.join(ROOT, "include", "impgpu_broker.h")).read()
     used = set(re.findall(r"\b(impgpu_[a-z0-9_]+)\s*\(", src))
     declared = set(re.findall(r"\b(impgpu_[a-z0-9_]+)\s*\(", header))
     assert used and used <= declared, used - declared

@@ -133,6 +133,10 @@ def test_every_kind_of_request_and_answer(broker):
     rc_o, small = orc.resize(frame, "100,0")
     assert (rc, code) == (0, 0) and (a.width, a.height) == (small.shape[1], small.shape[0])
     assert abs(a.brightness - orc.brightness(small)) < 1e-6
+    # the text exit
+    rc, code, step, got, a = c.run(blob=blob, resize="60,0", out=B.OUT_ASCII, ascii_args="")
+    rc_o, small = orc.resize(frame, "60,0")
+    assert (rc, code) == (0, 0) and got == orc.ascii_art(small, "")
     # errors keep their code and step (bridge.c's JobResult)
     rc, code, step, got, a = c.run(blob=blob, resize="5000,0,up", out=B.OUT_JPEG)
     rc_o, _ = orc.resize(frame, "5000,0,up")

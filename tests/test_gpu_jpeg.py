@@ -407,3 +407,97 @@ def test_jpeg_request_batch_end_to_end(gpu):
         assert np.array_equal(o.numpy(), want)
         im.release(); o.release()
     cfg.release()
+
+
+def _box_files():
+    """JPEG files this image ships (sample photographs of python packages: camera files, not files Pillow wrote for us)."""
+    import glob
+    pats = ["/usr/local/lib/python3.10/dist-packages/sklearn/datasets/images/*.jpg",
+            "/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/sample_data/*.jpg",
+            "/opt/conda/lib/python3.9/site-packages/skimage/data/*.jpg",
+            "/opt/conda/lib/python3.9/site-packages/anaconda_navigator/static/images/*.jpg",
+            "/opt/conda/lib/python3.9/site-packages/anaconda_navigator/static/images/logos/*.jpg",
+            "/usr/share/javascript/highlight.js/styles/*.jpg"]
+    return sorted(p for pat in pats for p in glob.glob(pat))
+
+
+def test_photographs_found_on_the_box_decode_to_pillows_pixels(gpu, huff):
+    """Files nobody made for this test -- other encoders, optimised tables, EXIF and ICC segments, odd sizes: each is either
+    refused with the reason impgpu_jpeg_classify names (the cvDecodeImage fallback takes it) or decodes to exactly the pixels
+    libjpeg-turbo gives (Pillow, converted to the B,G,R order cvDecodeImage returns), and the refusal is counted."""
+    Image = pytest.importorskip("PIL.Image")
+    import ctypes as C
+    files = _box_files()
+    if not files:
+        pytest.skip("no JPEG files on this box")
+    taken = refused = 0
+    before = (C.c_ulonglong * 13)()
+    gpu.lib.impgpu_jpeg_counters(before, 13)
+    for path in files:
+        blob = open(path, "rb").read()
+        kind = gpu.lib.impgpu_jpeg_classify(blob, len(blob))
+        rc, got = decode(gpu, blob)
+        if kind != 0:
+            assert rc in (gpu.IMP_ERROR_UNSUPPORTED, gpu.IMP_ERROR_DECODE_FAILED), (path, kind, rc)
+            refused += 1
+            continue
+        im = Image.open(io.BytesIO(blob))
+        if im.mode not in ("RGB", "L"):
+            continue
+        want = np.asarray(im)
+        want = want[:, :, ::-1] if want.ndim == 3 else want[:, :, None]
+        assert rc == 0, (path, rc)
+        assert np.array_equal(got, want), path
+        taken += 1
+    after = (C.c_ulonglong * 13)()
+    gpu.lib.impgpu_jpeg_counters(after, 13)
+    assert sum(after[5:13]) - sum(before[5:13]) == refused
+    assert taken > 0
+
+
+def test_slots_of_a_thread_are_shared_and_a_batch_belongs_to_its_thread(gpu):
+    """A thread has four slots for decodes in flight (impgpu.h).  With three batches begun, a one-call batch of 32 files
+    stays whole instead of failing for want of a second slot; with four begun, a further decode is refused (INVALID_ARGS),
+    not corrupted; _finish from another thread is refused and the batch is still its owner's."""
+    import ctypes as C
+    import threading
+    lib = gpu.lib
+    blob = encode(smooth_image(64, 64, 3), quality=90)
+    want = decode(gpu, blob)[1]
+    n = 32
+    blobs = (C.c_char_p * n)(*([blob] * n))
+    sizes = (C.c_size_t * n)(*([len(blob)] * n))
+    handles = []
+    for _ in range(3):
+        h = C.c_void_p()
+        assert lib.impgpu_batch_decode_jpeg_begin(blobs, sizes, 2, C.byref(h)) == 0
+        handles.append(h)
+    images = (C.c_void_p * n)()
+    codes = (C.c_int * n)()
+    assert lib.impgpu_batch_decode_jpeg(blobs, sizes, n, images, codes) == 0          # three slots held: stays whole
+    assert all(c == 0 for c in codes)
+    for i in range(n):
+        p = C.c_void_p(images[i])
+        lib.impgpu_image_release(C.byref(p))
+    h4 = C.c_void_p()
+    assert lib.impgpu_batch_decode_jpeg_begin(blobs, sizes, 2, C.byref(h4)) == 0
+    one = C.c_void_p()
+    assert lib.impgpu_image_decode_jpeg(blob, len(blob), C.byref(one)) == gpu.IMP_ERROR_INVALID_ARGS   # all four held
+    # another thread may not finish this thread's batch
+    seen = []
+    def other():
+        im2 = (C.c_void_p * 2)()
+        c2 = (C.c_int * 2)()
+        seen.append(lib.impgpu_batch_decode_jpeg_finish(C.byref(h4), im2, c2))
+    t = threading.Thread(target=other)
+    t.start(); t.join()
+    assert seen == [gpu.IMP_ERROR_INVALID_ARGS] and h4.value
+    for h in handles + [h4]:
+        im2 = (C.c_void_p * 2)()
+        c2 = (C.c_int * 2)()
+        assert lib.impgpu_batch_decode_jpeg_finish(C.byref(h), im2, c2) == 0 and list(c2) == [0, 0]
+        for i in range(2):
+            img = gpu.Image.__new__(gpu.Image)
+            p = C.c_void_p(im2[i])
+            lib.impgpu_image_release(C.byref(p))
+    assert np.array_equal(decode(gpu, blob)[1], want)                                  # the slots are all free again

@@ -126,3 +126,25 @@ def test_damaged_files_get_the_same_verdict_from_every_decoder():
                     assert np.array_equal(got0, oracle_coefficients(b))
                     agree += 1
     assert agree > 50       # plenty of damaged-but-decodable files among them (a flipped bit inside a coefficient's value)
+
+
+def test_classify_names_the_reason_of_a_refusal():
+    """impgpu_jpeg_classify (round 5): 0 = the device takes the file, else why the cvDecodeImage fallback gets it."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    arr = smooth_image(40, 40, 3)
+    cls = lambda b: imp.lib.impgpu_jpeg_classify(b, len(b))
+    assert cls(encode(arr, quality=90)) == 0
+    assert cls(encode(arr[:, :, 0], quality=90)) == 0                          # gray
+    assert cls(encode(arr, quality=90, progressive=True)) == 1
+    b = io.BytesIO()
+    Image.fromarray(np.dstack([arr, arr[:, :, :1]]), "CMYK").save(b, "JPEG", quality=90)
+    assert cls(b.getvalue()) == 4
+    assert cls(b"\x89PNG\r\n\x1a\n" + b"\0" * 64) == 7                        # not a JPEG
+    blob = encode(arr, quality=90)
+    sof = blob.index(b"\xff\xc0")
+    assert cls(blob[:sof + 4] + b"\x0c" + blob[sof + 5:]) == 3                 # 12-bit samples
+    assert cls(blob[:sof + 1] + b"\xc9" + blob[sof + 2:]) == 2                 # arithmetic coding
+    assert cls(blob[:sof + 7]) == 8                                            # cut inside the frame header
+    sos = blob.index(b"\xff\xda")
+    assert cls(blob[:sos + 4] + b"\x01" + blob[sos + 5:]) in (5, 8)            # a scan of one component of three
