@@ -535,13 +535,14 @@ static void bm_band_host(const std::vector<int>& ik, int r, int dil, int nchunk,
             }
 }
 
-template <int CN>
+template <int CN, bool WIDE>
 __global__ __launch_bounds__(256) void k_blur_mfma_rows(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
                                                         uint8_t* __restrict__ planes, long long pstride, int hp, int roww_pad,
                                                         const bm_v4i* __restrict__ bands, int r, int nchunk, int pitch_s, int bias) {
     extern __shared__ __attribute__((aligned(16))) uint8_t bm_smem[];
     uint8_t* s_src = bm_smem;                                       // [BM_H][pitch_s]: source bytes - 128, window column 0 = byte x0b - CN r
-    uint8_t* s_pl = bm_smem + (size_t)BM_H * pitch_s;               // [2][BM_W][BM_H + 16]: the row sums' low / high bytes - 128, transposed
+    uint8_t* s_pl = bm_smem + (size_t)BM_H * pitch_s;               // [2 or 3][BM_W][BM_H + 16]: the row sums' low / high bytes - 128 (WIDE: and bit 16), transposed
+    constexpr int NPL = WIDE ? 3 : 2;
     constexpr int PT = BM_H + 16;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     int tbx, tby, tbz;
@@ -583,40 +584,43 @@ __global__ __launch_bounds__(256) void k_blur_mfma_rows(const uint8_t* __restric
 #pragma unroll
         for (int c = 0; c < BM_MAXC; c++)
             if (c < nchunk) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(arow + 64 * c), band[c], acc, 0, 0, 0);
-        uint32_t lo = 0, hi = 0;
+        uint32_t lo = 0, hi = 0, top = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t S = (uint32_t)(acc[i] + bias);            // 0 .. 65535: the row sum of OpenCV's int32 row pass
+            const uint32_t S = (uint32_t)(acc[i] + bias);            // 0 .. 65535 (WIDE: below 2^17): the row sum of OpenCV's int32 row pass
             lo |= (S & 255u) << (8 * i);
-            hi |= (S >> 8) << (8 * i);
+            hi |= ((S >> 8) & 255u) << (8 * i);
+            top |= (S >> 16) << (8 * i);
         }
         uint8_t* col = s_pl + (size_t)(xg * 16 + (lane & 15)) * PT + rg * 16 + 4 * (lane >> 4);
         *(uint32_t*)col = lo ^ 0x80808080u;
         *(uint32_t*)(col + (size_t)BM_W * PT) = hi ^ 0x80808080u;
+        if constexpr (WIDE) *(uint32_t*)(col + 2 * (size_t)BM_W * PT) = top;          // 0 / 1 as it is
     }
     __syncthreads();
-    // the tile's two planes out, 64 contiguous bytes (64 rows) per byte column
+    // the tile's planes out, 64 contiguous bytes (64 rows) per byte column
     uint8_t* pl = planes + (long long)tbz * pstride;
-    for (int idx = t; idx < 2 * BM_W * 4; idx += 256) {
+    for (int idx = t; idx < NPL * BM_W * 4; idx += 256) {
         const int q = idx & 3, xb = (idx >> 2) & (BM_W - 1), p = idx >> 8;
         const uint4 v = *(const uint4*)(s_pl + (size_t)(p * BM_W + xb) * PT + q * 16);
         *(uint4*)(pl + ((size_t)p * roww_pad + x0b + xb) * hp + y0 + q * 16) = v;
     }
 }
 
-template <int CN>
+template <int CN, bool WIDE>
 __global__ __launch_bounds__(256) void k_blur_mfma_cols(const uint8_t* __restrict__ planes, long long pstride, int hp, int roww_pad,
                                                         uint8_t* __restrict__ dst, long long dstride, int dstep, int w, int h,
                                                         const bm_v4i* __restrict__ bands, int r, int nchunk, int pitch_p, int bias) {
     extern __shared__ __attribute__((aligned(16))) uint8_t bm_smem[];
-    uint8_t* s_pl = bm_smem;                                        // [2][BM_W][pitch_p]: row 0 = image row y0 - r
+    uint8_t* s_pl = bm_smem;                                        // [2 or 3][BM_W][pitch_p]: row 0 = image row y0 - r
+    constexpr int NPL = WIDE ? 3 : 2;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     int tbx, tby, tbz;
     bm_xcd_tile<true>(&tbx, &tby, &tbz);
     const int x0b = tbx * BM_W, y0 = tby * BM_H, roww = w * CN;
     const uint8_t* pl = planes + (long long)tbz * pstride;
     const int nrows = BM_H + 2 * r, n16 = (nrows + 15) >> 4;
-    for (int idx = t; idx < 2 * BM_W * n16; idx += 256) {
+    for (int idx = t; idx < NPL * BM_W * n16; idx += 256) {
         const int piece = idx % n16, xb = (idx / n16) & (BM_W - 1), p = idx / (n16 * BM_W);
         const uint8_t* colp = pl + ((size_t)p * roww_pad + x0b + xb) * hp;
         const int ya = y0 - r + piece * 16;
@@ -639,20 +643,21 @@ __global__ __launch_bounds__(256) void k_blur_mfma_cols(const uint8_t* __restric
     const int vec_end = roww & ~3;                                  // OpenCV's SSE2 column loop; behind it the scalar template
     for (int tile = wv; tile < (BM_W / 16) * (BM_H / 16); tile += 4) {
         const int xg = tile & 3, og = tile >> 2;
-        bm_v4i al = {0, 0, 0, 0}, ah = {0, 0, 0, 0};
+        bm_v4i al = {0, 0, 0, 0}, ah = {0, 0, 0, 0}, at = {0, 0, 0, 0};
         const uint8_t* acol = s_pl + (size_t)(xg * 16 + (lane & 15)) * pitch_p + og * 16 + 16 * (lane >> 4);
 #pragma unroll
         for (int c = 0; c < 3; c++)
             if (c < nchunk) {
                 al = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + 64 * c), band[c], al, 0, 0, 0);
                 ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + (size_t)BM_W * pitch_p + 64 * c), band[c], ah, 0, 0, 0);
+                if constexpr (WIDE) at = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + 2 * (size_t)BM_W * pitch_p + 64 * c), band[c], at, 0, 0, 0);
             }
         const int y = y0 + og * 16 + (lane & 15), xb = x0b + xg * 16 + 4 * (lane >> 4);
         if (y >= h || xb >= roww) continue;
         uint32_t px = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t T = (uint32_t)(al[i] + 256 * ah[i] + bias);        // the column sum in units of 2^-16
+            const uint32_t T = (uint32_t)(al[i] + 256 * ah[i] + 65536 * at[i] + bias);        // the column sum in units of 2^-16
             uint32_t q = T >> 16;
             const uint32_t rem = T & 0xffffu;
             if (xb + i < vec_end) q += (rem > 0x8000u || (rem == 0x8000u && (q & 1u))) ? 1u : 0u;   // cvRound: half to even
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma_cols(const uint8_t* __restric
 // Both passes in ONE launch for the radii whose tile fits LDS twice per compute unit: the rows of the tile AND its 2r halo rows
 // are reduced into the transposed planes in LDS (never in memory), then the columns.  The halo rows are reduced once per tile
 // row they border (x (64 + 2r) / 64 of the row pass: the matrix unit has the time), the row sums never leave the chip.
-template <int CN>
+template <int CN, bool WIDE>
 __global__ __launch_bounds__(256) void k_blur_mfma_fused(const uint8_t* __restrict__ src, long long sstride, int sstep, int w, int h,
                                                          uint8_t* __restrict__ dst, long long dstride, int dstep,
                                                          const bm_v4i* __restrict__ bands_r, const bm_v4i* __restrict__ bands_c, int r, int nrc, int ncc,
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma_fused(const uint8_t* __restri
     extern __shared__ __attribute__((aligned(16))) uint8_t bm_smem[];
     const int nr16 = (BM_H + 2 * r + 15) & ~15;                     // staged rows: image rows y0 - r .. (replicated past the borders)
     uint8_t* s_src = bm_smem;                                       // [nr16][pitch_s]
-    uint8_t* s_pl = bm_smem + (size_t)nr16 * pitch_s;               // [2][BM_W][pitch_p], row 0 = image row y0 - r
+    uint8_t* s_pl = bm_smem + (size_t)nr16 * pitch_s;               // [2 or 3][BM_W][pitch_p], row 0 = image row y0 - r
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     int tbx, tby, tbz;
     bm_xcd_tile<false>(&tbx, &tby, &tbz);
@@ -715,16 +720,18 @@ __global__ __launch_bounds__(256) void k_blur_mfma_fused(const uint8_t* __restri
 #pragma unroll
         for (int c = 0; c < BM_MAXC; c++)
             if (c < nrc) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(arow + 64 * c), band[c], acc, 0, 0, 0);
-        uint32_t lo = 0, hi = 0;
+        uint32_t lo = 0, hi = 0, top = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t S = (uint32_t)(acc[i] + bias_r);
             lo |= (S & 255u) << (8 * i);
-            hi |= (S >> 8) << (8 * i);
+            hi |= ((S >> 8) & 255u) << (8 * i);
+            top |= (S >> 16) << (8 * i);
         }
         uint8_t* col = s_pl + (size_t)(xg * 16 + (lane & 15)) * pitch_p + rg * 16 + 4 * (lane >> 4);
         *(uint32_t*)col = lo ^ 0x80808080u;
         *(uint32_t*)(col + (size_t)BM_W * pitch_p) = hi ^ 0x80808080u;
+        if constexpr (WIDE) *(uint32_t*)(col + 2 * (size_t)BM_W * pitch_p) = top;
     }
     bm_v4i bandc[3];
 #pragma unroll
@@ -734,20 +741,21 @@ __global__ __launch_bounds__(256) void k_blur_mfma_fused(const uint8_t* __restri
     const int vec_end = roww & ~3;
     for (int tile = wv; tile < (BM_W / 16) * (BM_H / 16); tile += 4) {
         const int xg = tile & 3, og = tile >> 2;
-        bm_v4i al = {0, 0, 0, 0}, ah = {0, 0, 0, 0};
+        bm_v4i al = {0, 0, 0, 0}, ah = {0, 0, 0, 0}, at = {0, 0, 0, 0};
         const uint8_t* acol = s_pl + (size_t)(xg * 16 + (lane & 15)) * pitch_p + og * 16 + 16 * (lane >> 4);
 #pragma unroll
         for (int c = 0; c < 3; c++)
             if (c < ncc) {
                 al = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + 64 * c), bandc[c], al, 0, 0, 0);
                 ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + (size_t)BM_W * pitch_p + 64 * c), bandc[c], ah, 0, 0, 0);
+                if constexpr (WIDE) at = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const bm_v4i*)(acol + 2 * (size_t)BM_W * pitch_p + 64 * c), bandc[c], at, 0, 0, 0);
             }
         const int y = y0 + og * 16 + (lane & 15), xb = x0b + xg * 16 + 4 * (lane >> 4);
         if (y >= h || xb >= roww) continue;
         uint32_t px = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t T = (uint32_t)(al[i] + 256 * ah[i] + bias_c);
+            const uint32_t T = (uint32_t)(al[i] + 256 * ah[i] + 65536 * at[i] + bias_c);
             uint32_t q = T >> 16;
             const uint32_t rem = T & 0xffffu;
             if (xb + i < vec_end) q += (rem > 0x8000u || (rem == 0x8000u && (q & 1u))) ? 1u : 0u;
@@ -767,15 +775,22 @@ static int launch_gaussian_mfma(const Frames& f, const std::vector<int>& ik, int
     long long sum = 0;
     int top = 0;
     for (int k : ik) { sum += k; top = std::max(top, k); }
-    if (top > 127 || sum > 257 || r < 1 || 2 * r + 1 > 250) return IMP_ERROR_UNSUPPORTED;
+    // (taps are operands of the i8 MFMA; 2 * 255 * sum * top < 2^24 keeps every product of OpenCV's float column pass exact)
+    if (top > 127 || sum > 511 || 2LL * 255 * sum * top >= (1LL << 24) || r < 1 || 2 * r + 1 > 250) return IMP_ERROR_UNSUPPORTED;
+    // Tap sums of 258 .. 260 (eleven of the sigmas 0.5 .. 25.0 in steps of 0.1, sigma = 4 among them) make row sums of 17
+    // bits: a third byte plane holds bit 16 and the column pass takes a third MFMA per chunk (round 5; those sigmas ran on
+    // the VALU kernels before).  The column sum is exact all the same: a partial sum can only round in float once it is past
+    // 256.0, and then the pixel saturates to 255 whatever the rounding did.
+    const bool wide = sum > 257;
+    const int npl = wide ? 3 : 2;
     const int cn = v.c, roww = v.w * cn;
     const int nrc = (16 + 2 * cn * r + 63) / 64, ncc = (16 + 2 * r + 63) / 64;
     if (nrc > BM_MAXC || ncc > 3) return IMP_ERROR_UNSUPPORTED;
     if ((f.dstep & 3) || ((uintptr_t)f.dst & 3) || (f.dst_stride & 3)) return IMP_ERROR_UNSUPPORTED;
     const int roww_pad = (roww + BM_W - 1) / BM_W * BM_W, hp = (v.h + BM_H - 1) / BM_H * BM_H;
     const int pitch_s = 64 * nrc + 64 + 16, pitch_p = 64 * ncc + 64 + 16;   // (+16: sixteen rows / byte columns start in sixteen different 16-byte slots of the banks)
-    const size_t lds_r = (size_t)BM_H * pitch_s + 2 * (size_t)BM_W * (BM_H + 16), lds_c = 2 * (size_t)BM_W * pitch_p;
-    const long long pstride = 2LL * roww_pad * hp;
+    const size_t lds_r = (size_t)BM_H * pitch_s + (size_t)npl * BM_W * (BM_H + 16), lds_c = (size_t)npl * BM_W * pitch_p;
+    const long long pstride = (long long)npl * roww_pad * hp;
     void *dev_k = nullptr, *planes = nullptr;
     std::vector<int> blob;                                   // the two passes' band operands, lane by lane
     bm_band_host(ik, r, cn, nrc, &blob);
@@ -784,21 +799,22 @@ static int launch_gaussian_mfma(const Frames& f, const std::vector<int>& ik, int
     if (int rc = upload_small(blob.data(), blob.size() * 4, &dev_k, s)) return rc;
     // one launch for the small radii (the halo rows are cheap there and four tiles fit a compute unit); IMPGPU_BLUR_MFMA2=1: always two (A/B)
     const int nr16 = (BM_H + 2 * r + 15) & ~15;
-    const size_t lds_f = (size_t)nr16 * pitch_s + 2 * (size_t)BM_W * pitch_p;
+    const size_t lds_f = (size_t)nr16 * pitch_s + (size_t)npl * BM_W * pitch_p;
     static const bool two = ab_env("IMPGPU_BLUR_MFMA2") != nullptr;
-    if (lds_f <= (size_t)ab_env_int("IMPGPU_BLUR_FUSE_KB", 40) * 1024 && !two && f.count <= 65535) {        // (measured at 1080p BGRA: sigma 2 19 us against 24 in two launches, sigma 8 32 against 30, sigma 12 48 against 35)
+    if (lds_f <= (size_t)ab_env_int("IMPGPU_BLUR_FUSE_KB", wide ? 50 : 40) * 1024 && !two && f.count <= 65535) {        // (measured at 1080p BGRA: sigma 2 19 us against 24 in two launches, sigma 8 32 against 30, sigma 12 48 against 35)
         hipError_t e = hipSuccess;
         const dim3 grid((unsigned)(roww_pad / BM_W), (unsigned)(hp / BM_H), (unsigned)f.count);
         const bm_v4i* br = (const bm_v4i*)dev_k;
         const bm_v4i* bc = (const bm_v4i*)((const int*)dev_k + off_c);
-#define IMP_BLUR_FUSED(CN_)                                                                                                          \
+#define IMP_BLUR_FUSED(CN_, W_)                                                                                                      \
     do {                                                                                                                             \
-        e = lds_limit_once<k_blur_mfma_fused<CN_>>();                                                                                \
+        e = lds_limit_once<k_blur_mfma_fused<CN_, W_>>();                                                                            \
         if (e == hipSuccess)                                                                                                         \
-            hipLaunchKernelGGL((k_blur_mfma_fused<CN_>), grid, dim3(256), lds_f, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, \
+            hipLaunchKernelGGL((k_blur_mfma_fused<CN_, W_>), grid, dim3(256), lds_f, s, f.src, f.src_stride, v.step, v.w, v.h, f.dst, f.dst_stride, \
                                f.dstep, br, bc, r, nrc, ncc, pitch_s, pitch_p, (int)(128 * sum), (int)(128 * sum * 257));             \
     } while (0)
-        if (cn == 4) IMP_BLUR_FUSED(4); else if (cn == 3) IMP_BLUR_FUSED(3); else IMP_BLUR_FUSED(1);
+        if (wide) { if (cn == 4) IMP_BLUR_FUSED(4, true); else if (cn == 3) IMP_BLUR_FUSED(3, true); else IMP_BLUR_FUSED(1, true); }
+        else { if (cn == 4) IMP_BLUR_FUSED(4, false); else if (cn == 3) IMP_BLUR_FUSED(3, false); else IMP_BLUR_FUSED(1, false); }
 #undef IMP_BLUR_FUSED
         if (e == hipSuccess) e = hipGetLastError();
         dev_free_on(dev_k, s);
@@ -814,18 +830,19 @@ static int launch_gaussian_mfma(const Frames& f, const std::vector<int>& ik, int
         const dim3 grid((unsigned)(roww_pad / BM_W), (unsigned)(hp / BM_H), (unsigned)n);
         const uint8_t* src = f.src + (long long)f0 * f.src_stride;
         uint8_t* dst = f.dst + (long long)f0 * f.dst_stride;
-#define IMP_BLUR_MFMA(CN_)                                                                                                                  \
+#define IMP_BLUR_MFMA(CN_, W_)                                                                                                              \
     do {                                                                                                                                    \
-        e = lds_limit_once<k_blur_mfma_rows<CN_>>();                                                                                        \
-        if (e == hipSuccess) e = lds_limit_once<k_blur_mfma_cols<CN_>>();                                                                   \
+        e = lds_limit_once<k_blur_mfma_rows<CN_, W_>>();                                                                                    \
+        if (e == hipSuccess) e = lds_limit_once<k_blur_mfma_cols<CN_, W_>>();                                                               \
         if (e == hipSuccess) {                                                                                                              \
-            hipLaunchKernelGGL((k_blur_mfma_rows<CN_>), grid, dim3(256), lds_r, s, src, f.src_stride, v.step, v.w, v.h, (uint8_t*)planes, pstride, hp, \
+            hipLaunchKernelGGL((k_blur_mfma_rows<CN_, W_>), grid, dim3(256), lds_r, s, src, f.src_stride, v.step, v.w, v.h, (uint8_t*)planes, pstride, hp, \
                                roww_pad, (const bm_v4i*)dev_k, r, nrc, pitch_s, bias_r);                                                       \
-            hipLaunchKernelGGL((k_blur_mfma_cols<CN_>), grid, dim3(256), lds_c, s, (const uint8_t*)planes, pstride, hp, roww_pad, dst, f.dst_stride, \
+            hipLaunchKernelGGL((k_blur_mfma_cols<CN_, W_>), grid, dim3(256), lds_c, s, (const uint8_t*)planes, pstride, hp, roww_pad, dst, f.dst_stride, \
                                f.dstep, v.w, v.h, (const bm_v4i*)((const int*)dev_k + off_c), r, ncc, pitch_p, bias_c);                                              \
         }                                                                                                                                   \
     } while (0)
-        if (cn == 4) IMP_BLUR_MFMA(4); else if (cn == 3) IMP_BLUR_MFMA(3); else IMP_BLUR_MFMA(1);
+        if (wide) { if (cn == 4) IMP_BLUR_MFMA(4, true); else if (cn == 3) IMP_BLUR_MFMA(3, true); else IMP_BLUR_MFMA(1, true); }
+        else { if (cn == 4) IMP_BLUR_MFMA(4, false); else if (cn == 3) IMP_BLUR_MFMA(3, false); else IMP_BLUR_MFMA(1, false); }
 #undef IMP_BLUR_MFMA
         if (e == hipSuccess) e = hipGetLastError();
     }

@@ -258,6 +258,8 @@ size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
     // round 4, the stage without rounds, one file at a time (profiles/r04_jpeg_chunk_ab.txt, ms at 256 / 512 / 1024 / 2048 bits):
     // 640x480 0.25 / 0.30 / 0.41 / 0.62, 1080p 4:2:0 0.32 / 0.36 / 0.46 / 0.67, 4:4:4 0.28 / 0.33 / 0.45 / 0.67, 4K 0.58 / 0.52 / 0.61 / 0.81
     // -- every kernel's time is the length of a chunk's walk until the chunks no longer fit the device at once
+    // (round 5, after the write walk and the launches got shorter: 128 / 256 / 512 bits 640x480 0.213 / 0.204 / 0.245, 1080p 0.341 / 0.290 / 0.321,
+    // 4K 0.786 / 0.553 / 0.492 -- 128-bit chunks lose everywhere: the walks' overlap is five blocks whatever the chunk)
     return file_bytes <= (size_t(1200) << 10) ? 32 : 64;
 }
 

@@ -151,6 +151,7 @@ struct JpegJob {
                                              // (null: the planes hold absolute DC terms -- the host's entropy stage)
     uint8_t* dst;                            // the frame
     int dstep;
+    uint32_t* verdict;                       // where k_jpeg_dcfix leaves header[0..3] for the host (pinned memory; null: the host copies them)
 };
 // a workgroup's record in the chain of k_jpeg_select (words):
 //   [1] 1 = its map is in [2]; 2 = its final word is in [3..5]
@@ -174,7 +175,8 @@ inline unsigned jpeg_entropy_blocks(unsigned nchunks) { return (nchunks + JPEG_H
 // sync_map for k_jpeg_select (jpeg_sync_blocks per job), chunk_map for k_jpeg_write and k_jpeg_dcfix (jpeg_entropy_blocks)
 // `marks`: null, or five events recorded behind k_jpeg_walks, _mend, _select, _write, _dcfix (impgpu_jpeg_profile)
 int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* sync_map, unsigned sync_blocks, const JpegMapEntry* chunk_map,
-                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s, hipEvent_t* marks = nullptr);
+                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s, hipEvent_t* marks = nullptr, bool small = false);
+// `small`: walks, mend and select as ONE launch (k_jpeg_entropy_small) -- for launches that do not fill the device anyway
 // dequantise + ISLOW IDCT + fancy upsampling + YCbCr->BGR, coefficient planes -> frames; all jobs of one sampling class
 int launch_jpeg_pixels(int hs, int vs, int ncomp, const JpegJob* jobs, const JpegMapEntry* tile_map, unsigned total_tiles, hipStream_t s);
 

@@ -72,16 +72,13 @@ constexpr int SB = JPEG_SYNC_BLOCK;
 // waited for -- the instruction stream of a table-driven decoder saturates the vector unit as long as nothing else holds the
 // workgroup's slots (as ONE kernel with the selection the workgroups of a compute unit went through their latency-bound
 // phases together, and the unit idled a third of the time).
-__global__ __launch_bounds__(SB) void k_jpeg_walks(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
-    __shared__ JpegHuffTabs L;
+// (the kernel's body as a function: k_jpeg_walks is this alone, k_jpeg_entropy_small runs it as the first of five phases)
+__device__ __forceinline__ void walks_body(JpegHuffTabs& L, const JpegJob& J, const uint32_t b, const bool publish_tabs) {
     const int t = threadIdx.x;
-    const JpegMapEntry me = block_map[blockIdx.x];
-    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
     const JpegFrame& F = J.F;           // (a reference: scalar loads from the table; a copy of the struct would live in scratch memory)
     load_tables(L, J.tables, t, SB);
     const uint32_t CHUNK_BITS = F.chunk_bits, OVERLAP = F.overlap_bits;
     const uint32_t B = (uint32_t)F.bpm, CPW = (uint32_t)SB / B;     // walks per chunk, chunks per workgroup
-    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
     const uint32_t g0 = b * CPW;
     const uint32_t nlive = min(CPW, F.nchunks - g0);
     const uint32_t k = (uint32_t)t / CPW, j = (uint32_t)t - k * CPW;
@@ -95,7 +92,7 @@ __global__ __launch_bounds__(SB) void k_jpeg_walks(const JpegJob* __restrict__ j
     auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };      // (a plain load: the lane comes back to the line for its next word, which a non-temporal load does not keep -- 313 against 465 us per 64 files in k_jpeg_walks)
     __syncthreads();
     // (the tables as the lanes read them, for k_jpeg_mend)
-    if (b == 0) for (int i = t; i < (int)(sizeof(JpegHuffTabs) / 4); i += SB) ((uint32_t*)J.tabs)[i] = ((const uint32_t*)&L)[i];
+    if (publish_tabs && b == 0) for (int i = t; i < (int)(sizeof(JpegHuffTabs) / 4); i += SB) ((uint32_t*)J.tabs)[i] = ((const uint32_t*)&L)[i];
     if (k >= B || j >= nlive) return;
     const uint32_t seg = J.chunk_seg[g], first = J.seg_first_chunk[seg];
     const uint32_t seg_start = first * CHUNK_BITS, seg_end = seg_start + J.seg_bits[seg];
@@ -112,24 +109,34 @@ __global__ __launch_bounds__(SB) void k_jpeg_walks(const JpegJob* __restrict__ j
     J.cand_n[at] = sp.n;
 }
 
+__global__ __launch_bounds__(SB) void k_jpeg_walks(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
+    __shared__ JpegHuffTabs L;
+    const JpegMapEntry me = block_map[blockIdx.x];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    walks_body(L, J, __builtin_amdgcn_readfirstlane(me.local), true);
+}
+
 // Which walk of a chunk does each exit candidate of the chunk before it lead into?  A lane per (chunk, candidate k): the same
 // state as an earlier candidate -> that one's answer ("twin"); one of the chunk's `in` states -> that walk; otherwise the
 // lane decodes the chunk once more from the candidate state (a "repair" walk -- one chunk in twenty needs one for some
 // candidate) and looks which of the chunk's walks it has joined by the end.  No barrier, nothing waited for: the few lanes
 // that walk are latency-bound and alone in their waves, so the kernel is as long as one walk however many there are.
-__global__ __launch_bounds__(SB) void k_jpeg_mend(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
-    __shared__ JpegHuffTabs L;
-    __shared__ uint32_t s_count;
-    __shared__ uint16_t s_items[SB];                                // the lanes (k * CPW + j) whose candidate needs a repair walk
+struct MendShared {
+    uint32_t count;
+    uint16_t items[SB];                                             // the lanes (k * CPW + j) whose candidate needs a repair walk
+};
+// FUSED = as a phase of k_jpeg_entropy_small: the tables are in L already, and no record of speculative steps is left (the
+// chunks ahead belong to workgroups that may not have walked yet: k_jpeg_select's chase decodes on from the state instead)
+template <bool FUSED>
+__device__ __forceinline__ void mend_body(JpegHuffTabs& L, MendShared& M, const JpegJob& J, const uint32_t b) {
+    uint32_t& s_count = M.count;
+    uint16_t* s_items = M.items;
     const int t = threadIdx.x;
-    const JpegMapEntry me = block_map[blockIdx.x];
-    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
     const JpegFrame& F = J.F;
-    for (int i = t; i < (int)(sizeof(JpegHuffTabs) / 4); i += SB) ((uint32_t*)&L)[i] = ((const uint32_t*)J.tabs)[i];
+    if (!FUSED) for (int i = t; i < (int)(sizeof(JpegHuffTabs) / 4); i += SB) ((uint32_t*)&L)[i] = ((const uint32_t*)J.tabs)[i];
     if (t == 0) s_count = 0;
     const uint32_t CHUNK_BITS = F.chunk_bits, OVERLAP = F.overlap_bits;
     const uint32_t B = (uint32_t)F.bpm, CPW = (uint32_t)SB / B;
-    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
     const uint32_t g0 = b * CPW;
     const uint32_t nlive = min(CPW, F.nchunks - g0);
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
@@ -188,8 +195,8 @@ __global__ __launch_bounds__(SB) void k_jpeg_mend(const JpegJob* __restrict__ jo
             // to be too.  Decode on, chunk by chunk, until the state IS one of a chunk's candidates, and leave what was
             // found on the way -- every chunk's entry state and slot count -- in a record k_jpeg_select can follow
             // without decoding anything (it used to: one lane, a chunk at a time, its successors waiting).
-            const uint32_t r = atomicAdd(J.ext_count, 1u);
-            uint32_t* R = r < J.ext_cap ? J.ext + (size_t)r * JPEG_EXT_WORDS : nullptr;
+            const uint32_t r = FUSED ? 0xffffffffu : atomicAdd(J.ext_count, 1u);
+            uint32_t* R = (!FUSED && r < J.ext_cap) ? J.ext + (size_t)r * JPEG_EXT_WORDS : nullptr;
             J.ext_idx[at] = R ? r : 0xffffffffu;
             if (R) {
                 uint64_t S = sp.out;
@@ -223,28 +230,37 @@ __global__ __launch_bounds__(SB) void k_jpeg_mend(const JpegJob* __restrict__ jo
     }
 }
 
-__global__ __launch_bounds__(SB) void k_jpeg_select(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map, uint32_t* __restrict__ launch_ticket) {
-    __shared__ uint64_t s_in[SB], s_out[SB], s_rep_out[SB];         // [k * CPW + j]: walk k of the workgroup's j-th chunk
-    __shared__ uint64_t s_pout[6];                                  // the exit candidates of the chunk in front of the workgroup
-    __shared__ uint32_t s_n[SB], s_rep_n[SB];
-    __shared__ uint32_t s_res_n[SB];                                // [j]
-    __shared__ uint32_t s_map[SB], s_scan[2][SB];                   // [j]: the chunk's map; the scan's two buffers
-    __shared__ uint8_t s_nib[SB], s_exact[SB], s_own[SB];           // s_own: the candidate whose answer this one shares (a twin's), else itself
-    __shared__ uint32_t s_ticket, s_jf, s_mode, s_idx0, s_fin, s_chases, s_ext, s_ei, s_from;
-    __shared__ uint64_t s_S;
-    const int t = threadIdx.x;
-    // workgroups are numbered in the order they START (a ticket), never by blockIdx: the one a workgroup waits for is then
-    // always running already
-    if (t == 0) s_ticket = atomicAdd(launch_ticket, 1u);
-    __syncthreads();
-    const JpegMapEntry me = block_map[__builtin_amdgcn_readfirstlane(s_ticket)];
+__global__ __launch_bounds__(SB) void k_jpeg_mend(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
+    __shared__ JpegHuffTabs L;
+    __shared__ MendShared M;
+    const JpegMapEntry me = block_map[blockIdx.x];
     const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    mend_body<false>(L, M, J, __builtin_amdgcn_readfirstlane(me.local));
+}
+
+struct SelShared {
+    uint64_t in[SB], out[SB], rep_out[SB];                          // [k * CPW + j]: walk k of the workgroup's j-th chunk
+    uint64_t pout[6];                                               // the exit candidates of the chunk in front of the workgroup
+    uint32_t n[SB], rep_n[SB];
+    uint32_t res_n[SB];                                             // [j]
+    uint32_t map[SB], scan[2][SB];                                  // [j]: the chunk's map; the scan's two buffers
+    uint8_t nib[SB], exact[SB], own[SB];                            // own: the candidate whose answer this one shares (a twin's), else itself
+    uint32_t jf, mode, idx0, fin, chases, ext, ei, from;
+    uint64_t S;
+};
+// (workgroup `b` of job J, numbered by TICKET: every workgroup it looks back at has started)
+__device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, const uint32_t b) {
+    auto& s_in = Z.in; auto& s_out = Z.out; auto& s_rep_out = Z.rep_out; auto& s_pout = Z.pout;
+    auto& s_n = Z.n; auto& s_rep_n = Z.rep_n; auto& s_res_n = Z.res_n; auto& s_map = Z.map; auto& s_scan = Z.scan;
+    auto& s_nib = Z.nib; auto& s_exact = Z.exact; auto& s_own = Z.own;
+    uint32_t &s_jf = Z.jf, &s_mode = Z.mode, &s_idx0 = Z.idx0, &s_fin = Z.fin, &s_chases = Z.chases, &s_ext = Z.ext, &s_ei = Z.ei, &s_from = Z.from;
+    uint64_t& s_S = Z.S;
+    const int t = threadIdx.x;
     const JpegFrame& F = J.F;
     struct { const uint32_t *words, *chunk_seg, *seg_first_chunk, *seg_bits; const JpegHuffDev* tables; uint32_t *header, *records; uint64_t* chunk_entry; uint32_t* chunk_n; } A =
         {J.words, J.chunk_seg, J.seg_first_chunk, J.seg_bits, J.tables, J.header, J.records, J.chunk_entry, J.chunk_n};
     const uint32_t CHUNK_BITS = F.chunk_bits;
     const uint32_t B = (uint32_t)F.bpm, CPW = (uint32_t)SB / B;     // walks per chunk, chunks per workgroup
-    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
     const uint32_t nblocks = (F.nchunks + CPW - 1) / CPW;
     const uint32_t g0 = b * CPW;
     const uint32_t nlive = min(CPW, F.nchunks - g0), jl = nlive - 1;
@@ -488,6 +504,18 @@ __global__ __launch_bounds__(SB) void k_jpeg_select(const JpegJob* __restrict__ 
     stamp(5);
 }
 
+__global__ __launch_bounds__(SB) void k_jpeg_select(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map, uint32_t* __restrict__ launch_ticket) {
+    __shared__ SelShared Z;
+    __shared__ uint32_t s_ticket;
+    // workgroups are numbered in the order they START (a ticket), never by blockIdx: the one a workgroup waits for is then
+    // always running already
+    if (threadIdx.x == 0) s_ticket = atomicAdd(launch_ticket, 1u);
+    __syncthreads();
+    const JpegMapEntry me = block_map[__builtin_amdgcn_readfirstlane(s_ticket)];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    select_body(Z, J, __builtin_amdgcn_readfirstlane(me.local));
+}
+
 constexpr int HB = JPEG_HUFF_BLOCK;
 
 // Sum of x[c] over the chunks c in [first, g0) -- g0 = the workgroup's first chunk, first = where the interval it belongs to
@@ -511,33 +539,34 @@ __device__ T sum_before(const T* x, int xstride, const T* tot, int stride, uint3
     return *s_acc;
 }
 
-__global__ __launch_bounds__(HB) void k_jpeg_write(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
-    __shared__ JpegHuffCompact L;                                   // (the tables as the host built them: this walk reads nothing the widened form adds)
-    __shared__ JpegBlockTabs K;
-    __shared__ uint32_t s_n[HB];
-    __shared__ uint8_t s_head[HB];                                  // 1 = an interval starts in or before this chunk (inside the workgroup)
-    __shared__ uint32_t s_carry;
-    __shared__ int s_tot[4];
+struct WriteShared {
+    JpegBlockTabs K;
+    uint32_t n[HB];
+    uint8_t head[HB];                                               // 1 = an interval starts in or before this chunk (inside the workgroup)
+    uint32_t carry;
+    int tot[4];
     // per lane: the block it is decoding.  144 bytes apart, not 128: with a power-of-two pitch every lane's coefficient k sits
     // in one of two banks and a wave's scattered 2-byte stores queue up behind each other (31 % of the LDS-active cycles were
     // bank conflicts, profiles/r04_jpeg_sq_counters.txt); 36 words apart the same k of sixteen lanes falls into sixteen banks
-    __shared__ __attribute__((aligned(16))) int16_t s_stage[HB][72];
-    __shared__ uint32_t s_list[HB / 64][128];                       // per wave: its complete blocks {where in LDS, where in the planes}
+    __attribute__((aligned(16))) int16_t stage[HB][72];
+    uint32_t list[HB / 64][128];                                    // per wave: its complete blocks {where in LDS, where in the planes}
+};
+// The workgroup's chunks are g0 .. g0 + own - 1, a lane each (k_jpeg_write: own = HB; as a phase of k_jpeg_entropy_small: the
+// chunks of a k_jpeg_select workgroup).  L: the tables, in either form.  wg_dc: where the workgroup's DC sums go.
+template <class Tabs>
+__device__ __forceinline__ void write_body(const Tabs& L, WriteShared& Y, const JpegJob& J, const uint32_t g0, const uint32_t own, int* wg_dc) {
+    JpegBlockTabs& K = Y.K;
+    auto& s_n = Y.n; auto& s_head = Y.head; uint32_t& s_carry = Y.carry; auto& s_tot = Y.tot; auto& s_stage = Y.stage; auto& s_list = Y.list;
     const int t = threadIdx.x;
-    const uint32_t clock0 = (uint32_t)wall_clock64();
     for (int i = t; i < HB * 72 / 8; i += HB) ((uint4*)&s_stage[0][0])[i] = make_uint4(0, 0, 0, 0);
-    const JpegMapEntry me = block_map[blockIdx.x];
-    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
     const JpegFrame& F = J.F;
     struct { const uint32_t *words, *chunk_seg, *seg_first_chunk, *seg_bits; const JpegHuffDev* tables; int16_t* coef; uint32_t *header, *records; } A =
         {J.words, J.chunk_seg, J.seg_first_chunk, J.seg_bits, J.tables, J.coef, J.header, J.records};
-    for (int i = t; i < (int)(sizeof(JpegHuffCompact) / 4); i += HB) ((uint32_t*)&L)[i] = ((const uint32_t*)A.tables)[i];
     load_block_tables(K, F, t);
     if (t < 4) s_tot[t] = 0;
     const uint32_t CHUNK_BITS = F.chunk_bits;
-    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
-    const uint32_t g0 = b * HB, g = g0 + (uint32_t)t;
-    const bool live = g < F.nchunks;
+    const uint32_t g = g0 + (uint32_t)t;
+    const bool live = (uint32_t)t < own && g < F.nchunks;
     uint32_t seg = 0, first = 0, seg_end = 0, limit = 0, own_n = 0;
     uint64_t entry = JPEG_STATE_NONE;
     bool origin = false;
@@ -619,21 +648,34 @@ __global__ __launch_bounds__(HB) void k_jpeg_write(const JpegJob* __restrict__ j
     for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_down(d0, o, 64); d1 += __shfl_down(d1, o, 64); d2 += __shfl_down(d2, o, 64); }
     if ((t & 63) == 0) { atomicAdd(&s_tot[0], d0); atomicAdd(&s_tot[1], d1); atomicAdd(&s_tot[2], d2); }
     __syncthreads();
-    if (t < 3) J.wg_dc[(size_t)b * 8 + t] = s_tot[t];
+    if (t < 3) wg_dc[t] = s_tot[t];
+}
+
+__global__ __launch_bounds__(HB) void k_jpeg_write(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
+    __shared__ JpegHuffCompact L;                                   // (the tables as the host built them: this walk reads nothing the widened form adds)
+    __shared__ WriteShared Y;
+    const int t = threadIdx.x;
+    const uint32_t clock0 = (uint32_t)wall_clock64();
+    const JpegMapEntry me = block_map[blockIdx.x];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    for (int i = t; i < (int)(sizeof(JpegHuffCompact) / 4); i += HB) ((uint32_t*)&L)[i] = ((const uint32_t*)J.tables)[i];
+    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
+    write_body(L, Y, J, b * HB, (uint32_t)HB, J.wg_dc + (size_t)b * 8);
     if (t == 0) { J.wg_dc[(size_t)b * 8 + 4] = (int)clock0; J.wg_dc[(size_t)b * 8 + 5] = (int)(uint32_t)wall_clock64(); }   // (IMPGPU_JPEG_TRACE=2)
 }
 
-__global__ __launch_bounds__(HB) void k_jpeg_dcfix(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
-    __shared__ int s_dc[3][HB];
-    __shared__ uint8_t s_head[HB];
-    __shared__ int s_carry[3];
+struct DcShared {
+    int dc[3][HB];
+    uint8_t head[HB];
+    int carry[3];
+};
+// tot / tot_stride / per: the DC sums of whole groups of `per` chunks (k_jpeg_write's workgroups, or k_jpeg_select's in the fused kernel)
+__device__ __forceinline__ void dcfix_body(DcShared& D, const JpegJob& J, const uint32_t g0, const uint32_t owned, const int* tot, int tot_stride, uint32_t per) {
+    auto& s_dc = D.dc; auto& s_head = D.head; auto& s_carry = D.carry;
     const int t = threadIdx.x;
-    const JpegMapEntry me = block_map[blockIdx.x];
-    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
     const JpegFrame& F = J.F;
-    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
-    const uint32_t g0 = b * HB, g = g0 + (uint32_t)t;
-    const bool live = g < F.nchunks;
+    const uint32_t g = g0 + (uint32_t)t;
+    const bool live = (uint32_t)t < owned && g < F.nchunks;
     int own[3] = {0, 0, 0};
     uint32_t ndc = 0;
     bool origin = false;
@@ -660,7 +702,7 @@ __global__ __launch_bounds__(HB) void k_jpeg_dcfix(const JpegJob* __restrict__ j
     }
     const uint32_t first0 = J.seg_first_chunk[J.chunk_seg[g0]];
     int carry[3];
-    for (int i = 0; i < 3; i++) carry[i] = sum_before<int>(J.chunk_dc + i, 4, J.wg_dc + i, 8, (uint32_t)HB, first0, g0, t, &s_carry[i]);
+    for (int i = 0; i < 3; i++) carry[i] = sum_before<int>(J.chunk_dc + i, 4, tot + i, tot_stride, per, first0, g0, t, &s_carry[i]);
     if (!live || ndc == 0) return;
     const bool open = !s_head[t];
     int base[3];
@@ -676,6 +718,62 @@ __global__ __launch_bounds__(HB) void k_jpeg_dcfix(const JpegJob* __restrict__ j
         J.dcadd[gb + i] = (int16_t)(c < nluma ? base[0] : (c - nluma == 0 ? base[1] : base[2]));
         c = c + 1 == bpm ? 0 : c + 1;
     }
+}
+
+__global__ __launch_bounds__(HB) void k_jpeg_dcfix(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
+    __shared__ DcShared D;
+    const JpegMapEntry me = block_map[blockIdx.x];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    // the file's verdict (status, counters: final since k_jpeg_write ended) straight into the host's pinned words -- a copy
+    // command between this kernel and k_jpeg_pixels cost the stream 8-10 us per launch
+    if (me.local == 0 && threadIdx.x < 4 && J.verdict) J.verdict[threadIdx.x] = J.header[threadIdx.x];
+    dcfix_body(D, J, __builtin_amdgcn_readfirstlane(me.local) * (uint32_t)HB, (uint32_t)HB, J.wg_dc, 8, (uint32_t)HB);
+}
+
+// ---------------------------------------------------------------- walks, mend and select in ONE launch (round 5)
+// A lone file -- and a broker's batch of a few -- spends its time in launches, not in work: each of the kernels above is a
+// latency-bound chain of 10-30 us with 15-25 us of launch, table load and tail around it.  Below the size where the kernels
+// fill the device (the same 4 MB at which the chunks grow to 256 bytes) the three phases that share a workgroup shape run
+// as ONE kernel: a workgroup owns its chunks through all three, numbered by ticket, and between phases it waits only for the
+// workgroup BEFORE it in its file -- the candidates of the chunk in front of its own (mend); select's look-back is the
+// chain it always was.  A workgroup never waits for a later one, later ones never start before earlier ones (tickets), the
+// wait is bounded and counted like k_jpeg_select's: no grid barrier, no co-residency assumed.  What a workgroup's lanes leave
+// for the next workgroup (its last chunk's candidates) is fenced by every lane before the flag that announces it.
+// k_jpeg_mend's speculative records look at chunks AHEAD and are not kept here (k_jpeg_select's chase decodes on from the
+// state instead).  k_jpeg_write and k_jpeg_dcfix stay launches of their own: they need the slot totals and DC sums of EVERY
+// workgroup back to the interval's first chunk -- a prefix over the whole file where there are no restart markers -- and with
+// them in the same kernel (measured: all five phases in one launch, the predecessors' totals waited for by the lanes in
+// parallel) a lone 1080p file took 0.52 ms against 0.31 and a 4K one 1.09 against 0.49: hundreds of workgroups polling flags
+// across the XCDs slow each other and the walks; a kernel boundary is the cheaper barrier there.  Only the 640 x 480 file
+// gained (0.220 against 0.234).
+struct FusedShared {
+    JpegHuffTabs L;
+    union { MendShared M; SelShared Z; } u;
+    uint32_t ticket;
+};
+
+__global__ __launch_bounds__(SB) void k_jpeg_entropy_small(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map, uint32_t* __restrict__ launch_ticket) {
+    __shared__ FusedShared X;
+    const int t = threadIdx.x;
+    if (t == 0) X.ticket = atomicAdd(launch_ticket, 1u);
+    __syncthreads();
+    const JpegMapEntry me = block_map[__builtin_amdgcn_readfirstlane(X.ticket)];
+    const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
+    const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
+    uint32_t* rec = J.records + (size_t)b * JPEG_CTL_REC;
+    // ---- 1. the walks of this workgroup's chunks
+    walks_body(X.L, J, b, false);
+    __threadfence();
+    __syncthreads();
+    if (t == 0) st_release(rec + 7, 1u);
+    // ---- 2. which walk does each of the predecessor chunk's candidates lead into (the chunk in front of the workgroup is
+    // the workgroup's before it)
+    if (b > 0 && t == 0 && !wait_flag_ge(rec - JPEG_CTL_REC + 7, 1u)) atomicOr(&J.header[1], JPEG_ST_CHAIN_TIMEOUT);
+    __syncthreads();
+    mend_body<true>(X.L, X.u.M, J, b);
+    __syncthreads();
+    // ---- 3. every chunk's true entry state
+    select_body(X.u.Z, J, b);
 }
 
 // ---------------------------------------------------------------- pixels
@@ -901,9 +999,19 @@ __global__ __launch_bounds__(256) void k_jpeg_pixels(const JpegJob* __restrict__
 }  // namespace
 
 int launch_jpeg_entropy(const JpegJob* jobs, const JpegMapEntry* sync_map, unsigned sync_blocks, const JpegMapEntry* chunk_map,
-                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s, hipEvent_t* marks) {
+                        unsigned chunk_blocks, uint32_t* ticket, hipStream_t s, hipEvent_t* marks, bool small) {
     if (sync_blocks == 0) return IMP_OK;
     auto mark = [&](int i) { if (marks) (void)hipEventRecord(marks[i], s); };
+    if (small) {
+        hipLaunchKernelGGL(k_jpeg_entropy_small, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map, ticket);
+        for (int i = 0; i < 3; i++) mark(i);                        // (the stage profile's slots of walks, mend and select: all under the first)
+        hipLaunchKernelGGL(k_jpeg_write, dim3(chunk_blocks), dim3(HB), 0, s, jobs, chunk_map);
+        mark(3);
+        hipLaunchKernelGGL(k_jpeg_dcfix, dim3(chunk_blocks), dim3(HB), 0, s, jobs, chunk_map);
+        mark(4);
+        IMP_HIP(hipGetLastError());
+        return IMP_OK;
+    }
     hipLaunchKernelGGL(k_jpeg_walks, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map);
     mark(0);
     hipLaunchKernelGGL(k_jpeg_mend, dim3(sync_blocks), dim3(SB), 0, s, jobs, sync_map);

@@ -87,6 +87,7 @@ struct Group {
     const size_t* sizes = nullptr;
     int count = 0;
     bool on_device = false, profile = false;
+    bool one_block = false;                         // d_side and d_ctl lie inside d_words' block (one upload for all three)
     void *d_words = nullptr, *d_coef = nullptr, *d_side = nullptr, *d_ctl = nullptr, *d_work = nullptr;
     void* mark = nullptr;                           // the point of the group's stream where its last kernel was enqueued
     hipStream_t stream = nullptr;                   // the lane's stream, or its side stream (a batch begun ahead: its decode overlaps what the thread enqueues next)
@@ -103,7 +104,7 @@ std::atomic<int> g_groups_in_flight{0};             // over all threads: groups 
 
 void group_release(Group& G) {
     for (int i = 0; i < 8; i++) if (G.ev[i]) { (void)hipEventDestroy(G.ev[i]); G.ev[i] = nullptr; }
-    void* blocks[5] = {G.d_words, G.d_coef, G.d_side, G.d_ctl, G.d_work};
+    void* blocks[5] = {G.d_words, G.d_coef, G.one_block ? nullptr : G.d_side, G.one_block ? nullptr : G.d_ctl, G.d_work};
     for (void* b : blocks)
         if (b) { if (G.stream && !on_lane_stream(G.stream)) dev_free_on(b, G.stream); else dev_free(b); }
     G.d_words = G.d_coef = G.d_side = G.d_ctl = G.d_work = nullptr;
@@ -246,15 +247,29 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         side += align_up(sync_blocks * sizeof(JpegMapEntry), 64);
         size_t side_tiles[5];
         for (int k = 0; k < 5; k++) { side_tiles[k] = side; side += align_up(tiles[k] * sizeof(JpegMapEntry), 64); }
-        rc = dev_alloc(side, &d_side);
+        // The scan words, the side blob and the (zeroed) control area cross the link as ONE copy when the pinned buffer the
+        // words were unstuffed into has room behind them (it is at least 8 MB): three commands on the stream -- two copies
+        // and a fill -- were 30-40 us of a lone file's 220 (tools/jpeg_stage_probe.py), the bytes themselves 3.
+        const size_t off_side = align_up(words_total, 256), off_ctl = off_side + align_up(side, 256), in_total = off_ctl + ctl_words * sizeof(uint32_t);
+        const bool one = G.one_block = on_device && stage_capacity(token) >= in_total;
+        if (one) {
+            rc = dev_alloc(in_total, &d_words);
+            if (!rc) { d_side = (uint8_t*)d_words + off_side; d_ctl = (uint8_t*)d_words + off_ctl; }
+        } else {
+            rc = dev_alloc(side, &d_side);
+            if (!rc && on_device) rc = dev_alloc(words_total, &d_words);
+            if (!rc && on_device) rc = dev_alloc(ctl_words * sizeof(uint32_t), &d_ctl);
+        }
         if (!rc) rc = dev_alloc(coef_total, &d_coef);
-        if (!rc && on_device) rc = dev_alloc(words_total, &d_words);
         if (!rc && on_device) rc = dev_alloc(work, &d_work);
         ctl_total = ctl_words;
-        if (!rc && on_device) rc = dev_alloc(ctl_words * sizeof(uint32_t), &d_ctl);
         if (!rc) rc = stream_join(s);                               // (side stream: the pool recycles in lane-stream order; the frames were allocated there too)
         if (rc) goto fail;
-        std::vector<uint8_t> blob(side);
+        std::vector<uint8_t> blob_mem(one ? 0 : side);
+        struct { uint8_t* p; uint8_t* data() const { return p; } } blob{one ? (uint8_t*)host + off_side : blob_mem.data()};
+        if (one) { std::memset((uint8_t*)host + words_total, 0, off_side - words_total); std::memset((uint8_t*)host + off_side, 0, in_total - off_side); }
+        uint32_t* verdict_dev = nullptr;                            // the device's view of the group's pinned verdict words
+        if (on_device && hipHostGetDevicePointer((void**)&verdict_dev, mailbox, 0) != hipSuccess) { verdict_dev = nullptr; (void)hipGetLastError(); }
         JpegJob* jobs = (JpegJob*)(blob.data() + side_jobs);
         JpegMapEntry* bmap = (JpegMapEntry*)(blob.data() + side_blocks);
         JpegMapEntry* smap = (JpegMapEntry*)(blob.data() + side_sync);
@@ -307,6 +322,7 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
             J.coef = (int16_t*)((uint8_t*)d_coef + p.coef_off);
             J.dst = p.im->d;
             J.dstep = p.im->step;
+            J.verdict = (on_device && verdict_dev) ? verdict_dev + 4 * j : nullptr;
             const int k = klass(p.F);
             const uint32_t ntiles = (uint32_t)(((p.F.width + JPEG_TILE_W - 1) / JPEG_TILE_W) * ((p.F.height + JPEG_TILE_H - 1) / JPEG_TILE_H));
             for (uint32_t tl = 0; tl < ntiles; tl++) tmap[k][nt[k]++] = JpegMapEntry{(uint32_t)j, tl};
@@ -317,24 +333,36 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
             for (int i = 0; i < 8; i++) if (hipEventCreate(&ev[i]) != hipSuccess) { ev[i] = nullptr; profile = false; }
             if (profile) (void)hipEventRecord(ev[0], s);
         }
-        rc = stage_upload(token, on_device ? d_words : d_coef, on_device ? words_total : coef_total);
+        rc = stage_upload(token, on_device ? d_words : d_coef, one ? in_total : on_device ? words_total : coef_total);
         token = nullptr;
-        if (!rc) rc = upload_to(d_side, blob.data(), side, s);      // (both copies ride the lane's stream; `s` is made to wait for them here)
+        if (!rc && !one) rc = upload_to(d_side, blob.data(), side, s);      // (both copies ride the lane's stream; `s` is made to wait for them here)
+        if (!rc && one) rc = stream_join(s);
         if (rc) goto fail;
         if (on_device) {
             // (the coefficient planes are not cleared: k_jpeg_write stores whole blocks)
-            if (hipMemsetAsync(d_ctl, 0, ctl_words * sizeof(uint32_t), s) != hipSuccess) {
+            if (!one && hipMemsetAsync(d_ctl, 0, ctl_words * sizeof(uint32_t), s) != hipSuccess) {
                 set_error("hipMemsetAsync(jpeg)", hipGetLastError());
                 rc = IMP_ERROR_DEVICE;
                 goto fail;
             }
             if (profile) (void)hipEventRecord(ev[1], s);
+            // a launch too small to fill the device with any of its kernels runs walks, mend and select as ONE launch
+            // (k_jpeg_entropy_small; measured, one file at a time, fused / five kernels: 640 x 480 0.221 / 0.235 ms, 720p equal,
+            // 1080p 0.323 / 0.313, 4K 0.546 / 0.510 -- from a few hundred KB on every phase is bound by what it computes, not by
+            // its launch, and a workgroup that waits inside a kernel holds slots a kernel boundary would have given to others).
+            // IMPGPU_JPEG_FUSED=0 keeps the five kernels, =1 fuses up to 4 MB (A/B, read per call).
+            const char* fz = std::getenv("IMPGPU_JPEG_FUSED");
+            const size_t fuse_up_to = fz && fz[0] == '1' ? (size_t(4) << 20) : (size_t(192) << 10);
+            const bool small = launch_bytes <= fuse_up_to && !(fz && fz[0] == '0');
             rc = launch_jpeg_entropy((const JpegJob*)((uint8_t*)d_side + side_jobs), (const JpegMapEntry*)((uint8_t*)d_side + side_sync), (unsigned)sync_blocks,
-                                     (const JpegMapEntry*)((uint8_t*)d_side + side_blocks), (unsigned)total_blocks, (uint32_t*)d_ctl, s, profile ? ev + 2 : nullptr);
+                                     (const JpegMapEntry*)((uint8_t*)d_side + side_blocks), (unsigned)total_blocks, (uint32_t*)d_ctl, s, profile ? ev + 2 : nullptr, small);
             if (rc) goto fail;
-            // the kernel's verdicts (did every interval decode to exactly its MCUs?) are read before a frame is handed on
-            const hipError_t e = hipMemcpyAsync(mailbox, (uint32_t*)d_ctl + 4, njobs * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-            if (e != hipSuccess) { set_error("hipMemcpyAsync(jpeg verdicts)", e); rc = IMP_ERROR_DEVICE; goto fail; }
+            // the kernel's verdicts (did every interval decode to exactly its MCUs?) are read before a frame is handed on:
+            // k_jpeg_dcfix has written them into the pinned words; copied only where the device cannot address those
+            if (!verdict_dev) {
+                const hipError_t e = hipMemcpyAsync(mailbox, (uint32_t*)d_ctl + 4, njobs * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+                if (e != hipSuccess) { set_error("hipMemcpyAsync(jpeg verdicts)", e); rc = IMP_ERROR_DEVICE; goto fail; }
+            }
         }
         static const int KH[5] = {1, 1, 2, 1, 2}, KV[5] = {1, 1, 1, 2, 2}, KN[5] = {1, 3, 3, 3, 3};
         for (int k = 0; k < 5 && !rc; k++)

@@ -7,8 +7,8 @@
 //
 //   host      headers (jcmarker.c order: SOI, APP0, DQT per table, SOF0, DHT per table, SOS), the quantisation tables of
 //             jpeg_quality_scaling, the derived Huffman code tables (built once)
-//   k_jpeg_enc_blocks   one lane per 8x8 block slot of the scan, in MCU order: colour conversion (jccolor.c's fixed-point
-//             tables) on the fly, edge replication (jcsample.c expand_right_edge, jcprepct.c expand_bottom_edge -- the
+//   k_jpeg_enc_blocks   eight lanes per 8x8 block slot of the scan (a row, then a column each; round 3: one lane per block), in
+//             MCU order: colour conversion (jccolor.c's fixed-point tables) on the fly, edge replication (jcsample.c expand_right_edge, jcprepct.c expand_bottom_edge -- the
 //             chroma rows past the last real one repeat THAT row), the 2x2 chroma box with its alternating 1,2 bias
 //             (h2v2_downsample), jfdctint.c's ISLOW DCT in registers, jcdctmgr.c's quantisation; the block goes to HBM as
 //             64 shorts in zigzag order.  Block slots beyond a component's own blocks (jccoefct.c's dummy blocks) are
@@ -90,57 +90,6 @@ __device__ __forceinline__ int enc_quant(int v, int q8) {
     return v < 0 ? -r : r;
 }
 
-// jccolor.c rgb_ycc_convert on one B,G,R pixel: which = 0 Y, 1 Cb, 2 Cr
-template <int CN>
-__device__ __forceinline__ int enc_sample(const uint8_t* p, int which) {
-    if (CN == 1) return p[0];
-    const int b = p[0], g = p[1], r = p[2];
-    if (which == 0) return (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
-    if (which == 1) return (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16;
-    return (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
-}
-
-template <int CN>
-__device__ __forceinline__ void enc_block(const EncJob& J, const uint16_t* __restrict__ qt, int comp, int bx, int by, short* __restrict__ out) {
-    int d[64];
-    if (comp == 0) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint8_t* row = J.src + (size_t)min(by * 8 + r, J.h - 1) * J.step;
-#pragma unroll
-            for (int i = 0; i < 8; i++) d[r * 8 + i] = enc_sample<CN>(row + (size_t)min(bx * 8 + i, J.w - 1) * CN, 0) - 128;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int cy = min(by * 8 + r, J.chh - 1);          // rows past the last real chroma row repeat that row
-            const uint8_t* r0 = J.src + (size_t)min(2 * cy, J.h - 1) * J.step;
-            const uint8_t* r1 = J.src + (size_t)min(2 * cy + 1, J.h - 1) * J.step;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int cx = bx * 8 + i;
-                const size_t x0 = (size_t)min(2 * cx, J.w - 1) * CN, x1 = (size_t)min(2 * cx + 1, J.w - 1) * CN;
-                const int s = enc_sample<CN>(r0 + x0, comp) + enc_sample<CN>(r0 + x1, comp) + enc_sample<CN>(r1 + x0, comp) +
-                              enc_sample<CN>(r1 + x1, comp) + 1 + (i & 1);       // bias 1, 2, 1, 2, ... along the row (cx and i have the same parity)
-                d[r * 8 + i] = (s >> 2) - 128;
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; r++) enc_fdct8<0>(d[r * 8], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5], d[r * 8 + 6], d[r * 8 + 7]);
-#pragma unroll
-    for (int i = 0; i < 8; i++) enc_fdct8<1>(d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i]);
-    const uint16_t* q = qt + (comp ? 64 : 0);
-    constexpr uint8_t ZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-    uint32_t* o = (uint32_t*)out;
-#pragma unroll
-    for (int k = 0; k < 64; k += 2) {
-        const int a = enc_quant(d[ZZ[k]], (int)q[ZZ[k]] << 3), b = enc_quant(d[ZZ[k + 1]], (int)q[ZZ[k + 1]] << 3);
-        o[k >> 1] = (uint32_t)(a & 0xffff) | ((uint32_t)b << 16);
-    }
-}
-
 // which component / block a slot of the scan is: false for a dummy slot
 __device__ __forceinline__ bool enc_slot(const EncJob& J, int mcu, int j, int* comp, int* bx, int* by) {
     const int my = mcu / J.mcuw, mx = mcu - my * J.mcuw;
@@ -150,23 +99,124 @@ __device__ __forceinline__ bool enc_slot(const EncJob& J, int mcu, int j, int* c
     return *bx < J.lbw && *by < J.lbh;
 }
 
+// jccolor.c rgb_ycc_convert on a pixel packed B | G << 8 | R << 16 (a gray sample in the low byte): which = 0 Y, 1 Cb, 2 Cr
+template <int CN>
+__device__ __forceinline__ int enc_sample_px(uint32_t px, int which) {
+    if (CN == 1) return (int)(px & 255u);
+    const int b = (int)(px & 255u), g = (int)((px >> 8) & 255u), r = (int)((px >> 16) & 255u);
+    if (which == 0) return (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
+    if (which == 1) return (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16;
+    return (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
+}
+
+// N pixels of a row from column x0 on, packed as enc_sample_px reads them; columns past the frame's last repeat it
+// (jcsample.c expand_right_edge).  Inside the frame and with 4-byte aligned rows the bytes come as dwords (a quarter of the
+// loads: a wave's 64 lanes read 64 different rows, so every load instruction is 64 separate accesses whatever its width).
+template <int CN, int N>
+__device__ __forceinline__ void enc_load_px(const uint8_t* __restrict__ row, int x0, int w, bool aligned, uint32_t* px) {
+    if (aligned && x0 + N <= w) {
+        constexpr int NW = (N * CN + 3) / 4;
+        uint32_t wd[NW + 1];
+        const uint32_t* p = (const uint32_t*)(row + (size_t)x0 * CN);      // x0 is a multiple of 8: x0 * CN is a multiple of 4
+#pragma unroll
+        for (int i = 0; i < NW; i++) wd[i] = p[i];
+        wd[NW] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if (CN == 4) px[i] = wd[i];
+            else if (CN == 1) px[i] = (wd[i >> 2] >> (8 * (i & 3))) & 255u;
+            else {
+                constexpr int dummy = 0; (void)dummy;
+                const int byte = 3 * i, k = byte >> 2, off = byte & 3;
+                px[i] = off == 0 ? wd[k] : off == 1 ? wd[k] >> 8 : (uint32_t)((((uint64_t)wd[k + 1] << 32) | wd[k]) >> (8 * off));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint8_t* q = row + (size_t)min(x0 + i, w - 1) * CN;
+            px[i] = CN == 1 ? (uint32_t)q[0] : (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+        }
+    }
+}
+
+// zigzag position of the coefficient at natural index n (the inverse of jpeg_natural_order)
+__constant__ uint8_t c_enc_zzinv[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+                                         10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+// Round 5: EIGHT lanes per block slot, a row each.  With a lane per block (round 3) a thumbnail's 882 blocks were 14 waves
+// whose lanes each made 192 (luma) or 768 (chroma) single-byte loads, two 8-point DCT passes over 64 registers and 64
+// quantisations in a row -- 44 us for a 224 x 168 answer, every request's fixed cost whatever the batch.  Here a lane loads
+// ONE row of its block (two source rows of sixteen pixels for chroma) as dwords, runs the row pass, hands its eight
+// results to the lane that owns the matching column through LDS, runs the column pass, quantises its eight coefficients
+// and stores them at their zigzag places: the same jccolor / jcsample / jfdctint / jcdctmgr arithmetic on an eighth of the
+// chain.  32 block slots per workgroup.
+template <int CN>
+__device__ __forceinline__ void enc_row_pass(const EncJob& J, int comp, int bx, int by, int r, bool aligned, int* d) {
+    if (comp == 0) {
+        const uint8_t* row = J.src + (size_t)min(by * 8 + r, J.h - 1) * J.step;
+        uint32_t px[8];
+        enc_load_px<CN, 8>(row, bx * 8, J.w, aligned, px);
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[i] = enc_sample_px<CN>(px[i], 0) - 128;
+    } else {
+        const int cy = min(by * 8 + r, J.chh - 1);              // rows past the last real chroma row repeat that row
+        const uint8_t* r0 = J.src + (size_t)min(2 * cy, J.h - 1) * J.step;
+        const uint8_t* r1 = J.src + (size_t)min(2 * cy + 1, J.h - 1) * J.step;
+        uint32_t p0[16], p1[16];
+        enc_load_px<CN, 16>(r0, bx * 16, J.w, aligned, p0);
+        enc_load_px<CN, 16>(r1, bx * 16, J.w, aligned, p1);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int s = enc_sample_px<CN>(p0[2 * i], comp) + enc_sample_px<CN>(p0[2 * i + 1], comp) + enc_sample_px<CN>(p1[2 * i], comp) +
+                          enc_sample_px<CN>(p1[2 * i + 1], comp) + 1 + (i & 1);     // bias 1, 2, 1, 2, ... along the row
+            d[i] = (s >> 2) - 128;
+        }
+    }
+    enc_fdct8<0>(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+}
+
+constexpr int ENC_BLOCKS_PER_WG = 32;
+
 __global__ __launch_bounds__(256) void k_jpeg_enc_blocks(const EncJob* __restrict__ jobs, const EncMap* __restrict__ map, const EncTables* __restrict__ tabs) {
+    __shared__ int s_t[ENC_BLOCKS_PER_WG][8][9];                    // [block][row][column]: the row pass's results (+1: the column reads of a wave spread over the banks)
     const EncMap m = map[blockIdx.x];
     const EncJob& J = jobs[m.job];
-    const int b = m.local + (int)threadIdx.x;
-    if (b >= J.nblocks) return;
-    const int mcu = b / J.bpm, j = b - mcu * J.bpm;
-    int comp, bx, by;
-    short* out = J.coef + (size_t)b * 64;
-    if (!enc_slot(J, mcu, j, &comp, &bx, &by)) {
-        int4* o = (int4*)out;
+    const int tid = threadIdx.x, r = tid & 7, bl = tid >> 3;
+    const int b = m.local + bl;
+    const bool live = b < J.nblocks;
+    int comp = 0, bx = 0, by = 0;
+    bool real = false;
+    if (live) {
+        const int mcu = b / J.bpm, j = b - mcu * J.bpm;
+        real = enc_slot(J, mcu, j, &comp, &bx, &by);
+    }
+    const bool aligned = !(((uintptr_t)J.src | (uintptr_t)J.step) & 3);
+    int d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (real) {
+        if (J.c == 1) enc_row_pass<1>(J, comp, bx, by, r, aligned, d);
+        else if (J.c == 3) enc_row_pass<3>(J, comp, bx, by, r, aligned, d);
+        else enc_row_pass<4>(J, comp, bx, by, r, aligned, d);
+    }
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[k] = int4{0, 0, 0, 0};
+    for (int i = 0; i < 8; i++) s_t[bl][r][i] = d[i];
+    __syncthreads();
+    if (!live) return;
+    short* out = J.coef + (size_t)b * 64;
+    if (!real) {                                                    // a dummy slot (jccoefct.c): zeros; its DC is resolved where it is read
+        ((int4*)out)[r] = int4{0, 0, 0, 0};
         return;
     }
-    if (J.c == 1) enc_block<1>(J, &tabs->q[0][0], comp, bx, by, out);
-    else if (J.c == 3) enc_block<3>(J, &tabs->q[0][0], comp, bx, by, out);
-    else enc_block<4>(J, &tabs->q[0][0], comp, bx, by, out);
+    int v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = s_t[bl][k][r];               // column r of the block
+    enc_fdct8<1>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    const uint16_t* q = &tabs->q[0][0] + (comp ? 64 : 0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int n = k * 8 + r;
+        out[c_enc_zzinv[n]] = (short)enc_quant(v[k], (int)q[n] << 3);
+    }
 }
 
 // ---------------------------------------------------------------- k_jpeg_enc_huff
@@ -659,7 +709,7 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
         const EncJob& J = jobs[k];
         o_coef[k] = coef_bytes; coef_bytes += (size_t)J.nblocks * 128;
         o_out[k] = out_bytes; out_bytes += ((size_t)J.out_cap + 255) & ~size_t(255);
-        for (int b = 0; b < J.nblocks; b += 256) map.push_back(EncMap{k, b});
+        for (int b = 0; b < J.nblocks; b += ENC_BLOCKS_PER_WG) map.push_back(EncMap{k, b});
         if (J.nseg) {
             o_ub[k] = aux_bytes; aux_bytes += 16;
             o_seg[k] = aux_bytes; aux_bytes += (size_t)J.nseg * 8;

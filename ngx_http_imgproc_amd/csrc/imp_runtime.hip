@@ -642,6 +642,8 @@ int stage_begin(size_t bytes, void** host, void** token) {
     return IMP_OK;
 }
 
+size_t stage_capacity(void* token) { return token ? ((Staging*)token)->cap : 0; }
+
 int stage_upload(void* token, void* dev, size_t bytes) {
     Lane* L = lane();
     if (!L) return no_env();

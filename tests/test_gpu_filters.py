@@ -303,3 +303,20 @@ def test_rotate_bgr_tiles(gpu, amount, shape):
     assert rc == 0
     assert np.array_equal(got, np.rot90(arr, k=-1 if amount == 90 else 1))
     assert np.array_equal(got, orc.filter(arr, "rotate=%d" % amount)[1])
+
+
+@pytest.mark.parametrize("sigma", ["1.7", "2.4", "3.3", "4", "6.5", "7.3", "7.4", "7.5", "7.7", "7.9", "10.5"])
+def test_blur_taps_summing_past_257_on_the_matrix_unit(gpu, sigma):
+    """The eleven sigmas between 0.5 and 25.0 (steps of 0.1) whose rounded taps sum to 258 .. 260: row sums of bright pixels
+    need 17 bits.  Round 5 gives them a third byte plane (bit 16) and a third MFMA per chunk instead of the VALU kernels;
+    bright frames are the ones that reach bit 16 -- all-255, noise in 200..255 -- next to ordinary noise, all three channel
+    counts, frames larger than one 64 x 64 tile and with a partial last tile."""
+    rng = np.random.Generator(np.random.PCG64(int(float(sigma) * 10)))
+    for c in (1, 3, 4):
+        frames = [np.full((70, 131, c), 255, np.uint8), rng.integers(200, 256, size=(133, 67, c), dtype=np.uint8),
+                  noise_image(96, 203, c, 5), rng.integers(250, 256, size=(3, 300, c), dtype=np.uint8)]
+        for arr in frames:
+            want = orc.gaussian(arr, float(np.float32(sigma)))
+            rc, got = run_filter(gpu, arr, "blur=" + sigma)
+            assert rc == 0
+            assert np.array_equal(got, want), "sigma %s c %d %r: max diff %d" % (sigma, c, arr.shape, np.abs(got.astype(int) - want.astype(int)).max())

@@ -2,8 +2,8 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/pmc_blur
 i=0
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS"; do
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_blur/p$i -- python3 $R/tools/blur_probe.py 8 4 16 > $R/gpurun_out/pmc_blur/p$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_blur/p$i.log; exit 1; }
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_blur/p$i -- python3 $R/tools/blur_probe.py ${BLUR_SIGMA:-8} ${BLUR_CN:-4} 16 > $R/gpurun_out/pmc_blur/p$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_blur/p$i.log; exit 1; }
 done
 python3 $R/tools/pmc_table.py $R/gpurun_out/pmc_blur
