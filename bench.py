@@ -165,8 +165,14 @@ def e2e(imp, n_requests, pinned):
     return n_requests / dt
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """Oracle cv_resize CUBIC on 1080p BGRA frames, one core, bounded sample.
+# the modes whose CPU leg is one cvResize: source (h, w), destination (w, h), interpolation
+CPU_RESIZE_MODES = {"cubic": ((1080, 1920), (224, 224), "INTER_CUBIC"), "area": ((1080, 1920), (224, 224), "INTER_AREA"),
+                    "lanczos": ((2160, 3840), (1920, 1080), "INTER_LANCZOS4")}
+
+
+def cpu_baseline(seconds_budget=12.0, mode="cubic"):
+    """The oracle on the host's cores, bounded sample: cv_resize of the mode's geometry (CUBIC on 1080p BGRA frames for the
+    headline; AREA and the 4K LANCZOS4 of cfg4 for their modes; every other mode reports the headline's and says so).
 
     Timed on oracle/liboracle_fast.so -- the oracle's sources built `-O3 -march=native` on this host, float
     contraction still off -- after checking that it returns the same bytes as the `-O2` checker build the tests use."""
@@ -191,28 +197,31 @@ def cpu_baseline(seconds_budget=12.0):
     except Exception:       # no compiler on this host: time the checker build and say so
         fast = None
 
+    matches = mode in CPU_RESIZE_MODES
+    (sh, sw), (dw, dh), interp_name = CPU_RESIZE_MODES[mode if matches else "cubic"]
+    interp = getattr(orc, interp_name)
     rng = np.random.Generator(np.random.PCG64(0x1A4D0001))
-    arrays = [rng.integers(0, 256, size=(1080, 1920, 4), dtype=np.uint8) for _ in range(4)]
+    arrays = [rng.integers(0, 256, size=(sh, sw, 4), dtype=np.uint8) for _ in range(4)]
     if fast is not None:
         lib = fast
-        frames = [C.c_void_p(lib.orc_image_from(a.ctypes.data, 1920, 1080, 4, 1920 * 4)) for a in arrays]
-        new_dst = lambda: C.c_void_p(lib.orc_image_create(224, 224, 4))
+        frames = [C.c_void_p(lib.orc_image_from(a.ctypes.data, sw, sh, 4, sw * 4)) for a in arrays]
+        new_dst = lambda: C.c_void_p(lib.orc_image_create(dw, dh, 4))
         dst = new_dst()
-        for a, f in zip(arrays, frames):       # same bytes as the checker build, or the number means nothing
-            lib.orc_cv_resize(f, dst, orc.INTER_CUBIC)
-            got = np.ctypeslib.as_array((C.c_uint8 * (224 * 224 * 4)).from_address(lib.orc_image_data(dst))).reshape(224, 224, 4)
-            assert np.array_equal(got, orc.cv_resize(a, 224, 224, orc.INTER_CUBIC)), "liboracle_fast.so differs from liboracle.so"
+        for a, f in zip(arrays[:1 if sh > 1080 else 4], frames):       # same bytes as the checker build, or the number means nothing
+            lib.orc_cv_resize(f, dst, interp)
+            got = np.ctypeslib.as_array((C.c_uint8 * (dw * dh * 4)).from_address(lib.orc_image_data(dst))).reshape(dh, dw, 4)
+            assert np.array_equal(got, orc.cv_resize(a, dw, dh, interp)), "liboracle_fast.so differs from liboracle.so"
     else:
         lib = orc.lib
         imgs = [orc.Img(a) for a in arrays]
         frames = [im.h for im in imgs]
-        new_dst = lambda: C.c_void_p(lib.orc_image_create(224, 224, 4))
+        new_dst = lambda: C.c_void_p(lib.orc_image_create(dw, dh, 4))
         dst = new_dst()
     n = 0
     t0 = time.perf_counter()
     while True:
         for f in frames:
-            lib.orc_cv_resize(f, dst, orc.INTER_CUBIC)
+            lib.orc_cv_resize(f, dst, interp)
         n += len(frames)
         dt = time.perf_counter() - t0
         if dt >= seconds_budget or n >= 4096:
@@ -230,7 +239,7 @@ def cpu_baseline(seconds_budget=12.0):
         out = new_dst()
         k = 0
         while time.perf_counter() < stop_at:
-            lib.orc_cv_resize(frames[k % len(frames)], out, orc.INTER_CUBIC)
+            lib.orc_cv_resize(frames[k % len(frames)], out, interp)
             k += 1
         counts[i] = k
 
@@ -257,8 +266,9 @@ def cpu_baseline(seconds_budget=12.0):
         "kind": "port",
         "build": "gcc " + flags + " (oracle/Makefile); bytes checked equal to the -O2 checker build on this sample",
         "cpu_model": cpu_model,
-        "sample": "%d frames 1920x1080 BGRA -> 224x224 INTER_CUBIC via the oracle (OpenCV 2.4.9 semantics restated in C), "
-                  "single thread, %.1f s" % (n, dt),
+        "sample": "%d frames %dx%d BGRA -> %dx%d %s via the oracle (OpenCV 2.4.9 semantics restated in C), "
+                  "single thread, %.1f s" % (n, sw, sh, dw, dh, interp_name, dt),
+        "workload_matches_mode": matches,
         # NOT every core of the host: `threads` independent workers (one GPU's share of the box), out of `host_cores` this
         # process may run on and `host_cpus` the machine has
         "multi_thread": {"value": round(sum(counts) / dt_all, 2), "threads": cores, "host_cores": open_cores, "host_cpus": os.cpu_count(),
@@ -932,7 +942,7 @@ def main():
             out["roofline"]["line_granular"] = {"bytes_per_launch": lg, "achieved": round(lg / (launch_ms * 1e-3) / 1e9, 1),
                                                 "frac": round(lg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(mode=args.mode)
         print(json.dumps(out), flush=True)
     del src, dst
     imp.env_destroy()

@@ -246,7 +246,7 @@ size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs) {
 // Copies the entropy-coded bytes out of the file: FF 00 becomes FF, fill FFs go, an RSTn marker closes the interval (the
 // rest of its chunk is filled with 1-bits, exactly what the encoder pads the last byte with) and the next one starts on a
 // chunk boundary.  Stops at EOI, at any other marker, or at the end of the file.
-size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
+size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes, bool busy) {
     if (const char* s = ab_env("IMPGPU_JPEG_CHUNK_WORDS")) {
         const int w = std::atoi(s);
         if (w == 8 || w == 16 || w == 32 || w == 64) return (size_t)w * 4;
@@ -255,6 +255,14 @@ size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes) {
     // 720p 0.83 / 0.84 / 0.94, 1080p 0.90 / 0.84 / 0.95, 4K 1.45 / 1.24 / 1.24; a queue's worth of files (28 MB) is a little
     // faster on 1024
     if (launch_bytes > (size_t(4) << 20)) return JPEG_CHUNK_BYTES_MAX;    // (a walk's overlap weighs half as much on 2048 bits as on 1024)
+    // Round 5: `busy` = other decode groups of this process are in flight (a broker's lanes under load).  Short chunks buy a lone
+    // file short chains with vector work the idle device has to spare -- every walk decodes its five-block overlap (about 750
+    // bits) on top of its chunk, 3.9 x the bits at 256-bit chunks against 1.7 x at 1024 -- but under load that work is what
+    // the lanes slow each other with.  One broker, four lanes, mixed pool, requests/s at 16 / 32 workers with every launch forced to
+    // 32 / 64 / 128 / 256-byte chunks: 12.7 / 15.4 k, 15.3 / 20.3 k, 15.5 / 22.7 k, 13.2 / 21.0 k (the rule below without `busy`:
+    // 14.2 / 20.0 k; a lone worker: 2.32 / 2.33 / 2.03 / 1.63 k).
+    if (busy && launch_bytes >= (size_t(2560) << 10)) return 128;
+    if (busy && launch_bytes >= (size_t(512) << 10)) return 64;
     // round 4, the stage without rounds, one file at a time (profiles/r04_jpeg_chunk_ab.txt, ms at 256 / 512 / 1024 / 2048 bits):
     // 640x480 0.25 / 0.30 / 0.41 / 0.62, 1080p 4:2:0 0.32 / 0.36 / 0.46 / 0.67, 4:4:4 0.28 / 0.33 / 0.45 / 0.67, 4K 0.58 / 0.52 / 0.61 / 0.81
     // -- every kernel's time is the length of a chunk's walk until the chunks no longer fit the device at once

@@ -91,7 +91,7 @@ struct JpegScan {
 // chunk once -- finish sooner on shorter chunks, while the resynchronising rounds take the same time either way (a round's
 // length and the number of rounds trade against each other).  launch_bytes = entropy-coded bytes of the whole launch.
 // IMPGPU_JPEG_CHUNK_WORDS = 8 | 16 | 32 overrides (A/B).
-size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes);
+size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes, bool busy = false);
 // How far in front of its chunk a synchronising walk starts: long enough to hold a block end or two of THIS file (its
 // entropy-coded bytes over its blocks), so that one of the walks has fallen into step with the true decoder by the chunk's
 // first bit.  IMPGPU_JPEG_OVERLAP (bits) overrides (A/B).

@@ -227,7 +227,27 @@ static Lane* lane() {
     static const bool bind = [] { const char* s = std::getenv("IMPGPU_NUMA_BIND"); return s && *s == '1'; }();
     if (bind) (void)numa_bind_thread(E);        // before the lane's pinned buffers are allocated (first touch)
     Lane* L = new Lane();
-    bool ok = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) == hipSuccess &&
+    // IMPGPU_LANE_CU_SPLIT=n (2, 4, 8; A/B builds only -- it LOST): the k-th lane of the process launches on a contiguous n-th of
+    // the device's CU mask bits -- which the hardware deals round over the XCDs, so a part spans all eight
+    // (tools/cu_place_probe.hip) -- instead of the whole device.  The idea: the broker's lanes run chains of small kernels side
+    // by side, and unmasked the workgroups of concurrent small kernels share compute units while others idle (4 streams x 64
+    // workgroups: 179 CUs used, 63 shared by up to four workgroups; masked: 256 used, none shared).  Measured with four lanes,
+    // requests/s at 1 / 8 / 16 / 32 workers: unmasked 2.26 / 10.3 / 14.2 / 20.0 k, quarters 1.98 / 9.3 / 12.8 / 17.5 k, halves
+    // 2.25 / 10.2 / 13.6 / 19.5 k -- the chains are slowed by the device's total vector work, not by where it lands.
+    static const int split = [] { const char* s = ab_env("IMPGPU_LANE_CU_SPLIT"); const int v = s ? std::atoi(s) : 0; return (v == 2 || v == 4 || v == 8) ? v : 0; }();
+    bool made = false;
+    if (split) {
+        static std::atomic<int> next_part{0};
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, E->device) == hipSuccess && prop.multiProcessorCount >= 8 * split && prop.multiProcessorCount <= 1024) {
+            const int ncu = prop.multiProcessorCount, per = ncu / split, part = next_part.fetch_add(1) % split;
+            uint32_t mask[32] = {0};
+            for (int i = part * per; i < (part + 1) * per; i++) mask[i / 32] |= 1u << (i % 32);
+            made = hipExtStreamCreateWithCUMask(&L->stream, (uint32_t)((ncu + 31) / 32), mask) == hipSuccess;
+            if (!made) { L->stream = nullptr; (void)hipGetLastError(); }
+        }
+    }
+    bool ok = (made || hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) == hipSuccess) &&
               hipEventCreateWithFlags(&L->join_ev, hipEventDisableTiming) == hipSuccess &&
               hipHostMalloc((void**)&L->ring, RING_SEGS * RING_SEG_BYTES + MAILBOX_BYTES, hipHostMallocDefault) == hipSuccess &&
               hipEventCreateWithFlags(&L->sync_ev, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;

@@ -43,10 +43,14 @@ def main():
         B["bytes"] += len(blob)
         B["names"].append(os.path.basename(path))
         try:
-            t0 = time.perf_counter()
-            im = Image.open(io.BytesIO(blob))
-            im.load()
-            B["host_ms"] += 1e3 * (time.perf_counter() - t0)
+            best = None
+            for _ in range(3):                                   # best of three: the first pass pays for page faults and imports
+                t0 = time.perf_counter()
+                im = Image.open(io.BytesIO(blob))
+                im.load()
+                dt = 1e3 * (time.perf_counter() - t0)
+                best = dt if best is None else min(best, dt)
+            B["host_ms"] += best
             B["pixels"] += im.size[0] * im.size[1]
         except Exception:
             pass

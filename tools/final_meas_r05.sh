@@ -27,6 +27,7 @@ a)
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/prof_fetch -- python3 $R/tools/pmc_probe.py > $R/$O/prof_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/prof_write -- python3 $R/tools/pmc_probe.py > $R/$O/prof_write.log 2>&1
   tail -1 $R/$O/prof_write.log
+  du -sh $R/$O | tail -1
   ;;
 b)
   make -C tests/c > /dev/null
@@ -41,21 +42,28 @@ b)
   python tools/jpeg_probe.py > $O/r05_jpeg_probe.txt 2>&1; tail -12 $O/r05_jpeg_probe.txt
   python tools/request_latency.py > $O/r05_request_latency.txt 2>&1; tail -6 $O/r05_request_latency.txt
   python tools/jpeg_tiny_probe.py > $O/r05_jpeg_small_files.txt 2>&1; tail -12 $O/r05_jpeg_small_files.txt
+  rm -f $O/jpeg_pool.bin; rm -rf $O/prof_jpeg_b      # (gpurun copies at most 64 MB back)
   ;;
 c)
   make -C tests/c > /dev/null
   BROKER_THREADS="2 3 4 6" SECONDS_PER_POINT=3 bash tools/r05_workers.sh
   bash tools/r05_broker_prof.sh 4 16 > $O/r05_broker_prof_4_16.txt 2>&1; cat $O/r05_broker_prof_4_16.txt | head -30
   timeout -k 10 300 python -m pytest tests/test_gpu_multiproc.py tests/test_gpu_broker.py -q -m gpu -s > $O/r05_multiproc.txt 2>&1; tail -8 $O/r05_multiproc.txt
+  rm -f $O/jpeg_pool.bin; rm -rf $O/prof_broker_4_16      # (gpurun copies at most 64 MB back; the trace's summary is in r05_broker_prof_4_16.txt)
   ;;
 d)
   PMC_BATCH=32 bash tools/pmc_mode.sh lanczos $O/pmc_r05_lanczos "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" > $O/r05_sq_cfg4.txt 2>&1 || true
   tail -30 $O/r05_sq_cfg4.txt
+  rm -rf $O/pmc_r05_lanczos
   bash tools/r05_pmc_mixed.sh > $O/r05_sq_cfg5.txt 2>&1 || true
   tail -40 $O/r05_sq_cfg5.txt
+  rm -rf $O/pmc_r05_mixed_4 $O/pmc_r05_mixed_3
   OUT=r05_jpeg_sq_counters.txt bash tools/pmc_jpeg.sh || true
+  rm -rf $O/pmc_jpeg $O/jpeg_pool.bin
   for sg in 2 4 8 16; do for cn in 4 3; do echo "== blur sigma $sg channels $cn"; bash tools/blur_prof.sh $sg $cn; done; done > $O/r05_blur_kernels.txt 2>&1
   BLUR_SIGMA=8 bash tools/pmc_blur.sh > $O/r05_blur_sq_counters.txt 2>&1 || true
+  rm -rf $O/pmc_blur $O/prof_blur
+  du -sh $O | tail -1
   ;;
 *) echo "usage: $0 a|b|c|d"; exit 2;;
 esac

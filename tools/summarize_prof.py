@@ -28,7 +28,7 @@ MODES = {"k_resize_taps<4, 4, 1>": "cubic", "k_resize_area_rows<4, 10>": "area",
          "k_resize_strip<4, 1, 4>": "upscale_x", "k_resize_strip2<2, 0, 4,": "linear_up",
          "k_resize_strip2<8, 2, 4, 1, 0>": "lanczos_up", "k_resize_strip2<8, 2, 4, 0, 1>": "lanczos_up",
          "k_resize_strip2<8, 2, 4, 1, 2>": "lanczos_15", "k_resize_strip2<8, 2, 4, 2, 1>": "lanczos_15",
-         "k_blur_mfma_fused<4>": "blur_sigma2", "k_blur_mfma_rows<4>": "blur_rows", "k_blur_mfma_cols<4>": "blur_cols"}
+         "k_blur_mfma_fused<4, false>": "blur_sigma2", "k_blur_mfma_rows<4, false>": "blur_rows", "k_blur_mfma_cols<4, false>": "blur_cols"}
 # (round 4: the 2x enlargements and the 1.5x reduction run k_resize_strip2 with different advance patterns, so their
 # dispatches no longer share a kernel name; the blur kernels' entries are per launch of ONE 1080p frame, batch 1)
 # frames per launch in tools/pmc_probe.py, as a divisor of PROBE_BATCH

@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--pool", default=os.path.join(ROOT, "gpurun_out", "jpeg_pool.bin"))
     ap.add_argument("--answers", default=None)
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for the broker (0: the runtime's default, 4)")
+    ap.add_argument("--cu-split", type=int, default=0, help="IMPGPU_LANE_CU_SPLIT for the broker: every lane on its own n-th of the CUs")
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.pool), exist_ok=True)
     make_pool(args.pool)
@@ -120,13 +121,19 @@ def main():
         broker = None
         name = "/impgpu-scaling-%d" % os.getpid()
         if args.mode == "broker":
-            broker = start_broker(name, args.threads, args.gather_us, env={"GPU_MAX_HW_QUEUES": str(args.hw_queues)} if args.hw_queues else None)
+            env = {}
+            if args.hw_queues:
+                env["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
+            if args.cu_split:
+                env["IMPGPU_LANE_CU_SPLIT"] = str(args.cu_split)
+            broker = start_broker(name, args.threads, args.gather_us, env=env or None)
         try:
             r = run_point(args.pool, args.mode, n, args.seconds, args.answers, name)
             if broker:
                 r["broker_threads"] = args.threads
                 r["gather_us"] = args.gather_us
-                r["hw_queues"] = args.hw_queues or 4
+                r["hw_queues"] = args.hw_queues or 8
+                r["cu_split"] = args.cu_split
             print(json.dumps(r), flush=True)
         finally:
             if broker:
