@@ -229,6 +229,7 @@ static int register_watermark(impgpu_client* c, impc_watermark* m) {
     if (bytes > c->hdr->f.slot_data_bytes) { snprintf(t_err, sizeof t_err, "watermark larger than a slot"); return IMP_ERROR_MALLOC_FAILED; }
     memcpy(c->data, m->pixels, bytes);
     s->in_kind = IMPB_IN_WATERMARK; s->out_kind = IMPB_OUT_INFO;
+    s->quality = 0; s->simple = 0; s->need_flatten = 0;          /* (nothing of the slot's last request rides along) */
     s->in_bytes = bytes; s->in_w = m->w; s->in_h = m->h; s->in_c = m->c; s->in_step = m->step;
     s->filter_count = 0; s->crop_at = s->gravity_at = s->resize_at = s->ascii_at = -1; s->watermark_id = 0;
     const unsigned epoch = c->hdr->f.epoch;

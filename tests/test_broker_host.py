@@ -69,3 +69,113 @@ def test_broker_rejects_bad_options(built):
     assert p.returncode == 2
     p = subprocess.run([built.BROKER_PATH, "--name", "no-slash"], capture_output=True, text=True, timeout=30)
     assert p.returncode == 2
+
+
+# ---- the worker side (glue/imp_gpu_client.c) against tests/c/mock_broker.c: the protocol without a GPU
+@pytest.fixture()
+def mock(built, tmp_path):
+    """start(mode) -> (name, Popen) of a mock broker serving a fresh segment; everything started is stopped afterwards"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), os.path.join(ROOT, "tests", "c", "_build", "mock_broker"),
+                           os.path.join(ROOT, "tests", "c", "_build", "client_asan")])
+    started = []
+
+    def start(mode="serve", slots=4, slot_kb=256, name=None):
+        name = name or "/impgpu-mock-%d-%d" % (os.getpid(), len(started))
+        p = subprocess.Popen([os.path.join(ROOT, "tests", "c", "_build", "mock_broker"), name, str(slots), str(slot_kb), mode],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.stdout.readline().strip() == "ready"
+        started.append((name, p))
+        return name, p
+
+    yield start
+    for name, p in started:
+        if p.poll() is None:
+            p.kill()
+        p.wait()
+        try:
+            os.unlink("/dev/shm" + name)
+        except OSError:
+            pass
+
+
+def test_round_trips_answers_and_operator_errors(built, mock):
+    name, _ = mock()
+    c = built.Client(name)
+    rc, code, step, got, a = c.run(blob=b"0123456789" * 100, crop="1,1", resize="224,0", filters=["gamma=2", "blur=1"])
+    assert (rc, code) == (0, 0) and got == (b"0123456789" * 100)[::-1]
+    assert (a.width, a.channels) == (2, 3)              # the mock echoes the filter count and the crop string's length: the job crossed intact
+    rc, code, step, got, a = c.run(blob=b"x" * 10, quality=1051)         # the mock answers "code 51 at step RESIZE"
+    assert (rc, code, step) == (0, 51, 4)
+    wid = c.prepare_watermark(__import__("numpy").zeros((4, 4, 4), "uint8"))
+    rc, code, step, got, a = c.run(blob=b"abc", watermark_id=wid)
+    assert (rc, code) == (0, 0) and a.height >= 1       # ... and the id the broker gave for the overlay
+    # an input larger than a slot is refused on the worker's side, nothing is sent
+    rc, code, step, got, a = c.run(blob=b"z" * (300 << 10))
+    assert rc == 2
+    st = c.stats()
+    assert st["served"] == 4 and st["epoch"] == 1
+    c.close()
+
+
+def test_more_workers_than_slots_is_said_so(built, mock):
+    name, _ = mock(slots=2)
+    a, b = built.Client(name), built.Client(name)
+    with pytest.raises(RuntimeError) as e:
+        built.Client(name)
+    assert "every slot" in str(e.value)
+    a.close()
+    c = built.Client(name)                              # a detached worker's slot is free again
+    assert c.run(blob=b"ok")[3] == b"ko"
+    b.close(); c.close()
+
+
+def test_a_broker_that_is_killed_fails_the_request_within_ticks(built, mock, monkeypatch):
+    """SIGKILL while the request is held: the worker notices at its next 50-ms tick (IMP_ERROR_DEVICE), long before the
+    10-s timeout; later requests fail at once; a new broker under the same name is found by the next request."""
+    import time
+    name, p = mock("mute")
+    c = built.Client(name)
+    import threading
+    out = {}
+
+    def ask():
+        t0 = time.time()
+        out["r"] = c.run(blob=b"hello")
+        out["dt"] = time.time() - t0
+        out["why"] = built.Client.last_error()            # (the text is the calling thread's)
+    t = threading.Thread(target=ask)
+    t.start()
+    time.sleep(0.3)
+    p.kill(); p.wait()
+    t.join(timeout=5)
+    assert not t.is_alive() and out["r"][0] == 90 and out["dt"] < 2.0, out
+    assert "went away" in out["why"]
+    t0 = time.time()
+    assert c.run(blob=b"again")[0] == 90 and time.time() - t0 < 0.5
+    mock(name=name)                                      # a fresh broker, a fresh segment under the old name
+    rc, code, step, got, a = c.run(blob=b"abc")
+    assert (rc, code) == (0, 0) and got == b"cba"
+    c.close()
+
+
+def test_a_broker_that_never_answers_runs_into_the_timeout_and_the_slot_is_abandoned(built, mock, monkeypatch):
+    monkeypatch.setenv("IMPGPU_BROKER_TIMEOUT_MS", "300")
+    name, p = mock("mute", slots=2)
+    c = built.Client(name)
+    import time
+    t0 = time.time()
+    rc = c.run(blob=b"hello")[0]
+    assert rc == 90 and 0.25 < time.time() - t0 < 2.0
+    assert "did not answer in time" in built.Client.last_error()
+    assert c.run(blob=b"second")[0] == 90                 # it claimed the other slot, which times out as well
+    with pytest.raises(RuntimeError):
+        built.Client(name)                                # both slots are held by requests the broker still owns
+    c.close()
+
+
+def test_client_under_the_sanitizers_and_across_fork(built, mock):
+    """glue/imp_gpu_client.c built with AddressSanitizer + UBSan: 300 requests of varying size checked byte by byte, then three
+    fork()ed copies of the attached process, each of which must claim a slot of its own and not touch the parent's."""
+    name, _ = mock(slots=6)
+    p = subprocess.run([os.path.join(ROOT, "tests", "c", "_build", "client_asan"), name, "300", "3"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip() == "ok 600", (p.returncode, p.stdout, p.stderr[-1500:])
