@@ -689,6 +689,13 @@ def main():
                     help="--stream --jpeg: the answers are JPEG files of quality Q too (the module's default is 86), encoded where the request was decoded")
     ap.add_argument("--jpeg-files", type=int, default=64, help="--stream --jpeg: distinct files the requests cycle through")
     ap.add_argument("--native", action="store_true", help="--stream --jpeg device: the request threads are C threads (tests/c/stream_harness.c), not Python's")
+    ap.add_argument("--workers", type=int, default=0, metavar="N",
+                    help="the reference's process model: N worker PROCESSES (tests/c/worker_harness.c), one synchronous request each "
+                         "(JPEG in -> resize=224,0 -> JPEG out), through impgpu_broker (--broker-lanes) or, with --in-process, each with "
+                         "libimpgpu.so linked in (at most 6 on a pool box); --seconds per point")
+    ap.add_argument("--in-process", action="store_true")
+    ap.add_argument("--broker-lanes", type=int, default=4)
+    ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--mixed", type=int, default=0, metavar="N",
                     help="BASELINE configs[4] with the N frames already in HBM: resize=224,0 over mixed sizes, one "
                          "impgpu_batch_resize_mixed call per step (and, for comparison, one launch per frame)")
@@ -698,6 +705,36 @@ def main():
     args = ap.parse_args()
     global NUMA_BIND
     NUMA_BIND = not args.no_numa
+
+    if args.workers:
+        # (before anything of this process touches the GPU: the workers and the broker are children, started here)
+        import subprocess
+
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import worker_scaling as ws
+
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+        pool = os.path.join(ROOT, "gpurun_out", "jpeg_pool.bin")
+        os.makedirs(os.path.dirname(pool), exist_ok=True)
+        if not os.path.exists(pool):                          # (made by a child: jpeg_pool imports nothing of the device, but torch is heavy)
+            subprocess.check_call([sys.executable, "-c", "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import worker_scaling as w; w.make_pool(%r)"
+                                   % (ROOT, os.path.join(ROOT, "tools"), pool)])
+        name = "/impgpu-bench-%d" % os.getpid()
+        broker = None if args.in_process else ws.start_broker(name, args.broker_lanes, 0)
+        try:
+            r = ws.run_point(pool, "direct" if args.in_process else "broker", args.workers, args.seconds, None, name)
+        finally:
+            if broker:
+                ws.stop_broker(broker)
+        print(json.dumps({
+            "metric": "requests/sec, N worker processes, one synchronous request each: JPEG in -> resize=224,0 -> JPEG out", "value": r["requests_per_s"],
+            "unit": "requests/sec", "n_gpus": 1, "higher_is_better": True, "dtype": "u8", "data": "synthetic (photograph-like quality-90 4:2:0 JPEG files, 256 px - 4K, Pillow-encoded)",
+            "config": {"workload": "BASELINE configs[4] from the reference's process model (docs/02 - Configuration.md:18 worker_processes; module.c:298 RunJob synchronous)",
+                       "workers": args.workers, "path": "libimpgpu.so in every worker" if args.in_process else "impgpu_broker, %d lanes" % args.broker_lanes,
+                       "seconds": args.seconds},
+            "latency_us": {"p50": r["p50_us"], "p95": r["p95_us"], "p99": r["p99_us"]}, "files_per_launch": r["mean_batch"],
+            "chain_timeouts": r["chain_timeouts"], "vs_baseline": None}))
+        return
 
     import torch
     import torch.distributed as dist

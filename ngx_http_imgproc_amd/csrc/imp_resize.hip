@@ -1263,7 +1263,24 @@ __global__ __launch_bounds__(256) void k_resize_strip2(RArgs a, const int* __res
 #ifndef DMA_WAVES
 #define DMA_WAVES 6
 #endif
-template <int KS, int MODE, int DEPTH, bool VSYM, int WPB>
+// MF (round 5): the HORIZONTAL pass on the matrix unit.  The counters (profiles/r05_sq_cfg4.txt) have this kernel bound by vector
+// issue -- 71 % busy, 61 % of the wave cycles queueing to issue -- at ~110 vector instructions per output pixel, 64 of them the
+// two horizontal passes (perm + dot2 per tap pair and channel).  At an exact 2x scale every column has the same taps, so a source
+// row's 64 x 4 horizontal sums are ONE banded product: C[16 x 16] = A[16 x 64] x B[64 x 16] with
+//   B[k][n] = byte k of WINDOW n of the row (window n = the 64 bytes from byte 32 n of the row slot: the taps of output pixels
+//             4n .. 4n + 3 of the strip lie in its bytes 4 .. 59; a lane's operand is one ds_read_b128, biased to signed by one XOR per dword),
+//   A[m][k] = the tap weight of (output o = m >> 2, channel c = m & 3) on byte k: tap j sits at k = 8 o + 4 + 4 j + c (the strip's
+//             first tap is dword 1 of the slot: sx00 = 2 dx0 - 3 = 1 mod 4 for interior strips), split into two signed bytes, two MFMAs,
+//   C[m][n] -> lane l holds reg r = channel r of output pixel 4 (l & 15) + (l >> 4) of the strip (operand maps of the 16x16x64 i8
+//             MFMA as probed on hardware, imp_blur.hip) -- exactly what the vertical pass wants in a lane, under a permuted
+//             lane -> pixel map, which only the stores have to know.
+// Integer and exact: pixels enter as p - 128 and 128 x (the weights' sum: 2048 give or take the table's rounding) is added back; the sums
+// are the same 32-bit integers.
+// Per source row a lane issues one LDS read, four XORs, two MFMAs and eight adds/shifts where it issued eight LDS reads and
+// thirty-two perm / dot2.  Border strips (clamped taps) keep the vector form.
+typedef int rz_v4i __attribute__((ext_vector_type(4)));
+
+template <int KS, int MODE, int DEPTH, bool VSYM, int WPB, bool MF = false>
 __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, const int* __restrict__ xofs, const short* __restrict__ xco,
                                                        const int* __restrict__ yofs, const short* __restrict__ yco, int vec_end,
                                                        int nbx, int bpf, int count) {
@@ -1328,6 +1345,48 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
 #pragma unroll
             for (int k = 0; k < KS; k++) p[k] = EDGE ? w[clampi(sx0e + k, 0, a.sw - 1) - wstart] : w[lane_dw + k];
         };
+        constexpr bool MFS = MF && !EDGE;                           // this strip's horizontal pass runs on the matrix unit
+        // the lane's output pixel within the strip (MFS: the MFMA's accumulator layout decides)
+        const int xl = MFS ? 4 * (lane & 15) + (lane >> 4) : lane;
+        rz_v4i band_hi = {0, 0, 0, 0}, band_lo = {0, 0, 0, 0};
+        int hbias = 0;                                              // 128 x (the weights' sum): what the bias of the pixels took away
+        if constexpr (MFS) {
+#pragma unroll
+            for (int k = 0; k < KS; k++) hbias += 128 * (int)xco[(size_t)dx0 * KS + k];
+            // A operand: lane l holds A[m = l & 15][k = 16 (l >> 4) .. + 15]
+            const int m = lane & 15, o = m >> 2, c = m & 3;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t hi = 0, lo = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int k = 16 * (lane >> 4) + 4 * q + b, t = k - 8 * o - 4 - c;
+                    int w = 0;
+                    if (t >= 0 && !(t & 3) && (t >> 2) < KS) w = (int)xco[(size_t)dx0 * KS + (t >> 2)];
+                    const int wl = (int)(int8_t)(w & 0xff), wh = (w - wl) >> 8;           // w = 256 wh + wl, both signed bytes (|w| < 2^15)
+                    lo |= (uint32_t)(wl & 0xff) << (8 * b);
+                    hi |= (uint32_t)(wh & 0xff) << (8 * b);
+                }
+                band_hi[q] = (int)hi;
+                band_lo[q] = (int)lo;
+            }
+        }
+        // the horizontal sums of source row r for this lane's output pixel, all four channels
+        auto hrow = [&](int r, int* h) {
+            if constexpr (MFS) {
+                const rz_v4i raw = *(const rz_v4i*)&lds[wv][r % R][32 * (lane & 15) + 16 * (lane >> 4)];
+                const rz_v4i d = {raw[0] ^ (int)0x80808080u, raw[1] ^ (int)0x80808080u, raw[2] ^ (int)0x80808080u, raw[3] ^ (int)0x80808080u};
+                const rz_v4i zero = {0, 0, 0, 0};
+                const rz_v4i ch = __builtin_amdgcn_mfma_i32_16x16x64_i8(band_hi, d, zero, 0, 0, 0);
+                const rz_v4i cl = __builtin_amdgcn_mfma_i32_16x16x64_i8(band_lo, d, zero, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; c++) h[c] = (ch[c] << 8) + cl[c] + hbias;
+            } else {
+                uint32_t p[KS];
+                window(r, p);
+                hpass_px<KS>(p, axp, h);
+            }
+        };
 
         // prologue: fill the ring, take the KS-2 rows above the first destination row, then top the queue up to
         // DEPTH iterations ahead (those rows reuse the slots just consumed)
@@ -1337,11 +1396,7 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
         for (int r = 0; r < R; r++) issue(r);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - (KS - 2)) : "memory");
 #pragma unroll
-        for (int k = 0; k < KS - 2; k++) {
-            uint32_t p[KS];
-            window(k, p);
-            hpass_px<KS>(p, axp, ring[k]);
-        }
+        for (int k = 0; k < KS - 2; k++) hrow(k, ring[k]);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = R; r < KS - 2 + 2 * DEPTH; r++) issue(r);
@@ -1350,6 +1405,8 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
         // whole groups of four rows of a full strip with a 16-byte aligned destination leave through the LDS patch
         const bool wide = !EDGE && UN == 4 && !(((uintptr_t)a.dst | (uintptr_t)a.dstep | (uintptr_t)a.dst_stride) & 15);
         const unsigned voff4 = (unsigned)(lane >> 4) * (unsigned)a.dstep + (unsigned)(lane & 15) * 16u;
+        const int dxl = dx0 + xl;                                  // this lane's destination column
+        const unsigned xl4 = (unsigned)xl * 4u;
         for (int i0 = 0; i0 < dyn; i0 += UN) {
             const bool park = wide && i0 + UN <= dyn;          // wave-uniform
             static_for<UN>([&](auto uc) {
@@ -1364,15 +1421,31 @@ __global__ __launch_bounds__(64 * WPB, DMA_WAVES) void k_resize_2x_dma(RArgs a, 
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    uint32_t p[KS], q[KS];
-                    window(r0, p);
-                    window(r0 + 1, q);
-                    hpass_px<KS>(p, axp, ring[(KS - 2 + 2 * u) % KS]);
-                    hpass_px<KS>(q, axp, ring[(KS - 1 + 2 * u) % KS]);
+                    if constexpr (MFS) {
+                        // both rows' operands and all four MFMAs first, the sums afterwards: a wave does not wait for a product it
+                        // has just asked for
+                        const rz_v4i ra = *(const rz_v4i*)&lds[wv][r0 % R][32 * (lane & 15) + 16 * (lane >> 4)];
+                        const rz_v4i rb = *(const rz_v4i*)&lds[wv][(r0 + 1) % R][32 * (lane & 15) + 16 * (lane >> 4)];
+                        const rz_v4i da = {ra[0] ^ (int)0x80808080u, ra[1] ^ (int)0x80808080u, ra[2] ^ (int)0x80808080u, ra[3] ^ (int)0x80808080u};
+                        const rz_v4i db = {rb[0] ^ (int)0x80808080u, rb[1] ^ (int)0x80808080u, rb[2] ^ (int)0x80808080u, rb[3] ^ (int)0x80808080u};
+                        const rz_v4i zero = {0, 0, 0, 0};
+                        const rz_v4i ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(band_hi, da, zero, 0, 0, 0);
+                        const rz_v4i al = __builtin_amdgcn_mfma_i32_16x16x64_i8(band_lo, da, zero, 0, 0, 0);
+                        const rz_v4i bh = __builtin_amdgcn_mfma_i32_16x16x64_i8(band_hi, db, zero, 0, 0, 0);
+                        const rz_v4i bl = __builtin_amdgcn_mfma_i32_16x16x64_i8(band_lo, db, zero, 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            ring[(KS - 2 + 2 * u) % KS][c] = (ah[c] << 8) + al[c] + hbias;
+                            ring[(KS - 1 + 2 * u) % KS][c] = (bh[c] << 8) + bl[c] + hbias;
+                        }
+                    } else {
+                        hrow(r0, ring[(KS - 2 + 2 * u) % KS]);
+                        hrow(r0 + 1, ring[(KS - 1 + 2 * u) % KS]);
+                    }
                     asm volatile("" ::: "memory");             // the slots just read may be refilled from here on
-                    const uint32_t px = vpass_px<KS, MODE, u, VSYM>(ring, by, dx, vec_end);
-                    if (park) s_tr[wv][u & 3][lane] = px;
-                    else if (!EDGE || live) *(uint32_t*)(D + ((unsigned)(dy0 + i) * (unsigned)a.dstep + lane4)) = px;
+                    const uint32_t px = vpass_px<KS, MODE, u, VSYM>(ring, by, EDGE ? dx : dxl, vec_end);
+                    if (park) s_tr[wv][u & 3][xl] = px;
+                    else if (!EDGE || live) *(uint32_t*)(D + ((unsigned)(dy0 + i) * (unsigned)a.dstep + (EDGE ? lane4 : xl4))) = px;
                 }
             });
             if (park) {
@@ -2476,6 +2549,8 @@ struct TableSet {
     int strip_a0 = -1, strip_a1 = -1;   // the footprint advances by a0 rows after even destination rows and a1 after odd ones (k_resize_strip2), or -1
     bool ysym = false;        // step2 and the one set of row weights is mirror-symmetric (vpass_px's VSYM form)
     bool step2 = false;       // xofs[d] = xofs[0] + 2d and yofs[d] = yofs[0] + 2d: k_resize_2x_roll applies
+    bool xuni = false;        // step2 and ONE set of column weights (k_resize_2x_dma's MF form)
+    int x0 = 0;               // xofs[0]: the first source column of destination column 0
     AreaDev area{};
 };
 using Key = std::tuple<int, int, int, int, int>;
@@ -2609,6 +2684,10 @@ static int get_tables(int interp, int sw, int sh, int dw, int dh, double scale_x
             for (int k = 0; k < ty.ksize; k++) ts.step2 = ts.step2 && ty.coef[(size_t)d * ty.ksize + k] == ty.coef[k];
         ts.ysym = ts.step2;
         for (int k = 0; k < ty.ksize && ts.ysym; k++) ts.ysym = ty.coef[k] == ty.coef[ty.ksize - 1 - k];
+        ts.xuni = ts.step2;
+        ts.x0 = tx.ofs[0];
+        for (int d = 1; d < dw && ts.xuni; d++)
+            for (int k = 0; k < tx.ksize; k++) ts.xuni = ts.xuni && tx.coef[(size_t)d * tx.ksize + k] == tx.coef[k];
     }
     void* devp = nullptr;
     if (int rc = upload_small(blob.data(), blob.size(), &devp, s)) return rc;     // asynchronous, ordered before later work on `s`
@@ -2856,7 +2935,12 @@ static int launch_cn(const RArgs& a, int count, int interp, double scale_x, doub
         else if (dma_depth == 4) IMP_DMA_W(KS_, MODE_, VEC_, VS_, 4);                                                    \
         else IMP_DMA_W(KS_, MODE_, VEC_, VS_, 3);                                                                        \
     } while (0)
-            if (dma_ok && interp == IMP_INTER_CUBIC) IMP_DMA(4, M_CUBIC, (a.dw * 4) & ~7, false);
+            // the horizontal pass on the matrix unit (k_resize_2x_dma's MF form) where every column has the same taps, the strips'
+            // first tap is dword 1 of its 16-byte granule (xofs[0] = 0: sx00 = 2 dx0 - 3), and the block is four waves deep
+            static const bool no_mf = ab_env("IMPGPU_NO_HMFMA") != nullptr;
+            const bool mf = dma_ok && ts.xuni && ts.ysym && !no_mf && wpb == 4 && dma_depth == 3 && interp == IMP_INTER_LANCZOS4 && ts.x0 == 0;
+            if (mf) hipLaunchKernelGGL((k_resize_2x_dma<8, M_LANCZOS, 3, true, 4, true>), dgrid, dim3(256), 0, s, a, ts.xofs, ts.xco, ts.yofs, ts.yco, 0, nbx, bpf, count);
+            else if (dma_ok && interp == IMP_INTER_CUBIC) IMP_DMA(4, M_CUBIC, (a.dw * 4) & ~7, false);
             else if (dma_ok && ts.ysym) IMP_DMA(8, M_LANCZOS, 0, true);
             else if (dma_ok) IMP_DMA(8, M_LANCZOS, 0, false);
 #undef IMP_DMA_W
