@@ -231,6 +231,7 @@ static int register_watermark(impgpu_client* c, impc_watermark* m) {
     s->in_kind = IMPB_IN_WATERMARK; s->out_kind = IMPB_OUT_INFO;
     s->quality = 0; s->simple = 0; s->need_flatten = 0;          /* (nothing of the slot's last request rides along) */
     s->in_bytes = bytes; s->in_w = m->w; s->in_h = m->h; s->in_c = m->c; s->in_step = m->step;
+    s->in_head_bytes = s->in_scan_at = s->in_scan_bytes = 0;
     s->filter_count = 0; s->crop_at = s->gravity_at = s->resize_at = s->ascii_at = -1; s->watermark_id = 0;
     const unsigned epoch = c->hdr->f.epoch;
     int rc = roundtrip(c);
@@ -257,6 +258,55 @@ int impgpu_client_prepare_watermark(impgpu_client* c, const unsigned char* pixel
     return IMP_OK;
 }
 
+/* (the marker walk of csrc/imp_jpeg.cpp's jpeg_parse, reduced to what decides "prepare or not", and jpeg_prepare_scan's
+ * copy for a file without restart intervals; tests/test_broker_host.py holds the two against each other) */
+int impgpu_jpeg_unstuff(const unsigned char* f, size_t size, unsigned char* out, size_t cap, size_t* head_bytes, size_t* scan_at,
+                        size_t* scan_bytes, size_t* total_bytes) {
+    if (!f || !out || size < 4 || f[0] != 0xFF || f[1] != 0xD8) return 0;
+    size_t at = 2, scan_begin = 0;
+    int frames = 0;
+    while (!scan_begin) {
+        if (at + 2 > size || f[at] != 0xFF) return 0;
+        while (at < size && f[at] == 0xFF) at++;
+        if (at >= size) return 0;
+        const int marker = f[at++];
+        if (marker == 0xD8 || marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7)) continue;
+        if (marker == 0xD9 || at + 2 > size) return 0;
+        const size_t len = ((size_t)f[at] << 8) | f[at + 1];
+        if (len < 2 || len > size - at) return 0;
+        if (marker == 0xC0 || marker == 0xC1) { if (frames++) return 0; }
+        else if (marker >= 0xC0 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) return 0;   /* another process */
+        else if (marker == 0xDD) { if (len != 4 || f[at + 2] || f[at + 3]) return 0; }                  /* a restart interval */
+        else if (marker == 0xDA) { if (!frames) return 0; scan_begin = at + len; }
+        at += len;
+    }
+    const size_t sa = (scan_begin + 255) & ~(size_t)255;
+    if (size - scan_begin < IMPB_PREPARE_MIN_SCAN || sa > cap || size - scan_begin > cap - sa || cap - sa - (size - scan_begin) < IMPGPU_JPEG_SCAN_TAIL) return 0;
+    unsigned char* o = out + sa;
+    size_t n = 0;
+    at = scan_begin;
+    for (;;) {
+        const unsigned char* ff = at < size ? (const unsigned char*)memchr(f + at, 0xFF, size - at) : NULL;
+        const size_t run = (ff ? (size_t)(ff - f) : size) - at;
+        memcpy(o + n, f + at, run);
+        n += run; at += run;
+        if (!ff) break;                                  /* no EOI: the MCU count decides */
+        size_t m = at + 1;
+        while (m < size && f[m] == 0xFF) m++;            /* fill bytes */
+        if (m >= size) break;
+        const int code = f[m];
+        if (code == 0x00 && m == at + 1) { o[n++] = 0xFF; at = m + 1; }
+        else if (code == 0x00 || (code >= 0xD0 && code <= 0xD7)) return 0;   /* FF FF 00, or RSTn without an interval: the library's verdict, on the file as it is */
+        else break;                                      /* EOI, or whatever follows the scan */
+    }
+    if (!n) return 0;
+    memcpy(out, f, scan_begin);
+    memset(out + scan_begin, 0, sa - scan_begin);
+    memset(o + n, 0xFF, IMPGPU_JPEG_SCAN_TAIL);
+    *head_bytes = scan_begin; *scan_at = sa; *scan_bytes = n; *total_bytes = sa + n + IMPGPU_JPEG_SCAN_TAIL;
+    return 1;
+}
+
 int impgpu_client_run(impgpu_client* c, const impgpu_client_request* r, impgpu_client_answer* a) {
     if (!c || !r || !a) return IMP_ERROR_INVALID_ARGS;
     memset(a, 0, sizeof *a);
@@ -277,9 +327,20 @@ int impgpu_client_run(impgpu_client* c, const impgpu_client_request* r, impgpu_c
     }
     impb_slot_fields* s = &c->slot->f;
     if (r->input_bytes > c->hdr->f.slot_data_bytes) { snprintf(t_err, sizeof t_err, "input larger than a slot"); return IMP_ERROR_MALLOC_FAILED; }
-    if (r->input) memcpy(c->data, r->input, r->input_bytes);
-    s->in_kind = (uint32_t)r->in_kind; s->out_kind = (uint32_t)r->out_kind;
     s->in_bytes = r->input_bytes;
+    s->in_head_bytes = s->in_scan_at = s->in_scan_bytes = 0;
+    if (r->input) {
+        /* a JPEG goes in with its scan out of the byte stuffing (the broker's lanes then make no pass over it: its bytes
+         * go to the device from this slot); $IMPGPU_BROKER_PREPARE=0 copies every file as it is */
+        size_t head = 0, sat = 0, sn = 0, total = 0;
+        static int prepare = -1;
+        if (prepare < 0) { const char* e = getenv("IMPGPU_BROKER_PREPARE"); prepare = !(e && e[0] == '0'); }
+        if (prepare && r->in_kind == IMPB_IN_FILE &&
+            impgpu_jpeg_unstuff(r->input, r->input_bytes, c->data, (size_t)c->hdr->f.slot_data_bytes, &head, &sat, &sn, &total)) {
+            s->in_bytes = total; s->in_head_bytes = head; s->in_scan_at = sat; s->in_scan_bytes = sn;
+        } else memcpy(c->data, r->input, r->input_bytes);
+    }
+    s->in_kind = (uint32_t)r->in_kind; s->out_kind = (uint32_t)r->out_kind;
     s->in_w = r->width; s->in_h = r->height; s->in_c = r->channels; s->in_step = r->step;
     s->quality = r->quality;
     size_t at = 0;

@@ -171,6 +171,29 @@ int   impgpu_batch_decode_jpeg(const unsigned char* const* blobs, const size_t* 
 typedef struct impgpu_jpeg_batch impgpu_jpeg_batch;
 int   impgpu_batch_decode_jpeg_begin(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_jpeg_batch** batch);
 int   impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** images, int* codes);
+/* Files whose entropy-coded segment has been taken out of its byte stuffing by the CALLER (round 5: a worker process does it
+ * while it copies its request into the broker's shared memory -- impgpu_jpeg_unstuff in libimpgpu_client.so -- so the pass over
+ * the compressed bytes is made by sixteen sleeping workers instead of the four threads that drive the device).
+ *   head, head_size   the file from SOI up to and including its SOS header (what jpeg headers parse); a file WITH a restart
+ *                     interval cannot be handed over this way (IMP_ERROR_INVALID_ARGS for that file);
+ *   scan, scan_size   the entropy-coded bytes that followed, FF 00 -> FF, fill bytes dropped, up to (not including) the marker
+ *                     that ends them; behind them the caller has written IMPGPU_JPEG_SCAN_TAIL bytes of 0xFF (not counted);
+ *                     scan = NULL: `head` is a whole file as it came (the two kinds may share a batch);
+ *   registered        != 0: `scan` lies in memory made known with impgpu_host_register -- the bytes go to the device from
+ *                     where they are (no pass over them on the calling thread at all); they must not change until the call
+ *                     returns.
+ * Pixels, codes and refusals are those of impgpu_batch_decode_jpeg on the original files. */
+#define IMPGPU_JPEG_SCAN_TAIL 512
+typedef struct {
+    const unsigned char* head; size_t head_size;
+    const unsigned char* scan; size_t scan_size;
+    int registered;
+} impgpu_jpeg_prepared;
+int   impgpu_batch_decode_jpeg_prepared(const impgpu_jpeg_prepared* files, int count, impgpu_image** images, int* codes);
+/* Page-locks `bytes` at `p` (hipHostRegister) so that copies out of it need no staging; impgpu_host_unregister before the
+ * memory goes away.  Needs impgpu_env_start. */
+int   impgpu_host_register(void* p, size_t bytes);
+int   impgpu_host_unregister(void* p);
 /* Where a decode call's time goes (per-stage timing): impgpu_jpeg_profile(1) makes every later decode call leave
  * its stages with the calling thread, impgpu_jpeg_stage_times reads the last call's, in microseconds:
  * [0] marker segments, [1] FF00 unstuffing into pinned memory, [2] tables + job table, [3] enqueue, [4] wait for the verdicts

@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define IMPB_MAGIC        0x42504D49u     /* "IMPB" */
-#define IMPB_VERSION      1u
+#define IMPB_VERSION      2u              /* 2: a JPEG file may arrive with its scan unstuffed (in_head_bytes, in_scan_at, in_scan_bytes) */
 #define IMPB_MAX_SLOTS    256
 #define IMPB_TEXT_BYTES   3072            /* the job's strings, NUL-separated */
 #define IMPB_MAX_FILTERS  32
@@ -83,6 +83,10 @@ typedef struct {
     /* ---- request ---- */
     uint32_t in_kind, out_kind;
     uint64_t in_bytes;
+    /* IMPB_IN_FILE, a JPEG the worker has prepared (impgpu_jpeg_unstuff; in_scan_bytes = 0: the file as it came): the data
+     * area holds the file's head [0, in_head_bytes), then at in_scan_at (256-byte aligned) in_scan_bytes of entropy-coded data
+     * out of their byte stuffing and IMPGPU_JPEG_SCAN_TAIL bytes of 0xFF; in_bytes covers all of it */
+    uint64_t in_head_bytes, in_scan_at, in_scan_bytes;
     int32_t  in_w, in_h, in_c, in_step; /* IMPB_IN_FRAME / IMPB_IN_WATERMARK */
     int32_t  quality;                   /* IMPB_OUT_JPEG */
     int32_t  simple, need_flatten, filter_count;
@@ -152,6 +156,16 @@ int         impgpu_client_run(impgpu_client* client, const impgpu_client_request
 int         impgpu_client_prepare_watermark(impgpu_client* client, const unsigned char* pixels, int width, int height,
                                             int channels, int step, int* id);
 const char* impgpu_client_last_error(void);
+/* What impgpu_client_run does with a JPEG file on its way into the slot (exported for tests and for callers that fill the
+ * input buffer themselves): if `file` is a Huffman-coded sequential JPEG (SOF0 / SOF1) with no restart interval whose scan
+ * has at least IMPB_PREPARE_MIN_SCAN bytes, writes into out[0, cap): the file up to and including its SOS header, then --
+ * at *scan_at, the next multiple of 256 -- the entropy-coded bytes with FF 00 -> FF and fill bytes dropped, up to the marker
+ * that ends them (the rules of jpeg_prepare_scan, csrc/imp_jpeg.cpp), then IMPGPU_JPEG_SCAN_TAIL bytes of 0xFF; returns 1.
+ * Returns 0 -- nothing of `out` is meaningful, send the file as it is -- for every other file (another process, restart
+ * markers, a marker sequence the library calls damaged, no room).  The pass costs what the memcpy into the slot cost. */
+#define IMPB_PREPARE_MIN_SCAN 40960     /* (what impgpu.h says of small launches: their Huffman stage stays on the host, which reads the file as it is) */
+int         impgpu_jpeg_unstuff(const unsigned char* file, size_t size, unsigned char* out, size_t cap,
+                                size_t* head_bytes, size_t* scan_at, size_t* scan_bytes, size_t* total_bytes);
 /* diagnostics: the broker's counters as the segment shows them now */
 int         impgpu_client_stats(impgpu_client* client, unsigned long long* served, unsigned long long* batches,
                                 unsigned* epoch, unsigned* broker_pid);

@@ -82,6 +82,10 @@ class CJob(C.Structure):
     ]
 
 
+class CJpegPrepared(C.Structure):                      # impgpu_jpeg_prepared
+    _fields_ = [("head", C.c_void_p), ("head_size", C.c_size_t), ("scan", C.c_void_p), ("scan_size", C.c_size_t), ("registered", C.c_int)]
+
+
 class CGifPage(C.Structure):
     _fields_ = [
         ("indices", C.c_void_p),
@@ -116,6 +120,9 @@ SIGNATURES = {
     "impgpu_jpeg_info": (C.c_int, [C.c_char_p, C.c_size_t, IP, IP, IP]),
     "impgpu_batch_decode_jpeg_begin": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, PP]),
     "impgpu_batch_decode_jpeg_finish": (C.c_int, [PP, PP, IP]),
+    "impgpu_batch_decode_jpeg_prepared": (C.c_int, [C.POINTER(CJpegPrepared), C.c_int, PP, IP]),
+    "impgpu_host_register": (C.c_int, [P, C.c_size_t]),
+    "impgpu_host_unregister": (C.c_int, [P]),
     "impgpu_image_decode_png": (C.c_int, [C.c_char_p, C.c_size_t, PP]),
     "impgpu_png_info": (C.c_int, [C.c_char_p, C.c_size_t, IP, IP, IP]),
     "impgpu_png_stage_times": (C.c_int, [C.POINTER(C.c_double), C.c_int]),

@@ -37,6 +37,7 @@ clib.impgpu_client_run.argtypes = [C.c_void_p, C.POINTER(CRequest), C.POINTER(CA
 clib.impgpu_client_prepare_watermark.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
 clib.impgpu_client_last_error.restype = C.c_char_p
 clib.impgpu_client_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+clib.impgpu_jpeg_unstuff.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
 clib.impgpu_client_input_buffer.argtypes = [C.c_void_p, C.c_size_t]
 clib.impgpu_client_input_buffer.restype = C.c_void_p
 

@@ -13,7 +13,7 @@
 // Nothing a worker writes into its slot is trusted further than a request is: the request record is copied out of shared
 // memory once and validated (sizes against the slot, offsets against the text area, frame geometry against the bytes).
 //
-//   impgpu_broker [--name /impgpu-broker-0] [--device 0] [--slots 64] [--slot-mb 32] [--threads 2] [--batch 64]
+//   impgpu_broker [--name /impgpu-broker-0] [--device 0] [--slots 64] [--slot-mb 32] [--register-mb 8] [--threads 2] [--batch 64]
 //                 [--gather-us 0] [--supervise] [--ready-file PATH]
 // --supervise: this process only forks and watches; the child is the broker.  A child that dies (a lost device, a bug) is
 // replaced by a FRESH child -- fork() from a parent that never touched the GPU, no exec of a process that did.
@@ -47,6 +47,7 @@ struct Options {
     int device = 0;
     int slots = 64;
     long slot_mb = 32;
+    long register_mb = 8;               // page-locked at the front of every slot (0: none)
     int threads = 2;
     int batch = 64;
     int gather_us = 0;
@@ -61,6 +62,7 @@ struct Segment {
     impb_slot* slots = nullptr;
     uint8_t* data = nullptr;
     uint64_t slot_bytes = 0;
+    uint64_t registered = 0;            // the first so many bytes of every slot's data area are page-locked (copies to the device start there)
     uint8_t* slot_data(int i) const { return data + (uint64_t)i * slot_bytes; }
 };
 
@@ -187,6 +189,11 @@ void prepare(Req& r, const Segment& S) {
         if (q.filter_at[i] < 0 || q.filter_at[i] >= IMPB_TEXT_BYTES) return fail(r, IMP_ERROR_INVALID_ARGS, IMP_STEP_VALIDATE, "bad filter offset");
         r.filters.push_back(q.text + q.filter_at[i]);
     }
+    if (q.in_scan_bytes) {              // a JPEG whose scan the worker has unstuffed (impgpu_jpeg_unstuff)
+        if (q.in_kind != IMPB_IN_FILE || q.in_head_bytes < 4 || q.in_head_bytes > q.in_scan_at || (q.in_scan_at & 255) || q.in_scan_at > q.in_bytes ||
+            q.in_scan_bytes > q.in_bytes - q.in_scan_at || q.in_bytes - q.in_scan_at - q.in_scan_bytes < IMPGPU_JPEG_SCAN_TAIL)
+            return fail(r, IMP_ERROR_INVALID_ARGS, IMP_STEP_VALIDATE, "prepared file: offsets past its bytes");
+    }
     if (q.in_kind != IMPB_IN_FILE) {
         const long long need = (long long)q.in_step * q.in_h;
         if (q.in_w <= 0 || q.in_h <= 0 || (q.in_c != 1 && q.in_c != 3 && q.in_c != 4) || (long long)q.in_step < (long long)q.in_w * q.in_c ||
@@ -291,17 +298,31 @@ struct Worker {
         // ---- decode (bridge.c:541-572): all JPEG files of the batch in one call
         blobs.clear(); sizes.clear();
         std::vector<size_t> who;
+        std::vector<impgpu_jpeg_prepared> pre;
+        bool any_prepared = false;
         for (size_t k = 0; k < n; k++) {
             Req& r = reqs[k];
             if (r.done) continue;
             r.step = IMP_STEP_DECODE;
-            if (r.q.in_kind == IMPB_IN_FILE && is_jpeg(r.in, r.q.in_bytes)) { blobs.push_back(r.in); sizes.push_back((size_t)r.q.in_bytes); who.push_back(k); }
+            if (r.q.in_kind != IMPB_IN_FILE || !is_jpeg(r.in, r.q.in_bytes)) continue;
+            blobs.push_back(r.in); sizes.push_back((size_t)r.q.in_bytes); who.push_back(k);
+            impgpu_jpeg_prepared f{r.in, (size_t)r.q.in_bytes, nullptr, 0, 0};
+            if (r.q.in_scan_bytes) {
+                // (its bytes go to the device from the slot when they lie in its page-locked part; the worker sleeps until DONE)
+                f.head_size = (size_t)r.q.in_head_bytes;
+                f.scan = r.in + r.q.in_scan_at;
+                f.scan_size = (size_t)r.q.in_scan_bytes;
+                f.registered = r.q.in_scan_at + r.q.in_scan_bytes + IMPGPU_JPEG_SCAN_TAIL <= S.registered;
+                any_prepared = true;
+            }
+            pre.push_back(f);
         }
         if (!who.empty()) {
             imgs.assign(who.size(), nullptr);
             codes.assign(who.size(), IMP_OK);
-            const int rc = who.size() == 1 ? (codes[0] = impgpu_image_decode_jpeg(blobs[0], sizes[0], &imgs[0]), IMP_OK)
-                                           : impgpu_batch_decode_jpeg(blobs.data(), sizes.data(), (int)who.size(), imgs.data(), codes.data());
+            const int rc = any_prepared ? impgpu_batch_decode_jpeg_prepared(pre.data(), (int)who.size(), imgs.data(), codes.data())
+                           : who.size() == 1 ? (codes[0] = impgpu_image_decode_jpeg(blobs[0], sizes[0], &imgs[0]), IMP_OK)
+                                             : impgpu_batch_decode_jpeg(blobs.data(), sizes.data(), (int)who.size(), imgs.data(), codes.data());
             for (size_t j = 0; j < who.size(); j++) {
                 Req& r = reqs[who[j]];
                 const int c = rc != IMP_OK ? rc : codes[j];
@@ -523,6 +544,15 @@ int serve(const Options& o) {
         return 4;
     }
     (void)impgpu_env_bind_thread();
+    // The front of every slot is page-locked: a JPEG a worker has unstuffed into it (glue/imp_gpu_client.c) goes to the device
+    // from where it lies.  Files that reach past it are staged like any caller's.  (Locking allocates the pages: 8 MB a slot.)
+    {
+        const uint64_t want = std::min<uint64_t>(S.slot_bytes, (uint64_t)o.register_mb << 20);
+        bool ok = want > 0;
+        for (uint32_t i = 0; ok && i < S.h->nslots; i++) ok = impgpu_host_register(S.slot_data((int)i), (size_t)want) == IMP_OK;
+        if (ok) S.registered = want;
+        else if (want) std::fprintf(stderr, "impgpu_broker: the slots could not be page-locked (%s): prepared files are staged\n", impgpu_last_error());
+    }
     std::vector<std::thread> threads;
     std::vector<Worker*> workers;
     for (int i = 0; i < o.threads; i++) {
@@ -602,12 +632,13 @@ int main(int argc, char** argv) {
         else if (a == "--device") o.device = std::atoi(val("--device"));
         else if (a == "--slots") o.slots = std::atoi(val("--slots"));
         else if (a == "--slot-mb") o.slot_mb = std::atol(val("--slot-mb"));
+        else if (a == "--register-mb") o.register_mb = std::max(0l, std::atol(val("--register-mb")));
         else if (a == "--threads") o.threads = std::atoi(val("--threads"));
         else if (a == "--batch") o.batch = std::atoi(val("--batch"));
         else if (a == "--gather-us") o.gather_us = std::atoi(val("--gather-us"));
         else if (a == "--ready-file") o.ready_file = val("--ready-file");
         else if (a == "--supervise") o.supervise = true;
-        else { std::fprintf(stderr, "usage: impgpu_broker [--name /impgpu-broker-0] [--device 0] [--slots 64] [--slot-mb 32] [--threads 2] [--batch 64] [--gather-us 0] [--supervise] [--ready-file PATH]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: impgpu_broker [--name /impgpu-broker-0] [--device 0] [--slots 64] [--slot-mb 32] [--register-mb 8] [--threads 2] [--batch 64] [--gather-us 0] [--supervise] [--ready-file PATH]\n"); return 2; }
     }
     if (o.slots < 1 || o.slots > IMPB_MAX_SLOTS || o.slot_mb < 1 || o.slot_mb > 4096 || o.threads < 1 || o.threads > 32 || o.batch < 1 || o.batch > 256 ||
         o.name.empty() || o.name[0] != '/') {

@@ -72,6 +72,10 @@ struct Prep {                                       // one file on its way to th
     size_t ctl_header = 0, ctl_records = 0, ctl_ext = 0;   // word offsets in the control area
     size_t work_off = 0;                            // bytes in the per-chunk work area (entry states, slot counts, DC sums)
     impgpu_image* im = nullptr;
+    size_t scan_len = 0;                            // entropy-coded bytes: as the file has them, or unstuffed by the caller (prepared)
+    const impgpu_jpeg_prepared* pre = nullptr;      // the caller has unstuffed the scan (impgpu_batch_decode_jpeg_prepared)
+    bool direct = false;                            // ... into registered memory: its words go to the device from there
+    size_t direct_off = 0;                          // bytes behind the staged part of the words' block
 };
 
 // A file whose blocks average more bits than this keeps its Huffman stage on the calling thread even inside a launch that is
@@ -101,10 +105,26 @@ struct Group {
     hipEvent_t ev[8] = {};
     Stopwatch sw;
     const void* owner = nullptr;                    // the thread that began the group (its slot, its lane): only it may finish it
+    const impgpu_jpeg_prepared* prep = nullptr;     // per file, or nullptr: every blob is a whole file
 };
 thread_local char t_thread_tag;                     // its address names the calling thread
 thread_local unsigned t_slots_busy = 0;             // bit k: mailbox slot k holds a group that has not been finished
 std::atomic<int> g_groups_in_flight{0};             // over all threads: groups begun and not finished
+
+// A prepared file as the file it came from (head, the scan with its 00s behind the FFs again, EOI): what the host's entropy
+// decoder reads -- the A/B path and the files a device launch defers (dense blocks), never the common case.
+std::vector<uint8_t> restuffed(const impgpu_jpeg_prepared& f) {
+    std::vector<uint8_t> out;
+    out.reserve(f.head_size + f.scan_size + f.scan_size / 64 + 16);
+    out.insert(out.end(), f.head, f.head + f.head_size);
+    for (size_t i = 0; i < f.scan_size; i++) {
+        out.push_back(f.scan[i]);
+        if (f.scan[i] == 0xFF) out.push_back(0);
+    }
+    out.push_back(0xFF);
+    out.push_back(0xD9);
+    return out;
+}
 
 void group_release(Group& G) {
     for (int i = 0; i < 8; i++) if (G.ev[i]) { (void)hipEventDestroy(G.ev[i]); G.ev[i] = nullptr; }
@@ -198,13 +218,14 @@ void host_parallel(const std::vector<int>& items, size_t bytes, Fn& fn) {
 // Everything up to the last enqueue: headers, the unstuffing copy (or the host's entropy decoding), job tables, uploads,
 // the entropy and pixel kernels, the verdicts' copy.  Does NOT wait.  A non-zero return means nothing is in flight and
 // nothing is held (codes[] of the caller are then filled by the caller from G.P where they are set, else with the return).
-int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes, int count, int force_host, bool side = false) {
+int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes, int count, int force_host, bool side = false,
+                const impgpu_jpeg_prepared* prep = nullptr) {
     Stopwatch& sw = G.sw;
     hipStream_t s = side ? lane_side_stream() : nullptr;
     if (!s) s = env_stream();
     if (!s) return IMP_ERROR_DEVICE;
     G.stream = s;
-    G.blobs = blobs; G.sizes = sizes; G.count = count;
+    G.blobs = blobs; G.sizes = sizes; G.count = count; G.prep = prep;
     G.P.assign((size_t)count, Prep());
     std::vector<Prep>& P = G.P;
     for (int k = 0; k < GROUP_SLOTS && G.slot < 0; k++)
@@ -214,11 +235,19 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
     G.owner = &t_thread_tag;
     g_groups_in_flight.fetch_add(1, std::memory_order_relaxed);
     // ---- headers, geometry, the sizes of everything
-    size_t words_total = 0, coef_total = 0;
+    size_t words_total = 0, coef_total = 0, direct_total = 0;
     for (int i = 0; i < count; i++) {
         Prep& p = P[(size_t)i];
         if (!blobs[i]) { p.code = IMP_ERROR_INVALID_ARGS; continue; }
+        if (prep && prep[i].scan) p.pre = &prep[i];
         p.code = jpeg_parse(blobs[i], sizes[i], &p.H);
+        // (a prepared file: its head ends where its scan began, and nothing cuts the scan into intervals)
+        if (!p.code && p.pre && (p.H.scan_begin != sizes[i] || p.H.restart_interval || !p.pre->scan_size)) {
+            set_error_text("prepared JPEG: the head does not end at its scan, or the file has a restart interval");
+            p.code = IMP_ERROR_INVALID_ARGS;
+            continue;
+        }
+        if (!p.code) p.scan_len = p.pre ? p.pre->scan_size : sizes[i] - p.H.scan_begin;
         if (!p.code && !frame_fits(p.H.width, p.H.height, p.H.ncomp)) { p.code = IMP_ERROR_UNSUPPORTED; p.H.why = JPEG_WHY_OTHER; }
         if (p.code == IMP_ERROR_UNSUPPORTED) g_count[4 + (p.H.why > 0 && p.H.why < JPEG_WHY_COUNT ? p.H.why : JPEG_WHY_OTHER)].fetch_add(1, std::memory_order_relaxed);
         else if (p.code == IMP_ERROR_DECODE_FAILED) g_count[4 + JPEG_WHY_COUNT].fetch_add(1, std::memory_order_relaxed);
@@ -229,22 +258,27 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         // Refused before anything is sized by what the header claims: an interval needs a data byte and its marker, a block a DC
         // code and an end-of-block code -- a few hundred bytes that announce 30000 x 30000 pixels, or a restart interval of one
         // MCU on a frame of 2^30, would otherwise have pinned and device memory allocated by the gigabyte before the decode fails.
-        const size_t scan_bytes = sizes[i] - p.H.scan_begin;
+        const size_t scan_bytes = p.scan_len;
         if (p.nsegs > scan_bytes / 3 + 1 || (size_t)p.F.total_slots / 64 > 4 * scan_bytes + 64) { p.code = IMP_ERROR_DECODE_FAILED; continue; }
         p.words_cap = align_up(jpeg_scan_capacity(scan_bytes, p.nsegs), JPEG_CHUNK_BYTES_MAX);
-        p.words_off = words_total;
-        words_total += p.words_cap;
+        p.direct = p.pre && p.pre->registered && !force_host;
+        if (p.direct) { p.direct_off = direct_total; direct_total += p.words_cap; }
+        else { p.words_off = words_total; words_total += p.words_cap; }
         p.coef_off = coef_total;
         coef_total += align_up((size_t)p.F.total_slots * sizeof(int16_t), 256);
     }
     size_t launch_bytes = 0;
     for (int i = 0; i < count; i++)
-        if (!P[(size_t)i].code) launch_bytes += sizes[i] - P[(size_t)i].H.scan_begin;
+        if (!P[(size_t)i].code) launch_bytes += P[(size_t)i].scan_len;
     const bool on_device = G.on_device = !force_host && entropy_on_device(launch_bytes);
+    if (!on_device && direct_total) {                               // (a launch of under 40 KB: its files are staged after all)
+        for (Prep& p : P) if (!p.code && p.direct) { p.direct = false; p.words_off = words_total; words_total += p.words_cap; }
+        direct_total = 0;
+    }
     if (on_device && !std::getenv("IMPGPU_JPEG_HUFF"))
         for (int i = 0; i < count; i++) {
             Prep& p = P[(size_t)i];
-            if (!p.code && (sizes[i] - p.H.scan_begin) * 8 > DENSE_BITS_PER_BLOCK * ((size_t)p.F.total_slots / 64)) {
+            if (!p.code && p.scan_len * 8 > DENSE_BITS_PER_BLOCK * ((size_t)p.F.total_slots / 64)) {
                 p.code = CODE_DEFERRED;
                 g_count[3].fetch_add(1, std::memory_order_relaxed);
             }
@@ -267,8 +301,19 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         const bool busy = g_groups_in_flight.load(std::memory_order_relaxed) > 1;    // (this group is counted already)
         auto prepare = [&](int i) {
             Prep& p = P[(size_t)i];
-            p.scan.chunk_bytes = jpeg_chunk_bytes_for(sizes[i] - p.H.scan_begin, launch_bytes, busy);
-            p.code = jpeg_prepare_scan(blobs[i], sizes[i], p.H, (uint8_t*)host + p.words_off, p.words_cap, &p.scan);
+            p.scan.chunk_bytes = jpeg_chunk_bytes_for(p.scan_len, launch_bytes, busy);
+            if (!p.pre) { p.code = jpeg_prepare_scan(blobs[i], sizes[i], p.H, (uint8_t*)host + p.words_off, p.words_cap, &p.scan); return; }
+            // the caller's unstuffed bytes are one interval: what jpeg_prepare_scan would have left -- the bytes, 1-bits up to
+            // the chunk boundary, one all-ones guard chunk (a registered scan brings them: IMPGPU_JPEG_SCAN_TAIL)
+            const size_t CBY = p.scan.chunk_bytes, n = p.pre->scan_size, padded = (n + CBY - 1) / CBY * CBY;
+            p.scan.seg_first_chunk.assign(1, 0u);
+            p.scan.seg_bits.assign(1, (uint32_t)(n * 8));
+            p.scan.nchunks = padded / CBY;
+            if ((uint64_t)padded * 8 >= (1ull << 32)) { p.code = IMP_ERROR_UNSUPPORTED; return; }
+            if (p.direct) return;
+            uint8_t* out = (uint8_t*)host + p.words_off;
+            std::memcpy(out, p.pre->scan, n);
+            std::memset(out + n, 0xFF, padded - n + JPEG_CHUNK_BYTES);
         };
         host_parallel(todo, launch_bytes, prepare);
     }
@@ -280,12 +325,15 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
                 p.F.nchunks = (unsigned)p.scan.nchunks;
                 p.F.nsegs = (unsigned)p.scan.seg_first_chunk.size();
                 p.F.chunk_bits = (unsigned)p.scan.chunk_bytes * 8;
-                p.F.overlap_bits = jpeg_overlap_bits_for(p.F.chunk_bits, sizes[i] - p.H.scan_begin, (size_t)p.F.total_slots / 64);
+                p.F.overlap_bits = jpeg_overlap_bits_for(p.F.chunk_bits, p.scan_len, (size_t)p.F.total_slots / 64);
             }
         } else {
             int16_t* planes = (int16_t*)((uint8_t*)host + p.coef_off);
             std::memset(planes, 0, (size_t)p.F.total_slots * sizeof(int16_t));
-            p.code = jpeg_host_entropy(blobs[i], sizes[i], p.H, planes, p.F);
+            if (p.pre) {
+                const std::vector<uint8_t> file = restuffed(*p.pre);
+                p.code = jpeg_host_entropy(file.data(), file.size(), p.H, planes, p.F);
+            } else p.code = jpeg_host_entropy(blobs[i], sizes[i], p.H, planes, p.F);
         }
         if (!p.code) p.code = image_new(p.H.width, p.H.height, p.H.ncomp, &p.im);
         if (!p.code) live++;
@@ -348,12 +396,14 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         // and a fill -- were 30-40 us of a lone file's 220 (tools/jpeg_stage_probe.py), the bytes themselves 3.
         const size_t off_side = align_up(words_total, 256), off_ctl = off_side + align_up(side, 256), in_total = off_ctl + ctl_words * sizeof(uint32_t);
         const bool one = G.one_block = on_device && stage_capacity(token) >= in_total;
+        // (the scans a caller unstuffed into registered memory lie behind what is staged: each arrives by a copy of its own)
+        const size_t direct_base = align_up(one ? in_total : words_total, 256);
         if (one) {
-            rc = dev_alloc(in_total, &d_words);
+            rc = dev_alloc(direct_base + direct_total, &d_words);
             if (!rc) { d_side = (uint8_t*)d_words + off_side; d_ctl = (uint8_t*)d_words + off_ctl; }
         } else {
             rc = dev_alloc(side, &d_side);
-            if (!rc && on_device) rc = dev_alloc(words_total, &d_words);
+            if (!rc && on_device) rc = dev_alloc(direct_base + direct_total, &d_words);
             if (!rc && on_device) rc = dev_alloc(ctl_words * sizeof(uint32_t), &d_ctl);
         }
         if (!rc) rc = dev_alloc(coef_total, &d_coef);
@@ -383,7 +433,7 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
                 if (rc) { p.code = rc; rc = IMP_OK; }               // (cannot happen after jpeg_parse; keeps the job inert)
                 jpeg_scan_meta(p.scan, &meta);
                 std::memcpy(blob.data() + p.side_meta, meta.data(), meta.size() * sizeof(uint32_t));
-                J.words = (const uint32_t*)((uint8_t*)d_words + p.words_off);
+                J.words = (const uint32_t*)((uint8_t*)d_words + (p.direct ? direct_base + p.direct_off : p.words_off));
                 J.chunk_seg = (const uint32_t*)((uint8_t*)d_side + p.side_meta);
                 J.seg_first_chunk = J.chunk_seg + p.F.nchunks;
                 J.seg_bits = J.seg_first_chunk + p.F.nsegs;
@@ -433,6 +483,12 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
         token = nullptr;
         if (!rc && !one) rc = upload_to(d_side, blob.data(), side, s);      // (both copies ride the lane's stream; `s` is made to wait for them here)
         if (!rc && one) rc = stream_join(s);
+        for (const Prep& p : P) {
+            if (rc || p.code || !p.direct) continue;
+            const hipError_t e = hipMemcpyAsync((uint8_t*)d_words + direct_base + p.direct_off, p.pre->scan, align_up(p.pre->scan_size, JPEG_CHUNK_BYTES_MAX) + JPEG_CHUNK_BYTES_MAX,
+                                                hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) { set_error("hipMemcpyAsync(jpeg scan)", e); rc = IMP_ERROR_DEVICE; }
+        }
         if (rc) goto fail;
         if (on_device) {
             // (the coefficient planes are not cleared: k_jpeg_write stores whole blocks)
@@ -585,7 +641,7 @@ fail:
 }
 
 // files a device group deferred (dense blocks: CODE_DEFERRED) are decoded in a host-entropy group of their own
-int group_deferred(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes) {
+int group_deferred(const unsigned char* const* blobs, const size_t* sizes, int count, impgpu_image** images, int* codes, const impgpu_jpeg_prepared* prep = nullptr) {
     std::vector<int> late;
     for (int i = 0; i < count; i++) if (codes[i] == CODE_DEFERRED) late.push_back(i);
     if (late.empty()) return IMP_OK;
@@ -593,9 +649,10 @@ int group_deferred(const unsigned char* const* blobs, const size_t* sizes, int c
     std::vector<size_t> s2(late.size());
     std::vector<impgpu_image*> i2(late.size(), nullptr);
     std::vector<int> c2(late.size(), IMP_OK);
-    for (size_t k = 0; k < late.size(); k++) { b2[k] = blobs[late[k]]; s2[k] = sizes[late[k]]; }
+    std::vector<impgpu_jpeg_prepared> p2;
+    for (size_t k = 0; k < late.size(); k++) { b2[k] = blobs[late[k]]; s2[k] = sizes[late[k]]; if (prep) p2.push_back(prep[late[k]]); }
     Group H;
-    int rc = group_begin(H, b2.data(), s2.data(), (int)late.size(), 1);
+    int rc = group_begin(H, b2.data(), s2.data(), (int)late.size(), 1, false, prep ? p2.data() : nullptr);
     if (!rc) rc = group_finish(H, i2.data(), c2.data());
     else for (size_t k = 0; k < late.size(); k++) c2[k] = H.P[k].code ? H.P[k].code : rc;
     for (size_t k = 0; k < late.size(); k++) { images[late[k]] = rc ? nullptr : i2[k]; codes[late[k]] = rc ? rc : c2[k]; }
@@ -686,6 +743,45 @@ int impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** im
     delete b;
     if (!rc) rc = group_deferred(blobs, sizes, count, images, codes);
     return rc;
+}
+
+int impgpu_batch_decode_jpeg_prepared(const impgpu_jpeg_prepared* files, int count, impgpu_image** images, int* codes) {
+    if (count < 0 || (count && (!files || !images || !codes))) return IMP_ERROR_INVALID_ARGS;
+    if (!env_ready()) { set_error_text("impgpu_env_start has not been called"); return IMP_ERROR_DEVICE; }
+    TraceRange tr("IMP_STEP_DECODE");
+    IMP_FAULT_POINT(IMP_STEP_DECODE);
+    std::vector<const unsigned char*> blobs((size_t)count);
+    std::vector<size_t> sizes((size_t)count);
+    for (int i = 0; i < count; i++) { blobs[(size_t)i] = files[i].head; sizes[(size_t)i] = files[i].head_size; images[i] = nullptr; codes[i] = IMP_OK; }
+    for (int at = 0; at < count; at += MAX_BATCH) {
+        const int n = count - at < MAX_BATCH ? count - at : MAX_BATCH;
+        Group A;
+        int rc = group_begin(A, blobs.data() + at, sizes.data() + at, n, 0, false, files + at);
+        if (rc) for (int i = 0; i < n; i++) codes[at + i] = A.P.size() > (size_t)i && A.P[(size_t)i].code ? A.P[(size_t)i].code : rc;
+        else rc = group_finish(A, images + at, codes + at);
+        if (!rc) rc = group_deferred(blobs.data() + at, sizes.data() + at, n, images + at, codes + at, files + at);
+        if (rc) {
+            for (int i = 0; i < at + n; i++) if (images[i]) impgpu_image_release(&images[i]);
+            for (int i = at + n; i < count; i++) { images[i] = nullptr; codes[i] = rc; }
+            return rc;
+        }
+    }
+    return IMP_OK;
+}
+
+int impgpu_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return IMP_ERROR_INVALID_ARGS;
+    if (!env_ready() || !env_stream()) { set_error_text("impgpu_env_start has not been called"); return IMP_ERROR_DEVICE; }
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { set_error("hipHostRegister", e); (void)hipGetLastError(); return IMP_ERROR_DEVICE; }
+    return IMP_OK;
+}
+
+int impgpu_host_unregister(void* p) {
+    if (!p) return IMP_ERROR_INVALID_ARGS;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { set_error("hipHostUnregister", e); (void)hipGetLastError(); return IMP_ERROR_DEVICE; }
+    return IMP_OK;
 }
 
 int impgpu_jpeg_counters(unsigned long long* counters, int n) {

@@ -178,8 +178,12 @@ __device__ __forceinline__ void enc_row_pass(const EncJob& J, int comp, int bx, 
 
 constexpr int ENC_BLOCKS_PER_WG = 32;
 
-__global__ __launch_bounds__(256) void k_jpeg_enc_blocks(const EncJob* __restrict__ jobs, const EncMap* __restrict__ map, const EncTables* __restrict__ tabs) {
+// (its first workgroup also clears the launch's result words -- verdicts the later kernels OR into, the compact area's
+// cursor: a fill command of its own on the stream was 4-5 us of a thumbnail's 80)
+__global__ __launch_bounds__(256) void k_jpeg_enc_blocks(const EncJob* __restrict__ jobs, const EncMap* __restrict__ map, const EncTables* __restrict__ tabs,
+                                                         uint32_t* __restrict__ result, int result_words) {
     __shared__ int s_t[ENC_BLOCKS_PER_WG][8][9];                    // [block][row][column]: the row pass's results (+1: the column reads of a wave spread over the banks)
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < result_words; i += 256) result[i] = 0u;
     const EncMap m = map[blockIdx.x];
     const EncJob& J = jobs[m.job];
     const int tid = threadIdx.x, r = tid & 7, bl = tid >> 3;
@@ -261,7 +265,7 @@ struct EncPut {                          // a lane's write head into the LDS win
     uint64_t acc;
     int nacc, wpos;
     __device__ __forceinline__ void start(uint32_t* w, int bit) { win = w; acc = 0; nacc = bit & 31; wpos = bit >> 5; }
-    __device__ __forceinline__ void put(uint32_t code, int len) {      // len <= 16, code < 2^len
+    __device__ __forceinline__ void put(uint32_t code, int len) {      // len <= 32 - 6, code < 2^len (nacc < 32 on entry: they fit the 64)
         if (len == 0) return;                                           // (a symbol without a code: cannot occur for 8-bit data)
         acc |= (uint64_t)code << (64 - nacc - len);
         nacc += len;
@@ -276,20 +280,22 @@ struct EncPut {                          // a lane's write head into the LDS win
 };
 
 // jchuff.c encode_one_block over a block in zigzag order, held in registers (32 dwords of two coefficients).  EMIT = false:
-// only the number of bits.
+// only the number of bits.  `tab` = the workgroup's copy of the component's two code tables in LDS ([0..255] DC, [256..511] AC,
+// entries (code << 8) | length): a walk makes up to 64 dependent lookups, and out of memory they were most of its time
+// (round 5: 224 x 168, one workgroup, 74 -> see DESIGN 4b).  A symbol's code and its extra bits leave as one put (<= 26 bits).
 template <bool EMIT>
-__device__ __forceinline__ int enc_code_block(const uint32_t (&cw)[32], int last_dc, int dc, const uint32_t* __restrict__ hdc, const uint32_t* __restrict__ hac, EncPut* P) {
+__device__ __forceinline__ int enc_code_block(const uint32_t (&cw)[32], int last_dc, int dc, const uint32_t* tab, EncPut* P) {
     int bits = 0;
     {
         int t = dc - last_dc, t2 = t;
         if (t < 0) { t = -t; t2--; }
         const int n = enc_nbits(t);
-        const uint32_t e = hdc[n];
+        const uint32_t e = tab[n];
         bits += (int)(e & 0xff) + n;
-        if (EMIT) { P->put(e >> 8, (int)(e & 0xff)); if (n) P->put((uint32_t)t2 & ((1u << n) - 1), n); }
+        if (EMIT) P->put(((e >> 8) << n) | ((uint32_t)t2 & ((1u << n) - 1)), (int)(e & 0xff) + n);
     }
     int run = 0;
-    const uint32_t zrl = hac[0xF0], eob = hac[0];
+    const uint32_t zrl = tab[256 + 0xF0], eob = tab[256];
 #pragma unroll
     for (int k = 1; k < 64; k++) {
         int t = (short)(cw[k >> 1] >> ((k & 1) * 16));
@@ -302,9 +308,9 @@ __device__ __forceinline__ int enc_code_block(const uint32_t (&cw)[32], int last
         int t2 = t;
         if (t < 0) { t = -t; t2--; }
         const int n = enc_nbits(t);
-        const uint32_t e = hac[(run << 4) + n];
+        const uint32_t e = tab[256 + (run << 4) + n];
         bits += (int)(e & 0xff) + n;
-        if (EMIT) { P->put(e >> 8, (int)(e & 0xff)); P->put((uint32_t)t2 & ((1u << n) - 1), n); }
+        if (EMIT) P->put(((e >> 8) << n) | ((uint32_t)t2 & ((1u << n) - 1)), (int)(e & 0xff) + n);
         run = 0;
     }
     if (run > 0) {
@@ -327,8 +333,10 @@ __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__
     __shared__ uint32_t s_win[ENC_WIN_WORDS];
     __shared__ int s_part[NT / 64], s_cnt[NT / 64], s_top[NT / 64];
     __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_huff[1024];
     const EncJob& J = jobs[blockIdx.x];
     const int tid = threadIdx.x;
+    for (int i = tid; i < 1024; i += NT) s_huff[i] = tabs->huff[i >> 8][i & 255];
     for (int i = tid; i < ENC_WIN_WORDS; i += NT) s_win[i] = 0;
     __syncthreads();
     int carry = 0;                      // bits of an unfinished byte at the top of s_win[0]
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__
         const bool live = b < J.nblocks;
         int bits = 0, dc = 0, last_dc = 0;
         uint32_t cw[32];
-        const uint32_t *hdc = tabs->huff[0], *hac = tabs->huff[1];
+        int tb = 0;
         if (live) {
             const int mcu = b / J.bpm, j = b - mcu * J.bpm;
             const uint4* blk = (const uint4*)(J.coef + (size_t)b * 64);
@@ -350,9 +358,9 @@ __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__
             }
             dc = enc_dc_of(J, mcu, j);
             if (J.bpm == 1) last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, 0) : 0;
-            else if (j >= 4) { last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, j) : 0; hdc = tabs->huff[2]; hac = tabs->huff[3]; }
+            else if (j >= 4) { last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, j) : 0; tb = 512; }
             else last_dc = j > 0 ? enc_dc_of(J, mcu, j - 1) : (mcu > 0 ? enc_dc_of(J, mcu - 1, 3) : 0);
-            bits = enc_code_block<false>(cw, last_dc, dc, hdc, hac, nullptr);
+            bits = enc_code_block<false>(cw, last_dc, dc, &s_huff[tb], nullptr);
         }
         int total;
         const int incl = enc_block_scan<NT>(bits, s_part, &total);
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__
         if (mine) {
             EncPut P;
             P.start(s_win, carry + incl - bits);
-            enc_code_block<true>(cw, last_dc, dc, hdc, hac, &P);
+            enc_code_block<true>(cw, last_dc, dc, &s_huff[tb], &P);
             P.finish();
         }
         __syncthreads();
@@ -477,17 +485,18 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_pack(const EncJob* __restrict_
     __shared__ uint32_t s_win[ENC_WIN_WORDS];
     __shared__ int s_part[4];
     __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_huff[1024];
     const int tid = threadIdx.x;
     if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    for (int i = tid; i < 1024; i += 256) s_huff[i] = tabs->huff[i >> 8][i & 255];
     for (int i = tid; i < ENC_WIN_WORDS; i += 256) s_win[i] = 0;
     __syncthreads();
     const EncSeg me = map[s_ticket];
     const EncJob& J = jobs[me.job];
     const int sg = me.local, b = sg * 256 + tid;
     const bool live = b < J.nblocks;
-    int bits = 0, dc = 0, last_dc = 0;
+    int bits = 0, dc = 0, last_dc = 0, tb = 0;
     uint32_t cw[32];
-    const uint32_t *hdc = tabs->huff[0], *hac = tabs->huff[1];
     if (live) {
         const int mcu = b / J.bpm, j = b - mcu * J.bpm;
         const uint4* blk = (const uint4*)(J.coef + (size_t)b * 64);
@@ -498,9 +507,9 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_pack(const EncJob* __restrict_
         }
         dc = enc_dc_of(J, mcu, j);
         if (J.bpm == 1) last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, 0) : 0;
-        else if (j >= 4) { last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, j) : 0; hdc = tabs->huff[2]; hac = tabs->huff[3]; }
+        else if (j >= 4) { last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, j) : 0; tb = 512; }
         else last_dc = j > 0 ? enc_dc_of(J, mcu, j - 1) : (mcu > 0 ? enc_dc_of(J, mcu - 1, 3) : 0);
-        bits = enc_code_block<false>(cw, last_dc, dc, hdc, hac, nullptr);
+        bits = enc_code_block<false>(cw, last_dc, dc, &s_huff[tb], nullptr);
     }
     int total;
     const int incl = enc_block_scan<256>(bits, s_part, &total);
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_pack(const EncJob* __restrict_
     if (live) {
         EncPut P;
         P.start(s_win, lead + incl - bits);
-        enc_code_block<true>(cw, last_dc, dc, hdc, hac, &P);
+        enc_code_block<true>(cw, last_dc, dc, &s_huff[tb], &P);
         P.finish();
     }
     __syncthreads();
@@ -759,9 +768,10 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     const uint8_t* sd = (const uint8_t*)side;
     const EncJob* djobs = (const EncJob*)(sd + o_jobs);
     uint32_t* cursor = (uint32_t*)res + (size_t)nj * 4;
-    hipError_t e = hipMemsetAsync(res, 0, res_bytes, s);        // the verdict words (the large frames' workgroups OR into them) and the compact area's cursor
-    if (e == hipSuccess && aux) e = hipMemsetAsync(aux, 0, aux_bytes, s);
-    hipLaunchKernelGGL(k_jpeg_enc_blocks, dim3((unsigned)map.size()), dim3(256), 0, s, djobs, (const EncMap*)(sd + o_map), (const EncTables*)sd);
+    hipError_t e = hipSuccess;                                  // (the verdict words and the compact area's cursor are cleared by k_jpeg_enc_blocks)
+    if (aux) e = hipMemsetAsync(aux, 0, aux_bytes, s);
+    hipLaunchKernelGGL(k_jpeg_enc_blocks, dim3((unsigned)map.size()), dim3(256), 0, s, djobs, (const EncMap*)(sd + o_map), (const EncTables*)sd,
+                       (uint32_t*)res, (int)(res_bytes / 4));
     if (nsmall) {
         bool wide = false;                                      // any frame of more than 256 block slots: 1024 per pass
         for (int k = 0; k < nsmall; k++) wide = wide || jobs[k].nblocks > 256;

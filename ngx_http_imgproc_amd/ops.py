@@ -287,6 +287,60 @@ def batch_decode_jpeg(blobs):
     return [(codes[i], Image(handle=imgs[i]) if codes[i] == 0 else None) for i in range(n)]
 
 
+def jpeg_unstuff(blob):
+    """impgpu_jpeg_unstuff of libimpgpu_client.so (what a worker does on the way into its slot) -> (head, scan) or None when
+    the file is to go as it is."""
+    from .broker import clib
+
+    blob = bytes(blob)
+    out = np.empty(len(blob) + 1024, np.uint8)
+    head, at, n, total = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    if not clib.impgpu_jpeg_unstuff(blob, len(blob), out.ctypes.data, out.size, C.byref(head), C.byref(at), C.byref(n), C.byref(total)):
+        return None
+    return out[:head.value].tobytes(), out[at.value:at.value + n.value].tobytes()
+
+
+def batch_decode_jpeg_prepared(files, pinned=False):
+    """impgpu_batch_decode_jpeg_prepared.  files: whole files (bytes) or (head, scan) pairs as jpeg_unstuff returns them;
+    pinned: the scans are put into impgpu_host_alloc memory and handed over as `registered`."""
+    from ._lib import CJpegPrepared
+
+    n = len(files)
+    arr = (CJpegPrepared * n)()
+    keep, pins = [], []
+    for i, f in enumerate(files):
+        if isinstance(f, (bytes, bytearray)):
+            b = np.frombuffer(bytes(f), np.uint8)
+            keep.append(b)
+            arr[i].head, arr[i].head_size, arr[i].scan, arr[i].scan_size, arr[i].registered = b.ctypes.data, b.size, None, 0, 0
+            continue
+        head, scan = f
+        h = np.frombuffer(bytes(head), np.uint8)
+        tail = 512                                                 # IMPGPU_JPEG_SCAN_TAIL
+        if pinned:
+            p = lib.impgpu_host_alloc(len(scan) + tail)
+            if not p:
+                raise ImpError(IMP_ERROR_DEVICE, "impgpu_host_alloc")
+            pins.append(p)
+            sc = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(len(scan) + tail,))
+        else:
+            sc = np.empty(len(scan) + tail, np.uint8)
+        sc[:len(scan)] = np.frombuffer(bytes(scan), np.uint8)
+        sc[len(scan):] = 0xFF
+        keep += [h, sc]
+        arr[i].head, arr[i].head_size, arr[i].scan, arr[i].scan_size, arr[i].registered = h.ctypes.data, h.size, sc.ctypes.data, len(scan), int(pinned)
+    imgs = (C.c_void_p * n)()
+    codes = (C.c_int * n)()
+    try:
+        rc = lib.impgpu_batch_decode_jpeg_prepared(arr, n, imgs, codes)
+    finally:
+        for p in pins:
+            lib.impgpu_host_free(p)
+    if rc:
+        raise ImpError(rc, "impgpu_batch_decode_jpeg_prepared")
+    return [(codes[i], Image(handle=imgs[i]) if codes[i] == 0 else None) for i in range(n)]
+
+
 def batch_encode_jpeg(images, quality=95):
     """impgpu_batch_encode_jpeg -> [(code, file bytes or None)] in the order of `images`."""
     n = len(images)

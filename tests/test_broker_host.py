@@ -179,3 +179,116 @@ def test_client_under_the_sanitizers_and_across_fork(built, mock):
     name, _ = mock(slots=6)
     p = subprocess.run([os.path.join(ROOT, "tests", "c", "_build", "client_asan"), name, "300", "3"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.strip() == "ok 600", (p.returncode, p.stdout, p.stderr[-1500:])
+
+
+# ---- impgpu_jpeg_unstuff: what a worker does to a JPEG on its way into the slot
+def _py_unstuff(blob):
+    """An independent restatement (ITU T.81 B.1.1.5 byte stuffing; the rules of csrc/imp_jpeg.cpp jpeg_prepare_scan for a
+    file without restart intervals): (head, scan) or None."""
+    b = bytes(blob)
+    if b[:2] != b"\xff\xd8":
+        return None
+    at, frames, scan_begin = 2, 0, None
+    while scan_begin is None:
+        if at + 2 > len(b) or b[at] != 0xFF:
+            return None
+        while at < len(b) and b[at] == 0xFF:
+            at += 1
+        if at >= len(b):
+            return None
+        m = b[at]
+        at += 1
+        if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7:
+            continue
+        if m == 0xD9 or at + 2 > len(b):
+            return None
+        ln = (b[at] << 8) | b[at + 1]
+        if ln < 2 or ln > len(b) - at:
+            return None
+        if m in (0xC0, 0xC1):
+            frames += 1
+            if frames > 1:
+                return None
+        elif 0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
+            return None
+        elif m == 0xDD and (ln != 4 or b[at + 2] or b[at + 3]):
+            return None
+        elif m == 0xDA:
+            if not frames:
+                return None
+            scan_begin = at + ln
+        at += ln
+    if len(b) - scan_begin < 40960:
+        return None
+    out = bytearray()
+    i = scan_begin
+    while i < len(b):
+        if b[i] != 0xFF:
+            out.append(b[i])
+            i += 1
+            continue
+        j = i + 1
+        while j < len(b) and b[j] == 0xFF:
+            j += 1
+        if j >= len(b):
+            break
+        if b[j] == 0 and j == i + 1:
+            out.append(0xFF)
+            i = j + 1
+        elif b[j] == 0 or 0xD0 <= b[j] <= 0xD7:
+            return None
+        else:
+            break
+    return (b[:scan_begin], bytes(out)) if out else None
+
+
+def _photo_jpeg(w, h, quality=90, **kw):
+    import io
+
+    from PIL import Image
+    from ngx_http_imgproc_amd.workloads import photo_like
+
+    f = io.BytesIO()
+    Image.fromarray(photo_like(h, w, seed=w + h)).save(f, "JPEG", quality=quality, **kw)
+    return f.getvalue()
+
+
+def test_unstuff_agrees_with_its_restatement(built):
+    import ngx_http_imgproc_amd as imp
+
+    files = [_photo_jpeg(640, 480), _photo_jpeg(1280, 720, 95, subsampling="4:4:4"), _photo_jpeg(800, 600, 85, optimize=True)]
+    for f in files:
+        assert f.count(b"\xff\x00") > 10                           # stuffed bytes do occur
+        got, want = imp.jpeg_unstuff(f), _py_unstuff(f)
+        assert want is not None and got == want
+        head, scan = got
+        assert f.startswith(head) and len(scan) < len(f) - len(head)
+    # the files that go as they are: small scans, restart intervals, progressive, not a JPEG, damaged marker sequences
+    small = _photo_jpeg(96, 64)
+    assert imp.jpeg_unstuff(small) is None and _py_unstuff(small) is None
+    assert imp.jpeg_unstuff(_photo_jpeg(640, 480, restart_marker_blocks=8)) is None
+    assert imp.jpeg_unstuff(_photo_jpeg(640, 480, progressive=True)) is None
+    assert imp.jpeg_unstuff(b"\x89PNG\r\n\x1a\n" + bytes(60000)) is None
+    f = bytearray(files[0])
+    head, scan = imp.jpeg_unstuff(bytes(f))
+    at = len(head) + 5000
+    for bad in (b"\xff\xd3", b"\xff\xff\x00"):                      # RSTn without an interval; FF FF 00
+        g = bytes(f[:at]) + bad + bytes(f[at:])
+        assert imp.jpeg_unstuff(g) is None and _py_unstuff(g) is None
+    # fill bytes in front of the closing marker, a file cut off in its scan, a trailing FF: taken, the same bytes
+    for g in (bytes(f[:-2]) + b"\xff\xff\xff\xd9", bytes(f[:len(f) - 3000]), bytes(f[:len(f) - 3000]) + b"\xff"):
+        assert imp.jpeg_unstuff(g) == _py_unstuff(g) and imp.jpeg_unstuff(g) is not None
+    # a marker other than EOI ends the scan where it stands
+    g = bytes(f[:at]) + b"\xff\xda" + bytes(f[at:])
+    assert len(imp.jpeg_unstuff(g)[1]) < len(scan) and imp.jpeg_unstuff(g) == _py_unstuff(g)
+
+
+def test_unstuff_respects_its_capacity(built):
+    f = _photo_jpeg(640, 480)
+    out = (C.c_uint8 * (len(f) + 2048))()
+    v = [C.c_size_t() for _ in range(4)]
+    args = [C.byref(x) for x in v]
+    assert built.clib.impgpu_jpeg_unstuff(f, len(f), out, len(f) + 2048, *args) == 1
+    head, at, n, total = (x.value for x in v)
+    assert at % 256 == 0 and at >= head and total == at + n + 512 and bytes(out[at + n:total]) == b"\xff" * 512
+    assert built.clib.impgpu_jpeg_unstuff(f, len(f), out, len(f), *args) == 0          # no room for the tail: as it is

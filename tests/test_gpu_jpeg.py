@@ -501,3 +501,80 @@ def test_slots_of_a_thread_are_shared_and_a_batch_belongs_to_its_thread(gpu):
             p = C.c_void_p(im2[i])
             lib.impgpu_image_release(C.byref(p))
     assert np.array_equal(decode(gpu, blob)[1], want)                                  # the slots are all free again
+
+
+def _pillow_bgr(blob):
+    Image = pytest.importorskip("PIL.Image")
+    a = np.asarray(Image.open(io.BytesIO(blob)))
+    return a if a.ndim == 2 else np.ascontiguousarray(a[:, :, ::-1])
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_files_unstuffed_by_the_caller_decode_to_the_same_pixels(gpu, huff, pinned):
+    """impgpu_batch_decode_jpeg_prepared (round 5: the worker of a broker takes the scan out of its byte stuffing while it
+    copies the file into shared memory): the frames of impgpu_batch_decode_jpeg -- and Pillow's -- whether the scans are
+    staged or go to the device from page-locked memory, whole files and prepared ones in one launch."""
+    from ngx_http_imgproc_amd.workloads import photo_like
+
+    files = [encode(photo_like(480, 640, seed=3), quality=90),
+             encode(photo_like(720, 1280, seed=4), quality=92, subsampling="4:4:4"),
+             encode(photo_like(600, 800, seed=5)[:, :, 0], quality=95),
+             encode(photo_like(1080, 1920, seed=6), quality=85, optimize=True),
+             encode(photo_like(300, 400, seed=7), quality=90, restart_marker_blocks=5),       # goes as it is (restart interval)
+             golden_blob("c420_q90_67x45")]                                                    # goes as it is (small)
+    prepared = [gpu.jpeg_unstuff(f) or f for f in files]
+    assert [isinstance(p, tuple) for p in prepared] == [True, True, True, True, False, False]
+    plain = gpu.batch_decode_jpeg(files)
+    got = gpu.batch_decode_jpeg_prepared(prepared, pinned=pinned)
+    for f, (c0, a), (c1, b) in zip(files, plain, got):
+        assert c0 == 0 and c1 == 0
+        x, y = a.numpy(), b.numpy()
+        a.release(); b.release()
+        assert np.array_equal(x, y)
+        want = _pillow_bgr(f)
+        assert np.array_equal(y if y.shape[2] > 1 else y[:, :, 0], want)
+    # one at a time too (the lone request of a lone worker)
+    c, im = gpu.batch_decode_jpeg_prepared([prepared[0]], pinned=pinned)[0]
+    assert c == 0 and np.array_equal(im.numpy(), _pillow_bgr(files[0]))
+    im.release()
+
+
+def test_prepared_files_the_device_defers_or_refuses(gpu, monkeypatch):
+    """Dense blocks (quality-100 noise) keep their Huffman stage on the host even inside a device launch: a prepared file is
+    put back into its stuffing for that.  A head that does not end at its scan, or announces restart intervals, is the
+    caller's mistake; a damaged scan gets the verdict the file would have got."""
+    monkeypatch.delenv("IMPGPU_JPEG_HUFF", raising=False)          # (forced to the device, nothing is deferred)
+    rng = np.random.default_rng(11)
+    noise = encode(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8), quality=100, subsampling="4:4:4")
+    ok = encode(smooth_image(480, 640, 3, seed=2), quality=90)
+    pn, pk = gpu.jpeg_unstuff(noise), gpu.jpeg_unstuff(ok)
+    assert pn and pk
+    import ctypes as C
+
+    def deferred():
+        cnt = (C.c_ulonglong * 16)()
+        assert gpu.lib.impgpu_jpeg_counters(cnt, 16) == 0
+        return cnt[3]
+
+    before = deferred()
+    (c0, a), (c1, b) = gpu.batch_decode_jpeg_prepared([pn, pk], pinned=True)
+    assert c0 == 0 and c1 == 0
+    assert np.array_equal(a.numpy(), _pillow_bgr(noise)) and np.array_equal(b.numpy(), _pillow_bgr(ok))
+    a.release(); b.release()
+    assert deferred() > before                                     # the noise file did take the deferred path
+    head, scan = pk
+    (c, im), = gpu.batch_decode_jpeg_prepared([(head[:-3], scan)])
+    assert c in (gpu.IMP_ERROR_INVALID_ARGS, gpu.IMP_ERROR_DECODE_FAILED) and im is None
+    dri = encode(smooth_image(480, 640, 3, seed=2), quality=90, restart_marker_blocks=4)
+    hd = dri[:dri.index(b"\xff\xda") + 14]
+    (c, im), = gpu.batch_decode_jpeg_prepared([(hd, scan)])
+    assert c == gpu.IMP_ERROR_INVALID_ARGS and im is None
+    # damage: the scan cut in half / bytes flipped -> the verdict and (if any) the pixels of the file damaged the same way
+    cut = scan[:len(scan) // 2]
+    (c, im), = gpu.batch_decode_jpeg_prepared([(head, cut)], pinned=True)
+    restuffed = head + cut.replace(b"\xff", b"\xff\x00") + b"\xff\xd9"
+    c_ref, ref = decode(gpu, restuffed)
+    assert c == c_ref
+    if c == 0:
+        assert np.array_equal(im.numpy(), ref)
+        im.release()

@@ -24,7 +24,7 @@ def pillow(a, q):
     return b.getvalue()
 
 
-for (h, w, n) in ((126, 224, 64), (1080, 1920, 4)):
+for (h, w, n) in ((126, 224, 64), (168, 224, 64), (224, 224, 64), (1080, 1920, 4)):
     frames = [photo_like(h, w, 100 + i) for i in range(n)]
     ims = [gpu.Image(f) for f in frames]
     one = timed(lambda: ims[0].encode_jpeg(90), 50)

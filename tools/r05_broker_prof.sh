@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 T=${1:-4}; W=${2:-16}; G=${3:-0}
 NAME=/impgpu-prof-$$
 OUT=$R/gpurun_out/prof_broker_${T}_${W}
-POOL=$R/gpurun_out/jpeg_pool.bin
+POOL=${POOL:-$R/gpurun_out/jpeg_pool.bin}
 [ -f $POOL ] || python3 -c "import sys; sys.path.insert(0,'$R/tools'); import worker_scaling as w; w.make_pool('$POOL')"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT; mkdir -p $OUT
