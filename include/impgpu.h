@@ -190,6 +190,11 @@ typedef struct {
     int registered;
 } impgpu_jpeg_prepared;
 int   impgpu_batch_decode_jpeg_prepared(const impgpu_jpeg_prepared* files, int count, impgpu_image** images, int* codes);
+/* ... and in two halves like impgpu_batch_decode_jpeg_begin, but on the calling thread's OWN stream: what the thread enqueues
+ * afterwards runs behind this decode, what it enqueued before runs in front of it (a broker lane begins the next batch's
+ * decode while the answers of the batch before are still being written: the device never waits for the host's share).
+ * The array is copied; head / scan bytes must stay readable until impgpu_batch_decode_jpeg_finish.  count <= 256. */
+int   impgpu_batch_decode_jpeg_prepared_begin(const impgpu_jpeg_prepared* files, int count, impgpu_jpeg_batch** batch);
 /* Page-locks `bytes` at `p` (hipHostRegister) so that copies out of it need no staging; impgpu_host_unregister before the
  * memory goes away.  Needs impgpu_env_start. */
 int   impgpu_host_register(void* p, size_t bytes);
@@ -228,6 +233,17 @@ int   impgpu_image_encode_jpeg(const impgpu_image* image, int quality, unsigned 
  * impgpu_image_encode_jpeg would give for frame i. */
 int   impgpu_batch_encode_jpeg(const impgpu_image* const* images, int count, int quality, unsigned char* const* outs,
                                const size_t* capacities, size_t* lengths, int* codes);
+/* The same in two halves (round 5, for a caller that serves more than one batch: a broker lane): _begin enqueues everything --
+ * kernels and the copy of the files' segments into pinned memory -- and does NOT wait; _finish sleeps until THAT encode is
+ * done (not what the thread enqueued behind it, e.g. the decode of the next batch), and fills outs[] / lengths[] / codes[] as
+ * impgpu_batch_encode_jpeg would.  The frames must stay alive until _finish.  Both halves belong to ONE thread.  The answers
+ * of an encode wait in one of the thread's TWO pinned staging buffers until they are fetched: with two encodes begun, anything
+ * else of that thread that stages through pinned memory (a third encode, a decode, an upload) returns IMP_ERROR_INVALID_ARGS
+ * until one is finished -- a lane keeps one in flight.  count <= 256. */
+typedef struct impgpu_jpeg_encode impgpu_jpeg_encode;
+int   impgpu_batch_encode_jpeg_begin(const impgpu_image* const* images, int count, int quality, impgpu_jpeg_encode** encode);
+int   impgpu_batch_encode_jpeg_finish(impgpu_jpeg_encode** encode, unsigned char* const* outs, const size_t* capacities,
+                                      size_t* lengths, int* codes);
 size_t impgpu_jpeg_encode_bound(int width, int height, int channels);
 /* the SOF header alone (host, no device): the size checks the module makes before decoding */
 int   impgpu_jpeg_info(const unsigned char* blob, size_t size, int* width, int* height, int* channels);

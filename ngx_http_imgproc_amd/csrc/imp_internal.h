@@ -80,6 +80,7 @@ int  upload_to(void* dev, const void* host, size_t bytes, hipStream_t s);   // t
 // Larger host-built blobs: fill the pinned buffer stage_begin returns, then stage_upload copies it to `dev` on the lane stream.
 int  stage_begin(size_t bytes, void** host, void** token);
 int  stage_upload(void* token, void* dev, size_t bytes);
+void stage_hold(void* token, bool held);                   // a download enqueued into the buffer is read by a later call: keep it out of circulation until then
 size_t stage_capacity(void* token);                       // bytes the buffer behind `token` really holds (>= what stage_begin was asked for)
 int  stage_upload_part(void* token, size_t offset, void* dev, size_t bytes, bool last);   // pieces of the same buffer; `last` fences it
 // Pool memory and caller-supplied ("foreign") streams -- the batch entry points.  The pool recycles blocks in the order

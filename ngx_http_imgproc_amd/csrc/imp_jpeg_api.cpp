@@ -695,7 +695,12 @@ int decode_group(const unsigned char* const* blobs, const size_t* sizes, int cou
 
 }  // namespace
 
-struct impgpu_jpeg_batch { Group G; };
+struct impgpu_jpeg_batch {
+    Group G;
+    std::vector<impgpu_jpeg_prepared> files;        // impgpu_batch_decode_jpeg_prepared_begin: its own copy of the caller's array
+    std::vector<const unsigned char*> blobs;
+    std::vector<size_t> sizes;
+};
 
 extern "C" {
 
@@ -740,9 +745,27 @@ int impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** im
     const size_t* sizes = b->G.sizes;
     const int count = b->G.count;
     int rc = group_finish(b->G, images, codes);
+    if (!rc) rc = group_deferred(blobs, sizes, count, images, codes, b->G.prep);
     delete b;
-    if (!rc) rc = group_deferred(blobs, sizes, count, images, codes);
     return rc;
+}
+
+int impgpu_batch_decode_jpeg_prepared_begin(const impgpu_jpeg_prepared* files, int count, impgpu_jpeg_batch** batch) {
+    if (!batch) return IMP_ERROR_INVALID_ARGS;
+    *batch = nullptr;
+    if (count <= 0 || count > MAX_BATCH || !files) return IMP_ERROR_INVALID_ARGS;
+    if (!env_ready()) { set_error_text("impgpu_env_start has not been called"); return IMP_ERROR_DEVICE; }
+    TraceRange tr("IMP_STEP_DECODE");
+    IMP_FAULT_POINT(IMP_STEP_DECODE);
+    impgpu_jpeg_batch* b = new impgpu_jpeg_batch();
+    b->files.assign(files, files + count);
+    b->blobs.resize((size_t)count);
+    b->sizes.resize((size_t)count);
+    for (int i = 0; i < count; i++) { b->blobs[(size_t)i] = files[i].head; b->sizes[(size_t)i] = files[i].head_size; }
+    const int rc = group_begin(b->G, b->blobs.data(), b->sizes.data(), count, 0, false, b->files.data());
+    if (rc) { delete b; return rc; }
+    *batch = b;
+    return IMP_OK;
 }
 
 int impgpu_batch_decode_jpeg_prepared(const impgpu_jpeg_prepared* files, int count, impgpu_image** images, int* codes) {

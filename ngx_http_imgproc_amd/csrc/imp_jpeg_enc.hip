@@ -670,25 +670,40 @@ constexpr int ENC_MAX_BATCH = 256;
 
 constexpr int ENC_BIG_BLOCKS = 2048;                            // frames of more block slots than this take the many-workgroup path
 
-int encode_group(const impgpu_image* const* images, int count, int quality, unsigned char* const* outs, const size_t* caps,
-                 size_t* lens, int* codes) {
+// An encode between the call that enqueued it (kernels and the copy of the segments into pinned memory) and the call that
+// fetches the files: what the second half needs of the first.
+struct EncState {
+    std::vector<EncJob> jobs;
+    std::vector<int> owner;                                     // job -> index into the caller's arrays
+    std::vector<std::vector<uint8_t>> heads;
+    std::vector<int> early;                                     // per image: IMP_OK, or what was wrong with it before anything ran
+    int count = 0;
+    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr, *aux = nullptr;
+    void *pin = nullptr, *token = nullptr, *mark = nullptr;
+    size_t res_bytes = 0, compact_cap = 0;
+    bool armed = false;                                         // something is in flight
+    void drop() { dev_free(coef); dev_free(out); dev_free(res); dev_free(side); dev_free(aux); coef = out = res = side = aux = nullptr; }
+};
+
+int encode_begin(const impgpu_image* const* images, int count, int quality, EncState& E) {
     hipStream_t s = env_stream();
     EncTables T;
     enc_static_tables(&T, quality);
     static const bool one_wg = ab_env("IMPGPU_JPEG_ENC_ONE_WG") != nullptr;       // A/B: every frame through k_jpeg_enc_huff
-    std::vector<EncJob> jobs;                                   // small frames first, then the large ones
-    std::vector<int> owner;                                     // job -> index into images
-    std::vector<std::vector<uint8_t>> heads;
+    std::vector<EncJob>& jobs = E.jobs;                         // small frames first, then the large ones
+    std::vector<int>& owner = E.owner;
+    std::vector<std::vector<uint8_t>>& heads = E.heads;
+    E.count = count;
+    E.early.assign((size_t)count, IMP_OK);
     for (int pass = 0; pass < 2; pass++)
         for (int i = 0; i < count; i++) {
             const impgpu_image* im = images[i];
             EncGeom g;
             if (pass == 0) {
-                lens[i] = 0;
-                codes[i] = (!im || !outs[i] || !enc_geom(im->w, im->h, im->c, &g)) ? IMP_ERROR_INVALID_ARGS : IMP_OK;
-                if (codes[i] == IMP_OK && (size_t)g.nblocks * ENC_BLOCK_BYTES + 16 > 0x7fffffffu) codes[i] = IMP_ERROR_INVALID_ARGS;
+                E.early[(size_t)i] = (!im || !enc_geom(im->w, im->h, im->c, &g)) ? IMP_ERROR_INVALID_ARGS : IMP_OK;
+                if (E.early[(size_t)i] == IMP_OK && (size_t)g.nblocks * ENC_BLOCK_BYTES + 16 > 0x7fffffffu) E.early[(size_t)i] = IMP_ERROR_INVALID_ARGS;
             }
-            if (codes[i] != IMP_OK) continue;
+            if (E.early[(size_t)i] != IMP_OK) continue;
             (void)enc_geom(im->w, im->h, im->c, &g);
             const bool big = !one_wg && g.nblocks > ENC_BIG_BLOCKS && (uint64_t)g.nblocks * 1658u < (1ull << 32);
             if (big != (pass == 1)) continue;
@@ -737,12 +752,12 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     compact_cap = (compact_cap + 255) & ~size_t(255);
     if (compact_cap > 0xfffffff0u) compact_cap = 0xfffffff0u & ~size_t(255);
     const size_t res_bytes = (((size_t)nj * 4 + 1) * 4 + 255) & ~size_t(255);
-    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr, *aux = nullptr;      // res = results | compact area
-    auto drop = [&]() { dev_free(coef); dev_free(out); dev_free(res); dev_free(side); dev_free(aux); };
+    E.res_bytes = res_bytes; E.compact_cap = compact_cap;
+    void *&coef = E.coef, *&out = E.out, *&res = E.res, *&side = E.side, *&aux = E.aux;      // res = results | compact area
     if (int rc = dev_alloc(coef_bytes, &coef)) return rc;
-    if (int rc = dev_alloc(out_bytes, &out)) { drop(); return rc; }
-    if (int rc = dev_alloc(res_bytes + compact_cap, &res)) { drop(); return rc; }
-    if (nsmall < nj) if (int rc = dev_alloc(aux_bytes, &aux)) { drop(); return rc; }
+    if (int rc = dev_alloc(out_bytes, &out)) { E.drop(); return rc; }
+    if (int rc = dev_alloc(res_bytes + compact_cap, &res)) { E.drop(); return rc; }
+    if (nsmall < nj) if (int rc = dev_alloc(aux_bytes, &aux)) { E.drop(); return rc; }
     for (int k = 0; k < nj; k++) {
         EncJob& J = jobs[k];
         J.coef = (short*)((uint8_t*)coef + o_coef[k]);
@@ -764,7 +779,7 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
     std::memcpy(blob.data() + o_map, map.data(), map.size() * sizeof(EncMap));
     if (!pack_map.empty()) std::memcpy(blob.data() + o_pack, pack_map.data(), pack_map.size() * sizeof(EncSeg));
     if (!stuff_map.empty()) std::memcpy(blob.data() + o_stuff, stuff_map.data(), stuff_map.size() * sizeof(EncSeg));
-    if (int rc = upload_small(blob.data(), blob.size(), &side, s)) { drop(); return rc; }
+    if (int rc = upload_small(blob.data(), blob.size(), &side, s)) { E.drop(); return rc; }
     const uint8_t* sd = (const uint8_t*)side;
     const EncJob* djobs = (const EncJob*)(sd + o_jobs);
     uint32_t* cursor = (uint32_t*)res + (size_t)nj * 4;
@@ -785,17 +800,36 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
         hipLaunchKernelGGL(k_jpeg_enc_stuff, dim3((unsigned)stuff_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_stuff), (uint32_t*)res, (uint32_t*)aux + 1);
     }
     if (e == hipSuccess) e = hipGetLastError();
-    void *pin = nullptr, *token = nullptr;
-    if (e == hipSuccess && stage_begin(res_bytes + compact_cap, &pin, &token) != IMP_OK) e = hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemcpyAsync(pin, res, res_bytes + compact_cap, hipMemcpyDeviceToHost, s);
-    if (e != hipSuccess) { set_error("jpeg encode", e); (void)hipStreamSynchronize(s); drop(); return IMP_ERROR_DEVICE; }
-    if (int rc = lane_wait()) { drop(); return rc; }
-    const uint32_t* seg = (const uint32_t*)pin;
-    const uint8_t* compact = (const uint8_t*)pin + res_bytes;
+    if (e == hipSuccess)
+        if (const int rc = stage_begin(res_bytes + compact_cap, &E.pin, &E.token)) { (void)hipStreamSynchronize(s); E.drop(); return rc; }    // (its own text: no pinned buffer free)
+    if (e == hipSuccess) e = hipMemcpyAsync(E.pin, res, res_bytes + compact_cap, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) { set_error("jpeg encode", e); (void)hipStreamSynchronize(s); E.drop(); return IMP_ERROR_DEVICE; }
+    stage_hold(E.token, true);                                  // (the answers are read out of it by encode_finish, possibly calls later)
+    if (int rc = lane_mark(&E.mark)) { (void)hipStreamSynchronize(s); stage_hold(E.token, false); E.drop(); return rc; }
+    E.armed = true;
+    return IMP_OK;
+}
+
+// The second half: waits for THAT encode (not for what the thread enqueued behind it), hands the files out.
+int encode_finish(EncState& E, unsigned char* const* outs, const size_t* caps, size_t* lens, int* codes) {
+    hipStream_t s = env_stream();
+    for (int i = 0; i < E.count; i++) { lens[i] = 0; codes[i] = E.early[(size_t)i] != IMP_OK ? E.early[(size_t)i] : outs[i] ? IMP_OK : IMP_ERROR_INVALID_ARGS; }
+    if (!E.armed) return IMP_OK;
+    E.armed = false;
+    const std::vector<EncJob>& jobs = E.jobs;
+    const std::vector<int>& owner = E.owner;
+    const std::vector<std::vector<uint8_t>>& heads = E.heads;
+    const int nj = (int)jobs.size();
+    void* mark = E.mark;
+    E.mark = nullptr;
+    if (int rc = lane_wait_mark(mark)) { (void)hipStreamSynchronize(s); stage_hold(E.token, false); E.drop(); return rc; }
+    const uint32_t* seg = (const uint32_t*)E.pin;
+    const uint8_t* compact = (const uint8_t*)E.pin + E.res_bytes;
     size_t more = 0;
     std::vector<size_t> at2((size_t)nj, 0);
     for (int k = 0; k < nj; k++) {
         const int i = owner[k];
+        if (codes[i] != IMP_OK) continue;
         lens[i] = heads[k].size() + seg[4 * k];
         if (seg[4 * k + 1]) {
             codes[i] = IMP_ERROR_DEVICE;
@@ -805,24 +839,41 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
         if (lens[i] > caps[i]) { codes[i] = IMP_ERROR_MALLOC_FAILED; continue; }       // lens[i] says what it takes
         if (seg[4 * k + 2] == 0xffffffffu) { at2[k] = more; more += (seg[4 * k] + 63) & ~size_t(63); }
     }
-    void* pin2 = nullptr;
+    void *pin2 = nullptr, *token2 = nullptr;
+    hipError_t e = hipSuccess;
+    bool straight = false;                                      // no pinned buffer free (two encodes begun): the large frames' segments go straight to the caller's memory
     if (more) {
-        if (stage_begin(more, &pin2, &token) != IMP_OK) { drop(); return IMP_ERROR_DEVICE; }
+        straight = stage_begin(more, &pin2, &token2) != IMP_OK;
         for (int k = 0; k < nj && e == hipSuccess; k++)
             if (codes[owner[k]] == IMP_OK && seg[4 * k + 2] == 0xffffffffu)
-                e = hipMemcpyAsync((uint8_t*)pin2 + at2[k], jobs[k].out, seg[4 * k], hipMemcpyDeviceToHost, s);
-        if (e != hipSuccess) { set_error("jpeg encode download", e); (void)hipStreamSynchronize(s); drop(); return IMP_ERROR_DEVICE; }
+                e = straight ? hipMemcpy(outs[owner[k]] + heads[k].size(), jobs[k].out, seg[4 * k], hipMemcpyDeviceToHost)
+                             : hipMemcpyAsync((uint8_t*)pin2 + at2[k], jobs[k].out, seg[4 * k], hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) { set_error("jpeg encode download", e); (void)hipStreamSynchronize(s); stage_hold(E.token, false); E.drop(); return IMP_ERROR_DEVICE; }
     }
-    drop();                                                     // stream-ordered: after the copies
-    if (more) if (int rc = lane_wait()) return rc;
+    E.drop();                                                   // stream-ordered: after the copies
+    if (more && !straight) {
+        void* m2 = nullptr;
+        int rc = lane_mark(&m2);
+        if (!rc) rc = lane_wait_mark(m2);
+        if (rc) { stage_hold(E.token, false); return rc; }
+    }
     for (int k = 0; k < nj; k++) {
         const int i = owner[k];
         if (codes[i] != IMP_OK) continue;
-        const uint8_t* from = seg[4 * k + 2] == 0xffffffffu ? (const uint8_t*)pin2 + at2[k] : compact + seg[4 * k + 2];
         std::memcpy(outs[i], heads[k].data(), heads[k].size());
+        if (seg[4 * k + 2] == 0xffffffffu && straight) continue;
+        const uint8_t* from = seg[4 * k + 2] == 0xffffffffu ? (const uint8_t*)pin2 + at2[k] : compact + seg[4 * k + 2];
         std::memcpy(outs[i] + heads[k].size(), from, seg[4 * k]);
     }
+    stage_hold(E.token, false);
     return IMP_OK;
+}
+
+int encode_group(const impgpu_image* const* images, int count, int quality, unsigned char* const* outs, const size_t* caps,
+                 size_t* lens, int* codes) {
+    EncState E;
+    if (int rc = encode_begin(images, count, quality, E)) return rc;
+    return encode_finish(E, outs, caps, lens, codes);
 }
 
 }  // namespace
@@ -830,6 +881,9 @@ int encode_group(const impgpu_image* const* images, int count, int quality, unsi
 }  // namespace imp
 
 using namespace imp;
+
+static thread_local char t_enc_thread_tag;                     // its address names the calling thread
+struct impgpu_jpeg_encode { EncState E; const void* owner = nullptr; };
 
 extern "C" {
 
@@ -850,6 +904,31 @@ int impgpu_batch_encode_jpeg(const impgpu_image* const* images, int count, int q
         if (int rc = encode_group(images + at, n, quality, outs + at, capacities + at, lengths + at, codes + at)) return rc;
     }
     return IMP_OK;
+}
+
+int impgpu_batch_encode_jpeg_begin(const impgpu_image* const* images, int count, int quality, impgpu_jpeg_encode** encode) {
+    if (!encode) return IMP_ERROR_INVALID_ARGS;
+    *encode = nullptr;
+    if (count <= 0 || count > ENC_MAX_BATCH || !images) return IMP_ERROR_INVALID_ARGS;
+    if (!env_ready()) { set_error("impgpu_env_start has not been called", hipErrorNotInitialized); return IMP_ERROR_DEVICE; }
+    TraceRange tr("IMP_STEP_ENCODE");
+    IMP_FAULT_POINT(IMP_STEP_ENCODE);
+    impgpu_jpeg_encode* h = new impgpu_jpeg_encode();
+    h->owner = &t_enc_thread_tag;
+    if (int rc = encode_begin(images, count, quality, h->E)) { delete h; return rc; }
+    *encode = h;
+    return IMP_OK;
+}
+
+int impgpu_batch_encode_jpeg_finish(impgpu_jpeg_encode** encode, unsigned char* const* outs, const size_t* capacities, size_t* lengths, int* codes) {
+    if (!encode || !*encode || !outs || !capacities || !lengths || !codes) return IMP_ERROR_INVALID_ARGS;
+    impgpu_jpeg_encode* h = *encode;
+    // (the staging buffer, the mark and the pool blocks belong to the beginning thread's lane)
+    if (h->owner != &t_enc_thread_tag) { set_error_text("impgpu_batch_encode_jpeg_finish from another thread than _begin"); return IMP_ERROR_INVALID_ARGS; }
+    *encode = nullptr;
+    const int rc = encode_finish(h->E, outs, capacities, lengths, codes);
+    delete h;
+    return rc;
 }
 
 int impgpu_image_encode_jpeg(const impgpu_image* image, int quality, unsigned char* out, size_t capacity, size_t* length) {

@@ -42,6 +42,7 @@ struct Staging {
     size_t cap = 0;
     hipEvent_t done = nullptr;
     bool busy = false;
+    bool held = false;                  // a download that has been enqueued into it is read later (stage_hold): not handed out meanwhile
     int small_streak = 0;               // reservations in a row that needed less than an eighth of the buffer
 };
 
@@ -566,6 +567,11 @@ void image_delete(impgpu_image* im) {
 static int stage_reserve(Lane* L, size_t bytes, Staging** out) {
     Staging* S = &L->stage[L->stage_next];
     L->stage_next = (L->stage_next + 1) % N_STAGE;
+    if (S->held) {                                             // (an answer begun and not fetched yet lies in it: the other one)
+        S = &L->stage[L->stage_next];
+        L->stage_next = (L->stage_next + 1) % N_STAGE;
+        if (S->held) { t_error = "both staging buffers of the thread hold answers that have not been fetched"; return IMP_ERROR_INVALID_ARGS; }
+    }
     if (S->busy) {
         IMP_HIP(hipEventSynchronize(S->done));
         S->busy = false;
@@ -663,6 +669,7 @@ int stage_begin(size_t bytes, void** host, void** token) {
 }
 
 size_t stage_capacity(void* token) { return token ? ((Staging*)token)->cap : 0; }
+void stage_hold(void* token, bool held) { if (token) ((Staging*)token)->held = held; }
 
 int stage_upload(void* token, void* dev, size_t bytes) {
     Lane* L = lane();

@@ -35,10 +35,11 @@ def scaling():
     return worker_scaling
 
 
-@pytest.fixture()
-def broker(scaling):
+@pytest.fixture(params=["one batch at a time", "the next batch unpacked behind the answers"])
+def broker(scaling, request):
     name = "/impgpu-test-%d" % os.getpid()
-    p = scaling.start_broker(name, threads=2, gather_us=0, slots=16, extra=["--slot-mb", "24"])
+    p = scaling.start_broker(name, threads=2, gather_us=0, slots=16,
+                             extra=["--slot-mb", "24", "--pipeline", "0" if request.param == "one batch at a time" else "1"])
     yield name, p
     err = scaling.stop_broker(p)
     assert p.returncode == 0, err[-800:]

@@ -156,3 +156,64 @@ def test_batch_of_large_and_small_frames(gpu):
         assert code == 0 and data == orc.jpeg_encode(f, 88)[1]
     for im in ims:
         im.release()
+
+
+def test_encode_in_two_halves_with_a_decode_between_them(gpu):
+    """impgpu_batch_encode_jpeg_begin / _finish (round 5): the files are the one-call form's although a prepared decode -- begun
+    on the same stream, like a broker lane's next batch -- was enqueued behind the encode and runs while the files are fetched;
+    a second encode begun before the first is finished is refused cleanly; _finish from another thread too."""
+    import ctypes as C
+    import threading
+
+    from ngx_http_imgproc_amd._lib import CJpegPrepared
+    from ngx_http_imgproc_amd.workloads import photo_like
+
+    frames = [photo_like(168, 224, 31), photo_like(126, 224, 32), photo_like(1080, 1920, 33), noise_image(40, 56, 1, 3)]
+    ims = [gpu.Image(f) for f in frames]
+    want = gpu.batch_encode_jpeg(ims, 86)
+    n = len(ims)
+    hs = (C.c_void_p * n)(*[im.h.value for im in ims])
+    enc = C.c_void_p()
+    assert gpu.lib.impgpu_batch_encode_jpeg_begin(hs, n, 86, C.byref(enc)) == 0 and enc.value
+    # the next batch's decode goes on the stream behind it
+    blob = want[2][1]
+    prepared = gpu.jpeg_unstuff(blob)
+    assert prepared
+    head = np.frombuffer(prepared[0], np.uint8)
+    scan = np.concatenate([np.frombuffer(prepared[1], np.uint8), np.full(512, 255, np.uint8)])
+    f = (CJpegPrepared * 1)()
+    f[0].head, f[0].head_size, f[0].scan, f[0].scan_size, f[0].registered = head.ctypes.data, head.size, scan.ctypes.data, len(prepared[1]), 0
+    dec = C.c_void_p()
+    assert gpu.lib.impgpu_batch_decode_jpeg_prepared_begin(f, 1, C.byref(dec)) == 0 and dec.value
+    # a second encode may be begun (the thread's other staging buffer); with both holding answers a third one -- like anything
+    # else that stages through pinned memory -- is refused, cleanly
+    again, third = C.c_void_p(), C.c_void_p()
+    assert gpu.lib.impgpu_batch_encode_jpeg_begin(hs, 2, 86, C.byref(again)) == 0 and again.value
+    assert gpu.lib.impgpu_batch_encode_jpeg_begin(hs, n, 86, C.byref(third)) == gpu.IMP_ERROR_INVALID_ARGS and not third.value
+    assert b"staging buffers" in gpu.lib.impgpu_last_error()
+    caps = [gpu.lib.impgpu_jpeg_encode_bound(im.shape[1], im.shape[0], im.shape[2]) for im in ims]
+    bufs = [np.empty(c, np.uint8) for c in caps]
+    outs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    ccaps = (C.c_size_t * n)(*caps)
+    lens = (C.c_size_t * n)()
+    codes = (C.c_int * n)()
+    other = []
+    t = threading.Thread(target=lambda: other.append(gpu.lib.impgpu_batch_encode_jpeg_finish(C.byref(enc), outs, ccaps, lens, codes)))
+    t.start(); t.join()
+    assert other == [gpu.IMP_ERROR_INVALID_ARGS] and enc.value               # still the owner's
+    assert gpu.lib.impgpu_batch_encode_jpeg_finish(C.byref(enc), outs, ccaps, lens, codes) == 0 and not enc.value
+    for i in range(n):
+        assert codes[i] == want[i][0] == 0
+        assert bufs[i][:lens[i]].tobytes() == want[i][1]
+    assert gpu.lib.impgpu_batch_encode_jpeg_finish(C.byref(again), outs, ccaps, lens, codes) == 0 and not again.value
+    for i in range(2):
+        assert codes[i] == 0 and bufs[i][:lens[i]].tobytes() == want[i][1]
+    img = (C.c_void_p * 1)()
+    code = (C.c_int * 1)()
+    assert gpu.lib.impgpu_batch_decode_jpeg_finish(C.byref(dec), img, code) == 0 and code[0] == 0
+    got = gpu.Image(handle=img[0])
+    rc, ref = gpu.Image.decode_jpeg(blob)
+    assert rc == 0 and np.array_equal(got.numpy(), ref.numpy())
+    got.release(); ref.release()
+    for im in ims:
+        im.release()
