@@ -54,6 +54,7 @@ struct Options {
     // lane also unpacks its successor and hands out its predecessor waits longer for its own answer.  It pays with a backlog
     // (a caller that keeps many requests in flight per connection); IMP's workers do not have one.
     bool pipeline = false;
+    long split_kb = 0;
     int threads = 2;
     int batch = 64;
     int gather_us = 0;
@@ -266,13 +267,22 @@ struct Worker {
 
     Worker(const Segment& s, const Options& o, int i) : S(s), O(o), id(i) {}
 
+    // --split-kb K (A/B): a launch takes files of ONE size class -- up to K KB, or above -- so that a small file does not wait
+    // for the decode of a large one it happens to share a launch with (a launch's kernels take what its longest file takes)
+    int klass_ = -1;
     int take(std::vector<int>& mine, int start) {
         const int n = (int)S.h->nslots;
         int got = 0;
+        if (mine.empty()) klass_ = -1;
         for (int k = 0; k < n && (int)mine.size() < O.batch; k++) {
             const int i = (start + k) % n;
             impb_slot_fields* s = &S.slots[i].f;
             if (aload(&s->state) != IMPB_SUBMITTED) continue;
+            if (O.split_kb > 0) {
+                const int kl = s->in_bytes > ((uint64_t)O.split_kb << 10) ? 1 : 0;
+                if (klass_ >= 0 && kl != klass_) continue;
+                klass_ = kl;
+            }
             uint32_t expect = IMPB_SUBMITTED;
             if (__atomic_compare_exchange_n(&s->state, &expect, (uint32_t)IMPB_TAKEN, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {
                 mine.push_back(i);
@@ -727,6 +737,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") o.device = std::atoi(val("--device"));
         else if (a == "--slots") o.slots = std::atoi(val("--slots"));
         else if (a == "--slot-mb") o.slot_mb = std::atol(val("--slot-mb"));
+        else if (a == "--split-kb") o.split_kb = std::atol(val("--split-kb"));
         else if (a == "--pipeline") o.pipeline = std::atoi(val("--pipeline")) != 0;
         else if (a == "--register-mb") o.register_mb = std::max(0l, std::atol(val("--register-mb")));
         else if (a == "--threads") o.threads = std::atoi(val("--threads"));

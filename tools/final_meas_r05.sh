@@ -48,6 +48,9 @@ c)
   make -C tests/c > /dev/null
   BROKER_THREADS="2 3 4 6" SECONDS_PER_POINT=3 bash tools/r05_workers.sh
   bash tools/r05_broker_prof.sh 4 16 > $O/r05_broker_prof_4_16.txt 2>&1; cat $O/r05_broker_prof_4_16.txt | head -30
+  timeout -k 10 300 bash tools/contention_probe.sh "1 2 4 5 6 8" > $O/r05_lane_contention.txt 2>&1; tail -5 $O/r05_lane_contention.txt
+  { timeout -k 10 120 bash tools/broker_host_phases.sh 4 16; IMPGPU_BROKER_PREPARE=0 timeout -k 10 120 bash tools/broker_host_phases.sh 4 16; } > $O/r05_broker_host_phases.txt 2>&1; cat $O/r05_broker_host_phases.txt
+  rm -rf $O/prof_broker_*
   timeout -k 10 300 python -m pytest tests/test_gpu_multiproc.py tests/test_gpu_broker.py -q -m gpu -s > $O/r05_multiproc.txt 2>&1; tail -8 $O/r05_multiproc.txt
   rm -f $O/jpeg_pool.bin; rm -rf $O/prof_broker_4_16      # (gpurun copies at most 64 MB back; the trace's summary is in r05_broker_prof_4_16.txt)
   ;;

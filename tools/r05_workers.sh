@@ -14,6 +14,12 @@ cd $R
     echo "## broker, $T threads, gather 0"
     python3 tools/worker_scaling.py broker 1 2 4 8 16 32 --threads $T --seconds ${SECONDS_PER_POINT:-3} || exit 1
   done
+  echo "## broker, 4 threads, the workers copy their files as they are (IMPGPU_BROKER_PREPARE=0: the lanes unstuff)"
+  IMPGPU_BROKER_PREPARE=0 python3 tools/worker_scaling.py broker 1 8 16 32 --threads 4 --seconds ${SECONDS_PER_POINT:-3} || exit 1
+  echo "## broker, 4 threads, --pipeline 1 (a lane unpacks the next batch behind the answers of the one before)"
+  python3 tools/worker_scaling.py broker 8 16 32 --threads 4 --pipeline 1 --seconds ${SECONDS_PER_POINT:-3} || exit 1
+  echo "## broker, 4 threads, --split-kb 400 (a launch takes files up to 400 KB, or above)"
+  python3 tools/worker_scaling.py broker 16 32 --threads 4 --split-kb 400 --seconds ${SECONDS_PER_POINT:-3} || exit 1
   echo "## broker, 2 threads, gather 50 us"
   python3 tools/worker_scaling.py broker 8 16 32 --threads 2 --gather-us 50 --seconds ${SECONDS_PER_POINT:-3} || exit 1
 } 2>&1 | tee $O

@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--pool", default=os.path.join(ROOT, "gpurun_out", "jpeg_pool.bin"))
     ap.add_argument("--answers", default=None)
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for the broker (0: the runtime's default, 4)")
-    ap.add_argument("--pipeline", type=int, default=1, help="0: the broker's lanes take one batch at a time (A/B)")
+    ap.add_argument("--split-kb", type=int, default=0, help="a launch takes files up to so many KB, or above (A/B)")
+    ap.add_argument("--pipeline", type=int, default=0, help="0: the broker's lanes take one batch at a time (A/B)")
     ap.add_argument("--cu-split", type=int, default=0, help="IMPGPU_LANE_CU_SPLIT for the broker: every lane on its own n-th of the CUs")
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.pool), exist_ok=True)
@@ -127,7 +128,7 @@ def main():
                 env["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
             if args.cu_split:
                 env["IMPGPU_LANE_CU_SPLIT"] = str(args.cu_split)
-            broker = start_broker(name, args.threads, args.gather_us, env=env or None, extra=["--pipeline", str(args.pipeline)])
+            broker = start_broker(name, args.threads, args.gather_us, env=env or None, extra=["--pipeline", str(args.pipeline), "--split-kb", str(args.split_kb)])
         try:
             r = run_point(args.pool, args.mode, n, args.seconds, args.answers, name)
             if broker:
