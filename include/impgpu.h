@@ -183,7 +183,7 @@ int   impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** 
  *                     where they are (no pass over them on the calling thread at all); they must not change until the call
  *                     returns.
  * Pixels, codes and refusals are those of impgpu_batch_decode_jpeg on the original files. */
-#define IMPGPU_JPEG_SCAN_TAIL 512
+#define IMPGPU_JPEG_SCAN_TAIL 1024
 typedef struct {
     const unsigned char* head; size_t head_size;
     const unsigned char* scan; size_t scan_size;

@@ -249,12 +249,12 @@ size_t jpeg_scan_capacity(size_t scan_bytes, size_t nsegs) {
 size_t jpeg_chunk_bytes_for(size_t file_bytes, size_t launch_bytes, bool busy) {
     if (const char* s = ab_env("IMPGPU_JPEG_CHUNK_WORDS")) {
         const int w = std::atoi(s);
-        if (w == 8 || w == 16 || w == 32 || w == 64) return (size_t)w * 4;
+        if (w == 8 || w == 16 || w == 32 || w == 64 || w == 128) return (size_t)w * 4;
     }
     // measured, one request at a time (profiles/r03_request_latency.txt; 256 / 512 / 1024 bits): 640x480 0.77 / 0.76 / 0.89 ms,
     // 720p 0.83 / 0.84 / 0.94, 1080p 0.90 / 0.84 / 0.95, 4K 1.45 / 1.24 / 1.24; a queue's worth of files (28 MB) is a little
     // faster on 1024
-    if (launch_bytes > (size_t(4) << 20)) return JPEG_CHUNK_BYTES_MAX;    // (a walk's overlap weighs half as much on 2048 bits as on 1024)
+    if (launch_bytes > (size_t(4) << 20)) return 256;                     // (a walk's overlap weighs half as much on 2048 bits as on 1024)
     // Round 5: `busy` = other decode groups of this process are in flight (a broker's lanes under load).  Short chunks buy a lone
     // file short chains with vector work the idle device has to spare -- every walk decodes its five-block overlap (about 750
     // bits) on top of its chunk, 3.9 x the bits at 256-bit chunks against 1.7 x at 1024 -- but under load that work is what
@@ -286,7 +286,7 @@ unsigned jpeg_overlap_bits_for(unsigned chunk_bits, size_t scan_bytes, size_t to
 
 int jpeg_prepare_scan(const uint8_t* blob, size_t size, const JpegHeader& H, uint8_t* out, size_t cap, JpegScan* scan) {
     const size_t CBY = scan->chunk_bytes;                                // 256, 128, 64 or 32
-    if (CBY != 256 && CBY != 128 && CBY != 64 && CBY != 32) return IMP_ERROR_INVALID_ARGS;
+    if (CBY != 512 && CBY != 256 && CBY != 128 && CBY != 64 && CBY != 32) return IMP_ERROR_INVALID_ARGS;
     scan->seg_first_chunk.clear();
     scan->seg_bits.clear();
     const size_t total_mcus = (size_t)H.mcux * H.mcuy;
@@ -537,12 +537,12 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     std::vector<uint32_t> meta;
     jpeg_scan_meta(scan, &meta);
     // ---- k_jpeg_walks, k_jpeg_mend, k_jpeg_select
-    std::vector<uint64_t> entry(n);
-    std::vector<uint32_t> slots(n), seg_end(n), limit(n);
+    std::vector<uint64_t> entry(n), middle(n, JPEG_STATE_NONE);      // middle: the true walk's state at the chunk's middle (k_jpeg_write's second lane)
+    std::vector<uint32_t> slots(n), slots_mid(n, 0), seg_end(n), limit(n);
     std::vector<char> origin(n);
     struct Cand {
-        uint64_t in[6], out[6], rep_out[6];
-        uint32_t n[6], rep_n[6];
+        uint64_t in[6], out[6], rep_out[6], mid[6], rep_mid[6];
+        uint32_t n[6], rep_n[6], nmid[6], rep_nmid[6];
         uint32_t map, via;                                           // via: bit k = the map's entry k comes from a repair walk
         bool exact;
     };
@@ -557,10 +557,10 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
         const uint32_t p0 = start - seg_start > F.overlap_bits ? start - F.overlap_bits : seg_start;
         Cand& c = cand[g];
         c.exact = p0 == seg_start;                                   // the walk starts where the interval does: no guess
-        for (uint32_t k = 0; k < 6; k++) { c.in[k] = c.out[k] = c.rep_out[k] = JPEG_STATE_NONE; c.n[k] = c.rep_n[k] = 0; }
+        for (uint32_t k = 0; k < 6; k++) { c.in[k] = c.out[k] = c.rep_out[k] = c.mid[k] = c.rep_mid[k] = JPEG_STATE_NONE; c.n[k] = c.rep_n[k] = c.nmid[k] = c.rep_nmid[k] = 0; }
         for (uint32_t k = 0; k < (c.exact ? 1u : B); k++) {
-            const JpegSpan sp = jpeg_span_walk(L, word1, jpeg_pack_state(p0, k, 0, 0), start, limit[g], seg_end[g], F);
-            c.in[k] = sp.in; c.out[k] = sp.out; c.n[k] = sp.n;
+            const JpegSpan sp = jpeg_span_walk(L, word1, jpeg_pack_state(p0, k, 0, 0), start, std::min(start + CB / 2, limit[g]), limit[g], seg_end[g], F);
+            c.in[k] = sp.in; c.out[k] = sp.out; c.n[k] = sp.n; c.mid[k] = sp.mid; c.nmid[k] = sp.nmid;
         }
     }
     // B. the maps: a predecessor's exit that is one of the chunk's `in` states selects that walk; one that is not is decoded
@@ -581,12 +581,12 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
             if (E == JPEG_STATE_NONE) {
             } else if (twin < 6) {
                 v = jpeg_map_at(c.map, twin); via = (c.via >> twin) & 1;
-                c.rep_out[k] = c.rep_out[twin]; c.rep_n[k] = c.rep_n[twin];
+                c.rep_out[k] = c.rep_out[twin]; c.rep_n[k] = c.rep_n[twin]; c.rep_mid[k] = c.rep_mid[twin]; c.rep_nmid[k] = c.rep_nmid[twin];
             } else {
                 for (uint32_t k1 = 0; k1 < B && v == JPEG_MAP_FAIL; k1++) if (c.in[k1] == E) v = k1;
                 if (v == JPEG_MAP_FAIL) {
-                    const JpegSpan sp = jpeg_span_walk(L, word1, E, (uint32_t)g * CB, limit[g], seg_end[g], F);
-                    c.rep_out[k] = sp.out; c.rep_n[k] = sp.n;
+                    const JpegSpan sp = jpeg_span_walk(L, word1, E, (uint32_t)g * CB, std::min((uint32_t)g * CB + CB / 2, limit[g]), limit[g], seg_end[g], F);
+                    c.rep_out[k] = sp.out; c.rep_n[k] = sp.n; c.rep_mid[k] = sp.mid; c.rep_nmid[k] = sp.nmid;
                     via = 1;
                     repairs++;
                     for (uint32_t k1 = 0; k1 < B && v == JPEG_MAP_FAIL; k1++) if (c.out[k1] == sp.out) v = k1;
@@ -604,13 +604,13 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
         uint32_t idx = 0;                                            // which of the predecessor's exits is the true one
         for (size_t g = 0; g < n; g++) {
             Cand& c = cand[g];
-            if (c.exact) { entry[g] = c.in[0]; slots[g] = c.n[0]; idx = 0; explicit_state = false; continue; }
+            if (c.exact) { entry[g] = c.in[0]; slots[g] = c.n[0]; middle[g] = c.mid[0]; slots_mid[g] = c.nmid[0]; idx = 0; explicit_state = false; continue; }
             if (explicit_state) {
                 chases++;
                 uint32_t k1 = 6;
                 for (uint32_t k = 0; k < B && k1 == 6; k++) if (c.in[k] == S) k1 = k;
                 if (k1 < 6) { entry[g] = S; slots[g] = c.n[k1]; idx = k1; explicit_state = false; continue; }
-                const JpegSpan sp = jpeg_span_walk(L, word1, S, (uint32_t)g * CB, limit[g], seg_end[g], F);
+                const JpegSpan sp = jpeg_span_walk(L, word1, S, (uint32_t)g * CB, limit[g], limit[g], seg_end[g], F);    // (a chunk reached by the chase: no middle state, one lane decodes it)
                 entry[g] = S; slots[g] = sp.n;
                 for (uint32_t k = 0; k < B && k1 == 6; k++) if (c.out[k] == sp.out) k1 = k;
                 if (k1 < 6) { idx = k1; explicit_state = false; } else S = sp.out;
@@ -619,10 +619,10 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
             const uint32_t v = jpeg_map_at(c.map, idx);
             if (!((c.via >> idx) & 1)) {
                 if (v == JPEG_MAP_FAIL) return IMP_ERROR_DEVICE;     // (the true exit of a chunk is never "no candidate")
-                entry[g] = c.in[v]; slots[g] = c.n[v]; idx = v;
+                entry[g] = c.in[v]; slots[g] = c.n[v]; middle[g] = c.mid[v]; slots_mid[g] = c.nmid[v]; idx = v;
             } else {
                 misses++;
-                entry[g] = cand[g - 1].out[idx]; slots[g] = c.rep_n[idx];
+                entry[g] = cand[g - 1].out[idx]; slots[g] = c.rep_n[idx]; middle[g] = c.rep_mid[idx]; slots_mid[g] = c.rep_nmid[idx];
                 if (v != JPEG_MAP_FAIL) idx = v;
                 else { S = c.rep_out[idx]; explicit_state = true; }
             }
@@ -632,40 +632,54 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
     g_sync_stats[4] = (int)CB; g_sync_stats[5] = (int)F.overlap_bits; g_sync_stats[6] = (int)B; g_sync_stats[7] = 0;
     if (rounds) *rounds = misses;
     *status = 0;
-    // ---- k_jpeg_write
-    std::vector<JpegDecoded> dec(n);
-    std::vector<uint32_t> slot0(n);
-    uint32_t run_n = 0;
+    // ---- k_jpeg_write: two lanes (units) per chunk where the chunk's middle state is known -- the first decodes the symbols
+    // that start before the middle, the second enters there; everything (slot prefix, budget, verdicts, DC sums) is per unit
+    struct Unit { size_t g; uint64_t entry; uint32_t limit, own_n; bool origin, tail; };
+    std::vector<Unit> units;
     for (size_t g = 0; g < n; g++) {
+        const bool have = (uint32_t)(middle[g] >> 48) == 0 && (uint32_t)middle[g] < limit[g];     // (as write_body decides it)
+        if (have) {
+            units.push_back(Unit{g, entry[g], std::min((uint32_t)g * CB + CB / 2, limit[g]), slots_mid[g], origin[g] != 0, false});
+            units.push_back(Unit{g, middle[g], limit[g], slots[g] - slots_mid[g], false, true});
+        } else units.push_back(Unit{g, entry[g], limit[g], slots[g], origin[g] != 0, true});
+    }
+    g_sync_stats[7] = (int)(units.size() - n);                       // chunks decoded by two lanes
+    const size_t nu = units.size();
+    std::vector<JpegDecoded> dec(nu);
+    std::vector<uint32_t> slot0(nu);
+    uint32_t run_n = 0;
+    for (size_t u = 0; u < nu; u++) {
+        const Unit& U = units[u];
+        const size_t g = U.g;
         const uint32_t sg = meta[g];
-        if (origin[g]) run_n = 0;
+        if (U.origin) run_n = 0;
         JpegWriteCtx W;
         W.coef = coef;
-        W.slot0 = slot0[g] = sg * (uint32_t)F.slots_per_seg + run_n;
-        W.dc0[0] = W.dc0[1] = W.dc0[2] = 0;                          // DC terms relative to the chunk's entry; k_jpeg_dcfix adds the rest
+        W.slot0 = slot0[u] = sg * (uint32_t)F.slots_per_seg + run_n;
+        W.dc0[0] = W.dc0[1] = W.dc0[2] = 0;                          // DC terms relative to the unit's entry; k_jpeg_dcfix adds the rest
         W.status = status;
         const uint32_t base_n = run_n;
-        run_n += slots[g];
+        run_n += U.own_n;
         const size_t last = (sg + 1 < F.nsegs ? scan.seg_first_chunk[sg + 1] : n) - 1;
         const uint32_t want = std::min<uint32_t>((uint32_t)F.slots_per_seg, F.total_slots - sg * (uint32_t)F.slots_per_seg);
-        const bool closes = g == last;
-        dec[g] = JpegDecoded{};
+        const bool closes = g == last && U.tail;
+        dec[u] = JpegDecoded{};
         if (!closes && run_n > want) { *status |= JPEG_ST_OVERRUN; continue; }
-        // the last chunk of an interval walks with the interval's remaining slots as a budget and gives the verdict
+        // the last unit of an interval walks with the interval's remaining slots as a budget and gives the verdict
         const uint32_t budget = closes ? (want >= base_n ? want - base_n : 0u) : 0xffffffffu;
-        dec[g] = jpeg_write_chunk(L, K, word1, entry[g], limit[g], seg_end[g], F, &W, budget);
+        dec[u] = jpeg_write_chunk(L, K, word1, U.entry, U.limit, seg_end[g], F, &W, budget);
         if (closes) {
-            const uint32_t pe = (uint32_t)dec[g].exit, fle = (uint32_t)(dec[g].exit >> 48);
+            const uint32_t pe = (uint32_t)dec[u].exit, fle = (uint32_t)(dec[u].exit >> 48);
             if ((fle & JPEG_FL_INVALID) || pe > seg_end[g] || seg_end[g] - pe >= 8) *status |= JPEG_ST_BAD_CODE;
-            if (base_n + dec[g].n != want) *status |= JPEG_ST_BAD_COUNT;
-        } else if (dec[g].n != slots[g]) *status |= JPEG_ST_BAD_COUNT;      // the lean walk and the full walk disagree: cannot happen
+            if (base_n + dec[u].n != want) *status |= JPEG_ST_BAD_COUNT;
+        } else if (dec[u].n != U.own_n) *status |= JPEG_ST_BAD_COUNT;      // the lean walk and the full walk disagree: cannot happen
     }
     // ---- k_jpeg_dcfix
     int run_dc[3] = {0, 0, 0};
-    for (size_t g = 0; g < n; g++) {
-        if (origin[g]) run_dc[0] = run_dc[1] = run_dc[2] = 0;
-        jpeg_dc_fixup(K, F, coef, slot0[g], entry[g], dec[g].ndc, run_dc);
-        for (int k = 0; k < 3; k++) run_dc[k] += dec[g].dc[k];
+    for (size_t u = 0; u < nu; u++) {
+        if (units[u].origin) run_dc[0] = run_dc[1] = run_dc[2] = 0;
+        jpeg_dc_fixup(K, F, coef, slot0[u], units[u].entry, dec[u].ndc, run_dc);
+        for (int k = 0; k < 3; k++) run_dc[k] += dec[u].dc[k];
     }
     return IMP_OK;
 }

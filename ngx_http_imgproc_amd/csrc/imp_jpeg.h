@@ -13,7 +13,7 @@ namespace imp {
 constexpr int JPEG_SUB_ENTRIES = 256;        // second-level entries per table (the Annex K tables need 128 or fewer)
 constexpr int JPEG_LOOKBITS = JPEG_LOOKBITS_N;   // codes up to this length resolve with one LDS lookup
 constexpr int JPEG_CHUNK_WORDS = 32;         // a decoder lane owns 1024 bits of the unstuffed stream -- or 512 / 256 for a launch too
-constexpr int JPEG_CHUNK_BYTES_MAX = 256;    // the longest chunk jpeg_prepare_scan cuts
+constexpr int JPEG_CHUNK_BYTES_MAX = 512;    // the longest chunk jpeg_prepare_scan cuts
 constexpr int JPEG_CHUNK_BYTES = JPEG_CHUNK_WORDS * 4;   // small to fill the device (JpegScan::chunk_bytes, chosen by jpeg_chunk_bytes_for)
 
 struct JpegHuffSpec {                        // a DHT table as the file gives it
@@ -75,6 +75,7 @@ struct JpegFrame {
     unsigned nchunks, nsegs;
     unsigned chunk_bits;                     // 1024, 512 or 256: what a lane of the entropy kernel owns
     unsigned overlap_bits;                   // how far in front of its chunk a walk of k_jpeg_select starts (jpeg_overlap_bits_for)
+    unsigned wsplit;                         // lanes of k_jpeg_write per chunk: 1, or 2 (the second enters at the chunk's middle, JpegSpan::mid)
 };
 
 // The entropy-coded segment made ready for the device: FF00 unstuffed, restart intervals cut at their RSTn markers, every
@@ -135,6 +136,8 @@ struct JpegJob {
                                              // (15 = none); | 16 = found by a repair walk; 32 | k2 = the same state as candidate k2: its answer
     uint64_t* rep_out;                       // ... the repair walk's exit state and slot count
     uint32_t* rep_n;
+    uint64_t *cand_mid, *rep_mid;            // [bpm][nchunks]: a walk's / a repair walk's state at the chunk's middle (JpegSpan::mid) ...
+    uint32_t *cand_nmid, *rep_nmid;          // ... and the slots it passed up to there
     struct JpegHuffTabs* tabs;               // the tables as the decoder lanes read them (written by k_jpeg_walks)
     uint32_t* ext_idx;                       // [bpm][nchunks]: the record of a candidate whose repair walk joined nothing (valid where cand_nib == 15 | 16)
     uint32_t* ext;                           // records of JPEG_EXT_WORDS words: [0] chunk, [1] candidate, [2] steps, [3] joined candidate of the last step's chunk
@@ -144,7 +147,10 @@ struct JpegJob {
     uint32_t ext_cap;
     uint64_t* chunk_entry;                   // per chunk, k_jpeg_select -> k_jpeg_write: the decoder state at its first symbol
     uint32_t* chunk_n;                       // ... and the coefficient slots its symbols pass
-    uint32_t* chunk_slot0;                   // per chunk, k_jpeg_write -> k_jpeg_dcfix: the slot of its first symbol
+    uint64_t* chunk_mid;                     // ... the state at its middle (a dead state: not known -- one lane decodes the whole chunk)
+    uint32_t* chunk_nmid;                    // ... and the slots passed up to there
+    // k_jpeg_write and k_jpeg_dcfix work in UNITS: F.wsplit lanes per chunk, unit u = chunk u / wsplit, half u % wsplit
+    uint32_t* chunk_slot0;                   // per unit, k_jpeg_write -> k_jpeg_dcfix: the slot of its first symbol
     int* chunk_dc;                           // ... and [4]: its DC differences summed per component, its DC symbols
     int* wg_dc;                              // [8] per workgroup of k_jpeg_write: the sums over its chunks [0..2]; its clock at start and end [4], [5]
     int16_t* dcadd;                          // per block, in scan order, k_jpeg_dcfix -> k_jpeg_pixels: what its DC term in the planes lacks
@@ -170,7 +176,7 @@ constexpr int JPEG_TILE_W = 256, JPEG_TILE_H = 64;   // pixels a workgroup of th
 struct JpegMapEntry { uint32_t job, local; };
 inline unsigned jpeg_sync_chunks_per_block(int bpm) { return (unsigned)JPEG_SYNC_BLOCK / (unsigned)bpm; }   // 256, 85, 64, 42
 inline unsigned jpeg_sync_blocks(unsigned nchunks, int bpm) { const unsigned c = jpeg_sync_chunks_per_block(bpm); return (nchunks + c - 1) / c; }
-inline unsigned jpeg_entropy_blocks(unsigned nchunks) { return (nchunks + JPEG_HUFF_BLOCK - 1) / JPEG_HUFF_BLOCK; }
+inline unsigned jpeg_entropy_blocks(unsigned nunits) { return (nunits + JPEG_HUFF_BLOCK - 1) / JPEG_HUFF_BLOCK; }   // (units: nchunks * wsplit)
 // `ticket` = one zeroed word per launch; both maps in job-major order (a job's workgroups in increasing order):
 // sync_map for k_jpeg_select (jpeg_sync_blocks per job), chunk_map for k_jpeg_write and k_jpeg_dcfix (jpeg_entropy_blocks)
 // `marks`: null, or five events recorded behind k_jpeg_walks, _mend, _select, _write, _dcfix (impgpu_jpeg_profile)

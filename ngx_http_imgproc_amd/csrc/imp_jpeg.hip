@@ -100,13 +100,14 @@ __device__ __forceinline__ void walks_body(JpegHuffTabs& L, const JpegJob& J, co
     const uint32_t p0 = start - seg_start > OVERLAP ? start - OVERLAP : seg_start;
     const bool exact = p0 == seg_start;                             // the walk starts where the interval does: nothing to guess
     JpegSpan sp;
-    sp.in = sp.out = JPEG_STATE_NONE;
-    sp.n = 0;
-    if (!exact || k == 0) sp = jpeg_span_walk(L, word, jpeg_pack_state(p0, k, 0, 0), start, limit, seg_end, F);
+    sp.in = sp.out = sp.mid = JPEG_STATE_NONE;
+    sp.n = sp.nmid = 0;
+    if (!exact || k == 0) sp = jpeg_span_walk(L, word, jpeg_pack_state(p0, k, 0, 0), start, min(start + CHUNK_BITS / 2, limit), limit, seg_end, F);
     const size_t at = (size_t)k * F.nchunks + g;                    // [k][chunk]: a wave's stores are neighbours
     J.cand_in[at] = sp.in;
     J.cand_out[at] = sp.out;
     J.cand_n[at] = sp.n;
+    if (F.wsplit > 1) { J.cand_mid[at] = sp.mid; J.cand_nmid[at] = sp.nmid; }
 }
 
 __global__ __launch_bounds__(SB) void k_jpeg_walks(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map) {
@@ -185,10 +186,11 @@ __device__ __forceinline__ void mend_body(JpegHuffTabs& L, MendShared& M, const 
         const size_t at = (size_t)k * N + g;
         const uint64_t E = J.cand_out[at - 1];
         uint32_t nib = JPEG_MAP_FAIL;
-        const JpegSpan sp = jpeg_span_walk(L, word, E, start, limit, seg_end, F);
+        const JpegSpan sp = jpeg_span_walk(L, word, E, start, min(start + CHUNK_BITS / 2, limit), limit, seg_end, F);
         for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_out[(size_t)k1 * N + g] == sp.out) nib = k1;
         J.rep_out[at] = sp.out;
         J.rep_n[at] = sp.n;
+        if (F.wsplit > 1) { J.rep_mid[at] = sp.mid; J.rep_nmid[at] = sp.nmid; }
         atomicAdd(&J.header[2], 1u);
         if (nib == JPEG_MAP_FAIL) {
             // It has joined none of the chunk's walks: they are all out of step here, and those of the next chunk tend
@@ -212,7 +214,7 @@ __device__ __forceinline__ void mend_body(JpegHuffTabs& L, MendShared& M, const 
                     for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && J.cand_in[(size_t)i * N + gc] == S) { k1 = i; nn = J.cand_n[(size_t)i * N + gc]; }
                     uint64_t out = S;
                     if (k1 == JPEG_MAP_FAIL) {
-                        const JpegSpan s2 = jpeg_span_walk(L, word, S, start2, limit2, send2, F);
+                        const JpegSpan s2 = jpeg_span_walk(L, word, S, start2, limit2, limit2, send2, F);
                         nn = s2.n;
                         out = s2.out;
                         for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && J.cand_out[(size_t)i * N + gc] == out) k1 = i;
@@ -249,7 +251,8 @@ struct SelShared {
     uint64_t S;
 };
 // (workgroup `b` of job J, numbered by TICKET: every workgroup it looks back at has started)
-__device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, const uint32_t b) {
+// Lw: the workgroup's tables in LDS where it has them (k_jpeg_entropy_small) -- a chase walks with those; else with the file's tables in memory
+__device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, const uint32_t b, const JpegHuffTabs* Lw = nullptr) {
     auto& s_in = Z.in; auto& s_out = Z.out; auto& s_rep_out = Z.rep_out; auto& s_pout = Z.pout;
     auto& s_n = Z.n; auto& s_rep_n = Z.rep_n; auto& s_res_n = Z.res_n; auto& s_map = Z.map; auto& s_scan = Z.scan;
     auto& s_nib = Z.nib; auto& s_exact = Z.exact; auto& s_own = Z.own;
@@ -377,20 +380,30 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
             uint64_t ent = JPEG_STATE_NONE;
             uint32_t n = 0;
             bool known = false;
-            if (s_exact[t]) { ent = s_in[t]; n = s_n[t]; known = true; }
+            // (where the chunk's middle state comes from: the walk, or the repair walk, that turned out to be the true one)
+            const uint64_t* mid_from = nullptr;
+            const uint32_t* nmid_from = nullptr;
+            size_t mid_at = 0;
+            if (s_exact[t]) { ent = s_in[t]; n = s_n[t]; known = true; mid_from = J.cand_mid; nmid_from = J.cand_nmid; mid_at = (size_t)g0 + t; }
             else if (idx_in != JPEG_MAP_FAIL) {
                 const uint32_t nb = s_nib[idx_in * CPW + t], v = nb & 15u;
                 if (!(nb & 16u)) {
-                    if (v != JPEG_MAP_FAIL) { ent = s_in[v * CPW + t]; n = s_n[v * CPW + t]; known = true; }
-                    else atomicMin(&s_jf, (uint32_t)t > 0 ? (uint32_t)t - 1 : 0u);   // (cannot happen: a true exit state is never "no candidate")
+                    if (v != JPEG_MAP_FAIL) {
+                        ent = s_in[v * CPW + t]; n = s_n[v * CPW + t]; known = true;
+                        mid_from = J.cand_mid; nmid_from = J.cand_nmid; mid_at = (size_t)v * F.nchunks + g0 + t;
+                    } else atomicMin(&s_jf, (uint32_t)t > 0 ? (uint32_t)t - 1 : 0u);   // (cannot happen: a true exit state is never "no candidate")
                 } else {
                     ent = t > 0 ? s_out[idx_in * CPW + t - 1] : s_pout[idx_in];
                     n = s_rep_n[idx_in * CPW + t];
                     known = true;
+                    mid_from = J.rep_mid; nmid_from = J.rep_nmid; mid_at = (size_t)s_own[idx_in * CPW + t] * F.nchunks + g0 + t;   // (a twin's walk was made by the candidate it shares its state with)
                     if (v == JPEG_MAP_FAIL) atomicMin(&s_jf, (uint32_t)t);            // its exit joined no walk: follow it from here
                 }
             }
-            if (known) { A.chunk_entry[g0 + t] = ent; s_res_n[t] = n; }
+            if (known) {
+                A.chunk_entry[g0 + t] = ent; s_res_n[t] = n;
+                if (F.wsplit > 1) { J.chunk_mid[g0 + t] = mid_from[mid_at]; J.chunk_nmid[g0 + t] = nmid_from[mid_at]; }
+            }
         }
         __syncthreads();
         const uint32_t jf = s_jf;
@@ -446,7 +459,10 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
                     else {
                         const uint32_t gg = g0 + jj, seg = A.chunk_seg[gg];
                         const uint32_t seg_end = A.seg_first_chunk[seg] * CHUNK_BITS + A.seg_bits[seg];
-                        const JpegSpan sp = jpeg_span_walk(L, word, S, gg * CHUNK_BITS, min((gg + 1) * CHUNK_BITS, seg_end), seg_end, F);
+                        const uint32_t lim = min((gg + 1) * CHUNK_BITS, seg_end);
+                        // (one lane, a chunk after the other, everybody behind it waiting: with the tables in memory a chunk took 8-9 us)
+                        const JpegSpan sp = Lw ? jpeg_span_walk(*Lw, word, S, gg * CHUNK_BITS, lim, lim, seg_end, F)
+                                               : jpeg_span_walk(L, word, S, gg * CHUNK_BITS, lim, lim, seg_end, F);
                         atomicAdd(&A.header[0], 1u);                // (diagnostics: walks this kernel had to do itself)
                         n = sp.n;
                         for (uint32_t i = 0; i < B; i++) if (k1 == JPEG_MAP_FAIL && s_out[i * CPW + jj] == sp.out) k1 = i;
@@ -455,6 +471,7 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
                 }
                 A.chunk_entry[g0 + jj] = ent;
                 s_res_n[jj] = n;
+                if (F.wsplit > 1) J.chunk_mid[g0 + jj] = JPEG_STATE_NONE;    // (a chunk reached by the chase: one lane decodes all of it)
             }
             if (jj >= nlive) {                                      // the workgroup's end: what the next one starts from --
                 if (R && ei >= rcount) close_record();
@@ -551,8 +568,11 @@ struct WriteShared {
     __attribute__((aligned(16))) int16_t stage[HB][72];
     uint32_t list[HB / 64][128];                                    // per wave: its complete blocks {where in LDS, where in the planes}
 };
-// The workgroup's chunks are g0 .. g0 + own - 1, a lane each (k_jpeg_write: own = HB; as a phase of k_jpeg_entropy_small: the
-// chunks of a k_jpeg_select workgroup).  L: the tables, in either form.  wg_dc: where the workgroup's DC sums go.
+// The workgroup's UNITS are g0 .. g0 + own - 1, a lane each: F.wsplit units per chunk -- unit u is chunk u / wsplit, and with
+// two the second one enters the chunk at its middle, in the state the chunk's true walk passed there (JpegJob::chunk_mid;
+// where that is not known the first unit decodes the whole chunk and the second has nothing to do).  Everything below --
+// slot prefix, budget, verdicts, DC sums -- is per unit; k_jpeg_select's per-chunk counts come apart into the two.
+// L: the tables, in either form.  wg_dc: where the workgroup's DC sums go.
 template <class Tabs>
 __device__ __forceinline__ void write_body(const Tabs& L, WriteShared& Y, const JpegJob& J, const uint32_t g0, const uint32_t own, int* wg_dc) {
     JpegBlockTabs& K = Y.K;
@@ -565,19 +585,30 @@ __device__ __forceinline__ void write_body(const Tabs& L, WriteShared& Y, const 
     load_block_tables(K, F, t);
     if (t < 4) s_tot[t] = 0;
     const uint32_t CHUNK_BITS = F.chunk_bits;
-    const uint32_t g = g0 + (uint32_t)t;
-    const bool live = (uint32_t)t < own && g < F.nchunks;
+    const uint32_t WS = F.wsplit > 1 ? 2u : 1u;
+    const uint32_t g = g0 + (uint32_t)t;                            // the unit
+    const uint32_t gc = WS == 2 ? g >> 1 : g, half = WS == 2 ? g & 1u : 0u;      // its chunk, which part of it
+    const bool live = (uint32_t)t < own && gc < F.nchunks;
     uint32_t seg = 0, first = 0, seg_end = 0, limit = 0, own_n = 0;
     uint64_t entry = JPEG_STATE_NONE;
-    bool origin = false;
+    bool origin = false, tail = true, idle = false;                 // tail: the chunk's last unit with anything to decode; idle: a second unit with nothing to decode
     if (live) {
-        seg = A.chunk_seg[g];
+        seg = A.chunk_seg[gc];
         first = A.seg_first_chunk[seg];
-        origin = first == g;
+        origin = first == gc && half == 0;
         seg_end = first * CHUNK_BITS + A.seg_bits[seg];
-        limit = min((g + 1) * CHUNK_BITS, seg_end);
-        entry = J.chunk_entry[g];
-        own_n = J.chunk_n[g];
+        limit = min((gc + 1) * CHUNK_BITS, seg_end);
+        entry = J.chunk_entry[gc];
+        own_n = J.chunk_n[gc];
+        if (WS == 2) {
+            const uint64_t mid = J.chunk_mid[gc];
+            // (a dead state: not known, or the walk ended before it got there; at or behind the chunk's end -- an interval's short
+            // last chunk, a symbol that spans the second half: nothing there for a second lane, and the first must close the interval)
+            const bool have = (uint32_t)(mid >> 48) == 0 && (uint32_t)mid < limit;
+            const uint32_t nmid = have ? J.chunk_nmid[gc] : 0u;
+            if (half == 0) { if (have) { limit = min(gc * CHUNK_BITS + CHUNK_BITS / 2, limit); own_n = nmid; tail = false; } }
+            else { entry = have ? mid : JPEG_STATE_NONE; own_n = have ? own_n - nmid : 0u; tail = have; idle = !have; }
+        }
     }
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
     const GlobalWords gwords = (GlobalWords)(uintptr_t)A.words;
@@ -599,8 +630,9 @@ __device__ __forceinline__ void write_body(const Tabs& L, WriteShared& Y, const 
         }
         __syncthreads();
     }
-    const uint32_t first0 = A.seg_first_chunk[A.chunk_seg[g0]];
-    const uint32_t carry = sum_before<uint32_t>(J.chunk_n, 1, A.records + 6, JPEG_CTL_REC, (uint32_t)SB / (uint32_t)F.bpm, first0, g0, t, &s_carry);
+    const uint32_t c0 = WS == 2 ? g0 >> 1 : g0;                      // (a workgroup begins with a chunk's first unit: HB is even)
+    const uint32_t first0 = A.seg_first_chunk[A.chunk_seg[c0]];
+    const uint32_t carry = sum_before<uint32_t>(J.chunk_n, 1, A.records + 6, JPEG_CTL_REC, (uint32_t)SB / (uint32_t)F.bpm, first0, c0, t, &s_carry);
     const bool open = !s_head[t];                                   // still in the interval that began in an earlier workgroup
     const uint32_t incl_n = s_n[t] + (open ? carry : 0u);
     // ---- decode, now knowing where every coefficient goes.  The last chunk of an interval walks with the interval's
@@ -613,7 +645,7 @@ __device__ __forceinline__ void write_body(const Tabs& L, WriteShared& Y, const 
         const uint32_t last_chunk_of_seg = live ? (seg + 1 < F.nsegs ? A.seg_first_chunk[seg + 1] : F.nchunks) - 1 : 0u;
         const uint32_t base_n = incl_n - own_n;
         const uint32_t slots_here = min((uint32_t)F.slots_per_seg, F.total_slots - seg * (uint32_t)F.slots_per_seg);
-        const bool closes = g == last_chunk_of_seg;
+        const bool closes = gc == last_chunk_of_seg && tail;
         JpegWriteCtx W;
         W.coef = A.coef;
         W.slot0 = slot0 = seg * (uint32_t)F.slots_per_seg + base_n;
@@ -621,7 +653,8 @@ __device__ __forceinline__ void write_body(const Tabs& L, WriteShared& Y, const 
         W.status = &A.header[1];
         W.stage = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&s_stage[t][0];
         W.list = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&s_list[t >> 6][0];
-        const bool overrun = live && !closes && incl_n > slots_here;              // would write outside the interval
+        // (an idle second unit stands behind the unit that closes its interval, whose count of the padding bits need not fit)
+        const bool overrun = live && !idle && !closes && incl_n > slots_here;     // would write outside the interval
         if (overrun) atomicOr(&A.header[1], JPEG_ST_OVERRUN);
         const uint32_t budget = closes ? (slots_here >= base_n ? slots_here - base_n : 0u) : 0xffffffffu;
         // (every lane of the wave takes part: finished blocks are written out by the lanes together)
@@ -674,13 +707,15 @@ __device__ __forceinline__ void dcfix_body(DcShared& D, const JpegJob& J, const 
     auto& s_dc = D.dc; auto& s_head = D.head; auto& s_carry = D.carry;
     const int t = threadIdx.x;
     const JpegFrame& F = J.F;
-    const uint32_t g = g0 + (uint32_t)t;
-    const bool live = (uint32_t)t < owned && g < F.nchunks;
+    const uint32_t WS = F.wsplit > 1 ? 2u : 1u;
+    const uint32_t g = g0 + (uint32_t)t;                            // the unit of k_jpeg_write (write_body)
+    const uint32_t gc = WS == 2 ? g >> 1 : g, half = WS == 2 ? g & 1u : 0u;
+    const bool live = (uint32_t)t < owned && gc < F.nchunks;
     int own[3] = {0, 0, 0};
     uint32_t ndc = 0;
     bool origin = false;
     if (live) {
-        origin = J.seg_first_chunk[J.chunk_seg[g]] == g;
+        origin = J.seg_first_chunk[J.chunk_seg[gc]] == gc && half == 0;
         const int* d = J.chunk_dc + (size_t)g * 4;
         own[0] = d[0]; own[1] = d[1]; own[2] = d[2]; ndc = (uint32_t)d[3];
     }
@@ -700,7 +735,7 @@ __device__ __forceinline__ void dcfix_body(DcShared& D, const JpegJob& J, const 
         }
         __syncthreads();
     }
-    const uint32_t first0 = J.seg_first_chunk[J.chunk_seg[g0]];
+    const uint32_t first0 = J.seg_first_chunk[J.chunk_seg[WS == 2 ? g0 >> 1 : g0]] * WS;      // (in units, like g0 and the DC sums)
     int carry[3];
     for (int i = 0; i < 3; i++) carry[i] = sum_before<int>(J.chunk_dc + i, 4, tot + i, tot_stride, per, first0, g0, t, &s_carry[i]);
     if (!live || ndc == 0) return;
@@ -710,7 +745,7 @@ __device__ __forceinline__ void dcfix_body(DcShared& D, const JpegJob& J, const 
     // the blocks that begin in the chunk are neighbours in the scan: their predictors go to a side array indexed by the
     // block's number there (k_jpeg_pixels adds them) -- a short each, side by side, where adding them to the DC terms in the
     // planes was a 2-byte read-modify-write into a line of its own per block
-    const uint32_t z = (uint32_t)(J.chunk_entry[g] >> 40) & 0xff;
+    const uint32_t z = (uint32_t)((half ? J.chunk_mid[gc] : J.chunk_entry[gc]) >> 40) & 0xff;      // (a second unit with DC terms entered at the middle state)
     const uint32_t bpm = (uint32_t)F.bpm, nluma = bpm == 1 ? 1u : bpm - 2, nblocks = F.total_slots >> 6;
     const uint32_t gb = (J.chunk_slot0[g] >> 6) + (z ? 1u : 0u);
     uint32_t c = gb % bpm;
@@ -761,19 +796,21 @@ __global__ __launch_bounds__(SB) void k_jpeg_entropy_small(const JpegJob* __rest
     const JpegJob& J = jobs[__builtin_amdgcn_readfirstlane(me.job)];
     const uint32_t b = __builtin_amdgcn_readfirstlane(me.local);
     uint32_t* rec = J.records + (size_t)b * JPEG_CTL_REC;
+    if (t == 0) rec[26] = (uint32_t)wall_clock64();                 // (IMPGPU_JPEG_TRACE=2: the workgroup's start, its walks done, its mend done)
     // ---- 1. the walks of this workgroup's chunks
     walks_body(X.L, J, b, false);
     __threadfence();
     __syncthreads();
-    if (t == 0) st_release(rec + 7, 1u);
+    if (t == 0) { rec[27] = (uint32_t)wall_clock64(); st_release(rec + 7, 1u); }
     // ---- 2. which walk does each of the predecessor chunk's candidates lead into (the chunk in front of the workgroup is
     // the workgroup's before it)
     if (b > 0 && t == 0 && !wait_flag_ge(rec - JPEG_CTL_REC + 7, 1u)) atomicOr(&J.header[1], JPEG_ST_CHAIN_TIMEOUT);
     __syncthreads();
     mend_body<true>(X.L, X.u.M, J, b);
     __syncthreads();
+    if (t == 0) rec[28] = (uint32_t)wall_clock64();
     // ---- 3. every chunk's true entry state
-    select_body(X.u.Z, J, b);
+    select_body(X.u.Z, J, b, &X.L);
 }
 
 // ---------------------------------------------------------------- pixels

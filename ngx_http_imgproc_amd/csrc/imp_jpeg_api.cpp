@@ -326,6 +326,13 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
                 p.F.nsegs = (unsigned)p.scan.seg_first_chunk.size();
                 p.F.chunk_bits = (unsigned)p.scan.chunk_bytes * 8;
                 p.F.overlap_bits = jpeg_overlap_bits_for(p.F.chunk_bits, p.scan_len, (size_t)p.F.total_slots / 64);
+                // k_jpeg_write decodes a chunk with two lanes, the second entering at the chunk's middle in the state the chunk's
+                // true walk passed there: its chain is half as long and the synchronising phases are none the longer.  Where the
+                // launch is a latency chain, that is (a lone 640 x 480: k_jpeg_write 65 -> 56 us, 4K 99 -> 89); a launch that fills
+                // the device gains nothing from shorter chains and loses to the second round of workgroups its LDS forces
+                // (64 files, 28 MB: 349 -> 415 us), so from 4 MB on -- where the chunks grow to 256 bytes -- a chunk keeps its
+                // one lane.  IMPGPU_JPEG_SPLIT=0 | 1 forces either (A/B, read per call).
+                { const char* sp = std::getenv("IMPGPU_JPEG_SPLIT"); p.F.wsplit = sp ? (sp[0] == '0' ? 1u : 2u) : launch_bytes > (size_t(4) << 20) ? 1u : 2u; }
             }
         } else {
             int16_t* planes = (int16_t*)((uint8_t*)host + p.coef_off);
@@ -372,11 +379,12 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
                 p.ctl_ext = ctl_words;
                 ctl_words += 4;
                 sync_blocks += jpeg_sync_blocks(p.F.nchunks, p.F.bpm);
-                total_blocks += jpeg_entropy_blocks(p.F.nchunks);
-                // per chunk: entry state (8 bytes), slots, first slot, DC sums [4]; per workgroup of k_jpeg_write: DC sums [4];
-                // per chunk and block of the MCU: what its walk found (two states, a slot count)
+                total_blocks += jpeg_entropy_blocks(p.F.nchunks * p.F.wsplit);
+                // per chunk: entry and middle state (8 bytes each), slots, slots up to the middle; per UNIT of k_jpeg_write
+                // (wsplit per chunk): first slot, DC sums [4]; per workgroup of k_jpeg_write: DC sums [4];
+                // per chunk and block of the MCU: what its walk and its repair walk found (64 bytes)
                 p.work_off = work;
-                work += align_up((size_t)p.F.nchunks * (32 + 40 * (size_t)p.F.bpm) + (size_t)jpeg_entropy_blocks(p.F.nchunks) * 32 + sizeof(JpegHuffTabs) + 64 +
+                work += align_up((size_t)p.F.nchunks * (24 + 20 * (size_t)p.F.wsplit + 64 * (size_t)p.F.bpm) + 8 + (size_t)jpeg_entropy_blocks(p.F.nchunks * p.F.wsplit) * 32 + sizeof(JpegHuffTabs) + 64 +
                                  ((size_t)p.F.nchunks / 8 + 16) * JPEG_EXT_WORDS * 4 + align_up((size_t)p.F.total_slots / 64 * 2, 64) + 64, 256);
             }
             p.side_qt = side;
@@ -441,25 +449,32 @@ int group_begin(Group& G, const unsigned char* const* blobs, const size_t* sizes
                 J.header = (uint32_t*)d_ctl + p.ctl_header;
                 J.records = (uint32_t*)d_ctl + p.ctl_records;
                 uint8_t* wk = (uint8_t*)d_work + p.work_off;
+                const size_t NC = p.F.nchunks, NU = NC * p.F.wsplit, NB = NC * (size_t)p.F.bpm;
                 J.chunk_entry = (uint64_t*)wk;
-                J.chunk_n = (uint32_t*)(wk + (size_t)p.F.nchunks * 8);
-                J.chunk_slot0 = (uint32_t*)(wk + (size_t)p.F.nchunks * 12);
-                J.chunk_dc = (int*)(wk + (size_t)p.F.nchunks * 16);
-                J.wg_dc = (int*)(wk + (size_t)p.F.nchunks * 32);
-                uint8_t* cd = wk + (size_t)p.F.nchunks * 32 + (size_t)jpeg_entropy_blocks(p.F.nchunks) * 32;
+                J.chunk_mid = (uint64_t*)(wk + NC * 8);
+                J.chunk_n = (uint32_t*)(wk + NC * 16);
+                J.chunk_nmid = (uint32_t*)(wk + NC * 20);
+                J.chunk_slot0 = (uint32_t*)(wk + NC * 24);
+                J.chunk_dc = (int*)(wk + NC * 24 + NU * 4);
+                J.wg_dc = (int*)(wk + NC * 24 + NU * 20);
+                uint8_t* cd = wk + align_up(NC * 24 + NU * 20, 8) + (size_t)jpeg_entropy_blocks((unsigned)NU) * 32;
                 J.cand_in = (uint64_t*)cd;
-                J.cand_out = (uint64_t*)(cd + (size_t)p.F.nchunks * 8 * (size_t)p.F.bpm);
-                J.rep_out = (uint64_t*)(cd + (size_t)p.F.nchunks * 16 * (size_t)p.F.bpm);
-                J.cand_n = (uint32_t*)(cd + (size_t)p.F.nchunks * 24 * (size_t)p.F.bpm);
-                J.rep_n = (uint32_t*)(cd + (size_t)p.F.nchunks * 28 * (size_t)p.F.bpm);
-                J.cand_nib = (uint8_t*)(cd + (size_t)p.F.nchunks * 32 * (size_t)p.F.bpm);       // (a byte each; the four-byte arrays go on at 36)
-                J.ext_idx = (uint32_t*)(cd + (size_t)p.F.nchunks * 36 * (size_t)p.F.bpm);
-                J.tabs = (JpegHuffTabs*)(cd + (size_t)p.F.nchunks * 40 * (size_t)p.F.bpm);
+                J.cand_out = (uint64_t*)(cd + NB * 8);
+                J.rep_out = (uint64_t*)(cd + NB * 16);
+                J.cand_mid = (uint64_t*)(cd + NB * 24);
+                J.rep_mid = (uint64_t*)(cd + NB * 32);
+                J.cand_n = (uint32_t*)(cd + NB * 40);
+                J.rep_n = (uint32_t*)(cd + NB * 44);
+                J.cand_nmid = (uint32_t*)(cd + NB * 48);
+                J.rep_nmid = (uint32_t*)(cd + NB * 52);
+                J.cand_nib = (uint8_t*)(cd + NB * 56);                                          // (a byte each; the four-byte arrays go on at 60)
+                J.ext_idx = (uint32_t*)(cd + NB * 60);
+                J.tabs = (JpegHuffTabs*)(cd + NB * 64);
                 J.ext = (uint32_t*)((uint8_t*)J.tabs + align_up(sizeof(JpegHuffTabs), 64));
                 J.ext_cap = (uint32_t)(p.F.nchunks / 8 + 16);
                 J.ext_count = (uint32_t*)d_ctl + p.ctl_ext;
                 J.dcadd = (int16_t*)((uint8_t*)J.ext + align_up((size_t)J.ext_cap * JPEG_EXT_WORDS * 4, 64));
-                for (unsigned b = 0; b < jpeg_entropy_blocks(p.F.nchunks); b++) bmap[nb++] = JpegMapEntry{(uint32_t)j, b};
+                for (unsigned b = 0; b < jpeg_entropy_blocks(p.F.nchunks * p.F.wsplit); b++) bmap[nb++] = JpegMapEntry{(uint32_t)j, b};
                 for (unsigned b = 0; b < jpeg_sync_blocks(p.F.nchunks, p.F.bpm); b++) smap[ns++] = JpegMapEntry{(uint32_t)j, b};
             }
             uint16_t* qt3 = (uint16_t*)(blob.data() + p.side_qt);
@@ -569,9 +584,9 @@ int group_finish(Group& G, impgpu_image** images, int* codes) {
                         }
                 for (const Prep& p : P) {                          // k_jpeg_write: every workgroup's start and end
                     if (p.code) continue;
-                    const unsigned nb2 = jpeg_entropy_blocks(p.F.nchunks);
+                    const unsigned nb2 = jpeg_entropy_blocks(p.F.nchunks * p.F.wsplit);
                     std::vector<int> wg((size_t)nb2 * 8);
-                    if (hipMemcpy(wg.data(), (uint8_t*)d_work + p.work_off + (size_t)p.F.nchunks * 32, wg.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
+                    if (hipMemcpy(wg.data(), (uint8_t*)d_work + p.work_off + (size_t)p.F.nchunks * (24 + 20 * (size_t)p.F.wsplit), wg.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
                     for (unsigned b = 0; b < nb2; b++)
                         std::fprintf(stderr, "ww %dx%d %u/%u: %.1f %.1f\n", p.H.width, p.H.height, b, nb2, (double)(int32_t)((uint32_t)wg[8 * b + 4] - t0) / 100.0,
                                      (double)(int32_t)((uint32_t)wg[8 * b + 5] - t0) / 100.0);
@@ -583,6 +598,7 @@ int group_finish(Group& G, impgpu_image** images, int* codes) {
                         const uint32_t* r = &ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 20];
                         std::fprintf(stderr, "wg %dx%d %u/%u:", p.H.width, p.H.height, b, nb);
                         for (int k = 0; k <= 5; k++) std::fprintf(stderr, " %.1f", r[k] ? (double)(int32_t)(r[k] - t0) / 100.0 : -1.0);
+                        if (r[6]) std::fprintf(stderr, " | fused: start %.1f walks %.1f mend %.1f", (double)(int32_t)(r[6] - t0) / 100.0, (double)(int32_t)(r[7] - t0) / 100.0, (double)(int32_t)(r[8] - t0) / 100.0);
                         std::fprintf(stderr, "\n");
                     }
                 }
@@ -728,7 +744,9 @@ int impgpu_batch_decode_jpeg_begin(const unsigned char* const* blobs, const size
     TraceRange tr("IMP_STEP_DECODE");
     IMP_FAULT_POINT(IMP_STEP_DECODE);
     impgpu_jpeg_batch* b = new impgpu_jpeg_batch();
-    const int rc = group_begin(b->G, blobs, sizes, count, 0, true);      // on the lane's side stream: what the thread enqueues before _finish overlaps it
+    // on the lane's side stream: what the thread enqueues before _finish overlaps it (IMPGPU_JPEG_AHEAD_STREAM=lane: behind it on the lane's own)
+    const char* where = std::getenv("IMPGPU_JPEG_AHEAD_STREAM");
+    const int rc = group_begin(b->G, blobs, sizes, count, 0, !(where && !std::strcmp(where, "lane")));
     if (rc) { delete b; return rc; }
     *batch = b;
     return IMP_OK;

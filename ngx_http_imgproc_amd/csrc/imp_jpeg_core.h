@@ -546,15 +546,18 @@ IMP_HD inline void jpeg_dc_fixup(const JpegBlockTabs& K, const JpegFrame& F, int
 // successor is SELECTED, not decoded again.  With one walk per block of the MCU (six for 4:2:0) the true state is almost
 // always among the `in`s once the overlap holds a block end or two -- bit position and coefficient index fall into step by
 // themselves, and every block phase is being tried.  
+// Round 5, second half: the walk also reports `mid`, the first state at or behind bit `half` (cross <= half <= limit; the
+// chunk's middle), and the slots passed up to there: k_jpeg_write then decodes the chunk with TWO lanes, the second entering
+// at `mid` -- its chain half as long, the synchronising phases none the longer (the walk passes that bit anyway).
 struct JpegSpan {
-    uint64_t in, out;
-    uint32_t n;
+    uint64_t in, out, mid;
+    uint32_t n, nmid;
 };
 template <class Tabs, class WordFn>
-IMP_HD inline JpegSpan jpeg_span_walk(const Tabs& L, WordFn word, uint64_t entry, uint32_t cross, uint32_t limit, uint32_t seg_end, const JpegFrame& F) {
+IMP_HD inline JpegSpan jpeg_span_walk(const Tabs& L, WordFn word, uint64_t entry, uint32_t cross, uint32_t half, uint32_t limit, uint32_t seg_end, const JpegFrame& F) {
     JpegSpan r;
-    r.in = r.out = entry;
-    r.n = 0;
+    r.in = r.out = r.mid = entry;
+    r.n = r.nmid = 0;
     uint32_t p = (uint32_t)entry;
     uint32_t c = (uint32_t)(entry >> 32) & 0xff, z = (uint32_t)(entry >> 40) & 0xff;
     if ((uint32_t)(entry >> 48)) return r;                          // a dead state stays what it is
@@ -572,14 +575,14 @@ IMP_HD inline JpegSpan jpeg_span_walk(const Tabs& L, WordFn word, uint64_t entry
     }
     JpegBitReader1<WordFn> bits(word);
     bits.start(p);
-    uint32_t fl = 0, blocks = 0, z0 = z;
+    uint32_t fl = 0, blocks = 0, z0 = z, passed = 0;
     // No look at the interval's end here (the write walk does that): only an interval's LAST chunk could meet the padding,
     // and its exit state and slot count are never used -- the chunk behind it starts a new interval.
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (int stage = 0; stage < 2; stage++) {
-        uint32_t target = fl ? 0u : (stage ? limit : cross);
+    for (int stage = 0; stage < 3; stage++) {
+        uint32_t target = fl ? 0u : (stage == 0 ? cross : stage == 1 ? half : limit);
         blocks = 0;
         z0 = z;
         while (p < target) {                                        // (an ending pulls `target` down to zero: one way out)
@@ -614,9 +617,11 @@ IMP_HD inline JpegSpan jpeg_span_walk(const Tabs& L, WordFn word, uint64_t entry
             c = ended ? cn : c;
         }
         if (stage == 0) r.in = jpeg_pack_state(p, c, z, fl);
+        else passed += 64u * blocks + z - z0;                       // (every block passed counts 64, whatever its last run claimed)
+        if (stage == 1) { r.mid = jpeg_pack_state(p, c, z, fl); r.nmid = passed; }
     }
     r.out = jpeg_pack_state(p, c, z, fl);
-    r.n = 64u * blocks + z - z0;                                    // (every block passed counts 64, whatever its last run claimed)
+    r.n = passed;
     return r;
 }
 

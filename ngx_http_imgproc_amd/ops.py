@@ -293,7 +293,7 @@ def jpeg_unstuff(blob):
     from .broker import clib
 
     blob = bytes(blob)
-    out = np.empty(len(blob) + 1024, np.uint8)
+    out = np.empty(len(blob) + 2048, np.uint8)
     head, at, n, total = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
     if not clib.impgpu_jpeg_unstuff(blob, len(blob), out.ctypes.data, out.size, C.byref(head), C.byref(at), C.byref(n), C.byref(total)):
         return None
@@ -316,7 +316,7 @@ def batch_decode_jpeg_prepared(files, pinned=False):
             continue
         head, scan = f
         h = np.frombuffer(bytes(head), np.uint8)
-        tail = 512                                                 # IMPGPU_JPEG_SCAN_TAIL
+        tail = 1024                                                # IMPGPU_JPEG_SCAN_TAIL
         if pinned:
             p = lib.impgpu_host_alloc(len(scan) + tail)
             if not p:

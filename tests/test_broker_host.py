@@ -290,5 +290,5 @@ def test_unstuff_respects_its_capacity(built):
     args = [C.byref(x) for x in v]
     assert built.clib.impgpu_jpeg_unstuff(f, len(f), out, len(f) + 2048, *args) == 1
     head, at, n, total = (x.value for x in v)
-    assert at % 256 == 0 and at >= head and total == at + n + 512 and bytes(out[at + n:total]) == b"\xff" * 512
+    assert at % 256 == 0 and at >= head and total == at + n + 1024 and bytes(out[at + n:total]) == b"\xff" * 1024
     assert built.clib.impgpu_jpeg_unstuff(f, len(f), out, len(f), *args) == 0          # no room for the tail: as it is

@@ -180,7 +180,7 @@ def test_encode_in_two_halves_with_a_decode_between_them(gpu):
     prepared = gpu.jpeg_unstuff(blob)
     assert prepared
     head = np.frombuffer(prepared[0], np.uint8)
-    scan = np.concatenate([np.frombuffer(prepared[1], np.uint8), np.full(512, 255, np.uint8)])
+    scan = np.concatenate([np.frombuffer(prepared[1], np.uint8), np.full(1024, 255, np.uint8)])
     f = (CJpegPrepared * 1)()
     f[0].head, f[0].head_size, f[0].scan, f[0].scan_size, f[0].registered = head.ctypes.data, head.size, scan.ctypes.data, len(prepared[1]), 0
     dec = C.c_void_p()
