@@ -42,6 +42,8 @@ b)
   python tools/jpeg_probe.py > $O/r05_jpeg_probe.txt 2>&1; tail -12 $O/r05_jpeg_probe.txt
   python tools/request_latency.py > $O/r05_request_latency.txt 2>&1; tail -6 $O/r05_request_latency.txt
   python tools/jpeg_tiny_probe.py > $O/r05_jpeg_small_files.txt 2>&1; tail -12 $O/r05_jpeg_small_files.txt
+  python tools/jpeg_stage_probe.py 2>&1 | grep -v amdgpu.ids > $O/r05_jpeg_stage_probe.txt; { echo "# IMPGPU_JPEG_SPLIT=0: one lane of k_jpeg_write per chunk"; IMPGPU_JPEG_SPLIT=0 python tools/jpeg_stage_probe.py 2>&1 | grep -v amdgpu.ids; } >> $O/r05_jpeg_stage_probe.txt; cat $O/r05_jpeg_stage_probe.txt
+  python tools/jpeg_enc_probe.py 2>&1 | grep -v amdgpu.ids > $O/r05_jpeg_enc_probe.txt; cat $O/r05_jpeg_enc_probe.txt
   rm -f $O/jpeg_pool.bin; rm -rf $O/prof_jpeg_b      # (gpurun copies at most 64 MB back)
   ;;
 c)
