@@ -292,3 +292,19 @@ def test_unstuff_respects_its_capacity(built):
     head, at, n, total = (x.value for x in v)
     assert at % 256 == 0 and at >= head and total == at + n + 1024 and bytes(out[at + n:total]) == b"\xff" * 1024
     assert built.clib.impgpu_jpeg_unstuff(f, len(f), out, len(f), *args) == 0          # no room for the tail: as it is
+
+
+def test_unstuff_on_damaged_files_under_the_sanitizers(built, tmp_path):
+    """What a worker runs over every request body before anything has looked at it: 6000 damaged copies of two files (cut
+    short, bytes flipped in scan and headers, marker pairs and FF runs dropped in, segment lengths spoiled) and output buffers
+    of exactly the capacity claimed, under AddressSanitizer / UBSan; every result of "taken" is checked against a byte-by-byte
+    unstuffing (tests/c/unstuff_fuzz.c)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), os.path.join(ROOT, "tests", "c", "_build", "unstuff_fuzz")])
+    exe = os.path.join(ROOT, "tests", "c", "_build", "unstuff_fuzz")
+    for k, blob in enumerate((_photo_jpeg(640, 480), _photo_jpeg(512, 384, 95, subsampling="4:4:4", optimize=True))):
+        path = tmp_path / ("f%d.jpg" % k)
+        path.write_bytes(blob)
+        r = subprocess.run([exe, str(path), "3000", str(k + 1)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-300:], r.stderr[-1500:])
+        taken = int(r.stdout.split()[1])
+        assert 300 < taken < 3000, r.stdout                       # both verdicts occur
