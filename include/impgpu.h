@@ -195,6 +195,15 @@ int   impgpu_batch_decode_jpeg_prepared(const impgpu_jpeg_prepared* files, int c
  * decode while the answers of the batch before are still being written: the device never waits for the host's share).
  * The array is copied; head / scan bytes must stay readable until impgpu_batch_decode_jpeg_finish.  count <= 256. */
 int   impgpu_batch_decode_jpeg_prepared_begin(const impgpu_jpeg_prepared* files, int count, impgpu_jpeg_batch** batch);
+/* The frames of a batch begun on the calling thread's own stream (impgpu_batch_decode_jpeg_prepared_begin), AHEAD of their verdicts:
+ * images[i] = the frame file i is being decoded into -- geometry final, pixels there once the batch's kernels have run, which is
+ * before anything the thread enqueues on it afterwards runs -- or NULL where there is none yet (refused at its header, or a file
+ * whose Huffman stage the host keeps: those come out of _finish as before).  Ownership passes to the caller; _finish then
+ * returns NULL for that file and its CODE: not IMP_OK = the frame does not hold the file's pixels (release it, or whatever was
+ * made of it, and fall back like for any refused file).  So a request's operators and its answer's encode can be enqueued
+ * BEHIND the decode and the thread waits once, at the end, instead of once for the verdicts and once for the answer: a lone
+ * 640 x 480 -> thumbnail -> JPEG request 0.29 -> see DESIGN 4b. */
+int   impgpu_batch_decode_jpeg_pending(impgpu_jpeg_batch* batch, impgpu_image** images);
 /* Page-locks `bytes` at `p` (hipHostRegister) so that copies out of it need no staging; impgpu_host_unregister before the
  * memory goes away.  Needs impgpu_env_start. */
 int   impgpu_host_register(void* p, size_t bytes);

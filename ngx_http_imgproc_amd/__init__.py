@@ -13,6 +13,6 @@ from .ops import (  # noqa: F401
     IMP_ERROR_TOO_MUCH_FILTERS, IMP_ERROR_DEVICE, IMP_ERROR_NO_SUCH_WATERMARK,
     INTER_NN, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4,
     Config, Image, env_start, env_destroy, sync,
-    jpeg_info, png_info, png_stage_times, batch_decode_jpeg, batch_decode_jpeg_prepared, jpeg_unstuff, batch_encode_jpeg, crop_geometry, resize_geometry, filter_check, check_destructive,
+    jpeg_info, png_info, png_stage_times, batch_decode_jpeg, batch_decode_jpeg_prepared, jpeg_unstuff, jpeg_request_one_wait, batch_encode_jpeg, crop_geometry, resize_geometry, filter_check, check_destructive,
     batch_cv_resize, batch_resize_mixed, ResizeItem, batch_resize_rotate_watermark, batch_filters, run_ops, Request, gif_compose,
 )

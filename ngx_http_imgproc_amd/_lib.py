@@ -122,6 +122,7 @@ SIGNATURES = {
     "impgpu_batch_decode_jpeg_finish": (C.c_int, [PP, PP, IP]),
     "impgpu_batch_decode_jpeg_prepared": (C.c_int, [C.POINTER(CJpegPrepared), C.c_int, PP, IP]),
     "impgpu_batch_decode_jpeg_prepared_begin": (C.c_int, [C.POINTER(CJpegPrepared), C.c_int, PP]),
+    "impgpu_batch_decode_jpeg_pending": (C.c_int, [P, PP]),
     "impgpu_batch_encode_jpeg_begin": (C.c_int, [PP, C.c_int, C.c_int, PP]),
     "impgpu_batch_encode_jpeg_finish": (C.c_int, [PP, PP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), IP]),
     "impgpu_host_register": (C.c_int, [P, C.c_size_t]),

@@ -55,6 +55,10 @@ struct Options {
     // (a caller that keeps many requests in flight per connection); IMP's workers do not have one.
     bool pipeline = false;
     long split_kb = 0;
+    // (Also measured and not kept: the frames taken ahead of their verdicts -- impgpu_batch_decode_jpeg_pending -- so that a batch's
+    // operators and answers are enqueued behind its decode and the lane waits once.  From C, in process, a lone request gains 8-11 us
+    // (tests/c/latency_harness.c); through the broker a lone worker's request is level (p50 0.36 ms both ways) and under load the
+    // lanes lose: 7.5 / 10.7 / 14.9 / 17.8 k requests/s at 4 / 8 / 16 / 32 workers against 8.6 / 11.9 / 16.8 / 23.5 k.)
     int threads = 2;
     int batch = 64;
     int gather_us = 0;

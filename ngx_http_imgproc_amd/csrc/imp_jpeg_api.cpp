@@ -74,6 +74,7 @@ struct Prep {                                       // one file on its way to th
     impgpu_image* im = nullptr;
     size_t scan_len = 0;                            // entropy-coded bytes: as the file has them, or unstuffed by the caller (prepared)
     const impgpu_jpeg_prepared* pre = nullptr;      // the caller has unstuffed the scan (impgpu_batch_decode_jpeg_prepared)
+    bool given = false;                             // the frame has been handed to the caller ahead of its verdict (impgpu_batch_decode_jpeg_pending)
     bool direct = false;                            // ... into registered memory: its words go to the device from there
     size_t direct_off = 0;                          // bytes behind the staged part of the words' block
 };
@@ -638,6 +639,7 @@ int group_finish(Group& G, impgpu_image** images, int* codes) {
 done:
     for (int i = 0; i < count; i++) {
         Prep& p = P[(size_t)i];
+        if (p.given) { images[i] = nullptr; codes[i] = p.code; continue; }      // (the caller has the frame: the code says whether it holds the file's pixels)
         if (p.code && p.im) { image_delete(p.im); p.im = nullptr; }
         images[i] = p.im;
         codes[i] = p.code;
@@ -648,7 +650,7 @@ fail:
     if (G.stream) (void)hipStreamSynchronize(G.stream);
     (void)lane_wait();                                              // nothing of this group may still be running when its buffers go back
     for (int i = 0; i < count; i++) {
-        if (P[(size_t)i].im) image_delete(P[(size_t)i].im);
+        if (P[(size_t)i].im && !P[(size_t)i].given) image_delete(P[(size_t)i].im);
         images[i] = nullptr;
         codes[i] = P[(size_t)i].code ? P[(size_t)i].code : rc;
     }
@@ -766,6 +768,22 @@ int impgpu_batch_decode_jpeg_finish(impgpu_jpeg_batch** batch, impgpu_image** im
     if (!rc) rc = group_deferred(blobs, sizes, count, images, codes, b->G.prep);
     delete b;
     return rc;
+}
+
+int impgpu_batch_decode_jpeg_pending(impgpu_jpeg_batch* batch, impgpu_image** images) {
+    if (!batch || !images) return IMP_ERROR_INVALID_ARGS;
+    Group& G = batch->G;
+    if (G.owner != &t_thread_tag) { set_error_text("impgpu_batch_decode_jpeg_pending from another thread than _begin"); return IMP_ERROR_INVALID_ARGS; }
+    // (only a batch whose kernels are on the thread's OWN stream: what the caller enqueues on the frames runs behind them)
+    if (G.stream && !on_lane_stream(G.stream)) { set_error_text("impgpu_batch_decode_jpeg_pending: the batch runs on the thread's second stream"); return IMP_ERROR_INVALID_ARGS; }
+    for (int i = 0; i < G.count; i++) {
+        Prep& p = G.P[(size_t)i];
+        images[i] = nullptr;
+        if (p.code || !p.im || p.given) continue;               // refused at its header, deferred to the host's Huffman stage, or handed out already
+        images[i] = p.im;
+        p.given = true;
+    }
+    return IMP_OK;
 }
 
 int impgpu_batch_decode_jpeg_prepared_begin(const impgpu_jpeg_prepared* files, int count, impgpu_jpeg_batch** batch) {

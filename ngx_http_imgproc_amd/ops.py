@@ -341,6 +341,60 @@ def batch_decode_jpeg_prepared(files, pinned=False):
     return [(codes[i], Image(handle=imgs[i]) if codes[i] == 0 else None) for i in range(n)]
 
 
+def jpeg_request_one_wait(blob, config, quality=86, **ops):
+    """A request end to end with ONE wait (round 5): the file's decode is begun on the thread's own stream, its frame taken
+    ahead of the verdict (impgpu_batch_decode_jpeg_pending), the operators (**ops as for run_ops) and the answer's encode are
+    enqueued behind it, and only then the verdict and the file are waited for.  Returns (code, file bytes or None): a code
+    other than 0 is the decode's -- the caller falls back exactly as after impgpu_image_decode_jpeg."""
+    from ._lib import CJpegPrepared
+
+    keep = np.frombuffer(bytes(blob), np.uint8)
+    f = (CJpegPrepared * 1)()
+    f[0].head, f[0].head_size, f[0].scan, f[0].scan_size, f[0].registered = keep.ctypes.data, keep.size, None, 0, 0
+    batch = C.c_void_p()
+    rc = lib.impgpu_batch_decode_jpeg_prepared_begin(f, 1, C.byref(batch))
+    if rc:
+        raise ImpError(rc, "impgpu_batch_decode_jpeg_prepared_begin")
+    img = (C.c_void_p * 1)()
+    code = (C.c_int * 1)()
+    rc = lib.impgpu_batch_decode_jpeg_pending(batch, img)
+    if rc or not img[0]:                                           # nothing to run ahead with: the two-wait form
+        lib.impgpu_batch_decode_jpeg_finish(C.byref(batch), img, code)
+        if code[0] or not img[0]:
+            return code[0] or IMP_ERROR_DECODE_FAILED, None
+        im = Image(handle=img[0])
+        rc, _ = run_ops(im, config, **ops)
+        out = im.encode_jpeg(quality) if rc == 0 else (rc, None)
+        im.release()
+        return out
+    im = Image(handle=img[0])
+    rc_ops, _ = run_ops(im, config, **ops)
+    enc = C.c_void_p()
+    rc_enc = IMP_ERROR_DEVICE
+    if rc_ops == 0:
+        hs = (C.c_void_p * 1)(im.h.value)
+        rc_enc = lib.impgpu_batch_encode_jpeg_begin(hs, 1, int(quality), C.byref(enc))
+    none = (C.c_void_p * 1)()
+    rc = lib.impgpu_batch_decode_jpeg_finish(C.byref(batch), none, code)
+    out = None
+    ecode = (C.c_int * 1)()
+    if rc_enc == 0:
+        cap = lib.impgpu_jpeg_encode_bound(im.shape[1], im.shape[0], im.shape[2])
+        buf = np.empty(cap, np.uint8)
+        outs = (C.c_void_p * 1)(buf.ctypes.data)
+        caps = (C.c_size_t * 1)(cap)
+        lens = (C.c_size_t * 1)()
+        rc2 = lib.impgpu_batch_encode_jpeg_finish(C.byref(enc), outs, caps, lens, ecode)
+        if rc2 == 0 and ecode[0] == 0:
+            out = buf[:lens[0]].tobytes()
+    im.release()
+    if rc or code[0]:
+        return rc or code[0], None                                 # the frame did not hold the file's pixels: the answer is dropped
+    if rc_ops:
+        return rc_ops, None
+    return (0, out) if out is not None else (rc_enc or ecode[0] or IMP_ERROR_DEVICE, None)
+
+
 def batch_encode_jpeg(images, quality=95):
     """impgpu_batch_encode_jpeg -> [(code, file bytes or None)] in the order of `images`."""
     n = len(images)

@@ -256,3 +256,24 @@ def test_a_worker_may_exit_with_its_env_alive(how):
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr[-800:])
     assert p.stdout.strip().splitlines()[-1] == "leaving"
     assert "still busy at exit" not in p.stderr
+
+
+@pytest.mark.gpu
+def test_one_request_with_one_wait_from_c(tmp_path):
+    """tests/c/latency_harness.c: the request an nginx worker runs -- JPEG in, resize=224,0, JPEG out -- in the library's two forms:
+    two waits (verdict, answer) and ONE (the frame taken ahead of its verdict with impgpu_batch_decode_jpeg_pending, operators and
+    the answer's encode enqueued behind the decode).  The harness compares the two files; here one of them is held to the oracle's."""
+    import json
+
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+    src = os.path.join(ROOT, "tests", "golden", "jpeg", "c420_q50_640x480.jpg")
+    p = subprocess.run([os.path.join(ROOT, "tests", "c", "_build", "latency_harness"), src, "20"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, IMPGPU_JPEG_HUFF="device"))
+    assert p.returncode == 0, p.stderr
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    print("\n" + json.dumps(r))
+    rc, frame = orc.jpeg_decode(open(src, "rb").read())
+    rc2, small = orc.resize(frame, "224,0")
+    rc3, want = orc.jpeg_encode(small, 86)
+    assert rc == rc2 == rc3 == 0
+    assert r["same_answer"] and r["answer_bytes"] == len(want)

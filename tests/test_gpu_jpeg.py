@@ -578,3 +578,41 @@ def test_prepared_files_the_device_defers_or_refuses(gpu, monkeypatch):
     if c == 0:
         assert np.array_equal(im.numpy(), ref)
         im.release()
+
+
+def test_frames_taken_ahead_of_their_verdicts(gpu, monkeypatch):
+    """impgpu_batch_decode_jpeg_pending (round 5): a request whose operators and answer are enqueued behind its decode and
+    that waits once gives the file the two-wait form gives; a scan that turns out damaged comes back with the decode's code
+    and no answer -- whatever had been made of its frame meanwhile; a file refused at its header (no frame to run ahead
+    with) takes the two-wait form inside the same call."""
+    from ngx_http_imgproc_amd.workloads import photo_like
+
+    cfg = gpu.Config()
+    blob = encode(photo_like(480, 640, seed=9), quality=90)
+    rc, im = gpu.Image.decode_jpeg(blob)
+    assert rc == 0
+    assert gpu.run_ops(im, cfg, resize="224,0")[0] == 0
+    rc, want = im.encode_jpeg(86)
+    im.release()
+    assert rc == 0
+    for _ in range(3):
+        assert gpu.jpeg_request_one_wait(blob, cfg, 86, resize="224,0") == (0, want)
+    # filters too (the whole operator segment runs on a frame whose pixels are not there yet when it is enqueued)
+    rc, im = gpu.Image.decode_jpeg(blob)
+    assert gpu.run_ops(im, cfg, crop="4,3,c,c", filters=["gamma=1.3", "rotate=90"])[0] == 0
+    rc, want2 = im.encode_jpeg(70)
+    im.release()
+    assert gpu.jpeg_request_one_wait(blob, cfg, 70, crop="4,3,c,c", filters=["gamma=1.3", "rotate=90"]) == (0, want2)
+    # a scan damaged in its middle: the verdict arrives behind the answer that was made of the frame, and wins
+    bad = bytearray(blob)
+    at = len(bad) // 2
+    bad[at:at + 64] = bytes(64)
+    rc_ref, _ = decode(gpu, bytes(bad))
+    rc, out = gpu.jpeg_request_one_wait(bytes(bad), cfg, 86, resize="224,0")
+    assert rc == rc_ref and (rc != 0) == (out is None)
+    # no frame ahead of the verdict for a progressive file: the code of the plain decode
+    prog = encode(photo_like(480, 640, seed=9), quality=90, progressive=True)
+    rc, out = gpu.jpeg_request_one_wait(prog, cfg, 86, resize="224,0")
+    assert rc == gpu.IMP_ERROR_UNSUPPORTED and out is None
+    # the thread's slots and buffers are its own again
+    assert gpu.jpeg_request_one_wait(blob, cfg, 86, resize="224,0") == (0, want)

@@ -40,6 +40,11 @@ for (w, h) in ((640, 480), (1280, 720), (1920, 1080), (3840, 2160)):
         im.release()
         return out
 
+    def device_one_wait():                                       # the same request with everything enqueued behind the decode: one wait
+        rc, out = gpu.jpeg_request_one_wait(blob, cfg, 86, resize="224,0")
+        assert rc == 0
+        return out
+
     def host():
         a = np.asarray(Image.open(io.BytesIO(blob)))
         small = a[:: max(1, h // 168), :: max(1, w // 224)][:168, :224]       # (a stand-in frame of the answer's size)
@@ -63,9 +68,12 @@ for (w, h) in ((640, 480), (1280, 720), (1920, 1080), (3840, 2160)):
         Image.fromarray(a).save(o, format="JPEG", quality=86, subsampling=2)
         return o.getvalue()
 
+    assert device_one_wait() == device()
+    o50, o95 = timed(device_one_wait, 60)
     d50, d95 = timed(device, 60)
     h50, h95 = timed(host, 20)
     f50, f95 = timed(device_full, 40)
     g50, g95 = timed(host_full, 10)
+    print("%4dx%-4d %8d B in | thumbnail answer, ONE wait: device median %6.3f ms, p95 %6.3f" % (w, h, len(blob), o50, o95))
     print("%4dx%-4d %8d B in | thumbnail answer: device median %6.2f ms, p95 %6.2f; host codecs alone (decode + encode, one core) %6.2f ms | full-size answer (filter-gamma): device %6.2f ms, p95 %6.2f; host codecs alone %6.2f ms"
           % (w, h, len(blob), d50, d95, h50, f50, f95, g50))
