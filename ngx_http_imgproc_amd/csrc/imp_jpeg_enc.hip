@@ -45,6 +45,11 @@ struct EncJob {
     uint32_t* chunk_rec;
     uint32_t* ubytes;
     int nseg, nchunk;
+    // frames of 257 .. 2048 block slots (k_jpeg_enc_huff_seg): hseg workgroups of hper blocks each, and their records --
+    // three (value, flag) pairs per workgroup, zeroed: [0] its bits, [2 hseg] the FF bytes among the file's bytes it owns,
+    // [4 hseg] the unfinished byte it leaves to the next one
+    uint32_t* hrec;
+    int hseg, hper;
 };
 struct EncMap { int job, local; };      // workgroup of k_jpeg_enc_blocks -> (image, first block slot)
 struct EncTables {
@@ -181,9 +186,10 @@ constexpr int ENC_BLOCKS_PER_WG = 32;
 // (its first workgroup also clears the launch's result words -- verdicts the later kernels OR into, the compact area's
 // cursor: a fill command of its own on the stream was 4-5 us of a thumbnail's 80)
 __global__ __launch_bounds__(256) void k_jpeg_enc_blocks(const EncJob* __restrict__ jobs, const EncMap* __restrict__ map, const EncTables* __restrict__ tabs,
-                                                         uint32_t* __restrict__ result, int result_words) {
+                                                         uint32_t* __restrict__ result, int result_words, uint32_t* __restrict__ records, int record_words) {
     __shared__ int s_t[ENC_BLOCKS_PER_WG][8][9];                    // [block][row][column]: the row pass's results (+1: the column reads of a wave spread over the banks)
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < result_words; i += 256) result[i] = 0u;
+    for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < record_words; i += (int)gridDim.x * 256) records[i] = 0u;   // (k_jpeg_enc_huff_seg's ticket and records)
     const EncMap m = map[blockIdx.x];
     const EncJob& J = jobs[m.job];
     const int tid = threadIdx.x, r = tid & 7, bl = tid >> 3;
@@ -590,6 +596,152 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_stuff(const EncJob* __restrict
     }
 }
 
+// ---------------------------------------------------------------- thumbnails: a few workgroups per image (round 5)
+// k_jpeg_enc_huff<1024> gives a 224 x 168 thumbnail's 924 blocks ONE workgroup: sixteen waves on one compute unit, four to a
+// SIMD, walk their blocks twice (35 us), and a request's answer waits for exactly that.  Here the image is cut into hseg
+// segments of hper <= 256 blocks, a workgroup (four waves, one per SIMD) each, in ONE launch -- k_jpeg_enc_pack and
+// k_jpeg_enc_stuff folded together, because a thumbnail's whole stream is a few KB and a second launch costs more than it:
+//   size the blocks, publish the segment's bit count, add up the counts before it (they run at the same time);
+//   emit the code into the LDS window at that bit offset within its first byte;
+//   the byte a segment shares with the next one belongs to the NEXT one (it holds that byte's last bit): a segment publishes its
+//   unfinished last byte and ORs its predecessor's into its first;
+//   count the FF bytes among the bytes it owns, publish, add up the counts before it, write its bytes with the 00s in place;
+//   the last segment pads with 1-bits and appends EOI; whoever finishes LAST (a counter) copies the file into the compact area.
+// Workgroups take a ticket when they start, so the ones a workgroup waits for are always running.
+__global__ __launch_bounds__(256) void k_jpeg_enc_huff_seg(const EncJob* __restrict__ jobs, const EncSeg* __restrict__ map, const EncTables* __restrict__ tabs,
+                                                           uint32_t* __restrict__ result, uint32_t* __restrict__ cursor, uint8_t* __restrict__ compact,
+                                                           uint32_t compact_cap, uint32_t* __restrict__ ticket) {
+    __shared__ uint32_t s_win[ENC_WIN_WORDS];
+    __shared__ uint32_t s_huff[1024];
+    __shared__ int s_part[4];
+    __shared__ uint32_t s_word;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_word = atomicAdd(ticket, 1u);
+    for (int i = tid; i < 1024; i += 256) s_huff[i] = tabs->huff[i >> 8][i & 255];
+    for (int i = tid; i < ENC_WIN_WORDS; i += 256) s_win[i] = 0;
+    __syncthreads();
+    const EncSeg me = map[s_word];
+    const EncJob& J = jobs[me.job];
+    const int sg = me.local, nseg = J.hseg;
+    const int b0 = sg * J.hper, b = b0 + tid;
+    const bool live = tid < J.hper && b < J.nblocks;
+    uint32_t* recA = J.hrec;
+    uint32_t* recC = J.hrec + 2 * nseg;
+    uint32_t* recB = J.hrec + 4 * nseg;
+    uint32_t* verdict = &result[4 * me.job + 1];
+    int bits = 0, dc = 0, last_dc = 0, tb = 0;
+    uint32_t cw[32];
+    if (live) {
+        const int mcu = b / J.bpm, j = b - mcu * J.bpm;
+        const uint4* blk = (const uint4*)(J.coef + (size_t)b * 64);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const uint4 q = blk[v];
+            cw[4 * v] = q.x; cw[4 * v + 1] = q.y; cw[4 * v + 2] = q.z; cw[4 * v + 3] = q.w;
+        }
+        dc = enc_dc_of(J, mcu, j);
+        if (J.bpm == 1) last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, 0) : 0;
+        else if (j >= 4) { last_dc = mcu > 0 ? enc_dc_of(J, mcu - 1, j) : 0; tb = 512; }
+        else last_dc = j > 0 ? enc_dc_of(J, mcu, j - 1) : (mcu > 0 ? enc_dc_of(J, mcu - 1, 3) : 0);
+        bits = enc_code_block<false>(cw, last_dc, dc, &s_huff[tb], nullptr);
+    }
+    int total;
+    const int incl = enc_block_scan<256>(bits, s_part, &total);
+    if (tid == 0) {
+        __hip_atomic_store(&recA[2 * sg], (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&recA[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                // (s_part is free again)
+    const uint32_t base = enc_sum_before(recA, sg, s_part, verdict);     // bits of the image in front of this segment
+    const int lead = (int)(base & 7u);
+    if (live) {
+        EncPut P;
+        P.start(s_win, lead + incl - bits);
+        enc_code_block<true>(cw, last_dc, dc, &s_huff[tb], &P);
+        P.finish();
+    }
+    __syncthreads();
+    const bool last = sg == nseg - 1;
+    int nbits = lead + total;
+    int nown = nbits >> 3;                                          // whole bytes of the window: byte 0 is the file's byte base >> 3
+    const int rem = nbits & 7;
+    if (tid == 0) {
+        if (last) {
+            if (rem) { atomicOr(&s_win[nown >> 2], ((1u << (8 - rem)) - 1) << (24 - (nown & 3) * 8)); }     // flush_bits: ones up to the byte boundary
+        } else {
+            const uint32_t part = rem ? (s_win[nown >> 2] >> (24 - (nown & 3) * 8)) & 0xffu : 0u;          // the byte the next segment finishes
+            __hip_atomic_store(&recB[2 * sg], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&recB[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lead) {                                                 // the top bits of this segment's first byte are its predecessor's
+            bool up = false;
+            for (int spin = 0; spin < (1 << 22) && !up; spin++) {
+                up = __hip_atomic_load(&recB[2 * (sg - 1) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (!up) __builtin_amdgcn_s_sleep(8);
+            }
+            if (!up) atomicOr(verdict, 2u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            atomicOr(&s_win[0], __hip_atomic_load(&recB[2 * (sg - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 24);
+        }
+    }
+    if (last && rem) nown++;
+    __syncthreads();
+    // the bytes this segment owns leave with a 00 behind every FF: a word-aligned run of bytes per thread
+    const int per = ((nown + 255) / 256 + 3) & ~3;
+    const int s = min(nown, tid * per), e = min(nown, s + per);
+    int ff = 0;
+    for (int i = s; i < e; i++) ff += ((s_win[i >> 2] >> (24 - (i & 3) * 8)) & 0xff) == 0xff;
+    int ff_total;
+    const int ff_incl = enc_block_scan<256>(ff, s_part, &ff_total);
+    if (tid == 0) {
+        __hip_atomic_store(&recC[2 * sg], (uint32_t)ff_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&recC[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const uint32_t ff_before = enc_sum_before(recC, sg, s_part, verdict);
+    {
+        long long at = (long long)(base >> 3) + ff_before + s + (ff_incl - ff);
+        for (int i = s; i < e; i++) {
+            const uint32_t v = (s_win[i >> 2] >> (24 - (i & 3) * 8)) & 0xff;
+            if (at < J.out_cap) J.out[at] = (uint8_t)v;
+            at++;
+            if (v == 0xff) { if (at < J.out_cap) J.out[at] = 0; at++; }
+        }
+    }
+    if (last && tid == 0) {
+        const long long out_pos = (long long)(base >> 3) + ff_before + nown + ff_total;
+        const bool fits = out_pos + 2 <= J.out_cap;
+        if (fits) { J.out[out_pos] = 0xff; J.out[out_pos + 1] = 0xd9; }
+        result[4 * me.job] = (uint32_t)(out_pos + 2);
+        if (!fits) atomicOr(verdict, 1u);
+    }
+    // whoever finishes last has every byte of the file behind it: it puts the copy the host fetches into the compact area
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_word = __hip_atomic_fetch_add(&result[4 * me.job + 3], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_word != (uint32_t)(nseg - 1)) return;                     // (uniform)
+    __threadfence();
+    const uint32_t len = __hip_atomic_load(&result[4 * me.job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    if (tid == 0) {
+        uint32_t at = 0xffffffffu;
+        if (ok) {
+            at = atomicAdd(cursor, (len + 15u) & ~15u);
+            if (at > compact_cap || len > compact_cap - at) at = 0xffffffffu;
+        }
+        result[4 * me.job + 2] = at;
+        s_word = at;
+    }
+    __syncthreads();
+    const uint32_t at = s_word;
+    if (at != 0xffffffffu) {
+        const uint4* src = (const uint4*)J.out;                     // both 16-byte aligned
+        uint4* dst = (uint4*)(compact + at);
+        for (uint32_t i = tid; i < (len + 15u) / 16u; i += 256) dst[i] = src[i];
+    }
+}
+
 // ---------------------------------------------------------------- host
 const EncTables& enc_static_tables(EncTables* scratch, int quality) {
     static uint32_t huff[4][256];
@@ -678,11 +830,11 @@ struct EncState {
     std::vector<std::vector<uint8_t>> heads;
     std::vector<int> early;                                     // per image: IMP_OK, or what was wrong with it before anything ran
     int count = 0;
-    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr, *aux = nullptr;
+    void *coef = nullptr, *out = nullptr, *res = nullptr, *side = nullptr, *aux = nullptr, *hrec = nullptr;
     void *pin = nullptr, *token = nullptr, *mark = nullptr;
     size_t res_bytes = 0, compact_cap = 0;
     bool armed = false;                                         // something is in flight
-    void drop() { dev_free(coef); dev_free(out); dev_free(res); dev_free(side); dev_free(aux); coef = out = res = side = aux = nullptr; }
+    void drop() { dev_free(coef); dev_free(out); dev_free(res); dev_free(side); dev_free(aux); dev_free(hrec); coef = out = res = side = aux = hrec = nullptr; }
 };
 
 int encode_begin(const impgpu_image* const* images, int count, int quality, EncState& E) {
@@ -695,7 +847,14 @@ int encode_begin(const impgpu_image* const* images, int count, int quality, EncS
     std::vector<std::vector<uint8_t>>& heads = E.heads;
     E.count = count;
     E.early.assign((size_t)count, IMP_OK);
-    for (int pass = 0; pass < 2; pass++)
+    // Thumbnails of 257 .. 2048 block slots: a few workgroups each (k_jpeg_enc_huff_seg) when the call is a request's or a broker
+    // batch's -- up to sixteen frames -- and ONE workgroup of 1024 threads each when it is a queue's worth: measured, same box,
+    // the lone call 72 -> 69 us at 224 x 168 and 86 -> 71 at 224 x 224 (1176 blocks: two passes of the one workgroup), the
+    // broker's four lanes 16.95 -> 17.4 k requests/s at 16 workers and 23.7 -> 24.6 k at 32; but 64 frames per call 447 -> 504 us
+    // and the eight-thread stream 46.8 -> 44.6 k.  IMPGPU_JPEG_ENC_SEG=0 | 1 forces either (A/B, read per call).
+    const char* segenv = std::getenv("IMPGPU_JPEG_ENC_SEG");
+    const bool seg_on = !one_wg && (segenv ? segenv[0] != '0' : count <= 16);
+    for (int pass = 0; pass < 3; pass++)                        // 0: frames of up to 256 block slots (or all small ones), 1: up to 2048 in segments, 2: the large ones
         for (int i = 0; i < count; i++) {
             const impgpu_image* im = images[i];
             EncGeom g;
@@ -706,7 +865,8 @@ int encode_begin(const impgpu_image* const* images, int count, int quality, EncS
             if (E.early[(size_t)i] != IMP_OK) continue;
             (void)enc_geom(im->w, im->h, im->c, &g);
             const bool big = !one_wg && g.nblocks > ENC_BIG_BLOCKS && (uint64_t)g.nblocks * 1658u < (1ull << 32);
-            if (big != (pass == 1)) continue;
+            const bool mid = !big && seg_on && g.nblocks > 256;
+            if ((big ? 2 : mid ? 1 : 0) != pass) continue;
             EncJob J{};
             J.src = im->d; J.w = im->w; J.h = im->h; J.c = im->c; J.step = im->step;
             J.mcuw = g.mcuw; J.mcuh = g.mcuh; J.bpm = g.bpm; J.nblocks = g.nblocks;
@@ -716,17 +876,24 @@ int encode_begin(const impgpu_image* const* images, int count, int quality, EncS
                 J.nseg = (g.nblocks + 255) / 256;
                 J.nchunk = (int)(((size_t)g.nblocks * 1658 / 8 + 8 + 16383) / 16384);
             }
+            if (mid) {
+                J.hseg = (g.nblocks + 255) / 256;
+                J.hper = (g.nblocks + J.hseg - 1) / J.hseg;     // (even shares: no segment is a handful of blocks)
+            }
             jobs.push_back(J);
             owner.push_back(i);
             heads.push_back(enc_headers(im->w, im->h, g.nc, T));
         }
     const int nj = (int)jobs.size();
     if (!nj) return IMP_OK;
-    int nsmall = 0;
+    int nsmall = 0, ntiny = 0;
     while (nsmall < nj && jobs[nsmall].nseg == 0) nsmall++;
+    while (ntiny < nsmall && jobs[ntiny].hseg == 0) ntiny++;
     // device memory: coefficient blocks | segments | for the large frames: unstuffed streams, records, tickets (one area, zeroed)
     std::vector<EncMap> map;
-    std::vector<EncSeg> pack_map, stuff_map;
+    std::vector<EncSeg> pack_map, stuff_map, hseg_map;
+    size_t hrec_words = 4;                                       // [0] = k_jpeg_enc_huff_seg's ticket, then 6 words per segment
+    std::vector<size_t> o_hrec((size_t)jobs.size(), 0);
     size_t coef_bytes = 0, out_bytes = 0, aux_bytes = 16;        // aux: [0] [1] = the two tickets
     std::vector<size_t> o_coef((size_t)nj), o_out((size_t)nj), o_u((size_t)nj), o_seg((size_t)nj), o_chk((size_t)nj), o_ub((size_t)nj);
     for (int k = 0; k < nj; k++) {
@@ -734,6 +901,10 @@ int encode_begin(const impgpu_image* const* images, int count, int quality, EncS
         o_coef[k] = coef_bytes; coef_bytes += (size_t)J.nblocks * 128;
         o_out[k] = out_bytes; out_bytes += ((size_t)J.out_cap + 255) & ~size_t(255);
         for (int b = 0; b < J.nblocks; b += ENC_BLOCKS_PER_WG) map.push_back(EncMap{k, b});
+        if (J.hseg) {
+            o_hrec[(size_t)k] = hrec_words; hrec_words += (size_t)J.hseg * 6;
+            for (int g = 0; g < J.hseg; g++) hseg_map.push_back(EncSeg{k, g});
+        }
         if (J.nseg) {
             o_ub[k] = aux_bytes; aux_bytes += 16;
             o_seg[k] = aux_bytes; aux_bytes += (size_t)J.nseg * 8;
@@ -754,7 +925,8 @@ int encode_begin(const impgpu_image* const* images, int count, int quality, EncS
     const size_t res_bytes = (((size_t)nj * 4 + 1) * 4 + 255) & ~size_t(255);
     E.res_bytes = res_bytes; E.compact_cap = compact_cap;
     void *&coef = E.coef, *&out = E.out, *&res = E.res, *&side = E.side, *&aux = E.aux;      // res = results | compact area
-    if (int rc = dev_alloc(coef_bytes, &coef)) return rc;
+    if (!hseg_map.empty()) if (int rc = dev_alloc(hrec_words * 4, &E.hrec)) return rc;
+    if (int rc = dev_alloc(coef_bytes, &coef)) { E.drop(); return rc; }
     if (int rc = dev_alloc(out_bytes, &out)) { E.drop(); return rc; }
     if (int rc = dev_alloc(res_bytes + compact_cap, &res)) { E.drop(); return rc; }
     if (nsmall < nj) if (int rc = dev_alloc(aux_bytes, &aux)) { E.drop(); return rc; }
@@ -762,6 +934,7 @@ int encode_begin(const impgpu_image* const* images, int count, int quality, EncS
         EncJob& J = jobs[k];
         J.coef = (short*)((uint8_t*)coef + o_coef[k]);
         J.out = (uint8_t*)out + o_out[k];
+        if (J.hseg) J.hrec = (uint32_t*)E.hrec + o_hrec[(size_t)k];
         if (J.nseg) {
             J.ustream = (uint32_t*)((uint8_t*)aux + o_u[k]);
             J.seg_rec = (uint32_t*)((uint8_t*)aux + o_seg[k]);
@@ -772,13 +945,15 @@ int encode_begin(const impgpu_image* const* images, int count, int quality, EncS
     // side blob: tables | jobs | map | segment map | chunk map
     auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
     const size_t o_jobs = up16(sizeof(EncTables)), o_map = o_jobs + up16(jobs.size() * sizeof(EncJob)),
-                 o_pack = o_map + up16(map.size() * sizeof(EncMap)), o_stuff = o_pack + up16(pack_map.size() * sizeof(EncSeg));
-    std::vector<uint8_t> blob(o_stuff + stuff_map.size() * sizeof(EncSeg) + 16);
+                 o_pack = o_map + up16(map.size() * sizeof(EncMap)), o_stuff = o_pack + up16(pack_map.size() * sizeof(EncSeg)),
+                 o_hseg = o_stuff + up16(stuff_map.size() * sizeof(EncSeg));
+    std::vector<uint8_t> blob(o_hseg + hseg_map.size() * sizeof(EncSeg) + 16);
     std::memcpy(blob.data(), &T, sizeof(T));
     std::memcpy(blob.data() + o_jobs, jobs.data(), jobs.size() * sizeof(EncJob));
     std::memcpy(blob.data() + o_map, map.data(), map.size() * sizeof(EncMap));
     if (!pack_map.empty()) std::memcpy(blob.data() + o_pack, pack_map.data(), pack_map.size() * sizeof(EncSeg));
     if (!stuff_map.empty()) std::memcpy(blob.data() + o_stuff, stuff_map.data(), stuff_map.size() * sizeof(EncSeg));
+    if (!hseg_map.empty()) std::memcpy(blob.data() + o_hseg, hseg_map.data(), hseg_map.size() * sizeof(EncSeg));
     if (int rc = upload_small(blob.data(), blob.size(), &side, s)) { E.drop(); return rc; }
     const uint8_t* sd = (const uint8_t*)side;
     const EncJob* djobs = (const EncJob*)(sd + o_jobs);
@@ -786,15 +961,18 @@ int encode_begin(const impgpu_image* const* images, int count, int quality, EncS
     hipError_t e = hipSuccess;                                  // (the verdict words and the compact area's cursor are cleared by k_jpeg_enc_blocks)
     if (aux) e = hipMemsetAsync(aux, 0, aux_bytes, s);
     hipLaunchKernelGGL(k_jpeg_enc_blocks, dim3((unsigned)map.size()), dim3(256), 0, s, djobs, (const EncMap*)(sd + o_map), (const EncTables*)sd,
-                       (uint32_t*)res, (int)(res_bytes / 4));
-    if (nsmall) {
-        bool wide = false;                                      // any frame of more than 256 block slots: 1024 per pass
-        for (int k = 0; k < nsmall; k++) wide = wide || jobs[k].nblocks > 256;
-        if (wide) hipLaunchKernelGGL(k_jpeg_enc_huff<1024>, dim3((unsigned)nsmall), dim3(1024), 0, s, djobs, (const EncTables*)sd, (uint32_t*)res, cursor,
+                       (uint32_t*)res, (int)(res_bytes / 4), (uint32_t*)E.hrec, E.hrec ? (int)hrec_words : 0);
+    if (ntiny) {                                                // (jobs [0, ntiny): one workgroup each)
+        bool wide = false;                                      // any frame of more than 256 block slots (IMPGPU_JPEG_ENC_SEG=0): 1024 per pass
+        for (int k = 0; k < ntiny; k++) wide = wide || jobs[k].nblocks > 256;
+        if (wide) hipLaunchKernelGGL(k_jpeg_enc_huff<1024>, dim3((unsigned)ntiny), dim3(1024), 0, s, djobs, (const EncTables*)sd, (uint32_t*)res, cursor,
                                      (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
-        else hipLaunchKernelGGL(k_jpeg_enc_huff<256>, dim3((unsigned)nsmall), dim3(256), 0, s, djobs, (const EncTables*)sd, (uint32_t*)res, cursor,
+        else hipLaunchKernelGGL(k_jpeg_enc_huff<256>, dim3((unsigned)ntiny), dim3(256), 0, s, djobs, (const EncTables*)sd, (uint32_t*)res, cursor,
                                 (uint8_t*)res + res_bytes, (uint32_t)compact_cap);
     }
+    if (!hseg_map.empty())
+        hipLaunchKernelGGL(k_jpeg_enc_huff_seg, dim3((unsigned)hseg_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_hseg), (const EncTables*)sd,
+                           (uint32_t*)res, cursor, (uint8_t*)res + res_bytes, (uint32_t)compact_cap, (uint32_t*)E.hrec);
     if (nsmall < nj) {
         hipLaunchKernelGGL(k_jpeg_enc_pack, dim3((unsigned)pack_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_pack), (const EncTables*)sd, (uint32_t*)res, (uint32_t*)aux);
         hipLaunchKernelGGL(k_jpeg_enc_stuff, dim3((unsigned)stuff_map.size()), dim3(256), 0, s, djobs, (const EncSeg*)(sd + o_stuff), (uint32_t*)res, (uint32_t*)aux + 1);

@@ -217,3 +217,40 @@ def test_encode_in_two_halves_with_a_decode_between_them(gpu):
     got.release(); ref.release()
     for im in ims:
         im.release()
+
+
+@pytest.mark.parametrize("seg", ["1", "0"])
+def test_thumbnails_in_segments_are_the_same_files(gpu, monkeypatch, seg):
+    """k_jpeg_enc_huff_seg (round 5: a frame of 257 .. 2048 block slots cut into segments of up to 256 blocks, a workgroup each,
+    bit offsets, the byte two segments share and the FF counts exchanged between them) against the oracle's files: block counts
+    around every segment boundary, gray frames (one block per MCU), noise (long codes: FF bytes, also at the seams), smooth
+    frames (a segment of a few hundred bits), high and low quality; forced on and forced off (the one-workgroup kernel), in one
+    batch with frames of the other two kinds."""
+    from ngx_http_imgproc_amd.workloads import photo_like
+
+    monkeypatch.setenv("IMPGPU_JPEG_ENC_SEG", seg)
+    shapes = [(168, 224, 3), (224, 224, 3), (126, 224, 3), (104, 104, 3), (112, 104, 3), (120, 104, 3),      # 924, 1176, 672, 294 (two segments), 294, 336 slots
+              (160, 168, 1), (136, 136, 1), (256, 264, 1),                                                     # gray: 420, 289, 1056 blocks
+              (299, 224, 4), (330, 224, 3)]                                                                     # 1596, 1764 slots: seven segments
+    frames = []
+    for k, (h, w, c) in enumerate(shapes):
+        kind = k % 3
+        f = photo_like(h, w, 40 + k) if kind == 0 else noise_image(h, w, 3, 60 + k) if kind == 1 else smooth_image(h, w, 3, seed=k)
+        f = np.ascontiguousarray(f[:, :, :1]) if c == 1 else np.dstack([f, np.full((h, w, 1), 255, np.uint8)]) if c == 4 else f
+        frames.append(f)
+    for q in (86, 100, 20):
+        ims = [gpu.Image(f) for f in frames]
+        got = gpu.batch_encode_jpeg(ims, q)
+        for (code, data), f in zip(got, frames):
+            assert code == 0 and data == orc.jpeg_encode(f, q)[1], (f.shape, q)
+        one = ims[1].encode_jpeg(q)
+        assert one == (0, got[1][1])
+        for im in ims:
+            im.release()
+    # with a tiny frame and a large one in the same call
+    mixed = [noise_image(40, 50, 3, 1), frames[0], smooth_image(1080, 1920, 3), frames[7], frames[10]]
+    ims = [gpu.Image(f) for f in mixed]
+    for (code, data), f in zip(gpu.batch_encode_jpeg(ims, 90), mixed):
+        assert code == 0 and data == orc.jpeg_encode(f, 90)[1]
+    for im in ims:
+        im.release()
