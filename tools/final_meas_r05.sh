@@ -54,6 +54,7 @@ c)
   { timeout -k 10 120 bash tools/broker_host_phases.sh 4 16; IMPGPU_BROKER_PREPARE=0 timeout -k 10 120 bash tools/broker_host_phases.sh 4 16; } > $O/r05_broker_host_phases.txt 2>&1; cat $O/r05_broker_host_phases.txt
   rm -rf $O/prof_broker_*
   timeout -k 10 300 python -m pytest tests/test_gpu_multiproc.py tests/test_gpu_broker.py -q -m gpu -s > $O/r05_multiproc.txt 2>&1; tail -8 $O/r05_multiproc.txt
+  python bench.py --workers 16 --seconds 3 > $O/r05_bench_workers.json 2>/dev/null; python bench.py --workers 32 --seconds 3 >> $O/r05_bench_workers.json 2>/dev/null; cat $O/r05_bench_workers.json | cut -c1-300
   rm -f $O/jpeg_pool.bin; rm -rf $O/prof_broker_4_16      # (gpurun copies at most 64 MB back; the trace's summary is in r05_broker_prof_4_16.txt)
   ;;
 d)
