@@ -207,3 +207,31 @@ def test_a_broker_that_dies_is_replaced_and_workers_carry_on(tmp_path, scaling):
     finally:
         err = scaling.stop_broker(p)
     assert "starting a fresh one" in err
+
+
+def test_a_worker_that_writes_its_slot_by_hand_gets_errors_not_memory(tmp_path, scaling, broker):
+    """tests/c/rogue_worker.c: request records a correct client never writes -- a prepared file's scan unaligned, reaching past
+    the bytes handed over, lying outside the slot, overlapped by its head, counts near 2^64, in_bytes past the slot; a head cut
+    short of its scan -- each answered with IMP_ERROR_INVALID_ARGS at its step (validation, or the decoder's own check), and
+    the same file handed over correctly right afterwards gets the oracle's answer: the broker is still there and still right."""
+    name, p = broker
+    blob = orc.jpeg_encode(_photo(600, 800, 21), 90)[1]
+    src = tmp_path / "in.jpg"
+    src.write_bytes(blob)
+    r = subprocess.run([os.path.join(ROOT, "tests", "c", "_build", "rogue_worker"), name, str(src)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    got = {}
+    for line in r.stdout.strip().splitlines():
+        w = line.split()
+        got[w[0]] = dict(rc=int(w[2]), code=int(w[4]), step=int(w[6]), bytes=int(w[8]))
+    print("\n" + r.stdout)
+    INVALID = 50                                                    # IMP_ERROR_INVALID_ARGS
+    for case in ("unaligned", "overlong", "outside", "overlap", "toolong", "huge"):
+        assert got[case]["rc"] == 0 and got[case]["code"] == INVALID and got[case]["bytes"] == 0, (case, got[case])
+    assert got["shorthead"]["rc"] == 0 and got["shorthead"]["code"] != 0 and got["shorthead"]["bytes"] == 0
+    rc, frame = orc.jpeg_decode(blob)
+    rc2, small = orc.resize(frame, "224,0")
+    rc3, want = orc.jpeg_encode(small, 86)
+    assert rc == rc2 == rc3 == 0
+    assert got["correct"] == dict(rc=0, code=0, step=got["correct"]["step"], bytes=len(want))
+    assert p.poll() is None                                         # the broker did not go away
