@@ -165,7 +165,10 @@ struct JpegJob {
 //   [3] the final word: 0..5 = that candidate of its last chunk is the true exit state; 15 = the state in [4..5] is;
 //       13 = the next chunk is step [5] of record [4]
 //   [6] coefficient slots passed by its chunks      [20..31] its clock at the phase boundaries (IMPGPU_JPEG_TRACE=2)
-constexpr int JPEG_EXT_STEPS = 6, JPEG_EXT_WORDS = 4 + 3 * JPEG_EXT_STEPS + 2;
+#ifndef JPEG_EXT_STEPS_N
+#define JPEG_EXT_STEPS_N 6     // chunks a repair walk that joined nothing decodes on through, speculatively, in k_jpeg_mend (A/B with -DJPEG_EXT_STEPS_N=4 / 2, 64 files: k_jpeg_mend 165 -> 156 / 154 us, k_jpeg_select level: the kernel is its repair walks, not these)
+#endif
+constexpr int JPEG_EXT_STEPS = JPEG_EXT_STEPS_N, JPEG_EXT_WORDS = 4 + 3 * JPEG_EXT_STEPS + 2;
 constexpr int JPEG_CTL_REC = 32;
 constexpr int JPEG_SYNC_BLOCK = 256;         // lanes per workgroup of k_jpeg_select: (chunk, block of the MCU) pairs
 #ifndef JPEG_HUFF_BLOCK_N
