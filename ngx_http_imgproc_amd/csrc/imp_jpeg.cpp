@@ -643,6 +643,8 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
             }
         }
     }
+    if (const char* tr = std::getenv("IMPGPU_JPEG_TRACE"); tr && !std::strcmp(tr, "3"))
+        for (size_t g = 0; g < n; g++) std::fprintf(stderr, "ce %zu %016llx %u\n", g, (unsigned long long)entry[g], slots[g]);
     g_sync_stats[0] = (int)n; g_sync_stats[1] = misses; g_sync_stats[2] = repairs; g_sync_stats[3] = chases;
     g_sync_stats[4] = (int)CB; g_sync_stats[5] = (int)F.overlap_bits; g_sync_stats[6] = (int)B; g_sync_stats[7] = 0;
     if (rounds) *rounds = misses;

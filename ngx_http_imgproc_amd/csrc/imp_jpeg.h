@@ -117,6 +117,9 @@ int jpeg_emulate_entropy(const uint8_t* blob, size_t size, const JpegHeader& H, 
 // ---- imp_jpeg.hip
 // status word the entropy kernels leave behind: 0 = every interval decoded to exactly its MCUs
 constexpr unsigned JPEG_ST_BAD_CODE = 1u, JPEG_ST_BAD_COUNT = 2u, JPEG_ST_CHAIN_TIMEOUT = 4u, JPEG_ST_OVERRUN = 8u;
+// a workgroup of k_jpeg_select took "every candidate leads to the same candidate" for "the true state leads there too", and its
+// predecessor's final word said otherwise (the true state was none of the candidates and had not fallen into step with them)
+constexpr unsigned JPEG_ST_CHAIN_GUESS = 16u;
 // One file of a launch.  All kernels take a table of these plus a map from workgroup number to (job, workgroup within
 // the job), so any number of files -- a request, an album, a queue's worth of requests -- costs the same few launches.
 struct JpegJob {
@@ -170,7 +173,10 @@ struct JpegJob {
 #endif
 constexpr int JPEG_EXT_STEPS = JPEG_EXT_STEPS_N, JPEG_EXT_WORDS = 4 + 3 * JPEG_EXT_STEPS + 2;
 constexpr int JPEG_CTL_REC = 32;
-constexpr int JPEG_SYNC_BLOCK = 256;         // lanes per workgroup of k_jpeg_select: (chunk, block of the MCU) pairs
+#ifndef JPEG_SYNC_BLOCK_N
+#define JPEG_SYNC_BLOCK_N 256  // (A/B: -DJPEG_SYNC_BLOCK_N=512 -- fewer, larger workgroups in k_jpeg_select's chain)
+#endif
+constexpr int JPEG_SYNC_BLOCK = JPEG_SYNC_BLOCK_N;         // lanes per workgroup of k_jpeg_select: (chunk, block of the MCU) pairs
 #ifndef JPEG_HUFF_BLOCK_N
 #define JPEG_HUFF_BLOCK_N 256
 #endif

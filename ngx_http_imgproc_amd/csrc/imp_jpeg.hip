@@ -248,6 +248,7 @@ struct SelShared {
     uint32_t map[SB], scan[2][SB];                                  // [j]: the chunk's map; the scan's two buffers
     uint8_t nib[SB], exact[SB], own[SB];                            // own: the candidate whose answer this one shares (a twin's), else itself
     uint32_t jf, mode, idx0, fin, chases, ext, ei, from;
+    uint32_t guessed;                                               // 1 + the candidate of the chunk in front that a CONSTANT map (no final word) named: checked at the end
     uint64_t S;
 };
 // (workgroup `b` of job J, numbered by TICKET: every workgroup it looks back at has started)
@@ -258,6 +259,7 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
     auto& s_nib = Z.nib; auto& s_exact = Z.exact; auto& s_own = Z.own;
     uint32_t &s_jf = Z.jf, &s_mode = Z.mode, &s_idx0 = Z.idx0, &s_fin = Z.fin, &s_chases = Z.chases, &s_ext = Z.ext, &s_ei = Z.ei, &s_from = Z.from;
     uint64_t& s_S = Z.S;
+    uint32_t& s_guessed = Z.guessed;
     const int t = threadIdx.x;
     const JpegFrame& F = J.F;
     struct { const uint32_t *words, *chunk_seg, *seg_first_chunk, *seg_bits; const JpegHuffDev* tables; uint32_t *header, *records; uint64_t* chunk_entry; uint32_t* chunk_n; } A =
@@ -277,7 +279,7 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
     const GlobalWords gwords = (GlobalWords)(uintptr_t)A.words;
     auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };      // (a plain load: the lane comes back to the line for its next word, which a non-temporal load does not keep -- 313 against 465 us per 64 files in k_jpeg_walks)
-    if (t == 0) { s_ext = 0xffffffffu; s_ei = 0; s_from = 0; s_jf = 0xffffffffu; s_mode = 0; s_idx0 = 0; s_fin = 0; s_chases = 0; s_S = 0; }
+    if (t == 0) { s_ext = 0xffffffffu; s_ei = 0; s_from = 0; s_jf = 0xffffffffu; s_mode = 0; s_idx0 = 0; s_fin = 0; s_chases = 0; s_S = 0; s_guessed = 0; }
 
     // ---- A. what the walks found (k_jpeg_walks) and where each of the predecessor's candidates leads (k_jpeg_mend), this
     // workgroup's chunks and the one in front of them
@@ -349,7 +351,11 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
                     break;                                          // nothing to learn behind a final word
                 }
                 acc = jpeg_map_then(r[2], acc);
-                if (jpeg_map_is_const(acc)) { idx0 = acc & 15u; mode = 0; }
+                // "whatever candidate comes in, this one goes out": taken for the true chain too, which holds when the true state
+                // in front of workgroup w is one of the candidates or falls into step with them inside these workgroups -- always,
+                // in a photograph; in a stream of dense blocks it may do neither.  So the guess is CHECKED against the
+                // predecessor's final word once this workgroup is done (below): a wrong one refuses the file.
+                if (jpeg_map_is_const(acc)) { idx0 = acc & 15u; mode = 0; s_guessed = 1u + idx0; }
             }
             if (mode == 2) {                                        // the maps do not say: the predecessor's final word, then
                 if (wait_flag_ge(prec + 1, 2u)) {
@@ -509,7 +515,9 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
     if ((t & 63) == 0) s_scan[0][t >> 6] = total;
     __syncthreads();
     if (t == 0) {
-        rec[6] = s_scan[0][0] + s_scan[0][1] + s_scan[0][2] + s_scan[0][3];
+        uint32_t all = 0;
+        for (int w = 0; w < SB / 64; w++) all += s_scan[0][w];
+        rec[6] = all;
         if (b + 1 < nblocks) {
             rec[3] = s_fin;
             rec[4] = (uint32_t)s_S;
@@ -517,6 +525,18 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
             st_release(rec + 1, 2u);
         }
         if (s_chases) atomicAdd(&A.header[3], s_chases);
+        // the guess of the look-back against what the workgroup in front really ended in (it has published by now, or is about
+        // to: nothing it waits for comes after this workgroup)
+        if (s_guessed) {
+            const uint64_t took = s_pout[s_guessed - 1u];
+            bool held = false;
+            if (wait_flag_ge(prec + 1, 2u)) {
+                const uint32_t kind = prec[3];
+                if (kind < 6) held = s_pout[kind] == took;          // (the same STATE: two candidates may be twins)
+                else if (kind == 15) held = ((uint64_t)prec[4] | ((uint64_t)prec[5] << 32)) == took;
+            } else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
+            if (!held) atomicOr(&A.header[1], JPEG_ST_CHAIN_GUESS);
+        }
     }
     stamp(5);
 }

@@ -605,6 +605,18 @@ int group_finish(Group& G, impgpu_image** images, int* codes) {
                 }
             }
         }
+        if (const char* tr = std::getenv("IMPGPU_JPEG_TRACE"); tr && !std::strcmp(tr, "3")) {
+            // every chunk's entry state and slot count as k_jpeg_select left them ("ce <chunk> <state> <slots>": the host model prints the same)
+            for (const Prep& p : P) {
+                if (p.code) continue;
+                std::vector<uint64_t> ent(p.F.nchunks);
+                std::vector<uint32_t> cn(p.F.nchunks);
+                const uint8_t* wk = (const uint8_t*)d_work + p.work_off;
+                if (hipMemcpy(ent.data(), wk, ent.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) continue;
+                if (hipMemcpy(cn.data(), wk + (size_t)p.F.nchunks * 16, cn.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
+                for (size_t g = 0; g < ent.size(); g++) std::fprintf(stderr, "ce %zu %016llx %u\n", g, (unsigned long long)ent[g], cn[g]);
+            }
+        }
         size_t j = 0;
         for (Prep& p : P) {
             if (p.code) continue;

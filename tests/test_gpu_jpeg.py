@@ -616,3 +616,31 @@ def test_frames_taken_ahead_of_their_verdicts(gpu, monkeypatch):
     assert rc == gpu.IMP_ERROR_UNSUPPORTED and out is None
     # the thread's slots and buffers are its own again
     assert gpu.jpeg_request_one_wait(blob, cfg, 86, resize="224,0") == (0, want)
+
+
+def test_dense_streams_forced_onto_the_device_are_exact_or_refused(gpu):
+    """Files of dense blocks (noise at quality 90-100: 300-700 bits per block) keep their Huffman stage on the host by default
+    (DENSE_BITS_PER_BLOCK); FORCED onto the device they are the chain's worst case -- hardly a walk falls into step inside its
+    overlap, nearly every chunk is reached by an explicit state.  Round 5 found k_jpeg_select's look-back taking "every candidate
+    leads to the same candidate" for "so does the true state" there; the guess is now checked against the predecessor's final
+    word (JPEG_ST_CHAIN_GUESS).  So: Pillow's pixels, or a clean refusal (the caller's cvDecodeImage path) -- never other pixels;
+    and the file that showed it is refused."""
+    Image = pytest.importorskip("PIL.Image")
+    seen_refusal = False
+    for (h, w) in [(240, 321), (512, 512), (333, 777), (64, 2048), (600, 200)]:
+        for q in (100, 95, 90):
+            for sub in ("4:2:0", "4:2:2", "4:4:4"):
+                blob = encode(noise_image(h, w, 3, h + w + q), quality=q, subsampling=sub)
+                rc, got = decode(gpu, blob)
+                if rc == 0:
+                    want = np.asarray(Image.open(io.BytesIO(blob)))[:, :, ::-1]
+                    assert np.array_equal(got, want), (h, w, q, sub)
+                else:
+                    assert rc == gpu.IMP_ERROR_DECODE_FAILED, (h, w, q, sub, rc)
+                    seen_refusal = seen_refusal or (h, w, q, sub) == (512, 512, 95, "4:2:0")
+    assert seen_refusal
+    # by default (the entropy stage's place chosen per file) the same file is decoded, on the host
+    os.environ.pop("IMPGPU_JPEG_HUFF", None)
+    blob = encode(noise_image(512, 512, 3, 512 + 512 + 95), quality=95, subsampling="4:2:0")
+    rc, got = decode(gpu, blob)
+    assert rc == 0 and np.array_equal(got, np.asarray(Image.open(io.BytesIO(blob)))[:, :, ::-1])
