@@ -644,3 +644,41 @@ def test_dense_streams_forced_onto_the_device_are_exact_or_refused(gpu):
     blob = encode(noise_image(512, 512, 3, 512 + 512 + 95), quality=95, subsampling="4:2:0")
     rc, got = decode(gpu, blob)
     assert rc == 0 and np.array_equal(got, np.asarray(Image.open(io.BytesIO(blob)))[:, :, ::-1])
+
+
+def test_files_nobody_chose_every_way_of_decoding_them(gpu, monkeypatch):
+    """A seeded sample of tools/jpeg_random_sweep.py (which runs 158 files): random sizes, content, quality, sampling, optimised
+    tables, restart intervals, gray -- one at a time, as one batch, prepared by the caller (staged and pinned): Pillow's pixels."""
+    Image = pytest.importorskip("PIL.Image")
+    from ngx_http_imgproc_amd.workloads import photo_like
+
+    monkeypatch.delenv("IMPGPU_JPEG_HUFF", raising=False)          # (the launch's size decides, as in production)
+    rng = np.random.default_rng(7)
+    files, wants = [], []
+    while len(files) < 40:
+        i = len(files)
+        h, w = int(rng.integers(8, 900)), int(rng.integers(8, 1200))
+        kind = int(rng.integers(0, 3))
+        a = photo_like(h, w, i) if kind == 0 else smooth_image(h, w, 3, seed=i) if kind == 1 else noise_image(h, w, 3, i)
+        kw = dict(quality=int(rng.choice([30, 60, 85, 92])), subsampling=str(rng.choice(["4:2:0", "4:2:2", "4:4:4"])))
+        r = int(rng.integers(0, 4))
+        if r == 1:
+            kw["optimize"] = True
+        if r == 2:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 40))
+        try:
+            blob = encode(a[:, :, 0], quality=kw["quality"]) if rng.integers(0, 8) == 0 else encode(a, **kw)
+        except OSError:
+            continue
+        d = np.asarray(Image.open(io.BytesIO(blob)))
+        files.append(blob)
+        wants.append(d[:, :, None] if d.ndim == 2 else d[:, :, ::-1])
+    prepared = [gpu.jpeg_unstuff(f) or f for f in files]
+    assert 5 < sum(isinstance(p, tuple) for p in prepared) < 40
+    for tag, res in (("lone", [gpu.batch_decode_jpeg([f])[0] for f in files]), ("batch", gpu.batch_decode_jpeg(files)),
+                     ("prepared", gpu.batch_decode_jpeg_prepared(prepared)), ("pinned", gpu.batch_decode_jpeg_prepared(prepared, pinned=True))):
+        for k, ((code, im), want) in enumerate(zip(res, wants)):
+            assert code == 0, (tag, k, code)
+            got = im.numpy()
+            im.release()
+            assert np.array_equal(got, want), (tag, k, want.shape)
