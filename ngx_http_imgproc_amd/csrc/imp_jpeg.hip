@@ -160,12 +160,22 @@ __device__ __forceinline__ void mend_body(JpegHuffTabs& L, MendShared& M, const 
             if (start - seg_start > OVERLAP) {
                 nib = JPEG_MAP_FAIL;
                 const uint64_t E = J.cand_out[at - 1];
+                // (all the states it is compared with are loaded at once: asked for one after the other, each only if the one
+                // before did not match, they were up to eleven trips to memory in a row)
+                uint64_t po[6], ci[6];
+#pragma unroll
+                for (uint32_t i = 0; i < 6; i++) {
+                    po[i] = i < k ? J.cand_out[(size_t)i * N + g - 1] : JPEG_STATE_NONE;
+                    ci[i] = i < B ? J.cand_in[(size_t)i * N + g] : JPEG_STATE_NONE;
+                }
                 int twin = -1;
-                for (uint32_t k2 = 0; k2 < k && twin < 0; k2++) if (J.cand_out[(size_t)k2 * N + g - 1] == E) twin = (int)k2;
+#pragma unroll
+                for (int i = 5; i >= 0; i--) twin = ((uint32_t)i < k && po[i] == E) ? i : twin;          // (the first that matches)
                 if (E == JPEG_STATE_NONE) {
                 } else if (twin >= 0) nib = 32u | (uint32_t)twin;   // bit 5: the answer is candidate `twin`'s
                 else {
-                    for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_in[(size_t)k1 * N + g] == E) nib = k1;
+#pragma unroll
+                    for (int i = 5; i >= 0; i--) nib = ((uint32_t)i < B && ci[i] == E) ? (uint32_t)i : nib;
                     walk = nib == JPEG_MAP_FAIL;
                 }
             }
@@ -186,8 +196,12 @@ __device__ __forceinline__ void mend_body(JpegHuffTabs& L, MendShared& M, const 
         const size_t at = (size_t)k * N + g;
         const uint64_t E = J.cand_out[at - 1];
         uint32_t nib = JPEG_MAP_FAIL;
+        uint64_t co[6];                                             // (asked for before the walk, there when it is over)
+#pragma unroll
+        for (uint32_t i = 0; i < 6; i++) co[i] = i < B ? J.cand_out[(size_t)i * N + g] : JPEG_STATE_NONE;
         const JpegSpan sp = jpeg_span_walk(L, word, E, start, min(start + CHUNK_BITS / 2, limit), limit, seg_end, F);
-        for (uint32_t k1 = 0; k1 < B; k1++) if (nib == JPEG_MAP_FAIL && J.cand_out[(size_t)k1 * N + g] == sp.out) nib = k1;
+#pragma unroll
+        for (int i = 5; i >= 0; i--) nib = ((uint32_t)i < B && co[i] == sp.out) ? (uint32_t)i : nib;
         J.rep_out[at] = sp.out;
         J.rep_n[at] = sp.n;
         if (F.wsplit > 1) { J.rep_mid[at] = sp.mid; J.rep_nmid[at] = sp.nmid; }
