@@ -81,6 +81,18 @@ def test_workers_through_the_broker_get_the_oracles_files(tmp_path, scaling, bro
     assert many["requests_per_s"] > 1.5 * one["requests_per_s"], (one, many)
 
 
+def test_sixteen_workers_for_a_while_every_answer_checked(tmp_path, scaling, broker):
+    """A soak: sixteen workers over the broker's lanes, every answer compared with the oracle's file, for IMPGPU_SOAK_SECONDS
+    (4 in the suite; profiles/r05_broker_soak.txt is a minute of it).  No mismatch, no refusal, no chain that timed out."""
+    name, _ = broker
+    pool, want = _pool_with_answers(tmp_path, scaling)
+    seconds = float(os.environ.get("IMPGPU_SOAK_SECONDS", "4"))
+    r = scaling.run_point(pool, "broker", 16, seconds, want, name)
+    print("\n" + json.dumps(r))
+    assert r["checked"] and r["mismatches"] == 0 and r["chain_timeouts"] == 0 and r["refused"] == 0, r
+    assert r["requests"] > 1000 * seconds, r
+
+
 def test_direct_workers_for_comparison(tmp_path, scaling):
     """The same worker linked against libimpgpu.so itself (a device context per worker): same files."""
     pool, want = _pool_with_answers(tmp_path, scaling)
