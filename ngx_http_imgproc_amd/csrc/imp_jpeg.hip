@@ -54,6 +54,23 @@ __device__ uint32_t wait_flag_ge(const uint32_t* flag, uint32_t want) {
     return 0;
 }
 
+// The chain of k_jpeg_select's workgroups speaks in ONE word per workgroup: flag << 30 | kind << 24 | map -- flag 1 = the map of
+// the workgroup's range is there, 2 = its final word too (kind: the true candidate of its last chunk, 0..5; 13 / 15 = a record /
+// a state to go on with, in words [4] [5] of the record).  Flag and payload in one atomic word: a reader needs ONE trip to
+// memory per workgroup it looks at and no fence (the workgroups sit on eight XCDs with an L2 each; a flag, an acquire fence and
+// a second read for the payload were two trips and an invalidate, 5 us a hop in a chain of workgroups that wait for each
+// other's final word -- profiles/r05_jpeg_select_chain.txt).  Only kinds 13 and 15 carry more, released and acquired as before.
+__device__ __forceinline__ uint32_t chain_word(uint32_t flag, uint32_t kind, uint32_t map) { return (flag << 30) | (kind << 24) | (map & 0xffffffu); }
+__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ uint32_t wait_word_ge(const uint32_t* word, uint32_t want) {       // the word once its flag is >= want (0: never came); no fence
+    for (int spin = 0; spin < (1 << 21); spin++) {
+        const uint32_t v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 30) >= want) return v;
+        __builtin_amdgcn_s_sleep(JPEG_POLL_SLEEP);
+    }
+    return 0;
+}
+
 // the Huffman tables of a job into LDS as a decoder lane reads them
 __device__ __forceinline__ void load_tables(JpegHuffTabs& L, const JpegHuffDev* tables, int t, int nthreads) {
     for (int i = t; i < 4 * (1 << JPEG_LOOKBITS); i += nthreads) L.lut[i >> JPEG_LOOKBITS][i & ((1 << JPEG_LOOKBITS) - 1)] = jpeg_lut_expand(tables[i >> JPEG_LOOKBITS].lut[i & ((1 << JPEG_LOOKBITS) - 1)]);
@@ -254,6 +271,7 @@ __global__ __launch_bounds__(SB) void k_jpeg_mend(const JpegJob* __restrict__ jo
     mend_body<false>(L, M, J, __builtin_amdgcn_readfirstlane(me.local));
 }
 
+constexpr int JPEG_SEL_RECS = 8;                                    // (a 1080p photograph leaves one record to two workgroups)
 struct SelShared {
     uint64_t in[SB], out[SB], rep_out[SB];                          // [k * CPW + j]: walk k of the workgroup's j-th chunk
     uint64_t pout[6];                                               // the exit candidates of the chunk in front of the workgroup
@@ -264,6 +282,12 @@ struct SelShared {
     uint32_t jf, mode, idx0, fin, chases, ext, ei, from;
     uint32_t guessed;                                               // 1 + the candidate of the chunk in front that a CONSTANT map (no final word) named: checked at the end
     uint64_t S;
+    uint32_t early;                                                 // the final word went out before the picking (below)
+    uint32_t extidx[SB];                                            // [k * CPW + j]: the record k_jpeg_mend left for a repair walk that joined nothing (else none)
+    uint32_t recbuf[JPEG_EXT_WORDS];                                // the record being followed, fetched whole
+    uint8_t midnone[SB];                                            // [j]: the chunk was reached by a chase (no middle state: one lane of k_jpeg_write decodes all of it)
+    uint32_t nrec, recno[JPEG_SEL_RECS];                            // records fetched ahead (phase A), by number
+    uint32_t recs[JPEG_SEL_RECS][JPEG_EXT_WORDS];
 };
 // (workgroup `b` of job J, numbered by TICKET: every workgroup it looks back at has started)
 // Lw: the workgroup's tables in LDS where it has them (k_jpeg_entropy_small) -- a chase walks with those; else with the file's tables in memory
@@ -293,18 +317,35 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
     typedef const uint32_t __attribute__((address_space(1))) * GlobalWords;
     const GlobalWords gwords = (GlobalWords)(uintptr_t)A.words;
     auto word = [&](uint32_t i) -> uint32_t { return gwords[i]; };      // (a plain load: the lane comes back to the line for its next word, which a non-temporal load does not keep -- 313 against 465 us per 64 files in k_jpeg_walks)
-    if (t == 0) { s_ext = 0xffffffffu; s_ei = 0; s_from = 0; s_jf = 0xffffffffu; s_mode = 0; s_idx0 = 0; s_fin = 0; s_chases = 0; s_S = 0; s_guessed = 0; }
+    if (t == 0) { s_ext = 0xffffffffu; s_ei = 0; s_from = 0; s_jf = 0xffffffffu; s_mode = 0; s_idx0 = 0; s_fin = 0; s_chases = 0; s_S = 0; s_guessed = 0; Z.early = 0; Z.nrec = 0; }
+    __syncthreads();                                                // (Z.nrec is counted up in phase A)
 
     // ---- A. what the walks found (k_jpeg_walks) and where each of the predecessor's candidates leads (k_jpeg_mend), this
     // workgroup's chunks and the one in front of them
     uint64_t my_in = JPEG_STATE_NONE, my_out = JPEG_STATE_NONE, my_rep_out = JPEG_STATE_NONE;
-    uint32_t my_n = 0, my_rep_n = 0, my_nib = JPEG_MAP_FAIL;
+    uint32_t my_n = 0, my_rep_n = 0, my_nib = JPEG_MAP_FAIL, my_ext = 0xffffffffu;
     if (lane_ok) {
         const size_t at = (size_t)k * F.nchunks + g;
         my_in = J.cand_in[at]; my_out = J.cand_out[at]; my_n = J.cand_n[at];
         my_nib = J.cand_nib[at];
         if (k == 0) s_exact[j] = (my_nib & 64u) ? 1 : 0;
         if (my_nib & 16u) { my_rep_out = J.rep_out[at]; my_rep_n = J.rep_n[at]; }
+        // (asked for here, with everything else: the lane that follows a record later finds its number in LDS)
+        if ((my_nib & 16u) && (my_nib & 15u) == JPEG_MAP_FAIL) my_ext = J.ext_idx[at];
+    }
+    Z.extidx[t] = my_ext;
+    Z.midnone[t] = 0;
+    if (my_ext < J.ext_cap) {                                       // ... and the record itself, while everybody is loading: the chase finds it in LDS
+        const uint32_t slot = atomicAdd(&Z.nrec, 1u);
+        if (slot < (uint32_t)JPEG_SEL_RECS) {
+            const uint32_t* G = J.ext + (size_t)my_ext * JPEG_EXT_WORDS;
+            uint32_t w[JPEG_EXT_WORDS];
+#pragma unroll
+            for (int i = 0; i < JPEG_EXT_WORDS; i++) w[i] = G[i];
+#pragma unroll
+            for (int i = 0; i < JPEG_EXT_WORDS; i++) Z.recs[slot][i] = w[i];
+            Z.recno[slot] = my_ext;
+        }
     }
     s_in[t] = my_in;
     s_out[t] = my_out;
@@ -335,36 +376,55 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
     }
     __syncthreads();
     stamp(3);
-    // ---- C. inclusive scan: P[j] = which candidate of chunk j follows from each candidate of the chunk in front of the workgroup
+    // ---- C. inclusive scan: P[j] = which candidate of chunk j follows from each candidate of the chunk in front of the workgroup.
+    // Up to 64 chunks (42 of a 4:2:0 file) are ONE wave's: the maps go from lane to lane in registers, no barrier between the
+    // steps -- the scan is redone after every chase, with the workgroups that wait for this one's final word behind it.
     int cur = 0;
-    for (uint32_t ofs = 1; ofs < nlive; ofs <<= 1) {
-        if ((uint32_t)t < nlive) {
-            const uint32_t mine = s_scan[cur][t];
-            s_scan[cur ^ 1][t] = (uint32_t)t >= ofs ? jpeg_map_then(s_scan[cur][t - ofs], mine) : mine;
+    auto scan_maps = [&]() {                                        // s_scan[0][0 .. nlive) -> its inclusive scan in s_scan[cur]
+        cur = 0;
+        if (nlive <= 64u) {
+            if (t < 64) {
+                uint32_t m = (uint32_t)t < nlive ? s_scan[0][t] : 0u;
+                for (uint32_t ofs = 1; ofs < nlive; ofs <<= 1) {
+                    const uint32_t before = __shfl_up(m, ofs, 64);
+                    m = (uint32_t)t >= ofs ? jpeg_map_then(before, m) : m;
+                }
+                if ((uint32_t)t < nlive) s_scan[0][t] = m;
+            }
+            __syncthreads();
+            return;
         }
-        cur ^= 1;
-        __syncthreads();
-    }
+        for (uint32_t ofs = 1; ofs < nlive; ofs <<= 1) {
+            if ((uint32_t)t < nlive) {
+                const uint32_t mine = s_scan[cur][t];
+                s_scan[cur ^ 1][t] = (uint32_t)t >= ofs ? jpeg_map_then(s_scan[cur][t - ofs], mine) : mine;
+            }
+            cur ^= 1;
+            __syncthreads();
+        }
+    };
+    scan_maps();
     if (t == 0) {
-        if (b + 1 < nblocks) { rec[2] = s_scan[cur][jl]; st_release(rec + 1, 1u); }
+        if (b + 1 < nblocks) st_relaxed(rec + 1, chain_word(1u, 0u, s_scan[cur][jl]));
         // ---- which of the predecessor's candidates is the true one?  Look back over the maps of the workgroups before, nearest
         // first, until what comes before no longer matters (a constant map: the usual case after ONE) or a final word is met.
         if (!s_exact[0]) {
             uint32_t acc = 0x543210u, idx0 = 0, mode = 2;           // mode 2 = not known yet
             for (int w = (int)b - 1; w >= 0 && mode == 2; w--) {
                 const uint32_t* r = A.records + (size_t)w * JPEG_CTL_REC;
-                const uint32_t have = wait_flag_ge(r + 1, 1u);
-                if (!have) break;
-                if (have == 2) {
-                    const uint32_t kind = r[3];
+                const uint32_t W = wait_word_ge(r + 1, 1u);
+                if (!W) break;
+                if ((W >> 30) == 2u) {
+                    const uint32_t kind = (W >> 24) & 15u;
                     if (kind < 6) { const uint32_t x = jpeg_map_at(acc, kind); if (x != JPEG_MAP_FAIL) { idx0 = x; mode = 0; } }
                     else if (w == (int)b - 1) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         if (kind == 13) { s_ext = r[4]; s_ei = r[5]; mode = 3; }
                         else { s_S = (uint64_t)r[4] | ((uint64_t)r[5] << 32); mode = 1; }
                     }
                     break;                                          // nothing to learn behind a final word
                 }
-                acc = jpeg_map_then(r[2], acc);
+                acc = jpeg_map_then(W & 0xffffffu, acc);
                 // "whatever candidate comes in, this one goes out": taken for the true chain too, which holds when the true state
                 // in front of workgroup w is one of the candidates or falls into step with them inside these workgroups -- always,
                 // in a photograph; in a stream of dense blocks it may do neither.  So the guess is CHECKED against the
@@ -372,11 +432,14 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
                 if (jpeg_map_is_const(acc)) { idx0 = acc & 15u; mode = 0; s_guessed = 1u + idx0; }
             }
             if (mode == 2) {                                        // the maps do not say: the predecessor's final word, then
-                if (wait_flag_ge(prec + 1, 2u)) {
-                    const uint32_t kind = prec[3];
+                if (const uint32_t W = wait_word_ge(prec + 1, 2u)) {
+                    const uint32_t kind = (W >> 24) & 15u;
                     if (kind < 6) { idx0 = kind; mode = 0; }
-                    else if (kind == 13) { s_ext = prec[4]; s_ei = prec[5]; mode = 3; }
-                    else { s_S = (uint64_t)prec[4] | ((uint64_t)prec[5] << 32); mode = 1; }
+                    else {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        if (kind == 13) { s_ext = prec[4]; s_ei = prec[5]; mode = 3; }
+                        else { s_S = (uint64_t)prec[4] | ((uint64_t)prec[5] << 32); mode = 1; }
+                    }
                 } else {
                     atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
                     s_S = JPEG_STATE_NONE;                          // a dead state: every chunk behind it stays empty, the verdict is "refused"
@@ -386,6 +449,15 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
             s_idx0 = idx0;
             s_mode = mode;
         }
+        // The FINAL word, as early as it is known: with the candidate in front of the workgroup in hand, the scan names the
+        // true candidate of the workgroup's last chunk unless a chunk on the way (and no interval's start behind it) left the
+        // candidates -- and a workgroup behind this one whose maps do not settle the matter waits for exactly this word.
+        // Published after the picking and the counting, every workgroup of such a chain added all of that to the wait of
+        // the next (profiles/r05_jpeg_select_chain.txt: 2.4 us a hop; chains of ten and more in a 1080p file).
+        if (s_mode == 0 && b + 1 < nblocks) {
+            const uint32_t x = jpeg_map_at(s_scan[cur][jl], s_idx0);
+            if (x != JPEG_MAP_FAIL) { st_relaxed(rec + 1, chain_word(2u, x, s_scan[cur][jl])); Z.early = 1u + x; }
+        }
     }
     __syncthreads();
     stamp(4);
@@ -393,17 +465,21 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
     // nothing, or a predecessor that hands on a record or a state), ONE lane follows it up to the chunk where the state is a
     // candidate again, and the chunks behind that are scanned and picked once more by all.
     uint32_t mode = s_mode, idx0 = s_idx0, from = 0;                // chunks below `from` are settled
+    // (where the chunk's middle state is to be copied from -- the walk, or the repair walk, that turned out to be the true one:
+    // remembered here and copied ONCE behind the rounds; copied inside them, the load in front of the store was a trip to
+    // memory per round with the workgroups that wait for this one's final word behind it)
+    const uint64_t* mid_from = nullptr;
+    const uint32_t* nmid_from = nullptr;
+    size_t mid_at = 0;
+    uint32_t rounds = 0;                                            // (IMPGPU_JPEG_TRACE=2)
     for (;;) {
+        rounds++;
         if ((uint32_t)t >= from && (uint32_t)t < nlive) {
             uint32_t idx_in = JPEG_MAP_FAIL;                        // which candidate of the chunk before is the true one
             if (mode == 0) idx_in = t == 0 ? idx0 : jpeg_map_at(s_scan[cur][t - 1], idx0);
             uint64_t ent = JPEG_STATE_NONE;
             uint32_t n = 0;
             bool known = false;
-            // (where the chunk's middle state comes from: the walk, or the repair walk, that turned out to be the true one)
-            const uint64_t* mid_from = nullptr;
-            const uint32_t* nmid_from = nullptr;
-            size_t mid_at = 0;
             if (s_exact[t]) { ent = s_in[t]; n = s_n[t]; known = true; mid_from = J.cand_mid; nmid_from = J.cand_nmid; mid_at = (size_t)g0 + t; }
             else if (idx_in != JPEG_MAP_FAIL) {
                 const uint32_t nb = s_nib[idx_in * CPW + t], v = nb & 15u;
@@ -422,13 +498,16 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
             }
             if (known) {
                 A.chunk_entry[g0 + t] = ent; s_res_n[t] = n;
-                if (F.wsplit > 1) { J.chunk_mid[g0 + t] = mid_from[mid_at]; J.chunk_nmid[g0 + t] = nmid_from[mid_at]; }
             }
         }
         __syncthreads();
         const uint32_t jf = s_jf;
         if (mode == 0 && jf == 0xffffffffu) {                       // everything picked
-            if (t == 0) { s_fin = jpeg_map_at(s_scan[cur][jl], idx0); s_S = 0; }   // (a constant map when an interval starts inside the workgroup)
+            if (t == 0) {                                           // (a constant map when an interval starts inside the workgroup)
+                s_fin = jpeg_map_at(s_scan[cur][jl], idx0); s_S = 0;
+                // (the word for the workgroup behind, before the counting below: it may be waiting for it)
+                if (!Z.early && b + 1 < nblocks && s_fin < 6u) { st_relaxed(rec + 1, chain_word(2u, s_fin, 0u)); Z.early = 1u + s_fin; }
+            }
             break;
         }
         if (t == 0) {
@@ -436,15 +515,32 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
             // and slot counts, up to the chunk where the state is a candidate again.  Only where there is no record (or it ends
             // unjoined) is an explicit state decoded on from, with the tables read from memory.
             const JpegHuffCompact& L = *(const JpegHuffCompact*)A.tables;
-            const size_t N = F.nchunks;
             uint32_t jn = 0, idx = 0, chases = 0, ei = 0, rcount = 0, rjoined = 15;
             bool expl = true;
             uint64_t S = JPEG_STATE_NONE;
-            const uint32_t* R = nullptr;                            // the record being followed
+            // The record being followed is fetched WHOLE, every word asked for at once, and read out of LDS from there on:
+            // word by word out of memory -- its number, its header, a step at a time, its last state -- a record was four to
+            // eight trips in a row by one lane with the workgroup (and those that wait for its final word) behind it.
+            const uint32_t* R = nullptr;
             uint32_t Rno = 0xffffffffu;
+            auto fetch_record = [&](uint32_t r) {
+                const uint32_t have = min(Z.nrec, (uint32_t)JPEG_SEL_RECS);
+                R = nullptr;
+                for (uint32_t i = 0; i < have; i++) if (Z.recno[i] == r) R = Z.recs[i];      // fetched ahead
+                if (!R) {
+                    const uint32_t* G = J.ext + (size_t)r * JPEG_EXT_WORDS;
+                    uint32_t w[JPEG_EXT_WORDS];
+#pragma unroll
+                    for (int i = 0; i < JPEG_EXT_WORDS; i++) w[i] = G[i];
+#pragma unroll
+                    for (int i = 0; i < JPEG_EXT_WORDS; i++) Z.recbuf[i] = w[i];
+                    R = Z.recbuf;
+                }
+                Rno = r; rcount = R[2]; rjoined = R[3];
+            };
             auto open_record = [&](uint32_t kk, uint32_t jj) {      // candidate kk of the chunk before jj left a record?
-                const uint32_t r = J.ext_idx[(size_t)s_own[kk * CPW + jj] * N + g0 + jj];
-                if (r < J.ext_cap) { Rno = r; R = J.ext + (size_t)r * JPEG_EXT_WORDS; ei = 0; rcount = R[2]; rjoined = R[3]; }
+                const uint32_t r = Z.extidx[(uint32_t)s_own[kk * CPW + jj] * CPW + jj];
+                if (r < J.ext_cap) { fetch_record(r); ei = 0; }
             };
             auto close_record = [&]() {
                 if (rjoined < 6) { idx = rjoined; expl = false; }
@@ -452,7 +548,7 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
                 R = nullptr;
             };
             if (mode == 1) S = s_S;
-            else if (mode == 3) { Rno = s_ext; R = J.ext + (size_t)Rno * JPEG_EXT_WORDS; ei = s_ei; rcount = R[2]; rjoined = R[3]; }
+            else if (mode == 3) { fetch_record(s_ext); ei = s_ei; }
             else {
                 const uint32_t idx_in = jf == 0 ? idx0 : jpeg_map_at(s_scan[cur][jf - 1], idx0);
                 S = s_rep_out[idx_in * CPW + jf];
@@ -491,7 +587,7 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
                 }
                 A.chunk_entry[g0 + jj] = ent;
                 s_res_n[jj] = n;
-                if (F.wsplit > 1) J.chunk_mid[g0 + jj] = JPEG_STATE_NONE;    // (a chunk reached by the chase: one lane decodes all of it)
+                Z.midnone[jj] = 1;                                  // (a chunk reached by the chase: one lane decodes all of it)
             }
             if (jj >= nlive) {                                      // the workgroup's end: what the next one starts from --
                 if (R && ei >= rcount) close_record();
@@ -510,21 +606,17 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
         idx0 = s_idx0;
         mode = 0;
         if ((uint32_t)t < nlive) s_scan[0][t] = (uint32_t)t < from ? jpeg_map_const(idx0) : s_map[t];
-        cur = 0;
         __syncthreads();
-        for (uint32_t ofs = 1; ofs < nlive; ofs <<= 1) {
-            if ((uint32_t)t < nlive) {
-                const uint32_t mine = s_scan[cur][t];
-                s_scan[cur ^ 1][t] = (uint32_t)t >= ofs ? jpeg_map_then(s_scan[cur][t - ofs], mine) : mine;
-            }
-            cur ^= 1;
-            __syncthreads();
-        }
+        scan_maps();
     }
     __syncthreads();
     // the final word for whoever looks back this far, the slot counts for k_jpeg_write
     uint32_t total = 0;
     if ((uint32_t)t < nlive) { const uint32_t n = s_res_n[t]; A.chunk_n[g0 + t] = n; total = n; }
+    if ((uint32_t)t < nlive && F.wsplit > 1) {
+        if (Z.midnone[t]) J.chunk_mid[g0 + t] = JPEG_STATE_NONE;
+        else if (mid_from) { J.chunk_mid[g0 + t] = mid_from[mid_at]; J.chunk_nmid[g0 + t] = nmid_from[mid_at]; }
+    }
     for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
     if ((t & 63) == 0) s_scan[0][t >> 6] = total;
     __syncthreads();
@@ -532,27 +624,31 @@ __device__ __forceinline__ void select_body(SelShared& Z, const JpegJob& J, cons
         uint32_t all = 0;
         for (int w = 0; w < SB / 64; w++) all += s_scan[0][w];
         rec[6] = all;
-        if (b + 1 < nblocks) {
-            rec[3] = s_fin;
-            rec[4] = (uint32_t)s_S;
-            rec[5] = (uint32_t)(s_S >> 32);
-            st_release(rec + 1, 2u);
+        if (b + 1 < nblocks && !Z.early) {
+            if (s_fin < 6u) st_relaxed(rec + 1, chain_word(2u, s_fin, 0u));        // (nobody reads a map behind a final word)
+            else {
+                rec[4] = (uint32_t)s_S;
+                rec[5] = (uint32_t)(s_S >> 32);
+                st_release(rec + 1, chain_word(2u, s_fin, 0u));
+            }
         }
+        if (Z.early && (Z.early - 1u != s_fin || s_S != 0)) atomicOr(&A.header[1], JPEG_ST_CHAIN_GUESS);   // (cannot happen: the early word IS the late one; a file it happened to is refused)
         if (s_chases) atomicAdd(&A.header[3], s_chases);
         // the guess of the look-back against what the workgroup in front really ended in (it has published by now, or is about
         // to: nothing it waits for comes after this workgroup)
         if (s_guessed) {
             const uint64_t took = s_pout[s_guessed - 1u];
             bool held = false;
-            if (wait_flag_ge(prec + 1, 2u)) {
-                const uint32_t kind = prec[3];
+            if (const uint32_t W = wait_word_ge(prec + 1, 2u)) {
+                const uint32_t kind = (W >> 24) & 15u;
                 if (kind < 6) held = s_pout[kind] == took;          // (the same STATE: two candidates may be twins)
-                else if (kind == 15) held = ((uint64_t)prec[4] | ((uint64_t)prec[5] << 32)) == took;
+                else if (kind == 15) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); held = ((uint64_t)prec[4] | ((uint64_t)prec[5] << 32)) == took; }
             } else atomicOr(&A.header[1], JPEG_ST_CHAIN_TIMEOUT);
             if (!held) atomicOr(&A.header[1], JPEG_ST_CHAIN_GUESS);
         }
     }
     stamp(5);
+    if (t == 0) { rec[29] = rounds; rec[30] = s_chases; }             // (IMPGPU_JPEG_TRACE=2: rounds of picking, chunks this workgroup chased)
 }
 
 __global__ __launch_bounds__(SB) void k_jpeg_select(const JpegJob* __restrict__ jobs, const JpegMapEntry* __restrict__ block_map, uint32_t* __restrict__ launch_ticket) {

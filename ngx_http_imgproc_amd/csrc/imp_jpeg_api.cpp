@@ -572,7 +572,8 @@ int group_finish(Group& G, impgpu_image** images, int* codes) {
     if (on_device) {
         if (const char* tr = std::getenv("IMPGPU_JPEG_TRACE"); tr && !std::strcmp(tr, "2")) {
             // the workgroups' clocks at their phase boundaries (the kernels' stamp()), microseconds since the launch's
-            // first workgroup started: wg: start | walks | candidates exchanged | maps | scan + look-back | done
+            // first workgroup started: wg: start | candidates loaded | twins | maps | scan + look-back | done (incl. the check of a guess), then
+            // the rounds of picking and the chunks the workgroup chased
             std::vector<uint32_t> ctl(ctl_total);
             if (hipMemcpy(ctl.data(), d_ctl, ctl_total * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
                 uint32_t t0 = 0;
@@ -599,6 +600,7 @@ int group_finish(Group& G, impgpu_image** images, int* codes) {
                         const uint32_t* r = &ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 20];
                         std::fprintf(stderr, "wg %dx%d %u/%u:", p.H.width, p.H.height, b, nb);
                         for (int k = 0; k <= 5; k++) std::fprintf(stderr, " %.1f", r[k] ? (double)(int32_t)(r[k] - t0) / 100.0 : -1.0);
+                        std::fprintf(stderr, " rounds %u chased %u", r[9], r[10]);
                         if (r[6]) std::fprintf(stderr, " | fused: start %.1f walks %.1f mend %.1f", (double)(int32_t)(r[6] - t0) / 100.0, (double)(int32_t)(r[7] - t0) / 100.0, (double)(int32_t)(r[8] - t0) / 100.0);
                         std::fprintf(stderr, "\n");
                     }

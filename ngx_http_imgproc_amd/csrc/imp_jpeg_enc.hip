@@ -466,20 +466,32 @@ __global__ __launch_bounds__(NT) void k_jpeg_enc_huff(const EncJob* __restrict__
 // Workgroups take a ticket when they start (never blockIdx): the ones a workgroup waits for are then always running.
 struct EncSeg { int job, local; };
 
+// A record of these chains is ONE word: the value with bit 31 = "it is there" -- one relaxed atomic store to publish it, one
+// relaxed atomic load (per look) to get it, no fence on either side: nothing else is handed over with it.  (As a value word
+// and a flag word, released and acquired, a reader made two trips to memory with a cache invalidate between them and the
+// writer a write-back before its flag: three such exchanges a thumbnail.)
+__device__ __forceinline__ void enc_publish(uint32_t* rec, uint32_t value) {
+    __hip_atomic_store(rec, (value & 0x7fffffffu) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t enc_await(const uint32_t* rec) {           // the word (bit 31 clear: it never came)
+    uint32_t v = 0;
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        v = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v & 0x80000000u) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return v;
+}
+
 __device__ __forceinline__ uint32_t enc_sum_before(const uint32_t* __restrict__ rec, int upto, int* s_part, uint32_t* verdict) {
-    // sum of rec[2 * p] over p < upto, each read once its flag rec[2 * p + 1] is up (the same bounded, relaxed poll as the
+    // sum of rec[2 * p] over p < upto, each read once it is there (enc_await: the same bounded, relaxed poll as the
     // decoder's chain); all threads of the block get the sum.  A wait that runs out says so in the image's verdict word
     // (bit 1): what is written from a wrong offset is not a file, and the host must not hand it on as one.
     uint32_t acc = 0;
     for (int p = threadIdx.x; p < upto; p += 256) {
-        bool up = false;
-        for (int spin = 0; spin < (1 << 22) && !up; spin++) {
-            up = __hip_atomic_load(&rec[2 * p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            if (!up) __builtin_amdgcn_s_sleep(8);
-        }
-        if (!up) atomicOr(verdict, 2u);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        acc += __hip_atomic_load(&rec[2 * p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t v = enc_await(&rec[2 * p]);
+        if (!(v & 0x80000000u)) atomicOr(verdict, 2u);
+        acc += v & 0x7fffffffu;
     }
     int total;
     (void)enc_block_scan<256>((int)acc, s_part, &total);
@@ -520,8 +532,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_pack(const EncJob* __restrict_
     int total;
     const int incl = enc_block_scan<256>(bits, s_part, &total);
     if (tid == 0) {
-        __hip_atomic_store(&J.seg_rec[2 * sg], (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&J.seg_rec[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        enc_publish(&J.seg_rec[2 * sg], (uint32_t)total);
     }
     __syncthreads();                                                // (s_part is free again)
     const uint32_t base = enc_sum_before(J.seg_rec, sg, s_part, &result[4 * me.job + 1]);    // bits of the image in front of this segment
@@ -572,8 +583,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_stuff(const EncJob* __restrict
     int total;
     const int incl = enc_block_scan<256>(ff, s_part, &total);
     if (tid == 0) {
-        __hip_atomic_store(&J.chunk_rec[2 * ck], (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&J.chunk_rec[2 * ck + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        enc_publish(&J.chunk_rec[2 * ck], (uint32_t)total);
     }
     __syncthreads();
     if (c0 >= nbytes) return;                                       // (uniform)
@@ -648,8 +658,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_huff_seg(const EncJob* __restr
     int total;
     const int incl = enc_block_scan<256>(bits, s_part, &total);
     if (tid == 0) {
-        __hip_atomic_store(&recA[2 * sg], (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&recA[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        enc_publish(&recA[2 * sg], (uint32_t)total);
     }
     __syncthreads();                                                // (s_part is free again)
     const uint32_t base = enc_sum_before(recA, sg, s_part, verdict);     // bits of the image in front of this segment
@@ -670,18 +679,12 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_huff_seg(const EncJob* __restr
             if (rem) { atomicOr(&s_win[nown >> 2], ((1u << (8 - rem)) - 1) << (24 - (nown & 3) * 8)); }     // flush_bits: ones up to the byte boundary
         } else {
             const uint32_t part = rem ? (s_win[nown >> 2] >> (24 - (nown & 3) * 8)) & 0xffu : 0u;          // the byte the next segment finishes
-            __hip_atomic_store(&recB[2 * sg], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&recB[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            enc_publish(&recB[2 * sg], part);
         }
         if (lead) {                                                 // the top bits of this segment's first byte are its predecessor's
-            bool up = false;
-            for (int spin = 0; spin < (1 << 22) && !up; spin++) {
-                up = __hip_atomic_load(&recB[2 * (sg - 1) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                if (!up) __builtin_amdgcn_s_sleep(8);
-            }
-            if (!up) atomicOr(verdict, 2u);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            atomicOr(&s_win[0], __hip_atomic_load(&recB[2 * (sg - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 24);
+            const uint32_t v = enc_await(&recB[2 * (sg - 1)]);
+            if (!(v & 0x80000000u)) atomicOr(verdict, 2u);
+            atomicOr(&s_win[0], (v & 0xffu) << 24);
         }
     }
     if (last && rem) nown++;
@@ -694,8 +697,7 @@ __global__ __launch_bounds__(256) void k_jpeg_enc_huff_seg(const EncJob* __restr
     int ff_total;
     const int ff_incl = enc_block_scan<256>(ff, s_part, &ff_total);
     if (tid == 0) {
-        __hip_atomic_store(&recC[2 * sg], (uint32_t)ff_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&recC[2 * sg + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        enc_publish(&recC[2 * sg], (uint32_t)ff_total);
     }
     __syncthreads();
     const uint32_t ff_before = enc_sum_before(recC, sg, s_part, verdict);
