@@ -1,3 +1,7 @@
+"""The clocks of k_jpeg_select's workgroups for ONE lone file (IMPGPU_JPEG_TRACE=2 on the fifth decode): on stderr a line per
+workgroup -- start | candidates loaded | twins | maps | scan + look-back | done, rounds of picking, chunks chased -- and per workgroup of
+k_jpeg_write its start and end.  profiles/r05_jpeg_select_chain.txt is cut from it.
+    python tools/jpeg_chain_trace.py 1920 1080 2> trace.txt"""
 import io, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
