@@ -155,7 +155,7 @@ struct JpegJob {
     // k_jpeg_write and k_jpeg_dcfix work in UNITS: F.wsplit lanes per chunk, unit u = chunk u / wsplit, half u % wsplit
     uint32_t* chunk_slot0;                   // per unit, k_jpeg_write -> k_jpeg_dcfix: the slot of its first symbol
     int* chunk_dc;                           // ... and [4]: its DC differences summed per component, its DC symbols
-    int* wg_dc;                              // [8] per workgroup of k_jpeg_write: the sums over its chunks [0..2]; its clock at start and end [4], [5]
+    int* wg_dc;                              // [8] per workgroup of k_jpeg_write: the sums over its chunks [0..2]; its clock at start and end [4], [5], at its walk's [6], [7]
     int16_t* dcadd;                          // per block, in scan order, k_jpeg_dcfix -> k_jpeg_pixels: what its DC term in the planes lacks
                                              // (null: the planes hold absolute DC terms -- the host's entropy stage)
     uint8_t* dst;                            // the frame

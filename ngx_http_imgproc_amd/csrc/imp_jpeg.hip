@@ -788,11 +788,13 @@ __device__ __forceinline__ void write_body(const Tabs& L, WriteShared& Y, const 
         if (overrun) atomicOr(&A.header[1], JPEG_ST_OVERRUN);
         const uint32_t budget = closes ? (slots_here >= base_n ? slots_here - base_n : 0u) : 0xffffffffu;
         // (every lane of the wave takes part: finished blocks are written out by the lanes together)
+        if (t == 0) wg_dc[6] = (int)(uint32_t)wall_clock64();        // (IMPGPU_JPEG_TRACE=2: the walk begins ... and is over)
 #if defined(__HIP_DEVICE_COMPILE__)
         e = jpeg_write_chunk_dev(L, K, word, entry, limit, seg_end, F, &W, budget, live && !overrun);
 #else
         e = jpeg_write_chunk(L, K, word, entry, limit, seg_end, F, &W, budget, live && !overrun);    // (the host pass only parses the kernel)
 #endif
+        if (t == 0) wg_dc[7] = (int)(uint32_t)wall_clock64();
         if (live && !overrun) {
             if (closes) {
                 const uint32_t pe = (uint32_t)e.exit, fle = (uint32_t)(e.exit >> 48);

@@ -584,14 +584,14 @@ int group_finish(Group& G, impgpu_image** images, int* codes) {
                             const uint32_t v = ctl[p.ctl_records + (size_t)b * JPEG_CTL_REC + 20];
                             if (!have || (int32_t)(v - t0) < 0) { t0 = v; have = true; }
                         }
-                for (const Prep& p : P) {                          // k_jpeg_write: every workgroup's start and end
+                for (const Prep& p : P) {                          // k_jpeg_write: every workgroup's start and end, and its walk's
                     if (p.code) continue;
                     const unsigned nb2 = jpeg_entropy_blocks(p.F.nchunks * p.F.wsplit);
                     std::vector<int> wg((size_t)nb2 * 8);
                     if (hipMemcpy(wg.data(), (uint8_t*)d_work + p.work_off + (size_t)p.F.nchunks * (24 + 20 * (size_t)p.F.wsplit), wg.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
                     for (unsigned b = 0; b < nb2; b++)
-                        std::fprintf(stderr, "ww %dx%d %u/%u: %.1f %.1f\n", p.H.width, p.H.height, b, nb2, (double)(int32_t)((uint32_t)wg[8 * b + 4] - t0) / 100.0,
-                                     (double)(int32_t)((uint32_t)wg[8 * b + 5] - t0) / 100.0);
+                        std::fprintf(stderr, "ww %dx%d %u/%u: %.1f %.1f walk %.1f %.1f\n", p.H.width, p.H.height, b, nb2, (double)(int32_t)((uint32_t)wg[8 * b + 4] - t0) / 100.0,
+                                     (double)(int32_t)((uint32_t)wg[8 * b + 5] - t0) / 100.0, (double)(int32_t)((uint32_t)wg[8 * b + 6] - t0) / 100.0, (double)(int32_t)((uint32_t)wg[8 * b + 7] - t0) / 100.0);
                 }
                 for (const Prep& p : P) {
                     if (p.code) continue;
